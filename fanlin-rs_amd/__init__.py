@@ -1,0 +1,420 @@
+"""fanlin-rs_amd -- host-side mirror of the fanlin-rs image hot path over the MI355X C ABI.
+
+The directory name follows the reference (``fanlin-rs``) and is not a valid Python
+identifier; load it with :func:`importlib` under the name ``fanlin_rs_amd`` (see
+``tests/conftest.py`` / ``__graft_entry__.py``).
+
+Everything here is plumbing over ``libfanlin_gpu.so`` (``include/fanlin_gpu.h``):
+
+* :class:`Query`  mirrors ``query::Query`` (reference ``src/query.rs:3-94``),
+* :class:`Format` mirrors ``content::Format`` (``src/content.rs:12-48``),
+* :class:`State`  mirrors the pixel part of ``handler::State::process_image``
+  (``src/handler.rs:185-309``): same parameter meaning, same order of operations,
+  errors surface as :class:`FanlinError` exactly where the reference returns ``Err``.
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+present, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfanlin_gpu.so")
+
+FE_NONE, FE_JFIF444, FE_WEBP420 = 0, 1, 2
+ACCEPT_WEBP, ACCEPT_AVIF = 1, 2
+OUT_KEEP, OUT_WEBP, OUT_AVIF = 0, 1, 2
+IMG_FRONTEND_PLANES, IMG_HAS_ALPHA = 1, 2
+BATCH_SAME_PARAMS = 1
+
+
+class FanlinError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"flgpu status {status}: {message}")
+        self.status = status
+
+
+class flgpu_image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("capacity", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("channels", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class flgpu_query(C.Structure):
+    _fields_ = [(n, C.c_uint8) for n in ("has_w", "has_h", "has_rgb", "has_quality", "has_crop", "has_blur",
+                                          "has_grayscale", "has_inverse", "has_avif", "has_webp",
+                                          "quality", "crop", "blur", "grayscale", "inverse", "avif", "webp", "reserved")] + \
+               [("w", C.c_uint32), ("h", C.c_uint32), ("rgb", C.c_char * 112)]
+
+
+class flgpu_params(C.Structure):
+    _fields_ = [("has_dims", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32),
+                ("fill_r", C.c_uint8), ("fill_g", C.c_uint8), ("fill_b", C.c_uint8), ("crop", C.c_uint8),
+                ("blur_sigma", C.c_float),
+                ("grayscale", C.c_uint8), ("inverse", C.c_uint8), ("quality", C.c_uint8), ("front_end", C.c_uint8)]
+
+
+class flgpu_plan(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("mid_c", "resampled", "resized_w", "resized_h", "crop_x", "crop_y",
+                                           "letterboxed", "place_x", "place_y", "out_w", "out_h", "out_c",
+                                           "plane_w", "plane_h", "chroma_w", "chroma_h")] + \
+               [("pixel_bytes", C.c_uint64), ("out_bytes", C.c_uint64)]
+
+
+class flgpu_config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_batch", C.c_uint32), ("flush_timeout_us", C.c_uint32),
+                ("profile", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+
+
+class flgpu_stats(C.Structure):
+    _fields_ = [("images", C.c_uint64), ("batches", C.c_uint64), ("queue_flushes", C.c_uint64),
+                ("tables_built", C.c_uint64), ("resample_launches", C.c_uint64), ("resample_ms", C.c_double),
+                ("resample_src_bytes", C.c_uint64), ("resample_dst_bytes", C.c_uint64),
+                ("generic_launches", C.c_uint64), ("blur_launches", C.c_uint64), ("blur_ms", C.c_double),
+                ("frontend_launches", C.c_uint64), ("frontend_ms", C.c_double)]
+
+
+# every symbol include/fanlin_gpu.h declares
+EXPORTED_SYMBOLS = (
+    "flgpu_query_parse", "flgpu_query_dimensions", "flgpu_query_fill_color", "flgpu_query_quality",
+    "flgpu_query_cropping", "flgpu_query_blur", "flgpu_query_grayscale", "flgpu_query_inverse",
+    "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
+    "flgpu_params_from_query", "flgpu_plan_output", "flgpu_create", "flgpu_destroy", "flgpu_transform",
+    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_export_tables", "flgpu_get_stats",
+    "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version",
+    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable",
+)
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libfanlin_gpu.so (built by ``__graft_entry__.build()``); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.flgpu_query_parse.argtypes = [C.c_char_p, C.POINTER(flgpu_query)]
+    lib.flgpu_query_parse.restype = C.c_int
+    lib.flgpu_query_dimensions.argtypes = [C.POINTER(flgpu_query), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.flgpu_query_fill_color.argtypes = [C.POINTER(flgpu_query)] + [C.POINTER(C.c_uint8)] * 3
+    lib.flgpu_query_fill_color.restype = None
+    lib.flgpu_query_quality.argtypes = [C.POINTER(flgpu_query)]
+    lib.flgpu_query_quality.restype = C.c_uint8
+    lib.flgpu_query_blur.argtypes = [C.POINTER(flgpu_query)]
+    lib.flgpu_query_blur.restype = C.c_float
+    for name in ("cropping", "grayscale", "inverse", "use_avif", "use_webp", "as_is", "unsupported_scale_size"):
+        f = getattr(lib, "flgpu_query_" + name)
+        f.argtypes = [C.POINTER(flgpu_query)]
+        f.restype = C.c_int
+    lib.flgpu_params_from_query.argtypes = [C.POINTER(flgpu_query), C.c_uint32, C.c_int, C.POINTER(flgpu_params), C.POINTER(C.c_int)]
+    lib.flgpu_plan_output.argtypes = [C.POINTER(flgpu_params), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(flgpu_plan)]
+    lib.flgpu_create.argtypes = [C.POINTER(flgpu_config), C.POINTER(C.c_int)]
+    lib.flgpu_create.restype = C.c_void_p
+    lib.flgpu_destroy.argtypes = [C.c_void_p]
+    lib.flgpu_destroy.restype = None
+    lib.flgpu_transform.argtypes = [C.c_void_p, C.POINTER(flgpu_image), C.POINTER(flgpu_params), C.POINTER(flgpu_image)]
+    lib.flgpu_transform_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params), C.POINTER(flgpu_image)]
+    lib.flgpu_transform_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params),
+                                                 C.POINTER(flgpu_image), C.c_void_p, C.c_uint32]
+    lib.flgpu_export_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.flgpu_get_stats.argtypes = [C.c_void_p, C.POINTER(flgpu_stats)]
+    lib.flgpu_reset_stats.argtypes = [C.c_void_p]
+    lib.flgpu_strerror.argtypes = [C.c_int]
+    lib.flgpu_strerror.restype = C.c_char_p
+    lib.flgpu_last_error.argtypes = [C.c_void_p]
+    lib.flgpu_last_error.restype = C.c_char_p
+    lib.flgpu_abi_version.restype = C.c_uint32
+    lib.flgpu_debug_axis_table.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.flgpu_debug_stream_schedulable.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
+    _lib = lib
+    return lib
+
+
+def _check(status: int, ctx: Optional[int] = None) -> None:
+    if status == 0:
+        return
+    lib = load_library()
+    msg = lib.flgpu_strerror(status).decode()
+    if ctx:
+        detail = lib.flgpu_last_error(ctx).decode()
+        if detail:
+            msg += f" ({detail})"
+    raise FanlinError(status, msg)
+
+
+class Format:
+    """content::Format (reference src/content.rs:12-48): bit 0 webp, bit 1 avif."""
+
+    def __init__(self, flags: int = 0):
+        self.flags = flags
+
+    def accept_webp(self) -> None:
+        self.flags |= ACCEPT_WEBP
+
+    def webp_accepted(self) -> bool:
+        return (self.flags & ACCEPT_WEBP) == ACCEPT_WEBP
+
+    def accept_avif(self) -> None:
+        self.flags |= ACCEPT_AVIF
+
+    def avif_accepted(self) -> bool:
+        return (self.flags & ACCEPT_AVIF) == ACCEPT_AVIF
+
+    @classmethod
+    def from_accept_header(cls, value: str) -> "Format":
+        """extract_accepted_image_formats (reference src/main.rs:255-274): exact MIME items, comma separated."""
+        f = cls()
+        for item in value.split(","):
+            if item == "image/webp":
+                f.accept_webp()
+            elif item == "image/avif":
+                f.accept_avif()
+        return f
+
+
+class Query:
+    """query::Query (reference src/query.rs:3-94), parsed with axum's Query extractor semantics."""
+
+    def __init__(self, raw: flgpu_query):
+        self._q = raw
+
+    @classmethod
+    def parse(cls, query_string: str) -> "Query":
+        q = flgpu_query()
+        _check(load_library().flgpu_query_parse(query_string.encode(), C.byref(q)))
+        return cls(q)
+
+    def fields(self) -> dict:
+        """Option fields as a dict (None = absent), for comparing with the reference's `want` structs."""
+        q = self._q
+        return {
+            "w": q.w if q.has_w else None, "h": q.h if q.has_h else None,
+            "rgb": q.rgb.decode() if q.has_rgb else None,
+            "quality": q.quality if q.has_quality else None, "crop": bool(q.crop) if q.has_crop else None,
+            "blur": q.blur if q.has_blur else None, "grayscale": bool(q.grayscale) if q.has_grayscale else None,
+            "inverse": bool(q.inverse) if q.has_inverse else None, "avif": bool(q.avif) if q.has_avif else None,
+            "webp": bool(q.webp) if q.has_webp else None,
+        }
+
+    def dimensions(self) -> Optional[Tuple[int, int]]:
+        w, h = C.c_uint32(), C.c_uint32()
+        return (w.value, h.value) if load_library().flgpu_query_dimensions(C.byref(self._q), C.byref(w), C.byref(h)) else None
+
+    def fill_color(self) -> Tuple[int, int, int]:
+        r, g, b = C.c_uint8(), C.c_uint8(), C.c_uint8()
+        load_library().flgpu_query_fill_color(C.byref(self._q), C.byref(r), C.byref(g), C.byref(b))
+        return (r.value, g.value, b.value)
+
+    def quality(self) -> int:
+        return int(load_library().flgpu_query_quality(C.byref(self._q)))
+
+    def cropping(self) -> bool:
+        return bool(load_library().flgpu_query_cropping(C.byref(self._q)))
+
+    def blur(self) -> float:
+        return float(load_library().flgpu_query_blur(C.byref(self._q)))
+
+    def grayscale(self) -> bool:
+        return bool(load_library().flgpu_query_grayscale(C.byref(self._q)))
+
+    def inverse(self) -> bool:
+        return bool(load_library().flgpu_query_inverse(C.byref(self._q)))
+
+    def use_avif(self) -> bool:
+        return bool(load_library().flgpu_query_use_avif(C.byref(self._q)))
+
+    def use_webp(self) -> bool:
+        return bool(load_library().flgpu_query_use_webp(C.byref(self._q)))
+
+    def as_is(self) -> bool:
+        return bool(load_library().flgpu_query_as_is(C.byref(self._q)))
+
+    def unsupported_scale_size(self) -> bool:
+        return bool(load_library().flgpu_query_unsupported_scale_size(C.byref(self._q)))
+
+    def to_params(self, content: Format = None, input_is_jpeg: bool = False) -> Tuple[flgpu_params, int]:
+        p, fmt = flgpu_params(), C.c_int()
+        _check(load_library().flgpu_params_from_query(C.byref(self._q), content.flags if content else 0,
+                                                      int(input_is_jpeg), C.byref(p), C.byref(fmt)))
+        return p, fmt.value
+
+
+def make_params(w: Optional[int] = None, h: Optional[int] = None, fill=(32, 32, 32), crop=False, blur_sigma=0.0,
+                grayscale=False, inverse=False, quality=75, front_end=FE_NONE) -> flgpu_params:
+    p = flgpu_params()
+    p.has_dims = 1 if (w is not None and h is not None) else 0
+    p.w, p.h = (w or 0), (h or 0)
+    p.fill_r, p.fill_g, p.fill_b = fill
+    p.crop = int(crop)
+    p.blur_sigma = blur_sigma
+    p.grayscale, p.inverse = int(grayscale), int(inverse)
+    p.quality, p.front_end = quality, front_end
+    return p
+
+
+def plan_output(params: flgpu_params, sw: int, sh: int, sc: int) -> flgpu_plan:
+    plan = flgpu_plan()
+    _check(load_library().flgpu_plan_output(C.byref(params), sw, sh, sc, C.byref(plan)))
+    return plan
+
+
+def debug_axis_table(in_size: int, out_size: int, gaussian: bool = False, sigma: float = 0.0):
+    """(left, count, weights) exactly as the runtime uploads them for one axis."""
+    lib = load_library()
+    left = (C.c_uint32 * out_size)()
+    count = (C.c_uint32 * out_size)()
+    ratio = max(in_size / out_size, 1.0)
+    cap = int(out_size * (2 * (2.0 * sigma if gaussian else 3.0) * ratio + 4)) + 16
+    w = (C.c_float * cap)()
+    total = C.c_uint64()
+    _check(lib.flgpu_debug_axis_table(in_size, out_size, int(gaussian), sigma, left, count, w, cap, C.byref(total)))
+    return (np.array(left, dtype=np.uint32), np.array(count, dtype=np.uint32), np.array(w[: total.value], dtype=np.float32))
+
+
+def debug_stream_schedulable(in_size: int, out_size: int, y0: int = 0, y1: Optional[int] = None) -> Tuple[bool, int]:
+    peak = C.c_uint32()
+    ok = load_library().flgpu_debug_stream_schedulable(in_size, out_size, y0, out_size if y1 is None else y1, C.byref(peak))
+    return bool(ok), peak.value
+
+
+@dataclass
+class Planes:
+    """Encoder front-end output: luma plane and two chroma planes (u8)."""
+    y: np.ndarray
+    u: np.ndarray
+    v: np.ndarray
+    has_alpha: bool = False
+
+
+def _as_image_array(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.ndim != 3 or not (1 <= a.shape[2] <= 4):
+        raise ValueError("image must be HxW or HxWxC with C in 1..4, dtype uint8")
+    return a
+
+
+def _split_output(buf: np.ndarray, plan: flgpu_plan, front_end: int, flags: int):
+    if front_end == FE_NONE:
+        return buf[: plan.pixel_bytes].reshape(plan.out_h, plan.out_w, plan.out_c)
+    ny = plan.plane_w * plan.plane_h
+    nc = plan.chroma_w * plan.chroma_h
+    return Planes(y=buf[:ny].reshape(plan.plane_h, plan.plane_w),
+                  u=buf[ny:ny + nc].reshape(plan.chroma_h, plan.chroma_w),
+                  v=buf[ny + nc:ny + 2 * nc].reshape(plan.chroma_h, plan.chroma_w),
+                  has_alpha=bool(flags & IMG_HAS_ALPHA))
+
+
+class State:
+    """Device context + the pixel part of handler::State::process_image.
+
+    ``process_pixels`` is the single-request entry (goes through the request-batching
+    queue, like one tokio worker calling ``process_image``); ``process_batch`` runs
+    many host images in one set of launches; ``process_batch_device`` takes device
+    pointers (PyTorch tensors) for HBM-resident batches.
+    """
+
+    def __init__(self, device: int = -1, max_batch: int = 0, flush_timeout_us: int = 0, profile: bool = False):
+        lib = load_library()
+        cfg = flgpu_config()
+        cfg.device, cfg.max_batch, cfg.flush_timeout_us, cfg.profile = device, max_batch, flush_timeout_us, int(profile)
+        st = C.c_int()
+        self._ctx = lib.flgpu_create(C.byref(cfg), C.byref(st))
+        if not self._ctx:
+            _check(st.value or 3)
+        self._lib = lib
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            self._lib.flgpu_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- host memory ---------------------------------------------------------
+    def process_pixels(self, image: np.ndarray, params: flgpu_params):
+        img = _as_image_array(image)
+        plan = plan_output(params, img.shape[1], img.shape[0], img.shape[2])
+        out = np.empty(max(int(plan.out_bytes), 1), dtype=np.uint8)
+        src = flgpu_image(img.ctypes.data, img.nbytes, img.shape[1], img.shape[0], img.shape[2], 0)
+        dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
+        _check(self._lib.flgpu_transform(self._ctx, C.byref(src), C.byref(params), C.byref(dst)), self._ctx)
+        return _split_output(out, plan, params.front_end, dst.flags)
+
+    def process_batch(self, images: Sequence[np.ndarray], params: Sequence[flgpu_params]) -> List:
+        n = len(images)
+        imgs = [_as_image_array(a) for a in images]
+        plans = [plan_output(params[i], imgs[i].shape[1], imgs[i].shape[0], imgs[i].shape[2]) for i in range(n)]
+        outs = [np.empty(max(int(pl.out_bytes), 1), dtype=np.uint8) for pl in plans]
+        srcs = (flgpu_image * n)(*[flgpu_image(a.ctypes.data, a.nbytes, a.shape[1], a.shape[0], a.shape[2], 0) for a in imgs])
+        dsts = (flgpu_image * n)(*[flgpu_image(o.ctypes.data, o.nbytes, 0, 0, 0, 0) for o in outs])
+        ps = (flgpu_params * n)(*params)
+        _check(self._lib.flgpu_transform_batch(self._ctx, n, srcs, ps, dsts), self._ctx)
+        return [_split_output(outs[i], plans[i], params[i].front_end, dsts[i].flags) for i in range(n)]
+
+    # -- device memory -------------------------------------------------------
+    def process_batch_device(self, src_ptrs: Sequence[int], shapes: Sequence[Tuple[int, int, int]],
+                             params, dst_ptrs: Sequence[int], dst_caps: Sequence[int], stream: int = 0) -> None:
+        """Enqueues n HBM-resident images. shapes[i] = (height, width, channels). ``params`` is one
+        flgpu_params (shared) or a sequence of n.  Asynchronous on ``stream`` (a hipStream_t value)."""
+        n = len(src_ptrs)
+        srcs = (flgpu_image * n)(*[flgpu_image(src_ptrs[i], shapes[i][0] * shapes[i][1] * shapes[i][2], shapes[i][1],
+                                               shapes[i][0], shapes[i][2], 0) for i in range(n)])
+        dsts = (flgpu_image * n)(*[flgpu_image(dst_ptrs[i], dst_caps[i], 0, 0, 0, 0) for i in range(n)])
+        if isinstance(params, flgpu_params):
+            ps, flags = (flgpu_params * 1)(params), BATCH_SAME_PARAMS
+        else:
+            ps, flags = (flgpu_params * n)(*params), 0
+        self._keep = (srcs, dsts, ps)
+        _check(self._lib.flgpu_transform_batch_device(self._ctx, n, srcs, ps, dsts, C.c_void_p(stream), flags), self._ctx)
+
+    def prepared_batch(self, src_ptrs, shapes, params, dst_ptrs, dst_caps):
+        """Pre-marshals a device batch so that the timed loop only pays for the C call."""
+        n = len(src_ptrs)
+        srcs = (flgpu_image * n)(*[flgpu_image(src_ptrs[i], shapes[i][0] * shapes[i][1] * shapes[i][2], shapes[i][1],
+                                               shapes[i][0], shapes[i][2], 0) for i in range(n)])
+        dsts = (flgpu_image * n)(*[flgpu_image(dst_ptrs[i], dst_caps[i], 0, 0, 0, 0) for i in range(n)])
+        if isinstance(params, flgpu_params):
+            ps, flags = (flgpu_params * 1)(params), BATCH_SAME_PARAMS
+        else:
+            ps, flags = (flgpu_params * n)(*params), 0
+        ctx, lib = self._ctx, self._lib
+
+        def run(stream: int = 0):
+            _check(lib.flgpu_transform_batch_device(ctx, n, srcs, ps, dsts, C.c_void_p(stream), flags), ctx)
+        run._keep = (srcs, dsts, ps)
+        return run
+
+    def export_tables(self) -> Tuple[int, int]:
+        ptr, nbytes = C.c_void_p(), C.c_uint64()
+        _check(self._lib.flgpu_export_tables(self._ctx, C.byref(ptr), C.byref(nbytes)), self._ctx)
+        return int(ptr.value or 0), int(nbytes.value)
+
+    def stats(self) -> dict:
+        s = flgpu_stats()
+        _check(self._lib.flgpu_get_stats(self._ctx, C.byref(s)), self._ctx)
+        return {name: getattr(s, name) for name, _ in flgpu_stats._fields_}
+
+    def reset_stats(self) -> None:
+        _check(self._lib.flgpu_reset_stats(self._ctx), self._ctx)

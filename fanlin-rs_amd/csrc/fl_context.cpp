@@ -1,0 +1,866 @@
+// fl_context.cpp -- host runtime behind the C ABI: device context, table
+// arena + caches, batch planner/launcher, host-memory staging and the
+// persistent request-batching queue.
+//
+// There is deliberately NO CPU fallback in this file: if HIP is unavailable
+// or a launch fails the caller gets an error code (reference behaviour on any
+// Err from process_image is the fallback image / 500, src/main.rs:185-195).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/fanlin_gpu.h"
+#include "fl_kernels.h"
+#include "fl_tables.h"
+
+using namespace fl;
+
+namespace {
+
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = std::max(bytes, (size_t)1 << 20);
+        want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(bytes, (size_t)1 << 16);
+        want = (want + 4095) & ~(size_t)4095;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// descriptor staging slot: pinned host copy + device copy, guarded by an event
+struct DescSlot {
+    PinnedBuf host;
+    DeviceBuf dev;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t> AxisKey; // in, out, filter, sigma bits
+
+struct StreamPlanKey {
+    AxisKey v, h;
+    uint32_t cx, cy, cw, ch, nbands;
+    bool operator<(const StreamPlanKey &o) const
+    {
+        return std::tie(v, h, cx, cy, cw, ch, nbands) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.nbands);
+    }
+};
+
+struct StreamPlan {
+    bool ok = false;
+    std::vector<StreamItem> items; // job field unset
+    uint32_t hmax = 0, nxs_max = 0;
+};
+
+struct Request {
+    const flgpu_image *src;
+    const flgpu_params *p;
+    flgpu_image *dst;
+    int status = 0;
+    bool done = false;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline uint32_t float_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+} // namespace
+
+struct flgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    flgpu_config cfg{};
+    std::mutex mu; // planning + launching is serialised per context
+
+    // read-only table arena
+    std::vector<uint32_t> h_arena;
+    uint32_t *d_arena = nullptr;
+    size_t arena_cap_words = 0, arena_uploaded = 0;
+    std::map<AxisKey, uint32_t> axis_off;
+    std::map<AxisKey, HostAxis> axis_host;
+    std::map<StreamPlanKey, StreamPlan> stream_plans;
+    uint32_t gamma_off = 0;
+
+    DescSlot slots[4];
+    int next_slot = 0;
+    DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_status;
+    DeviceBuf d_in, d_out;
+    PinnedBuf h_stage_in, h_stage_out;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_done = nullptr;
+
+    flgpu_stats stats{};
+    struct Pending { hipEvent_t a, b; int kind; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    std::string last_error;
+
+    // request queue
+    std::thread worker;
+    std::mutex qmu;
+    std::condition_variable qcv, qdone;
+    std::deque<Request *> queue;
+    bool stop = false;
+    bool worker_started = false;
+
+    int fail(hipError_t e, const char *what)
+    {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        last_error = buf;
+        return e == hipErrorOutOfMemory ? FLGPU_ERR_OOM : FLGPU_ERR_DEVICE;
+    }
+};
+
+#define FL_HIP(ctx, call, what) do { hipError_t e__ = (call); if (e__ != hipSuccess) return (ctx)->fail(e__, what); } while (0)
+
+namespace {
+
+constexpr size_t kArenaWords = (size_t)16 << 20; // 64 MiB of tables
+
+// ---- arena ---------------------------------------------------------------
+
+// Appends words, returns the word offset; 0 is never a valid offset (word 0 is a sentinel).
+uint32_t arena_append(flgpu_ctx *c, const void *data, size_t words, size_t align_words = 4)
+{
+    size_t off = align_up(c->h_arena.size(), align_words);
+    if (off + words > c->arena_cap_words) return 0;
+    c->h_arena.resize(off + words);
+    if (data) memcpy(c->h_arena.data() + off, data, words * 4);
+    return (uint32_t)off;
+}
+
+void arena_reset(flgpu_ctx *c)
+{
+    c->h_arena.clear();
+    c->h_arena.push_back(0xFA171200u); // sentinel so that no table sits at offset 0
+    c->arena_uploaded = 0;
+    c->axis_off.clear();
+    c->axis_host.clear();
+    c->stream_plans.clear();
+    std::vector<uint32_t> g;
+    build_webp_gamma(g);
+    c->gamma_off = arena_append(c, g.data(), g.size());
+}
+
+int arena_flush(flgpu_ctx *c, hipStream_t st)
+{
+    if (c->arena_uploaded == c->h_arena.size()) return FLGPU_OK;
+    const size_t from = c->arena_uploaded;
+    // pageable source: the runtime stages it before returning, so h_arena may grow afterwards
+    FL_HIP(c, hipMemcpyAsync(c->d_arena + from, c->h_arena.data() + from, (c->h_arena.size() - from) * 4, hipMemcpyHostToDevice, st),
+           "table upload");
+    c->arena_uploaded = c->h_arena.size();
+    return FLGPU_OK;
+}
+
+// Returns the header offset of the axis table, building it on a miss (0 = arena full).
+uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma, AxisKey *key_out, const HostAxis **host_out)
+{
+    AxisKey key(in, out, (uint32_t)f, float_bits(sigma));
+    if (key_out) *key_out = key;
+    auto it = c->axis_off.find(key);
+    if (it != c->axis_off.end()) {
+        if (host_out) *host_out = &c->axis_host[key];
+        return it->second;
+    }
+    HostAxis &ha = c->axis_host[key];
+    build_axis(in, out, f, sigma, ha);
+    c->stats.tables_built++;
+    AxisTable hdr{};
+    hdr.in_size = in; hdr.out_size = out; hdr.max_taps = ha.max_taps; hdr.total_taps = (uint32_t)ha.weights.size();
+    const uint32_t hoff = arena_append(c, nullptr, sizeof(AxisTable) / 4);
+    hdr.left_off = arena_append(c, ha.left.data(), out);
+    hdr.count_off = arena_append(c, ha.count.data(), out);
+    hdr.woff_off = arena_append(c, ha.woff.data(), out);
+    hdr.weights_off = arena_append(c, ha.weights.data(), ha.weights.size());
+    if (!hoff || !hdr.left_off || !hdr.count_off || !hdr.woff_off || !hdr.weights_off) {
+        c->axis_host.erase(key);
+        return 0;
+    }
+    memcpy(c->h_arena.data() + hoff, &hdr, sizeof(hdr));
+    c->axis_off[key] = hoff;
+    if (host_out) *host_out = &ha;
+    return hoff;
+}
+
+const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
+                                  uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs, uint32_t pre)
+{
+    StreamPlanKey key{vk, hk, cx, cy, cw, ch, nbands};
+    auto it = c->stream_plans.find(key);
+    if (it != c->stream_plans.end()) return &it->second;
+    StreamPlan plan;
+    const uint32_t T = 256, span_max = T * PXL;
+    // strips: fewest equal-width strips such that each has <= T output columns and <= T*PXL source pixels
+    std::vector<HostStrip> strips;
+    for (uint32_t ns = std::max(1u, (cw + T - 1) / T); ns <= cw; ++ns) {
+        strips.clear();
+        bool fits = true;
+        const uint32_t per = (cw + ns - 1) / ns;
+        for (uint32_t x = cx; x < cx + cw && fits; x += per) {
+            HostStrip s;
+            build_strip(ha, x, std::min(x + per, cx + cw), PXL, s);
+            if (s.sx1 - s.sx0 > span_max || s.x1 - s.x0 > T) fits = false;
+            strips.push_back(std::move(s));
+        }
+        if (fits) break;
+        strips.clear();
+    }
+    bool ok = !strips.empty();
+    struct Band { uint32_t y0, y1, r0, r1, sched_off; };
+    std::vector<Band> bands;
+    if (ok) {
+        const uint32_t per = (ch + nbands - 1) / nbands;
+        for (uint32_t y = cy; y < cy + ch && ok; y += per) {
+            Band b{y, std::min(y + per, cy + ch), 0, 0, 0};
+            std::vector<RowSched> sched;
+            if (!build_row_sched(va, b.y0, b.y1, b.r0, b.r1, sched)) { ok = false; break; }
+            b.sched_off = arena_append(c, sched.data(), sched.size() * sizeof(RowSched) / 4);
+            if (!b.sched_off) ok = false;
+            bands.push_back(b);
+        }
+    }
+    if (ok) {
+        for (auto &s : strips) {
+            const uint32_t hleft_off = arena_append(c, s.left_rel.data(), s.left_rel.size());
+            const uint32_t hw_off = arena_append(c, s.w4.data(), s.w4.size());
+            if (!hleft_off || !hw_off) { ok = false; break; }
+            plan.hmax = std::max(plan.hmax, s.hmax);
+            plan.nxs_max = std::max(plan.nxs_max, s.x1 - s.x0);
+            for (size_t bi = 0; bi < bands.size(); ++bi) {
+                const Band &b = bands[bi];
+                StreamItem it2{};
+                it2.y0 = b.y0; it2.y1 = b.y1; it2.x0 = s.x0; it2.x1 = s.x1; it2.r0 = b.r0; it2.r1 = b.r1;
+                it2.sx0 = s.sx0; it2.sched_off = b.sched_off; it2.hleft_off = hleft_off; it2.hw_off = hw_off; it2.hmax = s.hmax;
+                plan.items.push_back(it2);
+            }
+        }
+    }
+    if (ok && stream_lds_bytes(cs, pre, plan.hmax, plan.nxs_max) > 150 * 1024) ok = false;
+    plan.ok = ok;
+    if (!ok) plan.items.clear();
+    auto res = c->stream_plans.emplace(key, std::move(plan));
+    return &res.first->second;
+}
+
+// ---- events / profiling ----------------------------------------------------
+
+hipEvent_t get_event(flgpu_ctx *c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void resolve_pending(flgpu_ctx *c)
+{
+    for (auto &p : c->pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.kind == 0) c->stats.resample_ms += ms;
+            else if (p.kind == 1) c->stats.blur_ms += ms;
+            else c->stats.frontend_ms += ms;
+        }
+        c->event_pool.push_back(p.a);
+        c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+struct ProfileScope {
+    flgpu_ctx *c; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr;
+    ProfileScope(flgpu_ctx *c_, hipStream_t st_, int kind_) : c(c_), st(st_), kind(kind_)
+    {
+        if (!c->cfg.profile) return;
+        if (c->pending.size() > 2048) resolve_pending(c);
+        a = get_event(c); b = get_event(c);
+        if (a && b) (void)hipEventRecord(a, st);
+    }
+    ~ProfileScope()
+    {
+        if (a && b) { (void)hipEventRecord(b, st); c->pending.push_back({a, b, kind}); }
+    }
+};
+
+// ---- batch execution -------------------------------------------------------
+
+enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3 };
+
+struct Work {
+    flgpu_plan plan;
+    const flgpu_params *p;
+    uint32_t cs, pre, sw, sh;
+    Stage1Kind s1;
+    const uint8_t *src;
+    uint8_t *s1_dst;   // output of stage 1 (== src when S1_NONE)
+    uint8_t *blur_dst; // output of the blur stage (or null)
+    uint8_t *final_dst;
+    AxisKey vk, hk;
+    const HostAxis *va = nullptr, *ha = nullptr;
+    uint32_t vtab = 0, htab = 0;
+    const StreamPlan *splan = nullptr;
+};
+
+struct GroupKey {
+    uint32_t kind, cs, pre, lb;
+    bool operator<(const GroupKey &o) const { return std::tie(kind, cs, pre, lb) < std::tie(o.kind, o.cs, o.pre, o.lb); }
+};
+
+void fill_job(const Work &w, Job &j)
+{
+    memset(&j, 0, sizeof(j));
+    const flgpu_plan &pl = w.plan;
+    j.src = w.src;
+    j.dst = w.s1_dst;
+    j.src_bytes = w.sw * w.sh * w.cs;
+    j.sw = w.sw; j.sh = w.sh;
+    j.rw = pl.resized_w; j.rh = pl.resized_h;
+    j.cx = pl.crop_x; j.cy = pl.crop_y;
+    if (pl.letterboxed) {
+        j.cw = std::min(pl.resized_w - pl.crop_x, pl.out_w - pl.place_x);
+        j.ch = std::min(pl.resized_h - pl.crop_y, pl.out_h - pl.place_y);
+    } else {
+        j.cw = pl.out_w; j.ch = pl.out_h;
+    }
+    j.dw = pl.out_w; j.dh = pl.out_h;
+    j.ox = pl.place_x; j.oy = pl.place_y;
+    j.fill = (uint32_t)w.p->fill_r | ((uint32_t)w.p->fill_g << 8) | ((uint32_t)w.p->fill_b << 16) | (255u << 24);
+    j.vtab = w.vtab; j.htab = w.htab;
+}
+
+int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, bool same_params,
+                     flgpu_image *dsts, hipStream_t st)
+{
+    if (n == 0) return FLGPU_OK;
+    if (!srcs || !ps || !dsts) return FLGPU_ERR_INVALID_ARG;
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    if (!st) st = c->stream;
+    if (c->last_stream && c->last_stream != st && c->last_done) FL_HIP(c, hipStreamWaitEvent(st, c->last_done, 0), "stream handoff");
+
+    // ---- plan every image ------------------------------------------------
+    std::vector<Work> work(n);
+    size_t tmp_a_bytes = 0, tmp_b_bytes = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Work &w = work[i];
+        const flgpu_image &s = srcs[i];
+        w.p = same_params ? &ps[0] : &ps[i];
+        if (!s.data || !dsts[i].data) return FLGPU_ERR_INVALID_ARG;
+        int rc = flgpu_plan_output(w.p, s.width, s.height, s.channels, &w.plan);
+        if (rc) return rc;
+        if (s.capacity < (uint64_t)s.width * s.height * s.channels) return FLGPU_ERR_INVALID_ARG;
+        if (dsts[i].capacity < w.plan.out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
+        w.cs = s.channels; w.sw = s.width; w.sh = s.height;
+        w.pre = w.p->grayscale ? PRE_GRAY : (w.p->inverse ? PRE_INVERT : PRE_NONE);
+        w.src = s.data;
+        w.final_dst = dsts[i].data;
+        const flgpu_plan &pl = w.plan;
+        const bool cropped = pl.crop_x || pl.crop_y || pl.out_w != pl.resized_w || pl.out_h != pl.resized_h;
+        // grayscale of Luma/LumaA and "no-op" pre-ops change nothing
+        const bool pre_changes = (w.pre == PRE_INVERT) || (w.pre == PRE_GRAY && w.cs >= 3);
+        if (!pre_changes) w.pre = PRE_NONE;
+        if (pl.resampled) w.s1 = S1_GENERIC;
+        else if (pre_changes || pl.letterboxed || cropped) w.s1 = S1_PLACE;
+        else w.s1 = S1_NONE;
+        const bool blur = w.p->blur_sigma > 0.0f;
+        const bool fe = w.p->front_end != FLGPU_FE_NONE;
+        // buffer chain
+        if (w.s1 == S1_NONE) w.s1_dst = const_cast<uint8_t *>(w.src);
+        else if (!blur && !fe) w.s1_dst = w.final_dst;
+        else { w.s1_dst = reinterpret_cast<uint8_t *>(tmp_a_bytes); tmp_a_bytes += align_up(pl.pixel_bytes, 256); }
+        if (blur) {
+            if (!fe) w.blur_dst = w.final_dst;
+            else { w.blur_dst = reinterpret_cast<uint8_t *>(tmp_b_bytes); tmp_b_bytes += align_up(pl.pixel_bytes, 256); }
+        } else w.blur_dst = nullptr;
+    }
+    FL_HIP(c, c->d_tmp_a.reserve(tmp_a_bytes), "scratch A");
+    FL_HIP(c, c->d_tmp_b.reserve(tmp_b_bytes), "scratch B");
+    for (auto &w : work) {
+        const bool blur = w.p->blur_sigma > 0.0f, fe = w.p->front_end != FLGPU_FE_NONE;
+        if (w.s1 != S1_NONE && (blur || fe)) w.s1_dst = static_cast<uint8_t *>(c->d_tmp_a.p) + reinterpret_cast<size_t>(w.s1_dst);
+        if (blur && fe) w.blur_dst = static_cast<uint8_t *>(c->d_tmp_b.p) + reinterpret_cast<size_t>(w.blur_dst);
+    }
+
+    // ---- tables ------------------------------------------------------------
+    // first pass may overflow the arena: reset once and retry
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool full = false;
+        size_t n_resample = 0;
+        for (auto &w : work) n_resample += w.plan.resampled ? 1 : 0;
+        for (auto &w : work) {
+            if (!w.plan.resampled) continue;
+            w.vtab = get_axis(c, w.sh, w.plan.resized_h, FILTER_LANCZOS3, 0.0f, &w.vk, &w.va);
+            w.htab = get_axis(c, w.sw, w.plan.resized_w, FILTER_LANCZOS3, 0.0f, &w.hk, &w.ha);
+            if (!w.vtab || !w.htab) { full = true; break; }
+            // fused streaming kernel if the geometry allows it
+            w.s1 = S1_GENERIC;
+            const bool aligned = ((w.sw * w.cs) % 4u == 0) && ((uintptr_t)w.src % 4u == 0) &&
+                                 (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
+            const char *force = getenv("FLGPU_FORCE_GENERIC");
+            if (stream_supported(w.cs, w.pre) && aligned && !(force && force[0] == '1')) {
+                Job jtmp; fill_job(w, jtmp);
+                uint32_t nbands = 1;
+                const char *fb = getenv("FLGPU_FORCE_BANDS");
+                if (fb) nbands = (uint32_t)std::max(1, atoi(fb));
+                else if (n_resample < 512) {
+                    // small batches: split images into row bands so that the chip still gets >= ~1024 workgroups
+                    const uint32_t want = (uint32_t)((1024 + n_resample * 2 - 1) / (n_resample * 2));
+                    nbands = std::max(1u, std::min(want, jtmp.ch / 24u));
+                }
+                nbands = std::min(nbands, std::max(1u, jtmp.ch));
+                const StreamPlan *sp = get_stream_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, nbands, w.cs, w.pre);
+                if (c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
+                if (sp->ok) { w.s1 = S1_STREAM; w.splan = sp; }
+            }
+        }
+        for (auto &w : work) {
+            if (full) break;
+            if (w.p->blur_sigma > 0.0f) {
+                AxisKey k; const HostAxis *h;
+                if (!get_axis(c, w.plan.out_h, w.plan.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h) ||
+                    !get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h)) full = true;
+            }
+        }
+        if (!full) break;
+        if (attempt == 1) return FLGPU_ERR_OOM;
+        FL_HIP(c, hipStreamSynchronize(st), "arena reset sync");
+        FL_HIP(c, hipDeviceSynchronize(), "arena reset sync");
+        arena_reset(c);
+    }
+    { int rc = arena_flush(c, st); if (rc) return rc; }
+
+    // ---- descriptors ---------------------------------------------------------
+    std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
+    for (size_t i = 0; i < n; ++i) {
+        const Work &w = work[i];
+        if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1, w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        if (w.p->blur_sigma > 0.0f) blur_groups[{0, w.plan.out_c, 0, 0}].push_back(i);
+        if (w.p->front_end != FLGPU_FE_NONE) fe_groups[{w.p->front_end, 0, 0, 0}].push_back(i);
+    }
+    std::vector<Job> jobs;
+    std::vector<StreamItem> items;
+    std::vector<FrontendJob> fjobs;
+    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems; LaunchGeneric g; size_t lds; size_t mid_floats; };
+    std::vector<S1Launch> s1_launches, blur_launches;
+    struct FeLaunch { uint32_t kind, base, n, mw, mh; };
+    std::vector<FeLaunch> fe_launches;
+    size_t mid_floats_max = 0;
+    const size_t kMidCapFloats = (size_t)256 << 20; // 1 GiB of f32 intermediate per launch group
+
+    auto new_launch = [&](const GroupKey &k) {
+        S1Launch L{};
+        L.k = k; L.job_base = (uint32_t)jobs.size(); L.item_base = (uint32_t)items.size();
+        L.g.cs = k.cs; L.g.pre = k.pre; L.g.letterbox = k.lb;
+        return L;
+    };
+    for (auto &kv : s1_groups) {
+        const GroupKey &k = kv.first;
+        S1Launch L = new_launch(k);
+        for (size_t idx : kv.second) {
+            const Work &w = work[idx];
+            Job j; fill_job(w, j);
+            const size_t mid = (k.kind == S1_GENERIC) ? (size_t)w.sw * w.plan.resized_h * mid_channels(w.cs, w.pre) : 0;
+            if (k.kind == S1_GENERIC && L.njobs && L.mid_floats + mid > kMidCapFloats) {
+                s1_launches.push_back(L);
+                L = new_launch(k);
+            }
+            j.mid_off = (uint32_t)L.mid_floats;
+            L.mid_floats += mid;
+            mid_floats_max = std::max(mid_floats_max, L.mid_floats);
+            L.g.max_sw = std::max(L.g.max_sw, j.sw); L.g.max_rh = std::max(L.g.max_rh, j.rh);
+            L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
+            L.g.max_dw = std::max(L.g.max_dw, j.dw); L.g.max_dh = std::max(L.g.max_dh, j.dh);
+            if (k.kind == S1_STREAM) {
+                for (StreamItem it2 : w.splan->items) { it2.job = (uint32_t)jobs.size(); items.push_back(it2); }
+                L.nitems += (uint32_t)w.splan->items.size();
+                L.lds = std::max(L.lds, stream_lds_bytes(w.cs, w.pre, w.splan->hmax, w.splan->nxs_max));
+                c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
+                c->stats.resample_dst_bytes += w.plan.pixel_bytes;
+            }
+            jobs.push_back(j);
+            L.njobs++;
+        }
+        s1_launches.push_back(L);
+    }
+    for (auto &kv : blur_groups) {
+        const GroupKey &k = kv.first; // cs = channel count of the blurred image
+        S1Launch L = new_launch(k);
+        for (size_t idx : kv.second) {
+            const Work &w = work[idx];
+            const flgpu_plan &pl = w.plan;
+            Job j; memset(&j, 0, sizeof(j));
+            j.src = w.s1_dst; j.dst = w.blur_dst; j.src_bytes = (uint32_t)pl.pixel_bytes;
+            j.sw = pl.out_w; j.sh = pl.out_h; j.rw = pl.out_w; j.rh = pl.out_h; j.cw = pl.out_w; j.ch = pl.out_h;
+            j.dw = pl.out_w; j.dh = pl.out_h;
+            j.vtab = get_axis(c, pl.out_h, pl.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, nullptr, nullptr);
+            j.htab = get_axis(c, pl.out_w, pl.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, nullptr, nullptr);
+            const size_t mid = (size_t)pl.out_w * pl.out_h * pl.out_c;
+            if (L.njobs && L.mid_floats + mid > kMidCapFloats) { blur_launches.push_back(L); L = new_launch(k); }
+            j.mid_off = (uint32_t)L.mid_floats;
+            L.mid_floats += mid;
+            mid_floats_max = std::max(mid_floats_max, L.mid_floats);
+            L.g.max_sw = std::max(L.g.max_sw, j.sw); L.g.max_rh = std::max(L.g.max_rh, j.rh);
+            L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
+            jobs.push_back(j);
+            L.njobs++;
+        }
+        blur_launches.push_back(L);
+    }
+    size_t n_status = 0;
+    for (auto &kv : fe_groups) {
+        FeLaunch F{kv.first.kind, (uint32_t)fjobs.size(), 0, 0, 0};
+        for (size_t idx : kv.second) {
+            const Work &w = work[idx];
+            const flgpu_plan &pl = w.plan;
+            FrontendJob f; memset(&f, 0, sizeof(f));
+            f.src = w.blur_dst ? w.blur_dst : w.s1_dst;
+            f.dst = w.final_dst;
+            f.status = reinterpret_cast<uint32_t *>(n_status++ * 4 + 4); // patched below
+            f.w = pl.out_w; f.h = pl.out_h; f.c = pl.out_c;
+            f.plane_w = pl.plane_w; f.plane_h = pl.plane_h; f.chroma_w = pl.chroma_w; f.chroma_h = pl.chroma_h;
+            if (F.kind == FLGPU_FE_JFIF444) { F.mw = std::max(F.mw, f.plane_w); F.mh = std::max(F.mh, f.plane_h); }
+            else { F.mw = std::max(F.mw, f.chroma_w); F.mh = std::max(F.mh, f.chroma_h); }
+            fjobs.push_back(f);
+            F.n++;
+        }
+        fe_launches.push_back(F);
+    }
+    if (n_status) {
+        FL_HIP(c, c->d_status.reserve(n_status * 4), "status words");
+        FL_HIP(c, hipMemsetAsync(c->d_status.p, 0, n_status * 4, st), "status clear");
+        for (auto &f : fjobs) f.status = static_cast<uint32_t *>(c->d_status.p) + (reinterpret_cast<size_t>(f.status) / 4 - 1);
+    }
+    FL_HIP(c, c->d_mid.reserve(mid_floats_max * 4), "f32 intermediate");
+
+    // one staging slot: [jobs][items][fjobs]
+    const size_t jobs_b = align_up(jobs.size() * sizeof(Job), 256), items_b = align_up(items.size() * sizeof(StreamItem), 256),
+                 fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256);
+    const size_t desc_b = jobs_b + items_b + fjobs_b;
+    const Job *d_jobs = nullptr; const StreamItem *d_items = nullptr; const FrontendJob *d_fjobs = nullptr;
+    DescSlot *slot = nullptr;
+    if (desc_b) {
+        slot = &c->slots[c->next_slot];
+        c->next_slot = (c->next_slot + 1) % 4;
+        if (slot->busy) { FL_HIP(c, hipEventSynchronize(slot->done), "descriptor slot wait"); slot->busy = false; }
+        if (!slot->done) FL_HIP(c, hipEventCreateWithFlags(&slot->done, hipEventDisableTiming), "event");
+        FL_HIP(c, slot->host.reserve(desc_b), "pinned descriptors");
+        FL_HIP(c, slot->dev.reserve(desc_b), "device descriptors");
+        char *hp = static_cast<char *>(slot->host.p);
+        if (!jobs.empty()) memcpy(hp, jobs.data(), jobs.size() * sizeof(Job));
+        if (!items.empty()) memcpy(hp + jobs_b, items.data(), items.size() * sizeof(StreamItem));
+        if (!fjobs.empty()) memcpy(hp + jobs_b + items_b, fjobs.data(), fjobs.size() * sizeof(FrontendJob));
+        FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, st), "descriptor upload");
+        char *dp = static_cast<char *>(slot->dev.p);
+        d_jobs = reinterpret_cast<const Job *>(dp);
+        d_items = reinterpret_cast<const StreamItem *>(dp + jobs_b);
+        d_fjobs = reinterpret_cast<const FrontendJob *>(dp + jobs_b + items_b);
+    }
+
+    // ---- launches --------------------------------------------------------------
+    for (auto &L : s1_launches) {
+        L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
+        L.g.job_base = L.job_base; L.g.njobs = L.njobs;
+        if (L.k.kind == S1_PLACE) {
+            FL_HIP(c, launch_place(L.g, false, st), "place kernel");
+        } else if (L.k.kind == S1_GENERIC) {
+            if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
+            FL_HIP(c, launch_vpass_generic(L.g, st), "generic vertical pass");
+            FL_HIP(c, launch_hpass_generic(L.g, st), "generic horizontal pass");
+            c->stats.generic_launches++;
+        } else {
+            if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
+            LaunchStream s{};
+            s.jobs = d_jobs; s.items = d_items + L.item_base; s.arena = c->d_arena; s.nitems = L.nitems;
+            s.cs = L.k.cs; s.pre = L.k.pre; s.letterbox = L.k.lb; s.lds_bytes = L.lds;
+            {
+                ProfileScope ps(c, st, 0);
+                FL_HIP(c, launch_stream(s, st), "streaming resample kernel");
+            }
+            c->stats.resample_launches++;
+        }
+    }
+    for (auto &L : blur_launches) {
+        L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
+        L.g.job_base = L.job_base; L.g.njobs = L.njobs; L.g.pre = PRE_NONE; L.g.letterbox = 0;
+        ProfileScope ps(c, st, 1);
+        FL_HIP(c, launch_vpass_generic(L.g, st), "blur vertical pass");
+        FL_HIP(c, launch_hpass_generic(L.g, st), "blur horizontal pass");
+        c->stats.blur_launches++;
+    }
+    for (auto &F : fe_launches) {
+        ProfileScope ps(c, st, 2);
+        if (F.kind == FLGPU_FE_JFIF444) FL_HIP(c, launch_jfif444(d_fjobs, F.base, F.n, F.mw, F.mh, st), "jfif front end");
+        else FL_HIP(c, launch_webp420(d_fjobs, c->d_arena, c->gamma_off, F.base, F.n, F.mw, F.mh, st), "webp front end");
+        c->stats.frontend_launches++;
+    }
+    // plain copies for requests that change nothing
+    for (size_t i = 0; i < n; ++i) {
+        const Work &w = work[i];
+        if (w.s1 == S1_NONE && !(w.p->blur_sigma > 0.0f) && w.p->front_end == FLGPU_FE_NONE)
+            FL_HIP(c, hipMemcpyAsync(w.final_dst, w.src, w.plan.pixel_bytes, hipMemcpyDeviceToDevice, st), "copy");
+    }
+    if (slot) { FL_HIP(c, hipEventRecord(slot->done, st), "event record"); slot->busy = true; }
+    if (!c->last_done) FL_HIP(c, hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming), "event");
+    FL_HIP(c, hipEventRecord(c->last_done, st), "event record");
+    c->last_stream = st;
+
+    for (size_t i = 0; i < n; ++i) {
+        const flgpu_plan &pl = work[i].plan;
+        dsts[i].width = pl.out_w; dsts[i].height = pl.out_h; dsts[i].channels = pl.out_c;
+        dsts[i].flags = work[i].p->front_end != FLGPU_FE_NONE ? FLGPU_IMG_FRONTEND_PLANES : 0u;
+    }
+    c->stats.images += n;
+    c->stats.batches++;
+    return FLGPU_OK;
+}
+
+// Host-memory batch: stage in, run, stage out, wait.
+int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts)
+{
+    if (n == 0) return FLGPU_OK;
+    if (!srcs || !ps || !dsts) return FLGPU_ERR_INVALID_ARG;
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    std::vector<flgpu_image> dsrc(n), ddst(n);
+    std::vector<flgpu_plan> plans(n);
+    size_t in_b = 0, out_b = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!srcs[i].data || !dsts[i].data) return FLGPU_ERR_INVALID_ARG;
+        int rc = flgpu_plan_output(&ps[i], srcs[i].width, srcs[i].height, srcs[i].channels, &plans[i]);
+        if (rc) return rc;
+        const uint64_t sb = (uint64_t)srcs[i].width * srcs[i].height * srcs[i].channels;
+        if (srcs[i].capacity < sb) return FLGPU_ERR_INVALID_ARG;
+        if (dsts[i].capacity < plans[i].out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
+        dsrc[i] = srcs[i]; ddst[i] = dsts[i];
+        dsrc[i].data = reinterpret_cast<uint8_t *>(in_b); dsrc[i].capacity = sb; in_b += align_up(sb, 256);
+        ddst[i].data = reinterpret_cast<uint8_t *>(out_b); ddst[i].capacity = plans[i].out_bytes; out_b += align_up(plans[i].out_bytes, 256);
+    }
+    FL_HIP(c, c->d_in.reserve(in_b), "device input staging");
+    FL_HIP(c, c->d_out.reserve(out_b), "device output staging");
+    FL_HIP(c, c->h_stage_in.reserve(in_b), "pinned input staging");
+    FL_HIP(c, c->h_stage_out.reserve(out_b), "pinned output staging");
+    hipStream_t st = c->stream;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t off = reinterpret_cast<size_t>(dsrc[i].data);
+        memcpy(static_cast<char *>(c->h_stage_in.p) + off, srcs[i].data, dsrc[i].capacity);
+        dsrc[i].data = static_cast<uint8_t *>(c->d_in.p) + off;
+        ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
+    }
+    FL_HIP(c, hipMemcpyAsync(c->d_in.p, c->h_stage_in.p, in_b, hipMemcpyHostToDevice, st), "H2D");
+    int rc = run_batch_device(c, n, dsrc.data(), ps, false, ddst.data(), st);
+    if (rc) return rc;
+    FL_HIP(c, hipMemcpyAsync(c->h_stage_out.p, c->d_out.p, out_b, hipMemcpyDeviceToHost, st), "D2H");
+    std::vector<uint32_t> status_words;
+    FL_HIP(c, hipStreamSynchronize(st), "batch sync");
+    for (size_t i = 0; i < n; ++i) {
+        const size_t off = static_cast<uint8_t *>(ddst[i].data) - static_cast<uint8_t *>(c->d_out.p);
+        memcpy(dsts[i].data, static_cast<char *>(c->h_stage_out.p) + off, plans[i].out_bytes);
+        dsts[i].width = ddst[i].width; dsts[i].height = ddst[i].height; dsts[i].channels = ddst[i].channels; dsts[i].flags = ddst[i].flags;
+    }
+    return FLGPU_OK;
+}
+
+// ---- request queue ---------------------------------------------------------
+
+void worker_main(flgpu_ctx *c)
+{
+    const size_t max_batch = c->cfg.max_batch ? c->cfg.max_batch : 256;
+    const auto flush = std::chrono::microseconds(c->cfg.flush_timeout_us ? c->cfg.flush_timeout_us : 200);
+    for (;;) {
+        std::vector<Request *> batch;
+        {
+            std::unique_lock<std::mutex> lk(c->qmu);
+            c->qcv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
+            if (c->stop && c->queue.empty()) return;
+            // a first request arrived: wait for company until the batch is full or the flush timer fires
+            const auto deadline = std::chrono::steady_clock::now() + flush;
+            while (c->queue.size() < max_batch && !c->stop) {
+                if (c->qcv.wait_until(lk, deadline) == std::cv_status::timeout) break;
+            }
+            while (!c->queue.empty() && batch.size() < max_batch) { batch.push_back(c->queue.front()); c->queue.pop_front(); }
+        }
+        std::vector<flgpu_image> srcs(batch.size()), dsts(batch.size());
+        std::vector<flgpu_params> ps(batch.size());
+        for (size_t i = 0; i < batch.size(); ++i) { srcs[i] = *batch[i]->src; dsts[i] = *batch[i]->dst; ps[i] = *batch[i]->p; }
+        int rc;
+        {
+            std::lock_guard<std::mutex> g(c->mu);
+            rc = run_batch_host(c, batch.size(), srcs.data(), ps.data(), dsts.data());
+            c->stats.queue_flushes++;
+        }
+        {
+            std::lock_guard<std::mutex> lk(c->qmu);
+            for (size_t i = 0; i < batch.size(); ++i) {
+                if (!rc) { batch[i]->dst->width = dsts[i].width; batch[i]->dst->height = dsts[i].height; batch[i]->dst->channels = dsts[i].channels; batch[i]->dst->flags = dsts[i].flags; }
+                batch[i]->status = rc;
+                batch[i]->done = true;
+            }
+        }
+        c->qdone.notify_all();
+    }
+}
+
+} // namespace
+
+// ---- C ABI -------------------------------------------------------------------
+
+extern "C" {
+
+flgpu_ctx *flgpu_create(const flgpu_config *cfg, int *status)
+{
+    auto set = [&](int s) { if (status) *status = s; };
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set(FLGPU_ERR_NO_DEVICE); return nullptr; }
+    flgpu_ctx *c = new (std::nothrow) flgpu_ctx();
+    if (!c) { set(FLGPU_ERR_OOM); return nullptr; }
+    if (cfg) c->cfg = *cfg;
+    int dev = c->cfg.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { delete c; set(FLGPU_ERR_NO_DEVICE); return nullptr; }
+    c->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c; set(FLGPU_ERR_NO_DEVICE); return nullptr;
+    }
+    c->arena_cap_words = kArenaWords;
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_arena), kArenaWords * 4) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream); delete c; set(FLGPU_ERR_OOM); return nullptr;
+    }
+    arena_reset(c);
+    set(FLGPU_OK);
+    return c;
+}
+
+void flgpu_destroy(flgpu_ctx *c)
+{
+    if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(c->qmu);
+        c->stop = true;
+    }
+    c->qcv.notify_all();
+    if (c->worker_started) c->worker.join();
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    resolve_pending(c);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto &s : c->slots) { s.host.release(); s.dev.release(); if (s.done) (void)hipEventDestroy(s.done); }
+    if (c->last_done) (void)hipEventDestroy(c->last_done);
+    c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_status.release(); c->d_in.release(); c->d_out.release();
+    c->h_stage_in.release(); c->h_stage_out.release();
+    if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int flgpu_transform_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts,
+                                 void *hip_stream, uint32_t flags)
+{
+    if (!c) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    return run_batch_device(c, n, srcs, ps, (flags & FLGPU_BATCH_SAME_PARAMS) != 0, dsts, static_cast<hipStream_t>(hip_stream));
+}
+
+int flgpu_transform_batch(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts)
+{
+    if (!c) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    return run_batch_host(c, n, srcs, ps, dsts);
+}
+
+int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p, flgpu_image *dst)
+{
+    if (!c || !src || !p || !dst || !src->data || !dst->data) return FLGPU_ERR_INVALID_ARG;
+    // validate on the caller's thread so that one bad request cannot fail a shared batch
+    flgpu_plan plan;
+    int rc = flgpu_plan_output(p, src->width, src->height, src->channels, &plan);
+    if (rc) return rc;
+    if (src->capacity < (uint64_t)src->width * src->height * src->channels) return FLGPU_ERR_INVALID_ARG;
+    if (dst->capacity < plan.out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
+    Request r{src, p, dst};
+    {
+        std::unique_lock<std::mutex> lk(c->qmu);
+        if (c->stop) return FLGPU_ERR_SHUTDOWN;
+        if (!c->worker_started) { c->worker = std::thread(worker_main, c); c->worker_started = true; }
+        c->queue.push_back(&r);
+    }
+    c->qcv.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(c->qmu);
+        c->qdone.wait(lk, [&] { return r.done; });
+    }
+    return r.status;
+}
+
+int flgpu_export_tables(flgpu_ctx *c, void **device_ptr, uint64_t *bytes)
+{
+    if (!c || !device_ptr || !bytes) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    int rc = arena_flush(c, c->stream);
+    if (rc) return rc;
+    FL_HIP(c, hipStreamSynchronize(c->stream), "table sync");
+    *device_ptr = c->d_arena;
+    *bytes = (uint64_t)c->h_arena.size() * 4;
+    return FLGPU_OK;
+}
+
+int flgpu_get_stats(flgpu_ctx *c, flgpu_stats *out)
+{
+    if (!c || !out) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    resolve_pending(c);
+    *out = c->stats;
+    return FLGPU_OK;
+}
+
+int flgpu_reset_stats(flgpu_ctx *c)
+{
+    if (!c) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    resolve_pending(c);
+    c->stats = flgpu_stats{};
+    return FLGPU_OK;
+}
+
+const char *flgpu_last_error(flgpu_ctx *c) { return c ? c->last_error.c_str() : ""; }
+
+} // extern "C"

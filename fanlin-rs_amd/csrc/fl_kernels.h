@@ -1,0 +1,58 @@
+// fl_kernels.h -- launch interface between the host runtime and fl_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fl_types.h"
+
+namespace fl {
+
+// One image of an encoder-front-end launch.
+struct alignas(16) FrontendJob {
+    const uint8_t *src;   // interleaved pixels, w x h x c
+    uint8_t *dst;         // planes
+    uint32_t *status;     // optional: bit 0 set if any alpha != 255 (WEBP420)
+    uint32_t w, h, c;
+    uint32_t plane_w, plane_h;
+    uint32_t chroma_w, chroma_h;
+    uint32_t pad;
+};
+
+// A group of jobs sharing source channels / pre-op / letterbox flag.
+struct LaunchGeneric {
+    const Job *jobs;        // device array
+    const uint32_t *arena;  // device table arena
+    float *mid;             // device f32 intermediate (generic resample only)
+    uint32_t job_base;      // first job of the group inside `jobs`
+    uint32_t njobs;
+    uint32_t cs, pre;       // source channels, PreOp
+    uint32_t letterbox;     // destination is Rgba8 over the fill colour
+    uint32_t max_sw, max_rh;  // vertical pass grid
+    uint32_t max_cw, max_ch;  // horizontal pass grid
+    uint32_t max_dw, max_dh;  // placement grid
+};
+
+struct LaunchStream {
+    const Job *jobs;
+    const StreamItem *items; // device array, one per workgroup
+    const uint32_t *arena;
+    uint32_t nitems;
+    uint32_t cs, pre, letterbox;
+    size_t lds_bytes;
+};
+
+hipError_t launch_vpass_generic(const LaunchGeneric &g, hipStream_t st);
+hipError_t launch_hpass_generic(const LaunchGeneric &g, hipStream_t st);
+hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st);
+
+bool stream_supported(uint32_t cs, uint32_t pre);
+size_t stream_lds_bytes(uint32_t cs, uint32_t pre, uint32_t hmax, uint32_t nxs_max);
+hipError_t launch_stream(const LaunchStream &s, hipStream_t st);
+
+hipError_t launch_jfif444(const FrontendJob *fjobs, uint32_t job_base, uint32_t njobs, uint32_t max_pw, uint32_t max_ph,
+                          hipStream_t st);
+hipError_t launch_webp420(const FrontendJob *fjobs, const uint32_t *arena, uint32_t gamma_off, uint32_t job_base,
+                          uint32_t njobs, uint32_t max_cw, uint32_t max_ch, hipStream_t st);
+
+} // namespace fl

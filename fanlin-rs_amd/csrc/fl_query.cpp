@@ -1,0 +1,320 @@
+// fl_query.cpp -- host-only request model: query::Query (reference src/query.rs),
+// content::Format (src/content.rs) and the geometry decisions of
+// State::process_image (src/handler.rs:224-261).  No device code.
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/fanlin_gpu.h"
+#include "fl_tables.h"
+
+namespace {
+
+constexpr uint8_t kDefaultColor = 32;    // query.rs:17
+constexpr uint8_t kDefaultQuality = 75;  // query.rs:18
+constexpr float kDefaultBlurSigma = 0.0f; // query.rs:19
+constexpr uint32_t kWidthMin = 20, kWidthMax = 2000;   // query.rs:20
+constexpr uint32_t kHeightMin = 20, kHeightMax = 1000; // query.rs:21
+
+int hexval(char c)
+{
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+}
+
+// application/x-www-form-urlencoded decoding as form_urlencoded::parse does it
+std::string url_decode(const char *s, size_t n)
+{
+    std::string o;
+    o.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (s[i] == '+') o.push_back(' ');
+        else if (s[i] == '%' && i + 2 < n && hexval(s[i + 1]) >= 0 && hexval(s[i + 2]) >= 0) {
+            o.push_back((char)(hexval(s[i + 1]) * 16 + hexval(s[i + 2])));
+            i += 2;
+        } else o.push_back(s[i]);
+    }
+    return o;
+}
+
+// str::parse::<u32>() / ::<u8>(): optional '+', then decimal digits only, no overflow
+bool parse_uint(const std::string &v, uint64_t max, uint64_t *out)
+{
+    size_t i = 0;
+    if (i < v.size() && v[i] == '+') ++i;
+    if (i >= v.size()) return false;
+    uint64_t acc = 0;
+    for (; i < v.size(); ++i) {
+        if (v[i] < '0' || v[i] > '9') return false;
+        acc = acc * 10 + (uint64_t)(v[i] - '0');
+        if (acc > max) return false;
+    }
+    *out = acc;
+    return true;
+}
+
+bool parse_bool(const std::string &v, uint8_t *out)
+{
+    if (v == "true") { *out = 1; return true; }
+    if (v == "false") { *out = 0; return true; }
+    return false;
+}
+
+} // namespace
+
+extern "C" {
+
+int flgpu_query_parse(const char *query_string, flgpu_query *out)
+{
+    if (!query_string || !out) return FLGPU_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    const char *q = query_string;
+    const char *qm = strchr(q, '?');
+    if (qm) q = qm + 1;
+    else if (strstr(q, "://")) q = q + strlen(q); // a URI without a query part
+    size_t len = strcspn(q, "#");
+    size_t pos = 0;
+    while (pos <= len) {
+        size_t end = pos;
+        while (end < len && q[end] != '&') ++end;
+        if (end > pos) {
+            size_t eq = pos;
+            while (eq < end && q[eq] != '=') ++eq;
+            const std::string key = url_decode(q + pos, eq - pos);
+            const std::string val = eq < end ? url_decode(q + eq + 1, end - eq - 1) : std::string();
+            uint64_t u = 0;
+            // serde rejects a repeated known field ("duplicate field")
+#define FL_DUP(flag) do { if (out->flag) return FLGPU_ERR_PARSE; } while (0)
+            if (key == "w") { FL_DUP(has_w); if (!parse_uint(val, UINT32_MAX, &u)) return FLGPU_ERR_PARSE; out->w = (uint32_t)u; out->has_w = 1; }
+            else if (key == "h") { FL_DUP(has_h); if (!parse_uint(val, UINT32_MAX, &u)) return FLGPU_ERR_PARSE; out->h = (uint32_t)u; out->has_h = 1; }
+            else if (key == "rgb") { FL_DUP(has_rgb); strncpy(out->rgb, val.c_str(), sizeof(out->rgb) - 1); out->has_rgb = 1; }
+            else if (key == "quality") { FL_DUP(has_quality); if (!parse_uint(val, 255, &u)) return FLGPU_ERR_PARSE; out->quality = (uint8_t)u; out->has_quality = 1; }
+            else if (key == "crop") { FL_DUP(has_crop); if (!parse_bool(val, &out->crop)) return FLGPU_ERR_PARSE; out->has_crop = 1; }
+            else if (key == "blur") { FL_DUP(has_blur); if (!parse_uint(val, 255, &u)) return FLGPU_ERR_PARSE; out->blur = (uint8_t)u; out->has_blur = 1; }
+            else if (key == "grayscale") { FL_DUP(has_grayscale); if (!parse_bool(val, &out->grayscale)) return FLGPU_ERR_PARSE; out->has_grayscale = 1; }
+            else if (key == "inverse") { FL_DUP(has_inverse); if (!parse_bool(val, &out->inverse)) return FLGPU_ERR_PARSE; out->has_inverse = 1; }
+            else if (key == "avif") { FL_DUP(has_avif); if (!parse_bool(val, &out->avif)) return FLGPU_ERR_PARSE; out->has_avif = 1; }
+            else if (key == "webp") { FL_DUP(has_webp); if (!parse_bool(val, &out->webp)) return FLGPU_ERR_PARSE; out->has_webp = 1; }
+#undef FL_DUP
+            // unknown keys are ignored (no deny_unknown_fields on query::Query)
+        }
+        pos = end + 1;
+    }
+    return FLGPU_OK;
+}
+
+/* query.rs:28-33 */
+int flgpu_query_dimensions(const flgpu_query *q, uint32_t *w, uint32_t *h)
+{
+    if (q->has_w && q->has_h) { if (w) *w = q->w; if (h) *h = q->h; return 1; }
+    return 0;
+}
+
+/* query.rs:35-49: first three comma fields, each unparsable one becomes 32, fewer than three -> default */
+void flgpu_query_fill_color(const flgpu_query *q, uint8_t *r, uint8_t *g, uint8_t *b)
+{
+    uint8_t c[3] = {kDefaultColor, kDefaultColor, kDefaultColor};
+    if (q->has_rgb) {
+        uint8_t t[3];
+        int n = 0;
+        const char *s = q->rgb;
+        while (n < 3) {
+            const char *e = strchr(s, ',');
+            std::string field = e ? std::string(s, (size_t)(e - s)) : std::string(s);
+            uint64_t u;
+            t[n++] = parse_uint(field, 255, &u) ? (uint8_t)u : kDefaultColor;
+            if (!e) break;
+            s = e + 1;
+        }
+        if (n == 3) { c[0] = t[0]; c[1] = t[1]; c[2] = t[2]; }
+    }
+    *r = c[0]; *g = c[1]; *b = c[2];
+}
+
+uint8_t flgpu_query_quality(const flgpu_query *q) { return q->has_quality ? q->quality : kDefaultQuality; } /* query.rs:51-53 */
+int flgpu_query_cropping(const flgpu_query *q) { return q->has_crop && q->crop; }                        /* query.rs:55-57 */
+/* query.rs:59-62: any present value is clamped into 10..=20 */
+float flgpu_query_blur(const flgpu_query *q)
+{
+    if (!q->has_blur) return kDefaultBlurSigma;
+    float v = (float)q->blur;
+    return v < 10.0f ? 10.0f : (v > 20.0f ? 20.0f : v);
+}
+int flgpu_query_grayscale(const flgpu_query *q) { return q->has_grayscale && q->grayscale; }
+int flgpu_query_inverse(const flgpu_query *q) { return q->has_inverse && q->inverse; }
+int flgpu_query_use_avif(const flgpu_query *q) { return q->has_avif && q->avif; }
+int flgpu_query_use_webp(const flgpu_query *q) { return q->has_webp && q->webp; }
+/* query.rs:80-87 */
+int flgpu_query_as_is(const flgpu_query *q)
+{
+    return !flgpu_query_dimensions(q, nullptr, nullptr) && flgpu_query_blur(q) == kDefaultBlurSigma &&
+           !flgpu_query_grayscale(q) && !flgpu_query_inverse(q) && !flgpu_query_use_avif(q) && !flgpu_query_use_webp(q);
+}
+/* query.rs:89-93 */
+int flgpu_query_unsupported_scale_size(const flgpu_query *q)
+{
+    const uint32_t w = q->has_w ? q->w : 100, h = q->has_h ? q->h : 100;
+    return !(w >= kWidthMin && w <= kWidthMax) || !(h >= kHeightMin && h <= kHeightMax);
+}
+
+int flgpu_params_from_query(const flgpu_query *q, uint32_t accept_flags, int input_is_jpeg, flgpu_params *p, int *out_format)
+{
+    if (!q || !p) return FLGPU_ERR_INVALID_ARG;
+    memset(p, 0, sizeof(*p));
+    p->has_dims = (uint32_t)flgpu_query_dimensions(q, &p->w, &p->h);
+    flgpu_query_fill_color(q, &p->fill_r, &p->fill_g, &p->fill_b);
+    p->crop = (uint8_t)flgpu_query_cropping(q);
+    p->blur_sigma = flgpu_query_blur(q);
+    p->grayscale = (uint8_t)flgpu_query_grayscale(q);
+    p->inverse = (uint8_t)flgpu_query_inverse(q);
+    p->quality = flgpu_query_quality(q);
+    /* handler.rs:256-261: webp wins over avif, each only if the client accepts it */
+    int fmt = FLGPU_OUT_KEEP;
+    if (flgpu_query_use_webp(q) && (accept_flags & FLGPU_ACCEPT_WEBP)) fmt = FLGPU_OUT_WEBP;
+    else if (flgpu_query_use_avif(q) && (accept_flags & FLGPU_ACCEPT_AVIF)) fmt = FLGPU_OUT_AVIF;
+    if (out_format) *out_format = fmt;
+    /* lossy WebP (quality < 100, handler.rs:288-297) and JPEG have a device colour front end;
+       lossless WebP, AVIF, PNG, ... take interleaved pixels */
+    uint8_t qc = p->quality < 1 ? 1 : (p->quality > 100 ? 100 : p->quality);
+    if (fmt == FLGPU_OUT_WEBP) p->front_end = (qc == 100) ? FLGPU_FE_NONE : FLGPU_FE_WEBP420;
+    else if (fmt == FLGPU_OUT_KEEP && input_is_jpeg) p->front_end = FLGPU_FE_JFIF444;
+    else p->front_end = FLGPU_FE_NONE;
+    return FLGPU_OK;
+}
+
+int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t sc, flgpu_plan *plan)
+{
+    if (!p || !plan) return FLGPU_ERR_INVALID_ARG;
+    if (sw == 0 || sh == 0 || sc < 1 || sc > 4) return FLGPU_ERR_INVALID_ARG;
+    if ((uint64_t)sw * sh * sc >= (1ull << 31)) return FLGPU_ERR_UNSUPPORTED;
+    if (p->front_end > FLGPU_FE_WEBP420) return FLGPU_ERR_INVALID_ARG;
+    memset(plan, 0, sizeof(*plan));
+    /* handler.rs:224-228 */
+    plan->mid_c = p->grayscale ? (sc == 3 ? 1u : sc == 4 ? 2u : sc) : sc;
+    uint32_t cw = sw, chh = sh; /* current image size */
+    plan->resized_w = sw;
+    plan->resized_h = sh;
+    if (p->has_dims) {
+        if (p->w == 0 || p->h == 0) return FLGPU_ERR_INVALID_ARG;
+        if (p->w != sw || p->h != sh) {
+            uint32_t w2, h2;
+            fl::resize_dimensions(sw, sh, p->w, p->h, p->crop != 0, w2, h2);
+            if ((uint64_t)w2 * h2 * 4 >= (1ull << 31)) return FLGPU_ERR_UNSUPPORTED;
+            plan->resized_w = w2;
+            plan->resized_h = h2;
+            plan->resampled = (w2 != sw || h2 != sh) ? 1u : 0u; /* imageops::resize copies when the size is unchanged */
+            cw = w2;
+            chh = h2;
+            if (p->crop) {
+                /* DynamicImage::resize_to_fill + imageops::crop_dimms */
+                uint32_t x = 0, y = 0;
+                if ((uint64_t)p->w * h2 > (uint64_t)w2 * p->h) y = h2 >= p->h ? (h2 - p->h) / 2 : 0;
+                else x = w2 >= p->w ? (w2 - p->w) / 2 : 0;
+                x = x < w2 ? x : w2;
+                y = y < h2 ? y : h2;
+                plan->crop_x = x;
+                plan->crop_y = y;
+                cw = p->w < w2 - x ? p->w : w2 - x;
+                chh = p->h < h2 - y ? p->h : h2 - y;
+            }
+        }
+        if (p->w > cw || p->h > chh) {
+            /* handler.rs:238-248 */
+            plan->letterboxed = 1;
+            plan->place_x = (p->w > cw ? p->w - cw : cw - p->w) / 2;
+            plan->place_y = (p->h > chh ? p->h - chh : chh - p->h) / 2;
+            plan->out_w = p->w;
+            plan->out_h = p->h;
+            plan->out_c = 4;
+        }
+    }
+    if (!plan->letterboxed) {
+        plan->out_w = cw;
+        plan->out_h = chh;
+        plan->out_c = plan->mid_c;
+    }
+    plan->pixel_bytes = (uint64_t)plan->out_w * plan->out_h * plan->out_c;
+    switch (p->front_end) {
+    case FLGPU_FE_JFIF444:
+        plan->plane_w = (plan->out_w + 7u) & ~7u;
+        plan->plane_h = (plan->out_h + 7u) & ~7u;
+        plan->chroma_w = plan->plane_w;
+        plan->chroma_h = plan->plane_h;
+        plan->out_bytes = 3ull * plan->plane_w * plan->plane_h;
+        break;
+    case FLGPU_FE_WEBP420:
+        plan->plane_w = plan->out_w;
+        plan->plane_h = plan->out_h;
+        plan->chroma_w = (plan->out_w + 1u) >> 1;
+        plan->chroma_h = (plan->out_h + 1u) >> 1;
+        plan->out_bytes = (uint64_t)plan->plane_w * plan->plane_h + 2ull * plan->chroma_w * plan->chroma_h;
+        break;
+    default:
+        plan->out_bytes = plan->pixel_bytes;
+        break;
+    }
+    return FLGPU_OK;
+}
+
+int flgpu_debug_axis_table(uint32_t in_size, uint32_t out_size, int filter, float sigma, uint32_t *left, uint32_t *count,
+                           float *weights, uint64_t weights_cap, uint64_t *total)
+{
+    if (!in_size || !out_size || !left || !count || !weights || !total || filter < 0 || filter > 1) return FLGPU_ERR_INVALID_ARG;
+    fl::HostAxis a;
+    fl::build_axis(in_size, out_size, filter ? fl::FILTER_GAUSSIAN : fl::FILTER_LANCZOS3, sigma, a);
+    *total = a.weights.size();
+    if (a.weights.size() > weights_cap) return FLGPU_ERR_BUFFER_TOO_SMALL;
+    memcpy(left, a.left.data(), out_size * 4);
+    memcpy(count, a.count.data(), out_size * 4);
+    memcpy(weights, a.weights.data(), a.weights.size() * 4);
+    return FLGPU_OK;
+}
+
+int flgpu_debug_stream_schedulable(uint32_t in_size, uint32_t out_size, uint32_t y0, uint32_t y1, uint32_t *max_live)
+{
+    if (!in_size || !out_size || y0 >= y1 || y1 > out_size) return 0;
+    fl::HostAxis a;
+    fl::build_axis(in_size, out_size, fl::FILTER_LANCZOS3, 0.0f, a);
+    uint32_t r0, r1, peak = 0;
+    std::vector<fl::RowSched> sched;
+    const bool ok = fl::build_row_sched(a, y0, y1, r0, r1, sched);
+    if (ok) {
+        // every tap must appear exactly once and every output must be emitted exactly once
+        uint64_t taps = 0, emits = 0, want = 0;
+        for (auto &e : sched) { taps += (uint64_t)__builtin_popcount(e.live); emits += (uint64_t)__builtin_popcount(e.emit); peak = std::max<uint32_t>(peak, (uint32_t)__builtin_popcount(e.live)); }
+        for (uint32_t o = y0; o < y1; ++o) want += a.count[o];
+        if (taps != want || emits != y1 - y0) return 0;
+    } else {
+        // report the true peak so callers can see why it was refused
+        std::vector<uint32_t> live(in_size + 1, 0);
+        for (uint32_t o = y0; o < y1; ++o) for (uint32_t i = 0; i < a.count[o]; ++i) peak = std::max(peak, ++live[a.left[o] + i]);
+    }
+    if (max_live) *max_live = peak;
+    return ok ? 1 : 0;
+}
+
+const char *flgpu_strerror(int status)
+{
+    switch (status) {
+    case FLGPU_OK: return "ok";
+    case FLGPU_ERR_INVALID_ARG: return "invalid argument";
+    case FLGPU_ERR_UNSUPPORTED: return "request not supported by the device path";
+    case FLGPU_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case FLGPU_ERR_OOM: return "out of memory";
+    case FLGPU_ERR_DEVICE: return "HIP runtime error";
+    case FLGPU_ERR_PARSE: return "malformed query string";
+    case FLGPU_ERR_BUFFER_TOO_SMALL: return "destination buffer too small";
+    case FLGPU_ERR_SHUTDOWN: return "context is shutting down";
+    }
+    return "unknown status";
+}
+
+uint32_t flgpu_abi_version(void) { return FLGPU_ABI_VERSION; }
+
+} // extern "C"

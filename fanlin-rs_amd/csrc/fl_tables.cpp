@@ -1,0 +1,164 @@
+// fl_tables.cpp -- see fl_tables.h.  Compiled with -ffp-contract=off: the
+// window bounds depend on exact f32 evaluation order (floor/ceil of
+// (o + 0.5) * ratio -/+ support), as in image 0.25.6 imageops/sample.rs.
+#include "fl_tables.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace fl {
+
+namespace {
+
+constexpr float kPi = 3.14159265358979323846f; // f32::consts::PI
+
+// sample.rs sinc(): a = t * PI; t == 0 ? 1 : sin(a) / a
+inline float sinc(float t)
+{
+    const float a = t * kPi;
+    return t == 0.0f ? 1.0f : sinf(a) / a;
+}
+
+// sample.rs lanczos3_kernel(x) = lanczos(x, 3.0)
+inline float lanczos3(float x) { return fabsf(x) < 3.0f ? sinc(x) * sinc(x / 3.0f) : 0.0f; }
+
+// sample.rs gaussian(x, r) = ((2 PI).sqrt() * r).recip() * (-x.powi(2) / (2.0 * r.powi(2))).exp()
+inline float gaussian(float x, float r)
+{
+    const float norm = 1.0f / (sqrtf(2.0f * kPi) * r);
+    return norm * expf(-(x * x) / (2.0f * (r * r)));
+}
+
+inline int64_t clamp64(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+} // namespace
+
+void build_axis(uint32_t in_size, uint32_t out_size, Filter filter, float sigma, HostAxis &out)
+{
+    out = HostAxis();
+    out.in_size = in_size;
+    out.out_size = out_size;
+    out.left.resize(out_size);
+    out.count.resize(out_size);
+    out.woff.resize(out_size);
+    const float support = filter == FILTER_GAUSSIAN ? 2.0f * sigma : 3.0f;
+    const float ratio = (float)in_size / (float)out_size;
+    const float sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float src_support = support * sratio;
+    out.weights.reserve((size_t)out_size * (size_t)(2.0f * src_support + 3.0f));
+    for (uint32_t o = 0; o < out_size; ++o) {
+        float input = ((float)o + 0.5f) * ratio;
+        int64_t left = (int64_t)floorf(input - src_support);
+        left = clamp64(left, 0, (int64_t)in_size - 1);
+        int64_t right = (int64_t)ceilf(input + src_support);
+        right = clamp64(right, left + 1, (int64_t)in_size);
+        input = input - 0.5f;
+        const size_t base = out.weights.size();
+        float sum = 0.0f;
+        for (int64_t i = left; i < right; ++i) {
+            const float x = ((float)i - input) / sratio;
+            const float w = filter == FILTER_GAUSSIAN ? gaussian(x, sigma) : lanczos3(x);
+            out.weights.push_back(w);
+            sum += w;
+        }
+        for (size_t k = base; k < out.weights.size(); ++k) out.weights[k] /= sum;
+        out.left[o] = (uint32_t)left;
+        out.count[o] = (uint32_t)(right - left);
+        out.woff[o] = (uint32_t)base;
+        out.max_taps = std::max(out.max_taps, out.count[o]);
+    }
+}
+
+void resize_dimensions(uint32_t width, uint32_t height, uint32_t nwidth, uint32_t nheight, bool fill, uint32_t &ow,
+                       uint32_t &oh)
+{
+    const double wratio = (double)nwidth / (double)width;
+    const double hratio = (double)nheight / (double)height;
+    const double ratio = fill ? std::max(wratio, hratio) : std::min(wratio, hratio);
+    const uint64_t nw = std::max<uint64_t>((uint64_t)round((double)width * ratio), 1);
+    const uint64_t nh = std::max<uint64_t>((uint64_t)round((double)height * ratio), 1);
+    if (nw > (uint64_t)UINT32_MAX) {
+        const double r = (double)UINT32_MAX / (double)width;
+        ow = UINT32_MAX;
+        oh = std::max<uint32_t>((uint32_t)round((double)height * r), 1);
+    } else if (nh > (uint64_t)UINT32_MAX) {
+        const double r = (double)UINT32_MAX / (double)height;
+        ow = std::max<uint32_t>((uint32_t)round((double)width * r), 1);
+        oh = UINT32_MAX;
+    } else {
+        ow = (uint32_t)nw;
+        oh = (uint32_t)nh;
+    }
+}
+
+bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t &r0, uint32_t &r1, std::vector<RowSched> &out)
+{
+    out.clear();
+    if (y0 >= y1 || y1 > v.out_size) return false;
+    r0 = v.left[y0];
+    r1 = r0;
+    for (uint32_t o = y0; o < y1; ++o) {
+        // windows must start and end in output order: that is what makes "slot = o mod NACC" collision free
+        if (o > y0 && (v.left[o] < v.left[o - 1] || v.left[o] + v.count[o] < v.left[o - 1] + v.count[o - 1])) return false;
+        r1 = std::max(r1, v.left[o] + v.count[o]);
+    }
+    out.assign(r1 - r0, RowSched());
+    for (auto &e : out) memset(&e, 0, sizeof(e));
+    for (uint32_t o = y0; o < y1; ++o) {
+        const uint32_t slot = o % NACC;
+        for (uint32_t i = 0; i < v.count[o]; ++i) {
+            RowSched &e = out[v.left[o] + i - r0];
+            if (e.live & (1u << slot)) return false; // two live outputs would share a slot
+            e.live |= 1u << slot;
+            e.w[slot] = v.weights[v.woff[o] + i];
+        }
+        RowSched &last = out[v.left[o] + v.count[o] - 1 - r0];
+        if (!last.emit) last.first_out = o; // outputs complete in order, so the first one seen is the lowest
+        last.emit |= 1u << slot;
+    }
+    // an emitting slot must not be re-armed by a later output on the same row (cannot happen with
+    // monotone windows of >= 1 row, but the kernel relies on it)
+    return true;
+}
+
+void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t align_px, HostStrip &out)
+{
+    out = HostStrip();
+    out.x0 = x0;
+    out.x1 = x1;
+    uint32_t lo = UINT32_MAX, hi = 0, hmax = 0;
+    for (uint32_t x = x0; x < x1; ++x) {
+        lo = std::min(lo, h.left[x]);
+        hi = std::max(hi, h.left[x] + h.count[x]);
+        hmax = std::max(hmax, h.count[x]);
+    }
+    out.sx0 = lo - (lo % align_px);
+    out.sx1 = hi;
+    out.hmax = (hmax + 3u) & ~3u;
+    const uint32_t n = x1 - x0;
+    out.left_rel.resize(n);
+    out.w4.assign((size_t)out.hmax * n, 0.0f);
+    for (uint32_t x = x0; x < x1; ++x) {
+        const uint32_t xl = x - x0;
+        out.left_rel[xl] = h.left[x] - out.sx0;
+        for (uint32_t i = 0; i < h.count[x]; ++i)
+            out.w4[((size_t)(i >> 2) * n + xl) * 4 + (i & 3)] = h.weights[h.woff[x] + i];
+    }
+}
+
+void build_webp_gamma(std::vector<uint32_t> &out)
+{
+    // libwebp src/enc/picture_csp_enc.c: kGamma = 0.80, GAMMA_FIX = 12, GAMMA_TAB_FIX = 7
+    const double kGamma = 0.80;
+    const int kGammaFix = 12, kGammaTabFix = 7, kGammaTabSize = 1 << (kGammaFix - kGammaTabFix);
+    const int kGammaScale = (1 << kGammaFix) - 1;
+    const double scale = (double)(1 << kGammaTabFix) / kGammaScale;
+    const double norm = 1. / 255.;
+    out.clear();
+    for (int v = 0; v <= 255; ++v) out.push_back((uint32_t)(uint16_t)(pow(norm * v, kGamma) * kGammaScale + .5));
+    for (int v = 0; v <= kGammaTabSize; ++v) out.push_back((uint32_t)(int)(255. * pow(scale * v, 1. / kGamma) + .5));
+}
+
+} // namespace fl

@@ -1,0 +1,46 @@
+// fl_tables.h -- host-side construction of the read-only device tables:
+// per-axis resample weights (image 0.25.6 imageops/sample.rs index + weight
+// maths, evaluated in f32 exactly as the reference does), the per-row
+// accumulator schedule of the streaming kernel, per-strip horizontal weight
+// tiles, and libwebp's gamma tables.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "fl_types.h"
+
+namespace fl {
+
+enum Filter : uint32_t { FILTER_LANCZOS3 = 0, FILTER_GAUSSIAN = 1 };
+
+struct HostAxis {
+    uint32_t in_size = 0, out_size = 0, max_taps = 0;
+    std::vector<uint32_t> left, count, woff; // per output sample; woff = offset into weights
+    std::vector<float> weights;              // packed, normalised
+};
+
+// sample.rs vertical_sample / horizontal_sample window + weights for every output sample of one axis.
+void build_axis(uint32_t in_size, uint32_t out_size, Filter filter, float sigma, HostAxis &out);
+
+// image::math::utils::resize_dimensions
+void resize_dimensions(uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, bool fill, uint32_t &ow, uint32_t &oh);
+
+// Row schedule of output rows [y0,y1): one RowSched per source row in [r0,r1).
+// Returns false if more than NACC output rows are alive on some source row or
+// if the windows are not monotone (the streaming kernel then cannot be used).
+bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t &r0, uint32_t &r1, std::vector<RowSched> &out);
+
+// Horizontal tile of output columns [x0,x1): left[] relative to sx0 and
+// weights laid out [hmax/4][x1-x0][4] (tap-major float4, zero padded).
+struct HostStrip {
+    uint32_t x0 = 0, x1 = 0, sx0 = 0, sx1 = 0, hmax = 0;
+    std::vector<uint32_t> left_rel;
+    std::vector<float> w4;
+};
+void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t align_px, HostStrip &out);
+
+// libwebp picture_csp_enc.c InitGammaTables: kGammaToLinearTab[256] then kLinearToGammaTab[33], as int32.
+void build_webp_gamma(std::vector<uint32_t> &out);
+
+} // namespace fl

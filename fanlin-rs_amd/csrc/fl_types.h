@@ -1,0 +1,77 @@
+// fl_types.h -- descriptors shared between the host runtime and the HIP kernels.
+// All device-visible tables live in one "arena" of 32-bit words; descriptors
+// refer to them by word offset so a whole arena can be copied (or broadcast
+// to another GPU) as one blob.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fl {
+
+// Pointwise operation applied to the SOURCE-resolution image before
+// resampling (reference src/handler.rs:224-228: grayscale wins over inverse).
+enum PreOp : uint32_t { PRE_NONE = 0, PRE_GRAY = 1, PRE_INVERT = 2 };
+
+// Channels after the pre-op: grayscale turns Rgb8 into Luma8 and Rgba8 into LumaA8.
+__host__ __device__ constexpr uint32_t mid_channels(uint32_t cs, uint32_t pre)
+{
+    return pre == PRE_GRAY ? (cs == 3 ? 1u : cs == 4 ? 2u : cs) : cs;
+}
+
+// One image of a batch.  Geometry follows flgpu_plan.
+struct alignas(16) Job {
+    const uint8_t *src;     // source pixels (device)
+    uint8_t *dst;           // stage-1 destination: final pixels, or the blur input
+    uint32_t src_bytes;     // sw*sh*cs, for hardware range checking
+    uint32_t sw, sh;        // source size
+    uint32_t rw, rh;        // resize_exact target (== sw,sh when nothing is resampled)
+    uint32_t cx, cy;        // centre-crop origin inside the resized image
+    uint32_t cw, ch;        // size kept after the crop (== rw,rh without crop)
+    uint32_t dw, dh;        // destination size
+    uint32_t ox, oy;        // where the kept image lands inside the destination
+    uint32_t fill;          // r | g<<8 | b<<16 | 255<<24
+    uint32_t vtab, htab;    // arena word offsets of the AxisTable headers (vertical, horizontal)
+    uint32_t mid_off;       // generic path: float offset of this job's f32 intermediate
+    uint32_t pad0, pad1;
+};
+
+// Output-major weight table of one axis (image 0.25.6 sample.rs index maths).
+// Header followed by left[out], count[out], woff[out] and the packed weights.
+struct AxisTable {
+    uint32_t in_size, out_size;
+    uint32_t max_taps, total_taps;
+    uint32_t left_off, count_off, woff_off, weights_off; // word offsets from the arena base
+};
+
+// Streaming kernel: max output rows alive for one source row.
+constexpr int NACC = 8;
+// Pixels of one source row owned by one lane.
+constexpr int PXL = 4;
+
+// Per source row of a band: the weight each live accumulator slot applies to
+// this row, which slots are live, and which complete (emit) after it.
+struct RowSched {
+    float w[NACC];
+    uint32_t live;      // bit s: slot s accumulates this row
+    uint32_t emit;      // bit s: slot s is complete after this row
+    uint32_t first_out; // output row index of the lowest-numbered emitting slot's... see tables.cpp
+    uint32_t pad;
+};
+
+// One workgroup of the streaming resample kernel: a band of output rows x a strip of output columns.
+struct alignas(16) StreamItem {
+    uint32_t job;
+    uint32_t y0, y1;     // resized-image rows produced [y0,y1)
+    uint32_t x0, x1;     // resized-image columns produced [x0,x1)
+    uint32_t r0, r1;     // source rows walked [r0,r1)
+    uint32_t sx0;        // source pixel column of lane 0
+    uint32_t sched_off;  // arena word offset: RowSched[r1-r0]
+    uint32_t hleft_off;  // arena word offset: left[x1-x0], relative to sx0
+    uint32_t hw_off;     // arena word offset: weights, tap-major [hmax][x1-x0], zero padded
+    uint32_t hmax;       // taps per output column in this strip (max)
+    uint32_t flags;      // ITEM_* letterbox duties
+    uint32_t pad0, pad1, pad2;
+};
+enum : uint32_t { ITEM_FIRST_BAND = 1, ITEM_LAST_BAND = 2, ITEM_FIRST_STRIP = 4, ITEM_LAST_STRIP = 8 };
+
+} // namespace fl

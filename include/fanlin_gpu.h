@@ -1,0 +1,222 @@
+/*
+ * fanlin_gpu.h -- C ABI of the MI355X-native image hot path for fanlin-rs.
+ *
+ * This is the drop-in boundary: a reference-side shim (Rust `extern "C"`
+ * block) binds exactly these entry points and keeps the
+ * rest of fanlin-rs (axum handler, routing, origin fetch, codecs' entropy
+ * stages) unchanged.  Plain pointers and sizes only; no C++ or torch types;
+ * no exceptions cross this boundary; every function returns an flgpu_status
+ * (0 = ok) unless it returns a pointer.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * fanlin-rs repository root):
+ *
+ *   flgpu_query_parse / flgpu_query_*   src/query.rs:3-94   (query::Query + accessors)
+ *   FLGPU_ACCEPT_* flags                src/content.rs:12-48 (content::Format)
+ *   flgpu_params_from_query             src/handler.rs:224-261 (which accessors feed which step)
+ *   flgpu_plan_output                   image::math::utils::resize_dimensions +
+ *                                       DynamicImage::resize / resize_to_fill geometry +
+ *                                       the letterbox rule at src/handler.rs:229-249
+ *   flgpu_transform*                    the image-crate calls at src/handler.rs:225,227,233,
+ *                                       235,240-247,253 (grayscale, invert, resize,
+ *                                       resize_to_fill, from_pixel + overlay, blur)
+ *   front_end = FLGPU_FE_JFIF444        colour front end of jpeg::JpegEncoder::encode_image,
+ *                                       src/handler.rs:274-278
+ *   front_end = FLGPU_FE_WEBP420        WebPPictureImportRGBA + ARGB->YUV420 inside
+ *                                       webp::Encoder::encode, src/handler.rs:295-297
+ *   flgpu_create / flgpu_destroy        lifetime of handler::State, src/handler.rs:14-21,36-52
+ */
+#ifndef FANLIN_GPU_H
+#define FANLIN_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLGPU_ABI_VERSION 1
+
+typedef enum flgpu_status {
+    FLGPU_OK = 0,
+    FLGPU_ERR_INVALID_ARG = 1,   /* null pointer, zero-sized image, channels not in 1..4, ... */
+    FLGPU_ERR_UNSUPPORTED = 2,   /* valid request the device path does not cover */
+    FLGPU_ERR_NO_DEVICE = 3,     /* no usable HIP device: the library never falls back to the CPU */
+    FLGPU_ERR_OOM = 4,           /* host or device allocation failed */
+    FLGPU_ERR_DEVICE = 5,        /* a HIP call failed; see flgpu_last_error() */
+    FLGPU_ERR_PARSE = 6,         /* query string rejected (axum would answer 400) */
+    FLGPU_ERR_BUFFER_TOO_SMALL = 7,
+    FLGPU_ERR_SHUTDOWN = 8       /* context is being destroyed */
+} flgpu_status;
+
+/* Decoded image as the image crate holds it: tightly packed rows, top-left
+ * origin, interleaved u8 channels; 1 = Luma8, 2 = LumaA8, 3 = Rgb8, 4 = Rgba8. */
+typedef struct flgpu_image {
+    uint8_t *data;      /* host pointer (flgpu_transform, _batch) or device pointer (_batch_device) */
+    uint64_t capacity;  /* src: bytes valid at data; dst: bytes writable at data */
+    uint32_t width, height, channels;
+    uint32_t flags;     /* out: FLGPU_IMG_* */
+} flgpu_image;
+
+#define FLGPU_IMG_FRONTEND_PLANES 1u  /* dst->data holds encoder planes, not interleaved pixels */
+#define FLGPU_IMG_HAS_ALPHA       2u  /* WEBP420: picture has non-opaque alpha; planes were NOT produced */
+
+/* Encoder colour front end to run after the pixel pipeline. */
+typedef enum flgpu_front_end {
+    FLGPU_FE_NONE = 0,     /* dst = interleaved pixels, out_c channels */
+    FLGPU_FE_JFIF444 = 1,  /* dst = Y | Cb | Cr, each plane_w x plane_h (multiples of 8, edge replicated) */
+    FLGPU_FE_WEBP420 = 2   /* dst = Y (w x h) | U | V (each ceil(w/2) x ceil(h/2)), BT.601 limited range */
+} flgpu_front_end;
+
+/* content::Format bits (src/content.rs:15-16). */
+#define FLGPU_ACCEPT_WEBP 1u
+#define FLGPU_ACCEPT_AVIF 2u
+
+/* Output container chosen at src/handler.rs:256-261. */
+typedef enum flgpu_out_format { FLGPU_OUT_KEEP = 0, FLGPU_OUT_WEBP = 1, FLGPU_OUT_AVIF = 2 } flgpu_out_format;
+
+/* query::Query, field for field (src/query.rs:4-15); has_* = Option::is_some. */
+typedef struct flgpu_query {
+    uint8_t has_w, has_h, has_rgb, has_quality, has_crop, has_blur, has_grayscale, has_inverse, has_avif, has_webp;
+    uint8_t quality, crop, blur, grayscale, inverse, avif, webp;
+    uint8_t reserved;
+    uint32_t w, h;
+    char rgb[112];      /* NUL terminated copy of the raw `rgb` value (truncated if longer) */
+} flgpu_query;
+
+/* Exactly the accessor outputs of query::Query that the pixel pipeline consumes. */
+typedef struct flgpu_params {
+    uint32_t has_dims;                 /* Query::dimensions().is_some() */
+    uint32_t w, h;
+    uint8_t fill_r, fill_g, fill_b;    /* Query::fill_color() */
+    uint8_t crop;                      /* Query::cropping() */
+    float blur_sigma;                  /* Query::blur(): 0.0 or 10.0..=20.0 */
+    uint8_t grayscale, inverse;        /* Query::grayscale(), Query::inverse() */
+    uint8_t quality;                   /* Query::quality() (carried for the host encoder) */
+    uint8_t front_end;                 /* flgpu_front_end */
+} flgpu_params;
+
+/* Geometry decided on the host before any pixel is touched. */
+typedef struct flgpu_plan {
+    uint32_t mid_c;                    /* channels after grayscale/invert */
+    uint32_t resampled;                /* 1 if a Lanczos3 pass runs */
+    uint32_t resized_w, resized_h;     /* resize_exact target */
+    uint32_t crop_x, crop_y;           /* resize_to_fill centre-crop origin */
+    uint32_t letterboxed;              /* 1 if overlay onto the fill colour runs (output becomes Rgba8) */
+    uint32_t place_x, place_y;         /* overlay offset */
+    uint32_t out_w, out_h, out_c;      /* pixel image after letterbox/blur */
+    uint32_t plane_w, plane_h;         /* front end luma plane size */
+    uint32_t chroma_w, chroma_h;       /* front end chroma plane size */
+    uint64_t pixel_bytes;              /* out_w * out_h * out_c */
+    uint64_t out_bytes;                /* bytes the call writes to dst (pixels or planes) */
+} flgpu_plan;
+
+typedef struct flgpu_config {
+    int32_t device;            /* HIP device ordinal; -1 = current device */
+    uint32_t max_batch;        /* request-queue flush size (0 = default 256) */
+    uint32_t flush_timeout_us; /* request-queue flush timer (0 = default 200) */
+    uint32_t profile;          /* 1 = bracket kernels with HIP events and report them in flgpu_stats */
+    uint32_t reserved[4];
+} flgpu_config;
+
+typedef struct flgpu_stats {
+    uint64_t images;              /* images transformed */
+    uint64_t batches;             /* kernel batches launched */
+    uint64_t queue_flushes;       /* request-queue flushes */
+    uint64_t tables_built;        /* weight tables built (cache misses) */
+    uint64_t resample_launches;   /* launches of the fused resample kernel */
+    double resample_ms;           /* summed HIP-event time of those launches (profile = 1) */
+    uint64_t resample_src_bytes;  /* algorithmic bytes read by those launches */
+    uint64_t resample_dst_bytes;  /* algorithmic bytes written by those launches */
+    uint64_t generic_launches;    /* launches of the two-pass generic resample kernels */
+    uint64_t blur_launches;
+    double blur_ms;
+    uint64_t frontend_launches;
+    double frontend_ms;
+} flgpu_stats;
+
+typedef struct flgpu_ctx flgpu_ctx;
+
+/* ---- request model (host only, no device needed) ---------------------- */
+
+/* Parses "w=300&h=200&rgb=32,32,32" (the part after '?', or a whole URI) with
+ * the semantics of axum::extract::Query<query::Query>: unknown keys ignored,
+ * a known key with an unparsable value is an error.  Returns FLGPU_ERR_PARSE
+ * where axum would reject the request with 400. */
+int flgpu_query_parse(const char *query_string, flgpu_query *out);
+int flgpu_query_dimensions(const flgpu_query *q, uint32_t *w, uint32_t *h); /* 1 = Some */
+void flgpu_query_fill_color(const flgpu_query *q, uint8_t *r, uint8_t *g, uint8_t *b);
+uint8_t flgpu_query_quality(const flgpu_query *q);
+int flgpu_query_cropping(const flgpu_query *q);
+float flgpu_query_blur(const flgpu_query *q);
+int flgpu_query_grayscale(const flgpu_query *q);
+int flgpu_query_inverse(const flgpu_query *q);
+int flgpu_query_use_avif(const flgpu_query *q);
+int flgpu_query_use_webp(const flgpu_query *q);
+int flgpu_query_as_is(const flgpu_query *q);
+int flgpu_query_unsupported_scale_size(const flgpu_query *q);
+
+/* Query + content::Format -> pipeline parameters and the output container
+ * (src/handler.rs:256-261).  front_end is set to WEBP420 / JFIF444 / NONE from
+ * the chosen container and `input_is_jpeg` (JPEG stays JPEG, anything else
+ * keeps its own encoder and gets pixels). */
+int flgpu_params_from_query(const flgpu_query *q, uint32_t accept_flags, int input_is_jpeg,
+                            flgpu_params *params, int *out_format);
+
+/* Pure function: output geometry for a source of sw x sh x sc. */
+int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t sc, flgpu_plan *plan);
+
+/* ---- device context ---------------------------------------------------- */
+
+/* Returns NULL on failure; *status (optional) receives the reason. */
+flgpu_ctx *flgpu_create(const flgpu_config *cfg, int *status);
+void flgpu_destroy(flgpu_ctx *ctx);
+
+/* One image, host memory, blocking.  Thread-safe: concurrent callers are
+ * packed into shared kernel launches by the context's request queue. */
+int flgpu_transform(flgpu_ctx *ctx, const flgpu_image *src, const flgpu_params *p, flgpu_image *dst);
+
+/* n images, host memory, blocking: staged through pinned buffers, one set of launches. */
+int flgpu_transform_batch(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, const flgpu_params *ps,
+                          flgpu_image *dsts);
+
+/* n images already resident in device memory; dsts[i].data are device
+ * pointers.  Work is enqueued on `hip_stream` (a hipStream_t; NULL = the
+ * context's own stream) and the call returns once it is enqueued; the caller
+ * synchronises the stream.  ps may have n entries or, with FLGPU_BATCH_SAME_PARAMS,
+ * one entry shared by all images. */
+#define FLGPU_BATCH_SAME_PARAMS 1u
+int flgpu_transform_batch_device(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, const flgpu_params *ps,
+                                 flgpu_image *dsts, void *hip_stream, uint32_t flags);
+
+/* Installs read-only device tables received from another rank (the RCCL
+ * broadcast target in multi-GPU runs) / exports this context's copy. */
+int flgpu_export_tables(flgpu_ctx *ctx, void **device_ptr, uint64_t *bytes);
+
+int flgpu_get_stats(flgpu_ctx *ctx, flgpu_stats *out);
+int flgpu_reset_stats(flgpu_ctx *ctx);
+
+/* ---- diagnostics (host only; used by the CPU test-suite) ------------------- */
+
+/* The weight table the runtime uploads for one axis (filter 0 = Lanczos3 as used by
+ * resize, 1 = Gaussian of `sigma` with support 2*sigma as used by blur): left[o],
+ * count[o] for o < out_size and the packed normalised weights (image 0.25.6
+ * imageops/sample.rs maths).  *total receives the number of weights; returns
+ * FLGPU_ERR_BUFFER_TOO_SMALL if it exceeds weights_cap. */
+int flgpu_debug_axis_table(uint32_t in_size, uint32_t out_size, int filter, float sigma, uint32_t *left,
+                           uint32_t *count, float *weights, uint64_t weights_cap, uint64_t *total);
+
+/* Row schedule of the streaming kernel for output rows [y0,y1) of a Lanczos3 axis:
+ * returns 1 if the fused kernel can run it (<= 8 rows alive per source row), 0 if the
+ * generic two-pass kernels are used instead; *max_live receives the peak. */
+int flgpu_debug_stream_schedulable(uint32_t in_size, uint32_t out_size, uint32_t y0, uint32_t y1, uint32_t *max_live);
+
+const char *flgpu_strerror(int status);
+const char *flgpu_last_error(flgpu_ctx *ctx); /* detail of the last FLGPU_ERR_DEVICE on this context */
+uint32_t flgpu_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FANLIN_GPU_H */

@@ -1,0 +1,54 @@
+"""pytest configuration: the `gpu` marker, the package loader (the package directory is
+named after the reference, `fanlin-rs_amd`, which is not a Python identifier) and the
+CPU-oracle fixture."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_package():
+    if "fanlin_rs_amd" in sys.modules:
+        return sys.modules["fanlin_rs_amd"]
+    pkg_dir = os.path.join(ROOT, "fanlin-rs_amd")
+    spec = importlib.util.spec_from_file_location("fanlin_rs_amd", os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["fanlin_rs_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def fl():
+    mod = load_package()
+    if not os.path.exists(mod.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_state(fl):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("this test is marked gpu but no HIP device is visible")
+    st = fl.State(device=0, profile=True)
+    yield st
+    st.close()

@@ -1,0 +1,141 @@
+"""ctypes binding of the CPU oracle (oracle/libfanlin_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libfanlin_oracle.so")
+
+ARITH_REF, ARITH_FMA = 0, 1
+FILTER_LANCZOS3, FILTER_GAUSSIAN = 0, 1
+
+
+class fo_image(C.Structure):
+    _fields_ = [("w", C.c_uint32), ("h", C.c_uint32), ("c", C.c_uint32), ("px", C.POINTER(C.c_uint8))]
+
+
+class fo_params(C.Structure):
+    _fields_ = [("has_dims", C.c_int), ("w", C.c_uint32), ("h", C.c_uint32), ("fill", C.c_uint8 * 3),
+                ("crop", C.c_int), ("blur_sigma", C.c_float), ("grayscale", C.c_int), ("inverse", C.c_int)]
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.fo_build_weights.restype = C.c_long
+        lib.fo_free.argtypes = [C.c_void_p]
+
+    @staticmethod
+    def _img(a):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        im = fo_image(a.shape[1], a.shape[0], a.shape[2], a.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return im, a
+
+    def _take(self, im):
+        n = im.w * im.h * im.c
+        out = np.ctypeslib.as_array(im.px, shape=(n,)).copy().reshape(im.h, im.w, im.c) if n else np.zeros((im.h, im.w, im.c), np.uint8)
+        self.lib.fo_free(im.px)
+        return out
+
+    def resize_dimensions(self, w, h, nw, nh, fill):
+        ow, oh = C.c_uint32(), C.c_uint32()
+        self.lib.fo_resize_dimensions(w, h, nw, nh, int(fill), C.byref(ow), C.byref(oh))
+        return ow.value, oh.value
+
+    def build_weights(self, in_size, out_size, filt=FILTER_LANCZOS3, sigma=0.0):
+        left = (C.c_uint32 * out_size)()
+        count = (C.c_uint32 * out_size)()
+        off = (C.c_uint32 * (out_size + 1))()
+        ratio = max(in_size / out_size, 1.0)
+        support = 3.0 if filt == FILTER_LANCZOS3 else 2.0 * sigma
+        cap = int(out_size * (2 * support * ratio + 4)) + 16
+        w = (C.c_float * cap)()
+        n = self.lib.fo_build_weights(in_size, out_size, filt, C.c_float(sigma), left, count, off, w, C.c_size_t(cap))
+        assert n >= 0
+        return (np.array(left, dtype=np.uint32), np.array(count, dtype=np.uint32), np.array(off, dtype=np.uint32),
+                np.array(w[:n], dtype=np.float32))
+
+    def process_pixels(self, image, w=None, h=None, fill=(32, 32, 32), crop=False, blur_sigma=0.0, grayscale=False,
+                       inverse=False, arith=ARITH_REF):
+        im, keep = self._img(image)
+        p = fo_params()
+        p.has_dims = int(w is not None and h is not None)
+        p.w, p.h = (w or 0), (h or 0)
+        p.fill[0], p.fill[1], p.fill[2] = fill
+        p.crop, p.blur_sigma, p.grayscale, p.inverse = int(crop), blur_sigma, int(grayscale), int(inverse)
+        out = fo_image()
+        rc = self.lib.fo_process_pixels(C.byref(im), C.byref(p), arith, C.byref(out))
+        assert rc == 0
+        return self._take(out)
+
+    def resize_exact(self, image, nw, nh, arith=ARITH_REF, filt=FILTER_LANCZOS3):
+        im, keep = self._img(image)
+        out = fo_image()
+        assert self.lib.fo_resize_exact(C.byref(im), nw, nh, filt, arith, C.byref(out)) == 0
+        return self._take(out)
+
+    def blur(self, image, sigma, arith=ARITH_REF):
+        im, keep = self._img(image)
+        out = fo_image()
+        assert self.lib.fo_blur(C.byref(im), C.c_float(sigma), arith, C.byref(out)) == 0
+        return self._take(out)
+
+    def grayscale(self, image):
+        im, keep = self._img(image)
+        out = fo_image()
+        assert self.lib.fo_grayscale(C.byref(im), C.byref(out)) == 0
+        return self._take(out)
+
+    def invert(self, image):
+        a = np.ascontiguousarray(image, dtype=np.uint8).copy()
+        if a.ndim == 2:
+            a = a[:, :, None]
+        im = fo_image(a.shape[1], a.shape[0], a.shape[2], a.ctypes.data_as(C.POINTER(C.c_uint8)))
+        self.lib.fo_invert(C.byref(im))
+        return a
+
+    def letterbox(self, image, w, h, fill):
+        im, keep = self._img(image)
+        out = fo_image()
+        f = (C.c_uint8 * 3)(*fill)
+        assert self.lib.fo_letterbox(C.byref(im), w, h, f, C.byref(out)) == 0
+        return self._take(out)
+
+    def jpeg_ycbcr444(self, image):
+        im, keep = self._img(image)
+        pw, ph = (im.w + 7) & ~7, (im.h + 7) & ~7
+        buf = np.empty(3 * pw * ph, np.uint8)
+        ow, oh = C.c_uint32(), C.c_uint32()
+        assert self.lib.fo_jpeg_ycbcr444(C.byref(im), buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(ow), C.byref(oh)) == 0
+        n = pw * ph
+        return buf[:n].reshape(ph, pw), buf[n:2 * n].reshape(ph, pw), buf[2 * n:].reshape(ph, pw)
+
+    def webp_yuv420(self, image):
+        im, keep = self._img(image)
+        assert im.c == 4
+        cw, ch = (im.w + 1) // 2, (im.h + 1) // 2
+        buf = np.zeros(im.w * im.h * 2 + 2 * cw * ch, np.uint8)
+        has_alpha = self.lib.fo_webp_yuv420(C.byref(im), buf.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert has_alpha >= 0
+        ny, nc = im.w * im.h, cw * ch
+        return (buf[:ny].reshape(im.h, im.w), buf[ny:ny + nc].reshape(ch, cw), buf[ny + nc:ny + 2 * nc].reshape(ch, cw), bool(has_alpha))
+
+    def ycck_to_cmyk(self, raw):
+        a = np.ascontiguousarray(raw, dtype=np.uint8).copy()
+        self.lib.fo_ycck_to_cmyk(a.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(a.size // 4))
+        return a
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+
+
+def load():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(ORACLE_DIR, "fanlin_oracle.c")):
+        build()
+    return Oracle(C.CDLL(LIB))
