@@ -85,7 +85,8 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_cropping", "flgpu_query_blur", "flgpu_query_grayscale", "flgpu_query_inverse",
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
     "flgpu_params_from_query", "flgpu_plan_output", "flgpu_create", "flgpu_destroy", "flgpu_transform",
-    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_export_tables", "flgpu_get_stats",
+    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_export_tables", "flgpu_copy_tables",
+    "flgpu_import_tables", "flgpu_get_stats",
     "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version",
     "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable",
 )
@@ -101,6 +102,14 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(there is no CPU fallback)")
+    # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so).  Two HIP runtimes in one
+    # process cannot both own the device, so when torch is installed it must be loaded first: the
+    # library's libamdhip64.so.7 dependency then binds to torch's copy and both share one runtime.
+    # Without torch (e.g. under the Rust host) the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.flgpu_query_parse.argtypes = [C.c_char_p, C.POINTER(flgpu_query)]
     lib.flgpu_query_parse.restype = C.c_int
@@ -126,6 +135,8 @@ def load_library() -> C.CDLL:
     lib.flgpu_transform_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params),
                                                  C.POINTER(flgpu_image), C.c_void_p, C.c_uint32]
     lib.flgpu_export_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.flgpu_copy_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.flgpu_import_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.flgpu_get_stats.argtypes = [C.c_void_p, C.POINTER(flgpu_stats)]
     lib.flgpu_reset_stats.argtypes = [C.c_void_p]
     lib.flgpu_strerror.argtypes = [C.c_int]
@@ -410,6 +421,15 @@ class State:
         ptr, nbytes = C.c_void_p(), C.c_uint64()
         _check(self._lib.flgpu_export_tables(self._ctx, C.byref(ptr), C.byref(nbytes)), self._ctx)
         return int(ptr.value or 0), int(nbytes.value)
+
+    def copy_tables(self, dst_ptr: int, capacity: int) -> int:
+        """Device-to-device copy of the table blob into a caller-owned buffer; returns its size."""
+        nbytes = C.c_uint64()
+        _check(self._lib.flgpu_copy_tables(self._ctx, C.c_void_p(dst_ptr), capacity, C.byref(nbytes)), self._ctx)
+        return int(nbytes.value)
+
+    def import_tables(self, src_ptr: int, nbytes: int) -> None:
+        _check(self._lib.flgpu_import_tables(self._ctx, C.c_void_p(src_ptr), nbytes), self._ctx)
 
     def stats(self) -> dict:
         s = flgpu_stats()

@@ -421,6 +421,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
 
     // ---- tables ------------------------------------------------------------
     // first pass may overflow the arena: reset once and retry
+    const char *env_generic = getenv("FLGPU_FORCE_GENERIC");
+    const char *env_bands = getenv("FLGPU_FORCE_BANDS");
+    const bool force_generic = env_generic && env_generic[0] == '1';
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool full = false;
         size_t n_resample = 0;
@@ -434,12 +437,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             w.s1 = S1_GENERIC;
             const bool aligned = ((w.sw * w.cs) % 4u == 0) && ((uintptr_t)w.src % 4u == 0) &&
                                  (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
-            const char *force = getenv("FLGPU_FORCE_GENERIC");
-            if (stream_supported(w.cs, w.pre) && aligned && !(force && force[0] == '1')) {
+            if (stream_supported(w.cs, w.pre) && aligned && !force_generic) {
                 Job jtmp; fill_job(w, jtmp);
                 uint32_t nbands = 1;
-                const char *fb = getenv("FLGPU_FORCE_BANDS");
-                if (fb) nbands = (uint32_t)std::max(1, atoi(fb));
+                if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
                 else if (n_resample < 512) {
                     // small batches: split images into row bands so that the chip still gets >= ~1024 workgroups
                     const uint32_t want = (uint32_t)((1024 + n_resample * 2 - 1) / (n_resample * 2));
@@ -838,6 +839,33 @@ int flgpu_export_tables(flgpu_ctx *c, void **device_ptr, uint64_t *bytes)
     FL_HIP(c, hipStreamSynchronize(c->stream), "table sync");
     *device_ptr = c->d_arena;
     *bytes = (uint64_t)c->h_arena.size() * 4;
+    return FLGPU_OK;
+}
+
+int flgpu_copy_tables(flgpu_ctx *c, void *dst_device, uint64_t capacity, uint64_t *bytes)
+{
+    if (!c || !dst_device || !bytes) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    int rc = arena_flush(c, c->stream);
+    if (rc) return rc;
+    *bytes = (uint64_t)c->h_arena.size() * 4;
+    if (*bytes > capacity) return FLGPU_ERR_BUFFER_TOO_SMALL;
+    FL_HIP(c, hipMemcpyAsync(dst_device, c->d_arena, *bytes, hipMemcpyDeviceToDevice, c->stream), "table copy");
+    FL_HIP(c, hipStreamSynchronize(c->stream), "table sync");
+    return FLGPU_OK;
+}
+
+int flgpu_import_tables(flgpu_ctx *c, const void *src_device, uint64_t bytes)
+{
+    if (!c || !src_device) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    int rc = arena_flush(c, c->stream);
+    if (rc) return rc;
+    if (bytes != (uint64_t)c->h_arena.size() * 4) return FLGPU_ERR_INVALID_ARG; // layouts differ: not the same plan
+    FL_HIP(c, hipMemcpyAsync(c->d_arena, src_device, bytes, hipMemcpyDeviceToDevice, c->stream), "table import");
+    FL_HIP(c, hipStreamSynchronize(c->stream), "table sync");
     return FLGPU_OK;
 }
 

@@ -190,9 +190,17 @@ int flgpu_transform_batch(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, con
 int flgpu_transform_batch_device(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, const flgpu_params *ps,
                                  flgpu_image *dsts, void *hip_stream, uint32_t flags);
 
-/* Installs read-only device tables received from another rank (the RCCL
- * broadcast target in multi-GPU runs) / exports this context's copy. */
+/* Read-only device tables (weight tables, row schedules, gamma LUTs) as one blob.
+ * Multi-GPU runs build them on rank 0, broadcast the blob over RCCL/xGMI and install
+ * it on the other ranks, so every GPU resamples with byte-identical tables.
+ *   export: device pointer + size of this context's blob (valid until the next transform call);
+ *   copy:   device-to-device copy of the blob into a caller-owned device buffer;
+ *   import: overwrite this context's blob with `bytes` from a device buffer; the layout must
+ *           match what this context planned locally (same requests prepared in the same order),
+ *           otherwise FLGPU_ERR_INVALID_ARG. */
 int flgpu_export_tables(flgpu_ctx *ctx, void **device_ptr, uint64_t *bytes);
+int flgpu_copy_tables(flgpu_ctx *ctx, void *dst_device, uint64_t capacity, uint64_t *bytes);
+int flgpu_import_tables(flgpu_ctx *ctx, const void *src_device, uint64_t bytes);
 
 int flgpu_get_stats(flgpu_ctx *ctx, flgpu_stats *out);
 int flgpu_reset_stats(flgpu_ctx *ctx);

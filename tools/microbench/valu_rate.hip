@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, float w_in, unsig
 // Row-streaming read: each lane reads LANEB bytes per row, rows are ROWB bytes apart,
 // a workgroup walks `rows` rows of its own image.  Mimics the resample vertical pass.
 template <int LANEB>
-__global__ __launch_bounds__(256) void stream_kernel(const unsigned char* src, unsigned* out, unsigned rowb, unsigned rows, size_t img_bytes)
+__global__ __launch_bounds__(512) void stream_kernel(const unsigned char* src, unsigned* out, unsigned rowb, unsigned rows, size_t img_bytes)
 {
     const unsigned char* base = src + (size_t)blockIdx.x * img_bytes;
     auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)img_bytes, 0x00020000);
