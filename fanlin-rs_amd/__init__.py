@@ -25,7 +25,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfanlin_gpu.so")
+LIB_PATH = os.environ.get("FLGPU_LIB") or os.path.join(_HERE, "libfanlin_gpu.so")
 
 FE_NONE, FE_JFIF444, FE_WEBP420 = 0, 1, 2
 ACCEPT_WEBP, ACCEPT_AVIF = 1, 2

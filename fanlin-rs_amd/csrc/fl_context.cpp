@@ -84,6 +84,7 @@ struct StreamPlanKey {
 
 struct StreamPlan {
     bool ok = false;
+    uint32_t nacc = NACC;
     std::vector<StreamItem> items; // job field unset
     uint32_t hmax = 0, nxs_max = 0;
 };
@@ -245,6 +246,8 @@ const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxi
         strips.clear();
     }
     bool ok = !strips.empty();
+    // fewest accumulator slots that can hold every output row alive on one source row (fewer slots = fewer VGPRs)
+    plan.nacc = NACC;
     struct Band { uint32_t y0, y1, r0, r1, sched_off; };
     std::vector<Band> bands;
     if (ok) {
@@ -252,7 +255,7 @@ const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxi
         for (uint32_t y = cy; y < cy + ch && ok; y += per) {
             Band b{y, std::min(y + per, cy + ch), 0, 0, 0};
             std::vector<RowSched> sched;
-            if (!build_row_sched(va, b.y0, b.y1, b.r0, b.r1, sched)) { ok = false; break; }
+            if (!build_row_sched(va, b.y0, b.y1, plan.nacc, stream_block_rows(), b.r0, b.r1, sched)) { ok = false; break; }
             b.sched_off = arena_append(c, sched.data(), sched.size() * sizeof(RowSched) / 4);
             if (!b.sched_off) ok = false;
             bands.push_back(b);
@@ -472,14 +475,14 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
-        if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1, w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         if (w.p->blur_sigma > 0.0f) blur_groups[{0, w.plan.out_c, 0, 0}].push_back(i);
         if (w.p->front_end != FLGPU_FE_NONE) fe_groups[{w.p->front_end, 0, 0, 0}].push_back(i);
     }
     std::vector<Job> jobs;
     std::vector<StreamItem> items;
     std::vector<FrontendJob> fjobs;
-    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems; LaunchGeneric g; size_t lds; size_t mid_floats; };
+    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc; LaunchGeneric g; size_t lds; size_t mid_floats; };
     std::vector<S1Launch> s1_launches, blur_launches;
     struct FeLaunch { uint32_t kind, base, n, mw, mh; };
     std::vector<FeLaunch> fe_launches;
@@ -498,8 +501,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         for (size_t idx : kv.second) {
             const Work &w = work[idx];
             Job j; fill_job(w, j);
-            const size_t mid = (k.kind == S1_GENERIC) ? (size_t)w.sw * w.plan.resized_h * mid_channels(w.cs, w.pre) : 0;
-            if (k.kind == S1_GENERIC && L.njobs && L.mid_floats + mid > kMidCapFloats) {
+            const size_t mid = ((k.kind & 255u) == S1_GENERIC) ? (size_t)w.sw * w.plan.resized_h * mid_channels(w.cs, w.pre) : 0;
+            if ((k.kind & 255u) == S1_GENERIC && L.njobs && L.mid_floats + mid > kMidCapFloats) {
                 s1_launches.push_back(L);
                 L = new_launch(k);
             }
@@ -509,10 +512,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             L.g.max_sw = std::max(L.g.max_sw, j.sw); L.g.max_rh = std::max(L.g.max_rh, j.rh);
             L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
             L.g.max_dw = std::max(L.g.max_dw, j.dw); L.g.max_dh = std::max(L.g.max_dh, j.dh);
-            if (k.kind == S1_STREAM) {
+            if ((k.kind & 255u) == S1_STREAM) {
                 for (StreamItem it2 : w.splan->items) { it2.job = (uint32_t)jobs.size(); items.push_back(it2); }
                 L.nitems += (uint32_t)w.splan->items.size();
                 L.lds = std::max(L.lds, stream_lds_bytes(w.cs, w.pre, w.splan->hmax, w.splan->nxs_max));
+                L.nacc = w.splan->nacc;
                 c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
                 c->stats.resample_dst_bytes += w.plan.pixel_bytes;
             }
@@ -599,9 +603,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     for (auto &L : s1_launches) {
         L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
         L.g.job_base = L.job_base; L.g.njobs = L.njobs;
-        if (L.k.kind == S1_PLACE) {
+        if ((L.k.kind & 255u) == S1_PLACE) {
             FL_HIP(c, launch_place(L.g, false, st), "place kernel");
-        } else if (L.k.kind == S1_GENERIC) {
+        } else if ((L.k.kind & 255u) == S1_GENERIC) {
             if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
             FL_HIP(c, launch_vpass_generic(L.g, st), "generic vertical pass");
             FL_HIP(c, launch_hpass_generic(L.g, st), "generic horizontal pass");
@@ -610,7 +614,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
             LaunchStream s{};
             s.jobs = d_jobs; s.items = d_items + L.item_base; s.arena = c->d_arena; s.nitems = L.nitems;
-            s.cs = L.k.cs; s.pre = L.k.pre; s.letterbox = L.k.lb; s.lds_bytes = L.lds;
+            s.cs = L.k.cs; s.pre = L.k.pre; s.letterbox = L.k.lb; s.lds_bytes = L.lds; s.nacc = L.nacc;
             {
                 ProfileScope ps(c, st, 0);
                 FL_HIP(c, launch_stream(s, st), "streaming resample kernel");

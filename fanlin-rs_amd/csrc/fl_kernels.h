@@ -39,6 +39,7 @@ struct LaunchStream {
     const uint32_t *arena;
     uint32_t nitems;
     uint32_t cs, pre, letterbox;
+    uint32_t nacc;           // accumulator slots the row schedules were built for (7 or 8)
     size_t lds_bytes;
 };
 
@@ -47,6 +48,7 @@ hipError_t launch_hpass_generic(const LaunchGeneric &g, hipStream_t st);
 hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st);
 
 bool stream_supported(uint32_t cs, uint32_t pre);
+uint32_t stream_block_rows(); // source rows per block of the streaming kernel (emits are deferred to block ends)
 size_t stream_lds_bytes(uint32_t cs, uint32_t pre, uint32_t hmax, uint32_t nxs_max);
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st);
 

@@ -16,8 +16,13 @@
 // and writes rounded u8 pixels straight into the (letterboxed) destination.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fl_kernels.h"
+
+#ifndef FL_STREAM_DEPTH
+#define FL_STREAM_DEPTH 4 // source rows in flight per lane in the streaming kernel
+#endif
 
 namespace fl {
 
@@ -212,20 +217,32 @@ __global__ __launch_bounds__(256) void place_kernel(const Job *__restrict__ jobs
 // ---------------------------------------------------------------------------
 
 template <int CS> struct RowRaw;
-template <> struct RowRaw<1> { uint32_t d[1]; };
-template <> struct RowRaw<2> { uint32_t d[2]; };
-template <> struct RowRaw<3> { uint32_t d[3]; };
-template <> struct RowRaw<4> { uint32_t d[4]; };
+template <> struct RowRaw<1> { uint32_t v; __device__ uint32_t dw(int) const { return v; } };
+template <> struct RowRaw<2> { u32x2 v; __device__ uint32_t dw(int i) const { return i == 0 ? v.x : v.y; } };
+template <> struct RowRaw<3> { u32x3 v; __device__ uint32_t dw(int i) const { return i == 0 ? v.x : i == 1 ? v.y : v.z; } };
+template <> struct RowRaw<4> { u32x4 v; __device__ uint32_t dw(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; } };
 
+// Source-row loads are issued through inline asm so that they stay in flight across the horizontal pass:
+// hipcc's own s_waitcnt bookkeeping drains every outstanding load at the loop header once the loop body
+// contains global stores (vmcnt counts loads and stores together on gfx9), which turns the D-deep
+// prefetch ring into one exposed HBM round trip per block.  hipcc does not see these loads, so every
+// consumer sits behind wait_row<N>() (counted vmcnt; younger stores only make it wait longer, never
+// shorter, because vector-memory operations retire in order).
 template <int CS>
-__device__ __forceinline__ RowRaw<CS> load_row(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+__device__ __forceinline__ void load_row(RowRaw<CS> &r, u32x4 rsrc, uint32_t voff)
 {
-    RowRaw<CS> r;
-    if (CS == 1) { r.d[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
-    if (CS == 2) { u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0); r.d[0] = v.x; r.d[1] = v.y; }
-    if (CS == 3) { u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, 0); r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; }
-    if (CS == 4) { u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0); r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w; }
-    return r;
+    if (CS == 1) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(r.v) : "v"(voff), "s"(rsrc) : "memory");
+    if (CS == 2) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(r.v) : "v"(voff), "s"(rsrc) : "memory");
+    if (CS == 3) asm volatile("buffer_load_dwordx3 %0, %1, %2, 0 offen" : "=v"(r.v) : "v"(voff), "s"(rsrc) : "memory");
+    if (CS == 4) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r.v) : "v"(voff), "s"(rsrc) : "memory");
+}
+
+// Waits until at most N vector-memory operations younger than the wanted row are outstanding and
+// makes the row's registers "produced here" for the compiler.
+template <int N, int CS>
+__device__ __forceinline__ void wait_row(RowRaw<CS> &r)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r.v) : "n"(N) : "memory");
 }
 
 // PXL pixels of CS bytes, packed in CS dwords -> PXL*MC floats with the pre-op applied.
@@ -235,7 +252,7 @@ __device__ __forceinline__ void convert_row(const RowRaw<CS> &raw, float *v)
     constexpr int MC = mid_channels(CS, PRE);
     uint32_t d[CS];
 #pragma unroll
-    for (int k = 0; k < CS; ++k) d[k] = raw.d[k];
+    for (int k = 0; k < CS; ++k) d[k] = raw.dw(k);
     if (PRE == PRE_INVERT) {
         // 255 - c on every colour byte; alpha bytes (LumaA / Rgba) keep their value.
         constexpr uint32_t m = (CS == 2) ? 0x00ff00ffu : 0x00ffffffu; // bytes that are colour, per pixel-aligned dword
@@ -269,9 +286,11 @@ __host__ __device__ constexpr int mid_stride(int mc) { return mc == 3 ? 4 : mc; 
 // strip walks its taps in order (zero-padded to hmax4*4), rounds and stores.
 extern __shared__ __attribute__((aligned(16))) float fl_lds[];
 
+// Horizontal pass of one finished intermediate row held in LDS.  Lane x of the
+// strip walks its taps in order (zero-padded to hmax4*4), rounds and stores.
 template <int MC, bool LB>
-__device__ __noinline__ void hpass_row(uint32_t hw4_off, uint32_t hmax4, uint32_t nxs, int32_t hleft, uint8_t *dst,
-                                       uint32_t pix_index, uint32_t fill)
+__device__ __forceinline__ void hpass_row(uint32_t rowbuf_off, uint32_t hw4_off, uint32_t hmax4, uint32_t nxs, int32_t hleft,
+                                          uint8_t *dst, uint32_t pix_index, uint32_t fill)
 {
     constexpr int MS = mid_stride(MC);
     const uint32_t xl = threadIdx.x;
@@ -280,7 +299,7 @@ __device__ __noinline__ void hpass_row(uint32_t hw4_off, uint32_t hmax4, uint32_
     float acc[MC];
 #pragma unroll
     for (int k = 0; k < MC; ++k) acc[k] = 0.0f;
-    const float *p = fl_lds + (size_t)hleft * MS;
+    const float *p = fl_lds + rowbuf_off + (size_t)hleft * MS;
     for (uint32_t q = 0; q < hmax4; ++q) {
         const f32x4 w = hw4[q * nxs + xl];
 #pragma unroll
@@ -304,11 +323,52 @@ __device__ __noinline__ void hpass_row(uint32_t hw4_off, uint32_t hmax4, uint32_
     store_pixel<MC, LB>(dst, pix_index + xl, c, fill);
 }
 
-template <int CS, int PRE, bool LB, int D>
+// Workgroup barrier that orders LDS traffic only.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Finished vertical row of one accumulator slot -> LDS (f32, unrounded); the slot is re-armed with zeros.
+template <int MC>
+__device__ __forceinline__ void flush_slot(float *acc, float *rowbuf, uint32_t tid)
+{
+    constexpr int MS = mid_stride(MC);
+#pragma unroll
+    for (int p = 0; p < PXL; ++p) {
+        float *o = rowbuf + (size_t)(tid * PXL + p) * MS;
+        if (MS == 4) {
+            f32x4 q;
+            q.x = acc[p * MC];
+            q.y = MC > 1 ? acc[p * MC + 1] : 0.0f;
+            q.z = MC > 2 ? acc[p * MC + 2] : 0.0f;
+            q.w = MC > 3 ? acc[p * MC + 3] : 0.0f;
+            *reinterpret_cast<f32x4 *>(o) = q;
+        } else {
+#pragma unroll
+            for (int c = 0; c < MC; ++c) o[c] = acc[p * MC + c];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PXL * MC; ++j) acc[j] = 0.0f;
+}
+
+// NA = accumulator slots (output rows alive per source row; the host picks the smallest that fits),
+// D  = source rows kept in flight per lane.
+template <int CS, int PRE, bool LB, int NA, int D>
 __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restrict__ jobs,
                                                               const StreamItem *__restrict__ items,
-                                                              const uint32_t *__restrict__ arena)
+                                                              const uint32_t *__restrict__ arena
+#ifdef FL_ABLATE
+                                                              , uint32_t ablate // experiments: 1 = no horizontal pass, 2 = no flush/barrier, 4 = no FMAs
+#endif
+                                                              )
 {
+#ifndef FL_ABLATE
+    constexpr uint32_t ablate = 0;
+#endif
     constexpr int MC = mid_channels(CS, PRE);
     constexpr int MS = mid_stride(MC);
     constexpr int NV = PXL * MC;
@@ -321,10 +381,12 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
     const uint32_t nxs = it.x1 - it.x0;
     const uint32_t hmax4 = it.hmax >> 2;
 
-    // LDS: [ rowbuf: (T*PXL + hmax) pixels x MS floats | hw4: hmax4 x nxs float4 ]
+    // LDS: [ sch: 2 x SCHED_CHUNK RowSched | rowbuf: (T*PXL + hmax) pixels x MS floats | hw4: hmax4 x nxs float4 ]
+    constexpr uint32_t SCH_WORDS = SCHED_CHUNK * (sizeof(RowSched) / 4);
+    uint32_t *sch = reinterpret_cast<uint32_t *>(lds);
     const uint32_t rowbuf_px = T * PXL + it.hmax;
-    float *rowbuf = lds;
-    const uint32_t hw4_off = (rowbuf_px * MS + 3u) & ~3u; // float offset of the weights inside the dynamic LDS block
+    float *rowbuf = lds + 2 * SCH_WORDS;
+    const uint32_t hw4_off = 2 * SCH_WORDS + ((rowbuf_px * MS + 3u) & ~3u); // float offset of the weights inside the dynamic LDS block
     f32x4 *hw4 = reinterpret_cast<f32x4 *>(lds + hw4_off);
 
     // stage the strip's horizontal weights and zero the row buffer (its tail is only ever read with zero weights)
@@ -332,77 +394,112 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
         const f32x4 *src4 = reinterpret_cast<const f32x4 *>(arena + it.hw_off);
         for (uint32_t i = tid; i < hmax4 * nxs; i += T) hw4[i] = src4[i];
         for (uint32_t i = tid; i < rowbuf_px * MS; i += T) rowbuf[i] = 0.0f;
+        for (uint32_t i = tid; i < SCH_WORDS; i += T) sch[i] = arena[it.sched_off + i]; // first schedule chunk
     }
     const int32_t hleft = tid < nxs ? (int32_t)arena[it.hleft_off + tid] : 0;
 
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(jb.src), 0, (int)jb.src_bytes, 0x00020000);
+    // raw buffer descriptor (stride 0): base, num_records = image bytes (hardware range check), DST_SEL/format word
+    u32x4 rs;
+    {
+        const uint64_t base = reinterpret_cast<uint64_t>(jb.src);
+        rs.x = (uint32_t)base;
+        rs.y = (uint32_t)(base >> 32) & 0xffffu;
+        rs.z = jb.src_bytes;
+        rs.w = 0x00020000u;
+    }
     const uint32_t pitch = jb.sw * CS;
-    const uint32_t voff = (it.sx0 + tid * PXL) * CS;
-    const RowSched *sched = reinterpret_cast<const RowSched *>(arena + it.sched_off);
+    const uint32_t voff = (it.sx0 + tid * PXL) * CS + it.r0 * pitch;
+    const uint32_t rowbuf_off = 2 * SCH_WORDS;
+    const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (it.x0 - jb.cx);
 
-    float acc[NACC][NV];
+    float acc[NA][NV];
 #pragma unroll
-    for (int s = 0; s < NACC; ++s)
+    for (int s = 0; s < NA; ++s)
 #pragma unroll
         for (int k = 0; k < NV; ++k) acc[s][k] = 0.0f;
 
+    // whole byte offset goes through voffset: rows past the image end are range-checked by the buffer descriptor and read 0
     RowRaw<CS> ring[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) ring[k] = load_row<CS>(rs, voff + (it.r0 + k) * pitch, 0);
+    for (int k = 0; k < D; ++k) load_row<CS>(ring[k], rs, voff + k * pitch);
 
     __syncthreads();
 
-    const uint32_t nrows = it.r1 - it.r0;
+    // Main loop: blocks of D source rows.  Inside a block the code is straight line (loads, byte->f32
+    // conversion, one v_pk_fma_f32 per accumulator pair with the weight as an SGPR operand); rows that
+    // complete an output row only record it, and the completed rows are flushed to LDS and run through
+    // the horizontal pass between blocks.  The host guarantees that a completed slot is not re-armed
+    // before the end of its block (build_row_sched, `defer` argument).
+    // The row schedule (8 weights + live/emit masks per source row) is staged through LDS in chunks of
+    // SCHED_CHUNK rows, double buffered: fetching it row by row with scalar loads exposes one scalar-cache
+    // miss per row, which was the largest single stall of the loop.  The next chunk is fetched into two
+    // VGPRs at the start of a chunk and written to the other LDS buffer at its end.
+    const uint32_t nrows = it.r1 - it.r0; // the host pads the schedule to a whole number of chunks
+    uint32_t g0 = 0, g1 = 0;
     for (uint32_t rb = 0; rb < nrows; rb += D) {
+        const uint32_t in_chunk = rb % SCHED_CHUNK;
+        const uint32_t *schc = sch + ((rb / SCHED_CHUNK) & 1u) * SCH_WORDS + in_chunk * (sizeof(RowSched) / 4);
+        const bool fetch_next = in_chunk == 0 && rb + SCHED_CHUNK < nrows;
+        if (fetch_next) {
+            const uint32_t *nx = arena + it.sched_off + (size_t)(rb / SCHED_CHUNK + 1) * SCH_WORDS;
+            g0 = nx[tid];
+            if (tid + T < SCH_WORDS) g1 = nx[tid + T];
+        }
+        uint32_t em = 0, oy = 0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const uint32_t ri = rb + k;
-            if (ri < nrows) {
-                const RowRaw<CS> cur = ring[k];
-                // whole byte offset in voffset: rows past the image end are range-checked by the buffer descriptor and return 0
-                ring[k] = load_row<CS>(rs, voff + (it.r0 + ri + D) * pitch, 0);
-                float v[NV];
-                convert_row<CS, PRE>(cur, v);
-                const RowSched sc = sched[ri];
+            // wave-uniform LDS reads (broadcast): weights stay in VGPRs, the masks go to SGPRs
+            const f32x4 w03 = *reinterpret_cast<const f32x4 *>(schc + k * 12);
+            const f32x4 w47 = *reinterpret_cast<const f32x4 *>(schc + k * 12 + 4);
+            const u32x4 msk = *reinterpret_cast<const u32x4 *>(schc + k * 12 + 8);
+            // unconditional refill: rows past the band are harmless extra reads, rows past the image read 0
+            // (convert first, refill second: the slot's registers are dead by then, so the refill lands in place)
+            float v[NV];
+            wait_row<D - 1, CS>(ring[k]); // the D - 1 younger rows stay in flight
+            convert_row<CS, PRE>(ring[k], v);
+            load_row<CS>(ring[k], rs, voff + (ri + D) * pitch);
+            const uint32_t live = __builtin_amdgcn_readfirstlane(msk.x), emit = __builtin_amdgcn_readfirstlane(msk.y);
 #pragma unroll
-                for (int s = 0; s < NACC; ++s) {
-                    if (sc.live & (1u << s)) {
-                        const float w = sc.w[s];
+            for (int s = 0; s < NA; ++s) {
+                if ((live & (1u << s)) && !(ablate & 4u)) {
+                    const float w = s == 0 ? w03.x : s == 1 ? w03.y : s == 2 ? w03.z : s == 3 ? w03.w
+                                  : s == 4 ? w47.x : s == 5 ? w47.y : s == 6 ? w47.z : w47.w;
 #pragma unroll
-                        for (int j = 0; j < NV; ++j) acc[s][j] = __builtin_fmaf(v[j], w, acc[s][j]);
-                    }
-                }
-                if (sc.emit) {
-#pragma unroll
-                    for (int s = 0; s < NACC; ++s) {
-                        if (sc.emit & (1u << s)) {
-                            const uint32_t oy = sc.first_out + ((s - sc.first_out) & (NACC - 1));
-                            // finished vertical row -> LDS (f32, unrounded), reset the slot
-#pragma unroll
-                            for (int p = 0; p < PXL; ++p) {
-                                float *o = rowbuf + (size_t)(tid * PXL + p) * MS;
-                                if (MS == 4) {
-                                    f32x4 q;
-                                    q.x = acc[s][p * MC];
-                                    q.y = MC > 1 ? acc[s][p * MC + 1] : 0.0f;
-                                    q.z = MC > 2 ? acc[s][p * MC + 2] : 0.0f;
-                                    q.w = MC > 3 ? acc[s][p * MC + 3] : 0.0f;
-                                    *reinterpret_cast<f32x4 *>(o) = q;
-                                } else {
-#pragma unroll
-                                    for (int c = 0; c < MC; ++c) o[c] = acc[s][p * MC + c];
-                                }
-                            }
-#pragma unroll
-                            for (int j = 0; j < NV; ++j) acc[s][j] = 0.0f;
-                            __syncthreads();
-                            const uint32_t pix = (jb.oy + oy - jb.cy) * jb.dw + jb.ox + (it.x0 - jb.cx);
-                            hpass_row<MC, LB>(hw4_off, hmax4, nxs, hleft, jb.dst, pix, jb.fill);
-                            __syncthreads();
-                        }
-                    }
+                    for (int j = 0; j < NV; ++j) acc[s][j] = __builtin_fmaf(v[j], w, acc[s][j]);
                 }
             }
+            if (emit) {
+                if (!em) oy = __builtin_amdgcn_readfirstlane(msk.z); // outputs complete in order: first_out, first_out + 1, ...
+                em |= emit;
+            }
+        }
+        // g0/g1 were loaded by the compiler's own bookkeeping; publish the next chunk before its first use
+        if (in_chunk + D == SCHED_CHUNK && rb + D < nrows) {
+            uint32_t *nb = sch + (((rb / SCHED_CHUNK) + 1) & 1u) * SCH_WORDS;
+            nb[tid] = g0;
+            if (tid + T < SCH_WORDS) nb[tid + T] = g1;
+            lds_barrier();
+        }
+        if (ablate & 2u) em = 0;
+        while (em) { // wave-uniform; usually zero or one iteration
+            const uint32_t s = oy % NA;
+            em &= ~(1u << s);
+            switch (s) {
+            case 0: flush_slot<MC>(acc[0], rowbuf, tid); break;
+            case 1: if (NA > 1) flush_slot<MC>(acc[NA > 1 ? 1 : 0], rowbuf, tid); break;
+            case 2: if (NA > 2) flush_slot<MC>(acc[NA > 2 ? 2 : 0], rowbuf, tid); break;
+            case 3: if (NA > 3) flush_slot<MC>(acc[NA > 3 ? 3 : 0], rowbuf, tid); break;
+            case 4: if (NA > 4) flush_slot<MC>(acc[NA > 4 ? 4 : 0], rowbuf, tid); break;
+            case 5: if (NA > 5) flush_slot<MC>(acc[NA > 5 ? 5 : 0], rowbuf, tid); break;
+            case 6: if (NA > 6) flush_slot<MC>(acc[NA > 6 ? 6 : 0], rowbuf, tid); break;
+            default: if (NA > 7) flush_slot<MC>(acc[NA > 7 ? 7 : 0], rowbuf, tid); break;
+            }
+            // LDS-only hand-off (no vmcnt drain: the prefetched rows and the pixel stores stay in flight)
+            lds_barrier();
+            if (!(ablate & 1u)) hpass_row<MC, LB>(rowbuf_off, hw4_off, hmax4, nxs, hleft, jb.dst, pix_base + oy * jb.dw, jb.fill);
+            lds_barrier();
+            ++oy;
         }
     }
 }
@@ -574,8 +671,11 @@ size_t stream_lds_bytes(uint32_t cs, uint32_t pre, uint32_t hmax, uint32_t nxs_m
 {
     const uint32_t ms = mid_stride(mid_channels(cs, pre));
     const size_t rowbuf = (((size_t)(256 * PXL + hmax) * ms + 3) & ~(size_t)3) * sizeof(float);
-    return rowbuf + (size_t)(hmax / 4) * nxs_max * 16;
+    return 2 * SCHED_CHUNK * sizeof(RowSched) + rowbuf + (size_t)(hmax / 4) * nxs_max * 16;
 }
+
+uint32_t stream_block_rows() { return FL_STREAM_DEPTH; }
+static_assert(SCHED_CHUNK % FL_STREAM_DEPTH == 0, "schedule chunks must hold whole blocks");
 
 bool stream_supported(uint32_t cs, uint32_t pre)
 {
@@ -583,21 +683,30 @@ bool stream_supported(uint32_t cs, uint32_t pre)
     return cs == 3 || cs == 4;
 }
 
+template <int CS, int PRE, bool LB, int NA, int D>
+static hipError_t launch_stream_v(const LaunchStream &s, hipStream_t st)
+{
+    auto k = resample_stream_kernel<CS, PRE, LB, NA, D>;
+    if (s.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+#ifdef FL_ABLATE
+    const char *ab = getenv("FLGPU_ABLATE");
+    hipLaunchKernelGGL(k, dim3(s.nitems), dim3(256), s.lds_bytes, st, s.jobs, s.items, s.arena, (uint32_t)(ab ? atoi(ab) : 0));
+#else
+    hipLaunchKernelGGL(k, dim3(s.nitems), dim3(256), s.lds_bytes, st, s.jobs, s.items, s.arena);
+#endif
+    FL_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 template <int CS, int PRE>
 static hipError_t launch_stream_t(const LaunchStream &s, hipStream_t st)
 {
-    constexpr int D = 4;
-    if (s.letterbox) {
-        auto k = resample_stream_kernel<CS, PRE, true, D>;
-        if (s.lds_bytes > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k, dim3(s.nitems), dim3(256), s.lds_bytes, st, s.jobs, s.items, s.arena);
-    } else {
-        auto k = resample_stream_kernel<CS, PRE, false, D>;
-        if (s.lds_bytes > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k, dim3(s.nitems), dim3(256), s.lds_bytes, st, s.jobs, s.items, s.arena);
-    }
-    FL_LAUNCH_CHECK();
-    return hipSuccess;
+    constexpr int D = FL_STREAM_DEPTH;
+    if (s.letterbox) return launch_stream_v<CS, PRE, true, NACC, D>(s, st);
+    return launch_stream_v<CS, PRE, false, NACC, D>(s, st);
 }
 
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st)

@@ -283,7 +283,7 @@ int flgpu_debug_stream_schedulable(uint32_t in_size, uint32_t out_size, uint32_t
     fl::build_axis(in_size, out_size, fl::FILTER_LANCZOS3, 0.0f, a);
     uint32_t r0, r1, peak = 0;
     std::vector<fl::RowSched> sched;
-    const bool ok = fl::build_row_sched(a, y0, y1, r0, r1, sched);
+    const bool ok = fl::build_row_sched(a, y0, y1, fl::NACC, 1, r0, r1, sched);
     if (ok) {
         // every tap must appear exactly once and every output must be emitted exactly once
         uint64_t taps = 0, emits = 0, want = 0;

@@ -93,10 +93,11 @@ void resize_dimensions(uint32_t width, uint32_t height, uint32_t nwidth, uint32_
     }
 }
 
-bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t &r0, uint32_t &r1, std::vector<RowSched> &out)
+bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t nacc, uint32_t block, uint32_t &r0,
+                     uint32_t &r1, std::vector<RowSched> &out)
 {
     out.clear();
-    if (y0 >= y1 || y1 > v.out_size) return false;
+    if (y0 >= y1 || y1 > v.out_size || nacc < 1 || nacc > (uint32_t)NACC || block < 1) return false;
     r0 = v.left[y0];
     r1 = r0;
     for (uint32_t o = y0; o < y1; ++o) {
@@ -104,10 +105,18 @@ bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t &r0, 
         if (o > y0 && (v.left[o] < v.left[o - 1] || v.left[o] + v.count[o] < v.left[o - 1] + v.count[o - 1])) return false;
         r1 = std::max(r1, v.left[o] + v.count[o]);
     }
-    out.assign(r1 - r0, RowSched());
+    // whole blocks for the kernel loop, whole chunks for its LDS staging of the schedule
+    const uint32_t padded = (r1 - r0 + block - 1) / block * block;
+    out.assign((padded + SCHED_CHUNK - 1) / SCHED_CHUNK * SCHED_CHUNK, RowSched());
     for (auto &e : out) memset(&e, 0, sizeof(e));
+    // deferred flush: output o + nacc must start in a later block than the one in which output o completes
+    for (uint32_t o = y0; o + nacc < y1; ++o) {
+        const uint32_t done_block = (v.left[o] + v.count[o] - 1 - r0) / block;
+        const uint32_t rearm_block = (v.left[o + nacc] - r0) / block;
+        if (rearm_block <= done_block) return false;
+    }
     for (uint32_t o = y0; o < y1; ++o) {
-        const uint32_t slot = o % NACC;
+        const uint32_t slot = o % nacc;
         for (uint32_t i = 0; i < v.count[o]; ++i) {
             RowSched &e = out[v.left[o] + i - r0];
             if (e.live & (1u << slot)) return false; // two live outputs would share a slot

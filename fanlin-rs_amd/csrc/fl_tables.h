@@ -27,9 +27,14 @@ void build_axis(uint32_t in_size, uint32_t out_size, Filter filter, float sigma,
 void resize_dimensions(uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, bool fill, uint32_t &ow, uint32_t &oh);
 
 // Row schedule of output rows [y0,y1): one RowSched per source row in [r0,r1).
-// Returns false if more than NACC output rows are alive on some source row or
+// Output row o uses accumulator slot o % nacc (nacc <= NACC).
+// Returns false if more than nacc output rows are alive on some source row or
 // if the windows are not monotone (the streaming kernel then cannot be used).
-bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t &r0, uint32_t &r1, std::vector<RowSched> &out);
+// `block`: the kernel walks the rows in blocks of `block` rows (counted from r0) and flushes completed
+// output rows only at block ends, so a slot must not be re-armed inside the block in which it completed;
+// the schedule is padded with empty rows to a whole number of blocks.
+bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t nacc, uint32_t block, uint32_t &r0,
+                     uint32_t &r1, std::vector<RowSched> &out);
 
 // Horizontal tile of output columns [x0,x1): left[] relative to sx0 and
 // weights laid out [hmax/4][x1-x0][4] (tap-major float4, zero padded).

@@ -47,6 +47,8 @@ struct AxisTable {
 constexpr int NACC = 8;
 // Pixels of one source row owned by one lane.
 constexpr int PXL = 4;
+// Rows of the schedule staged in LDS at a time (double buffered); schedules are padded to whole chunks.
+constexpr int SCHED_CHUNK = 32;
 
 // Per source row of a band: the weight each live accumulator slot applies to
 // this row, which slots are live, and which complete (emit) after it.
