@@ -247,7 +247,12 @@ const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxi
     }
     bool ok = !strips.empty();
     // fewest accumulator slots that can hold every output row alive on one source row (fewer slots = fewer VGPRs)
-    plan.nacc = NACC;
+    // fewest accumulator slots whose schedule works for the whole kept range (fewer slots = fewer VGPRs and fewer idle FMAs)
+    {
+        uint32_t r0 = 0, r1 = 0;
+        std::vector<RowSched> probe;
+        plan.nacc = build_row_sched(va, cy, cy + ch, 7, stream_block_rows(), r0, r1, probe) ? 7 : NACC;
+    }
     struct Band { uint32_t y0, y1, r0, r1, sched_off; };
     std::vector<Band> bands;
     if (ok) {

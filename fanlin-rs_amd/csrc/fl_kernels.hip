@@ -73,9 +73,19 @@ __device__ __forceinline__ uint32_t blend_over_fill(uint32_t fill, uint32_t r, u
     return (o_r & 255u) | ((o_g & 255u) << 8) | ((o_b & 255u) << 16) | ((o_a & 255u) << 24);
 }
 
+// One dword / byte to global memory, invisible to hipcc's s_waitcnt bookkeeping (see load_row below).
+__device__ __forceinline__ void store_hidden_b32(void *p, uint32_t v)
+{
+    asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_hidden_b8(void *p, uint32_t v)
+{
+    asm volatile("global_store_byte %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+}
+
 // Writes one resampled pixel (MC rounded channels in c[]) to the destination.
 // LB = letterboxed: destination is Rgba8, pixel converted with to_rgba() and blended onto the fill.
-template <int MC, bool LB>
+template <int MC, bool LB, bool HIDDEN = false>
 __device__ __forceinline__ void store_pixel(uint8_t *dst, uint32_t pix_index, const uint32_t *c, uint32_t fill)
 {
     if (LB) {
@@ -84,11 +94,15 @@ __device__ __forceinline__ void store_pixel(uint8_t *dst, uint32_t pix_index, co
         else if (MC == 2) v = blend_over_fill(fill, c[0], c[0], c[0], c[1]);
         else if (MC == 3) v = c[0] | (c[1] << 8) | (c[2] << 16) | (255u << 24);
         else v = blend_over_fill(fill, c[0], c[1], c[2], c[3]);
-        reinterpret_cast<uint32_t *>(dst)[pix_index] = v;
+        if (HIDDEN) store_hidden_b32(reinterpret_cast<uint32_t *>(dst) + pix_index, v);
+        else reinterpret_cast<uint32_t *>(dst)[pix_index] = v;
     } else {
         uint8_t *p = dst + (size_t)pix_index * MC;
 #pragma unroll
-        for (int k = 0; k < MC; ++k) p[k] = (uint8_t)c[k];
+        for (int k = 0; k < MC; ++k) {
+            if (HIDDEN) store_hidden_b8(p + k, c[k]);
+            else p[k] = (uint8_t)c[k];
+        }
     }
 }
 
@@ -222,27 +236,20 @@ template <> struct RowRaw<2> { u32x2 v; __device__ uint32_t dw(int i) const { re
 template <> struct RowRaw<3> { u32x3 v; __device__ uint32_t dw(int i) const { return i == 0 ? v.x : i == 1 ? v.y : v.z; } };
 template <> struct RowRaw<4> { u32x4 v; __device__ uint32_t dw(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; } };
 
-// Source-row loads are issued through inline asm so that they stay in flight across the horizontal pass:
-// hipcc's own s_waitcnt bookkeeping drains every outstanding load at the loop header once the loop body
-// contains global stores (vmcnt counts loads and stores together on gfx9), which turns the D-deep
-// prefetch ring into one exposed HBM round trip per block.  hipcc does not see these loads, so every
-// consumer sits behind wait_row<N>() (counted vmcnt; younger stores only make it wait longer, never
-// shorter, because vector-memory operations retire in order).
+// Source-row loads are ordinary (compiler-counted) raw buffer loads.  What keeps them in flight across
+// the horizontal pass is that the kernel's only global STORES (store_pixel_hidden) are issued from
+// inline asm: on gfx9 loads and stores share vmcnt, and once hipcc sees a store inside the row loop it
+// drains every outstanding load at the loop header (s_waitcnt vmcnt(0)), turning the D-deep prefetch
+// ring into one exposed HBM round trip per block.  Hidden stores are safe: vector-memory operations
+// retire in order, so a younger store the compiler does not know about can only make its counted
+// waits longer, never shorter.
 template <int CS>
-__device__ __forceinline__ void load_row(RowRaw<CS> &r, u32x4 rsrc, uint32_t voff)
+__device__ __forceinline__ void load_row(RowRaw<CS> &r, __amdgpu_buffer_rsrc_t rs, uint32_t voff)
 {
-    if (CS == 1) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(r.v) : "v"(voff), "s"(rsrc) : "memory");
-    if (CS == 2) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(r.v) : "v"(voff), "s"(rsrc) : "memory");
-    if (CS == 3) asm volatile("buffer_load_dwordx3 %0, %1, %2, 0 offen" : "=v"(r.v) : "v"(voff), "s"(rsrc) : "memory");
-    if (CS == 4) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r.v) : "v"(voff), "s"(rsrc) : "memory");
-}
-
-// Waits until at most N vector-memory operations younger than the wanted row are outstanding and
-// makes the row's registers "produced here" for the compiler.
-template <int N, int CS>
-__device__ __forceinline__ void wait_row(RowRaw<CS> &r)
-{
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r.v) : "n"(N) : "memory");
+    if constexpr (CS == 1) r.v = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0);
+    if constexpr (CS == 2) r.v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+    if constexpr (CS == 3) r.v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, 0, 0);
+    if constexpr (CS == 4) r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
 }
 
 // PXL pixels of CS bytes, packed in CS dwords -> PXL*MC floats with the pre-op applied.
@@ -308,9 +315,9 @@ __device__ __forceinline__ void hpass_row(uint32_t rowbuf_off, uint32_t hw4_off,
             if (MS == 4) {
                 const f32x4 px = *reinterpret_cast<const f32x4 *>(p + (q * 4 + j) * 4);
                 acc[0] = __builtin_fmaf(px.x, wj, acc[0]);
-                if (MC > 1) acc[1] = __builtin_fmaf(px.y, wj, acc[1]);
-                if (MC > 2) acc[2] = __builtin_fmaf(px.z, wj, acc[2]);
-                if (MC > 3) acc[3] = __builtin_fmaf(px.w, wj, acc[3]);
+                if constexpr (MC > 1) acc[1] = __builtin_fmaf(px.y, wj, acc[1]);
+                if constexpr (MC > 2) acc[2] = __builtin_fmaf(px.z, wj, acc[2]);
+                if constexpr (MC > 3) acc[3] = __builtin_fmaf(px.w, wj, acc[3]);
             } else {
 #pragma unroll
                 for (int k = 0; k < MC; ++k) acc[k] = __builtin_fmaf(p[(q * 4 + j) * MS + k], wj, acc[k]);
@@ -320,7 +327,7 @@ __device__ __forceinline__ void hpass_row(uint32_t rowbuf_off, uint32_t hw4_off,
     uint32_t c[MC];
 #pragma unroll
     for (int k = 0; k < MC; ++k) c[k] = round_u8(acc[k]);
-    store_pixel<MC, LB>(dst, pix_index + xl, c, fill);
+    store_pixel<MC, LB, true>(dst, pix_index + xl, c, fill);
 }
 
 // Workgroup barrier that orders LDS traffic only.
@@ -398,15 +405,8 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
     }
     const int32_t hleft = tid < nxs ? (int32_t)arena[it.hleft_off + tid] : 0;
 
-    // raw buffer descriptor (stride 0): base, num_records = image bytes (hardware range check), DST_SEL/format word
-    u32x4 rs;
-    {
-        const uint64_t base = reinterpret_cast<uint64_t>(jb.src);
-        rs.x = (uint32_t)base;
-        rs.y = (uint32_t)(base >> 32) & 0xffffu;
-        rs.z = jb.src_bytes;
-        rs.w = 0x00020000u;
-    }
+    // raw buffer descriptor (stride 0): num_records = image bytes, so the hardware range-checks every lane
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(jb.src), 0, (int)jb.src_bytes, 0x00020000);
     const uint32_t pitch = jb.sw * CS;
     const uint32_t voff = (it.sx0 + tid * PXL) * CS + it.r0 * pitch;
     const uint32_t rowbuf_off = 2 * SCH_WORDS;
@@ -445,35 +445,39 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
             g0 = nx[tid];
             if (tid + T < SCH_WORDS) g1 = nx[tid + T];
         }
-        uint32_t em = 0, oy = 0;
+        // block summary (row 0 of the block): which slots complete inside this block, first completed output row
+        const u32x4 meta = *reinterpret_cast<const u32x4 *>(schc + 8);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const uint32_t ri = rb + k;
-            // wave-uniform LDS reads (broadcast): weights stay in VGPRs, the masks go to SGPRs
+            // wave-uniform LDS reads (broadcast).  Dead slots carry weight 0, so the accumulate below is
+            // branch free: acc + v * 0 leaves a finished or not yet started slot untouched, and skipping
+            // it with scalar branches costs more than the idle v_pk_fma_f32 it saves.
             const f32x4 w03 = *reinterpret_cast<const f32x4 *>(schc + k * 12);
             const f32x4 w47 = *reinterpret_cast<const f32x4 *>(schc + k * 12 + 4);
-            const u32x4 msk = *reinterpret_cast<const u32x4 *>(schc + k * 12 + 8);
             // unconditional refill: rows past the band are harmless extra reads, rows past the image read 0
             // (convert first, refill second: the slot's registers are dead by then, so the refill lands in place)
             float v[NV];
-            wait_row<D - 1, CS>(ring[k]); // the D - 1 younger rows stay in flight
-            convert_row<CS, PRE>(ring[k], v);
-            load_row<CS>(ring[k], rs, voff + (ri + D) * pitch);
-            const uint32_t live = __builtin_amdgcn_readfirstlane(msk.x), emit = __builtin_amdgcn_readfirstlane(msk.y);
+            convert_row<CS, PRE>(ring[k], v); // hipcc waits for this row only: the D - 1 younger rows stay in flight
+            // Keep the refill below the conversion: hoisted above it, the refill needs fresh registers and the
+            // ring is then rotated with v_mov behind a vmcnt(0) at the loop end.  The empty asm makes the
+            // refill's address depend on every converted value, so all reads of the old row precede it.
+            uint32_t roff = voff + (ri + D) * pitch;
 #pragma unroll
-            for (int s = 0; s < NA; ++s) {
-                if ((live & (1u << s)) && !(ablate & 4u)) {
+            for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(roff) : "v"(v[j]));
+            load_row<CS>(ring[k], rs, roff);
+            if (!(ablate & 4u)) {
+#pragma unroll
+                for (int s = 0; s < NA; ++s) {
                     const float w = s == 0 ? w03.x : s == 1 ? w03.y : s == 2 ? w03.z : s == 3 ? w03.w
                                   : s == 4 ? w47.x : s == 5 ? w47.y : s == 6 ? w47.z : w47.w;
 #pragma unroll
                     for (int j = 0; j < NV; ++j) acc[s][j] = __builtin_fmaf(v[j], w, acc[s][j]);
                 }
             }
-            if (emit) {
-                if (!em) oy = __builtin_amdgcn_readfirstlane(msk.z); // outputs complete in order: first_out, first_out + 1, ...
-                em |= emit;
-            }
         }
+        uint32_t em = __builtin_amdgcn_readfirstlane(meta.y); // outputs complete in order: first_out, first_out + 1, ...
+        uint32_t oy = __builtin_amdgcn_readfirstlane(meta.z);
         // g0/g1 were loaded by the compiler's own bookkeeping; publish the next chunk before its first use
         if (in_chunk + D == SCHED_CHUNK && rb + D < nrows) {
             uint32_t *nb = sch + (((rb / SCHED_CHUNK) + 1) & 1u) * SCH_WORDS;
@@ -705,8 +709,8 @@ template <int CS, int PRE>
 static hipError_t launch_stream_t(const LaunchStream &s, hipStream_t st)
 {
     constexpr int D = FL_STREAM_DEPTH;
-    if (s.letterbox) return launch_stream_v<CS, PRE, true, NACC, D>(s, st);
-    return launch_stream_v<CS, PRE, false, NACC, D>(s, st);
+    if (s.letterbox) return s.nacc <= 7 ? launch_stream_v<CS, PRE, true, 7, D>(s, st) : launch_stream_v<CS, PRE, true, 8, D>(s, st);
+    return s.nacc <= 7 ? launch_stream_v<CS, PRE, false, 7, D>(s, st) : launch_stream_v<CS, PRE, false, 8, D>(s, st);
 }
 
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st)

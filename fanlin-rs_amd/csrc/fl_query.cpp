@@ -288,6 +288,7 @@ int flgpu_debug_stream_schedulable(uint32_t in_size, uint32_t out_size, uint32_t
         // every tap must appear exactly once and every output must be emitted exactly once
         uint64_t taps = 0, emits = 0, want = 0;
         for (auto &e : sched) { taps += (uint64_t)__builtin_popcount(e.live); emits += (uint64_t)__builtin_popcount(e.emit); peak = std::max<uint32_t>(peak, (uint32_t)__builtin_popcount(e.live)); }
+        // (with block = 1 every row is its own block, so the folded emit masks are the per-row ones)
         for (uint32_t o = y0; o < y1; ++o) want += a.count[o];
         if (taps != want || emits != y1 - y0) return 0;
     } else {

@@ -127,8 +127,19 @@ bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t nacc,
         if (!last.emit) last.first_out = o; // outputs complete in order, so the first one seen is the lowest
         last.emit |= 1u << slot;
     }
-    // an emitting slot must not be re-armed by a later output on the same row (cannot happen with
-    // monotone windows of >= 1 row, but the kernel relies on it)
+    // the kernel flushes at block ends: fold every block's emits into its first row
+    for (size_t b0 = 0; b0 < out.size(); b0 += block) {
+        uint32_t em = 0, first = 0;
+        for (size_t k = 0; k < block; ++k) {
+            RowSched &e = out[b0 + k];
+            if (e.emit && !em) first = e.first_out;
+            em |= e.emit;
+            e.emit = 0;
+            e.first_out = 0;
+        }
+        out[b0].emit = em;
+        out[b0].first_out = first;
+    }
     return true;
 }
 

@@ -53,10 +53,10 @@ constexpr int SCHED_CHUNK = 32;
 // Per source row of a band: the weight each live accumulator slot applies to
 // this row, which slots are live, and which complete (emit) after it.
 struct RowSched {
-    float w[NACC];
-    uint32_t live;      // bit s: slot s accumulates this row
-    uint32_t emit;      // bit s: slot s is complete after this row
-    uint32_t first_out; // output row index of the lowest-numbered emitting slot's... see tables.cpp
+    float w[NACC];      // weight of this source row in each slot; 0 for slots that are not alive
+    uint32_t live;      // bit s: slot s accumulates this row (diagnostics; the kernel relies on w == 0)
+    uint32_t emit;      // first row of a block: slots that complete inside the block (flushed at its end)
+    uint32_t first_out; // first row of a block: output row index of the first slot that completes in it
     uint32_t pad;
 };
 
