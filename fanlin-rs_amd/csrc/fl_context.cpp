@@ -86,7 +86,7 @@ struct StreamPlan {
     bool ok = false;
     uint32_t nacc = NACC;
     std::vector<StreamItem> items; // job field unset
-    uint32_t hmax = 0, nxs_max = 0;
+    size_t lds_bytes = 0;
 };
 
 struct Request {
@@ -229,7 +229,7 @@ const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxi
     auto it = c->stream_plans.find(key);
     if (it != c->stream_plans.end()) return &it->second;
     StreamPlan plan;
-    const uint32_t T = 256, span_max = T * PXL;
+    const uint32_t T = stream_lanes(), span_max = T * PXL;
     // strips: fewest equal-width strips such that each has <= T output columns and <= T*PXL source pixels
     std::vector<HostStrip> strips;
     for (uint32_t ns = std::max(1u, (cw + T - 1) / T); ns <= cw; ++ns) {
@@ -238,7 +238,7 @@ const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxi
         const uint32_t per = (cw + ns - 1) / ns;
         for (uint32_t x = cx; x < cx + cw && fits; x += per) {
             HostStrip s;
-            build_strip(ha, x, std::min(x + per, cx + cw), PXL, s);
+            build_strip(ha, x, std::min(x + per, cx + cw), T, PXL, s);
             if (s.sx1 - s.sx0 > span_max || s.x1 - s.x0 > T) fits = false;
             strips.push_back(std::move(s));
         }
@@ -268,21 +268,21 @@ const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxi
     }
     if (ok) {
         for (auto &s : strips) {
-            const uint32_t hleft_off = arena_append(c, s.left_rel.data(), s.left_rel.size());
-            const uint32_t hw_off = arena_append(c, s.w4.data(), s.w4.size());
-            if (!hleft_off || !hw_off) { ok = false; break; }
-            plan.hmax = std::max(plan.hmax, s.hmax);
-            plan.nxs_max = std::max(plan.nxs_max, s.x1 - s.x0);
+            const uint32_t wt_off = arena_append(c, s.wt.data(), s.wt.size());
+            const uint32_t po_off = arena_append(c, s.po.data(), s.po.size());
+            if (!wt_off || !po_off) { ok = false; break; }
+            plan.lds_bytes = std::max(plan.lds_bytes, stream_lds_bytes(s.jmax, s.x1 - s.x0, s.ks));
             for (size_t bi = 0; bi < bands.size(); ++bi) {
                 const Band &b = bands[bi];
                 StreamItem it2{};
                 it2.y0 = b.y0; it2.y1 = b.y1; it2.x0 = s.x0; it2.x1 = s.x1; it2.r0 = b.r0; it2.r1 = b.r1;
-                it2.sx0 = s.sx0; it2.sched_off = b.sched_off; it2.hleft_off = hleft_off; it2.hw_off = hw_off; it2.hmax = s.hmax;
+                it2.sx0 = s.sx0; it2.sched_off = b.sched_off; it2.wt_off = wt_off; it2.po_off = po_off;
+                it2.jmax = s.jmax; it2.kmax = s.kmax; it2.ks = s.ks;
                 plan.items.push_back(it2);
             }
         }
     }
-    if (ok && stream_lds_bytes(cs, pre, plan.hmax, plan.nxs_max) > 150 * 1024) ok = false;
+    if (ok && plan.lds_bytes > 150 * 1024) ok = false;
     plan.ok = ok;
     if (!ok) plan.items.clear();
     auto res = c->stream_plans.emplace(key, std::move(plan));
@@ -520,7 +520,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if ((k.kind & 255u) == S1_STREAM) {
                 for (StreamItem it2 : w.splan->items) { it2.job = (uint32_t)jobs.size(); items.push_back(it2); }
                 L.nitems += (uint32_t)w.splan->items.size();
-                L.lds = std::max(L.lds, stream_lds_bytes(w.cs, w.pre, w.splan->hmax, w.splan->nxs_max));
+                L.lds = std::max(L.lds, w.splan->lds_bytes);
                 L.nacc = w.splan->nacc;
                 c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
                 c->stats.resample_dst_bytes += w.plan.pixel_bytes;

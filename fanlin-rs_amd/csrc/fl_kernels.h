@@ -49,7 +49,8 @@ hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st
 
 bool stream_supported(uint32_t cs, uint32_t pre);
 uint32_t stream_block_rows(); // source rows per block of the streaming kernel (emits are deferred to block ends)
-size_t stream_lds_bytes(uint32_t cs, uint32_t pre, uint32_t hmax, uint32_t nxs_max);
+size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks);
+uint32_t stream_lanes(); // lanes (threads) per workgroup of the streaming kernel
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st);
 
 hipError_t launch_jfif444(const FrontendJob *fjobs, uint32_t job_base, uint32_t njobs, uint32_t max_pw, uint32_t max_ph,

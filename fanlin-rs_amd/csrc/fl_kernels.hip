@@ -178,15 +178,24 @@ __global__ __launch_bounds__(256) void hpass_generic_kernel(const Job *__restric
     const uint32_t n = arena[tab->count_off + x];
     const float *w = reinterpret_cast<const float *>(arena + tab->weights_off + arena[tab->woff_off + x]);
     const float *p = mid + (size_t)jb.mid_off + ((size_t)y * jb.sw + left) * MC;
-    float acc[MC];
+    // Horizontal summation order of every kernel in this file (and of the oracle's FO_ARITH_FMA mode):
+    // taps are grouped by aligned blocks of 4 source pixels; inside a block one fused multiply-add per
+    // tap in ascending order starting from 0, then the block sums are added in ascending order.
+    float acc[MC], part[MC];
 #pragma unroll
-    for (int k = 0; k < MC; ++k) acc[k] = 0.0f;
+    for (int k = 0; k < MC; ++k) { acc[k] = 0.0f; part[k] = 0.0f; }
     for (uint32_t i = 0; i < n; ++i) {
+        if (i != 0 && ((left + i) & 3u) == 0u) {
+#pragma unroll
+            for (int k = 0; k < MC; ++k) { acc[k] = acc[k] + part[k]; part[k] = 0.0f; }
+        }
         const float wi = w[i];
 #pragma unroll
-        for (int k = 0; k < MC; ++k) acc[k] = __builtin_fmaf(p[k], wi, acc[k]);
+        for (int k = 0; k < MC; ++k) part[k] = __builtin_fmaf(p[k], wi, part[k]);
         p += MC;
     }
+#pragma unroll
+    for (int k = 0; k < MC; ++k) acc[k] = acc[k] + part[k];
     uint32_t c[MC];
 #pragma unroll
     for (int k = 0; k < MC; ++k) c[k] = round_u8(acc[k]);
@@ -286,49 +295,8 @@ __device__ __forceinline__ void convert_row(const RowRaw<CS> &raw, float *v)
     }
 }
 
-// LDS floats per pixel of the intermediate row (3 padded to 4 so a pixel is one ds_read_b128).
-__host__ __device__ constexpr int mid_stride(int mc) { return mc == 3 ? 4 : mc; }
 
-// Horizontal pass of one finished intermediate row held in LDS.  Lane x of the
-// strip walks its taps in order (zero-padded to hmax4*4), rounds and stores.
 extern __shared__ __attribute__((aligned(16))) float fl_lds[];
-
-// Horizontal pass of one finished intermediate row held in LDS.  Lane x of the
-// strip walks its taps in order (zero-padded to hmax4*4), rounds and stores.
-template <int MC, bool LB>
-__device__ __forceinline__ void hpass_row(uint32_t rowbuf_off, uint32_t hw4_off, uint32_t hmax4, uint32_t nxs, int32_t hleft,
-                                          uint8_t *dst, uint32_t pix_index, uint32_t fill)
-{
-    constexpr int MS = mid_stride(MC);
-    const uint32_t xl = threadIdx.x;
-    if (xl >= nxs) return;
-    const f32x4 *hw4 = reinterpret_cast<const f32x4 *>(fl_lds + hw4_off);
-    float acc[MC];
-#pragma unroll
-    for (int k = 0; k < MC; ++k) acc[k] = 0.0f;
-    const float *p = fl_lds + rowbuf_off + (size_t)hleft * MS;
-    for (uint32_t q = 0; q < hmax4; ++q) {
-        const f32x4 w = hw4[q * nxs + xl];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float wj = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
-            if (MS == 4) {
-                const f32x4 px = *reinterpret_cast<const f32x4 *>(p + (q * 4 + j) * 4);
-                acc[0] = __builtin_fmaf(px.x, wj, acc[0]);
-                if constexpr (MC > 1) acc[1] = __builtin_fmaf(px.y, wj, acc[1]);
-                if constexpr (MC > 2) acc[2] = __builtin_fmaf(px.z, wj, acc[2]);
-                if constexpr (MC > 3) acc[3] = __builtin_fmaf(px.w, wj, acc[3]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < MC; ++k) acc[k] = __builtin_fmaf(p[(q * 4 + j) * MS + k], wj, acc[k]);
-            }
-        }
-    }
-    uint32_t c[MC];
-#pragma unroll
-    for (int k = 0; k < MC; ++k) c[k] = round_u8(acc[k]);
-    store_pixel<MC, LB, true>(dst, pix_index + xl, c, fill);
-}
 
 // Workgroup barrier that orders LDS traffic only.
 __device__ __forceinline__ void lds_barrier()
@@ -338,28 +306,12 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Finished vertical row of one accumulator slot -> LDS (f32, unrounded); the slot is re-armed with zeros.
-template <int MC>
-__device__ __forceinline__ void flush_slot(float *acc, float *rowbuf, uint32_t tid)
+// Takes the finished vertical row out of one accumulator slot (registers) and re-arms the slot.
+template <int NV>
+__device__ __forceinline__ void take_slot(float *acc, float *e)
 {
-    constexpr int MS = mid_stride(MC);
 #pragma unroll
-    for (int p = 0; p < PXL; ++p) {
-        float *o = rowbuf + (size_t)(tid * PXL + p) * MS;
-        if (MS == 4) {
-            f32x4 q;
-            q.x = acc[p * MC];
-            q.y = MC > 1 ? acc[p * MC + 1] : 0.0f;
-            q.z = MC > 2 ? acc[p * MC + 2] : 0.0f;
-            q.w = MC > 3 ? acc[p * MC + 3] : 0.0f;
-            *reinterpret_cast<f32x4 *>(o) = q;
-        } else {
-#pragma unroll
-            for (int c = 0; c < MC; ++c) o[c] = acc[p * MC + c];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < PXL * MC; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < NV; ++j) { e[j] = acc[j]; acc[j] = 0.0f; }
 }
 
 // NA = accumulator slots (output rows alive per source row; the host picks the smallest that fits),
@@ -368,16 +320,15 @@ template <int CS, int PRE, bool LB, int NA, int D>
 __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restrict__ jobs,
                                                               const StreamItem *__restrict__ items,
                                                               const uint32_t *__restrict__ arena
-#ifdef FL_ABLATE
-                                                              , uint32_t ablate // experiments: 1 = no horizontal pass, 2 = no flush/barrier, 4 = no FMAs
-#endif
-                                                              )
+)
 {
-#ifndef FL_ABLATE
+    // experiments only (-DFL_ABLATE=mask): 1 = no horizontal pass, 2 = no flush/barrier, 4 = no FMAs
+#ifdef FL_ABLATE
+    constexpr uint32_t ablate = FL_ABLATE;
+#else
     constexpr uint32_t ablate = 0;
 #endif
     constexpr int MC = mid_channels(CS, PRE);
-    constexpr int MS = mid_stride(MC);
     constexpr int NV = PXL * MC;
     constexpr uint32_t T = 256;
     float *lds = fl_lds;
@@ -386,30 +337,29 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
     const Job jb = jobs[it.job];
     const uint32_t tid = threadIdx.x;
     const uint32_t nxs = it.x1 - it.x0;
-    const uint32_t hmax4 = it.hmax >> 2;
 
-    // LDS: [ sch: 2 x SCHED_CHUNK RowSched | rowbuf: (T*PXL + hmax) pixels x MS floats | hw4: hmax4 x nxs float4 ]
+    // LDS: [ sch: 2 x SCHED_CHUNK RowSched | WT: jmax x T float4 | PO: jmax x T u32 | pbuf: (nxs * ks + 1) float4 ]
     constexpr uint32_t SCH_WORDS = SCHED_CHUNK * (sizeof(RowSched) / 4);
     uint32_t *sch = reinterpret_cast<uint32_t *>(lds);
-    const uint32_t rowbuf_px = T * PXL + it.hmax;
-    float *rowbuf = lds + 2 * SCH_WORDS;
-    const uint32_t hw4_off = 2 * SCH_WORDS + ((rowbuf_px * MS + 3u) & ~3u); // float offset of the weights inside the dynamic LDS block
-    f32x4 *hw4 = reinterpret_cast<f32x4 *>(lds + hw4_off);
+    const uint32_t jmax = it.jmax, kmax = it.kmax, ks = it.ks;
+    f32x4 *wt = reinterpret_cast<f32x4 *>(lds + 2 * SCH_WORDS);
+    uint32_t *po = reinterpret_cast<uint32_t *>(lds + 2 * SCH_WORDS + jmax * T * 4);
+    const uint32_t pbuf_off = 2 * SCH_WORDS + jmax * T * 5; // float offset, a multiple of 4
+    f32x4 *pbuf = reinterpret_cast<f32x4 *>(lds + pbuf_off);
 
-    // stage the strip's horizontal weights and zero the row buffer (its tail is only ever read with zero weights)
+    // stage the strip's horizontal tables and zero the partial-sum buffer (slots no lane writes stay 0 forever)
     {
-        const f32x4 *src4 = reinterpret_cast<const f32x4 *>(arena + it.hw_off);
-        for (uint32_t i = tid; i < hmax4 * nxs; i += T) hw4[i] = src4[i];
-        for (uint32_t i = tid; i < rowbuf_px * MS; i += T) rowbuf[i] = 0.0f;
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(arena + it.wt_off);
+        for (uint32_t i = tid; i < jmax * T; i += T) { wt[i] = wsrc[i]; po[i] = arena[it.po_off + i]; }
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t i = tid; i < nxs * ks + 1; i += T) pbuf[i] = zero;
         for (uint32_t i = tid; i < SCH_WORDS; i += T) sch[i] = arena[it.sched_off + i]; // first schedule chunk
     }
-    const int32_t hleft = tid < nxs ? (int32_t)arena[it.hleft_off + tid] : 0;
 
     // raw buffer descriptor (stride 0): num_records = image bytes, so the hardware range-checks every lane
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(jb.src), 0, (int)jb.src_bytes, 0x00020000);
     const uint32_t pitch = jb.sw * CS;
     const uint32_t voff = (it.sx0 + tid * PXL) * CS + it.r0 * pitch;
-    const uint32_t rowbuf_off = 2 * SCH_WORDS;
     const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (it.x0 - jb.cx);
 
     float acc[NA][NV];
@@ -447,14 +397,19 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
         }
         // block summary (row 0 of the block): which slots complete inside this block, first completed output row
         const u32x4 meta = *reinterpret_cast<const u32x4 *>(schc + 8);
+        const uint32_t sch_base = (uint32_t)(schc - sch); // dword offset of this block's first row inside the dynamic LDS block
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const uint32_t ri = rb + k;
             // wave-uniform LDS reads (broadcast).  Dead slots carry weight 0, so the accumulate below is
             // branch free: acc + v * 0 leaves a finished or not yet started slot untouched, and skipping
             // it with scalar branches costs more than the idle v_pk_fma_f32 it saves.
-            const f32x4 w03 = *reinterpret_cast<const f32x4 *>(schc + k * 12);
-            const f32x4 w47 = *reinterpret_cast<const f32x4 *>(schc + k * 12 + 4);
+            // (the opaque offset stops hipcc from hoisting all D rows' weight reads to the top of the block,
+            // which costs 8 VGPRs per row of look-ahead)
+            uint32_t so = sch_base + k * 12;
+            asm volatile("" : "+v"(so));
+            const f32x4 w03 = *reinterpret_cast<const f32x4 *>(fl_lds + so);
+            const f32x4 w47 = *reinterpret_cast<const f32x4 *>(fl_lds + so + 4);
             // unconditional refill: rows past the band are harmless extra reads, rows past the image read 0
             // (convert first, refill second: the slot's registers are dead by then, so the refill lands in place)
             float v[NV];
@@ -475,6 +430,14 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
                     for (int j = 0; j < NV; ++j) acc[s][j] = __builtin_fmaf(v[j], w, acc[s][j]);
                 }
             }
+            // One row at a time: left alone, hipcc converts all D rows and reads all D weight sets up front
+            // and sinks every FMA to the end of the block, which costs 20 VGPRs per row of look-ahead (and a
+            // wave per SIMD).  The empty asm pins each accumulator's value here, the barrier pins the rest.
+#pragma unroll
+            for (int s = 0; s < NA; ++s)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(acc[s][j]));
+            __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t em = __builtin_amdgcn_readfirstlane(meta.y); // outputs complete in order: first_out, first_out + 1, ...
         uint32_t oy = __builtin_amdgcn_readfirstlane(meta.z);
@@ -489,19 +452,57 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
         while (em) { // wave-uniform; usually zero or one iteration
             const uint32_t s = oy % NA;
             em &= ~(1u << s);
+            float e[NV]; // the finished f32 row: this lane's PXL pixels x MC channels
             switch (s) {
-            case 0: flush_slot<MC>(acc[0], rowbuf, tid); break;
-            case 1: if (NA > 1) flush_slot<MC>(acc[NA > 1 ? 1 : 0], rowbuf, tid); break;
-            case 2: if (NA > 2) flush_slot<MC>(acc[NA > 2 ? 2 : 0], rowbuf, tid); break;
-            case 3: if (NA > 3) flush_slot<MC>(acc[NA > 3 ? 3 : 0], rowbuf, tid); break;
-            case 4: if (NA > 4) flush_slot<MC>(acc[NA > 4 ? 4 : 0], rowbuf, tid); break;
-            case 5: if (NA > 5) flush_slot<MC>(acc[NA > 5 ? 5 : 0], rowbuf, tid); break;
-            case 6: if (NA > 6) flush_slot<MC>(acc[NA > 6 ? 6 : 0], rowbuf, tid); break;
-            default: if (NA > 7) flush_slot<MC>(acc[NA > 7 ? 7 : 0], rowbuf, tid); break;
+            case 0: take_slot<NV>(acc[0], e); break;
+            case 1: take_slot<NV>(acc[NA > 1 ? 1 : 0], e); break;
+            case 2: take_slot<NV>(acc[NA > 2 ? 2 : 0], e); break;
+            case 3: take_slot<NV>(acc[NA > 3 ? 3 : 0], e); break;
+            case 4: take_slot<NV>(acc[NA > 4 ? 4 : 0], e); break;
+            case 5: take_slot<NV>(acc[NA > 5 ? 5 : 0], e); break;
+            case 6: take_slot<NV>(acc[NA > 6 ? 6 : 0], e); break;
+            default: take_slot<NV>(acc[NA > 7 ? 7 : 0], e); break;
+            }
+            if (!(ablate & 1u)) {
+                // Horizontal pass, step 1 (all lanes): this lane's 4 pixels -> one partial sum per output
+                // column whose window they touch.  Weights and target slots come from per-lane tables, so
+                // every LDS access is lane-contiguous (no bank conflicts).
+#pragma unroll 4
+                for (uint32_t j = 0; j < jmax; ++j) { // jmax is a multiple of 4 (host pads with zero weights -> dummy slot)
+                    const f32x4 w = wt[j * T + tid];
+                    const uint32_t slot = po[j * T + tid];
+                    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int p = 0; p < PXL; ++p) {
+                        const float wp = p == 0 ? w.x : p == 1 ? w.y : p == 2 ? w.z : w.w;
+#pragma unroll
+                        for (int c = 0; c < MC; ++c) part[c] = __builtin_fmaf(e[p * MC + c], wp, part[c]);
+                    }
+                    f32x4 q;
+                    q.x = part[0]; q.y = part[1]; q.z = part[2]; q.w = part[3];
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(pbuf) + slot) = q;
+                }
             }
             // LDS-only hand-off (no vmcnt drain: the prefetched rows and the pixel stores stay in flight)
             lds_barrier();
-            if (!(ablate & 1u)) hpass_row<MC, LB>(rowbuf_off, hw4_off, hmax4, nxs, hleft, jb.dst, pix_base + oy * jb.dw, jb.fill);
+            if (!(ablate & 1u) && tid < nxs) {
+                // step 2 (one lane per output column): add the partial sums in ascending pixel order
+                float sum[MC];
+#pragma unroll
+                for (int c = 0; c < MC; ++c) sum[c] = 0.0f;
+                const f32x4 *pp = pbuf + tid * ks;
+                for (uint32_t k = 0; k < kmax; ++k) {
+                    const f32x4 q = pp[k];
+                    sum[0] = sum[0] + q.x;
+                    if constexpr (MC > 1) sum[1] = sum[1] + q.y;
+                    if constexpr (MC > 2) sum[2] = sum[2] + q.z;
+                    if constexpr (MC > 3) sum[3] = sum[3] + q.w;
+                }
+                uint32_t c8[MC];
+#pragma unroll
+                for (int c = 0; c < MC; ++c) c8[c] = round_u8(sum[c]);
+                store_pixel<MC, LB, true>(jb.dst, pix_base + oy * jb.dw + tid, c8, jb.fill);
+            }
             lds_barrier();
             ++oy;
         }
@@ -671,12 +672,12 @@ hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st
     return hipErrorInvalidValue;
 }
 
-size_t stream_lds_bytes(uint32_t cs, uint32_t pre, uint32_t hmax, uint32_t nxs_max)
+size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks)
 {
-    const uint32_t ms = mid_stride(mid_channels(cs, pre));
-    const size_t rowbuf = (((size_t)(256 * PXL + hmax) * ms + 3) & ~(size_t)3) * sizeof(float);
-    return 2 * SCHED_CHUNK * sizeof(RowSched) + rowbuf + (size_t)(hmax / 4) * nxs_max * 16;
+    return 2 * SCHED_CHUNK * sizeof(RowSched) + (size_t)jmax * 256 * 20 + ((size_t)nxs * ks + 1) * 16;
 }
+
+uint32_t stream_lanes() { return 256; }
 
 uint32_t stream_block_rows() { return FL_STREAM_DEPTH; }
 static_assert(SCHED_CHUNK % FL_STREAM_DEPTH == 0, "schedule chunks must hold whole blocks");
@@ -695,12 +696,7 @@ static hipError_t launch_stream_v(const LaunchStream &s, hipStream_t st)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes);
         if (e != hipSuccess) return e;
     }
-#ifdef FL_ABLATE
-    const char *ab = getenv("FLGPU_ABLATE");
-    hipLaunchKernelGGL(k, dim3(s.nitems), dim3(256), s.lds_bytes, st, s.jobs, s.items, s.arena, (uint32_t)(ab ? atoi(ab) : 0));
-#else
     hipLaunchKernelGGL(k, dim3(s.nitems), dim3(256), s.lds_bytes, st, s.jobs, s.items, s.arena);
-#endif
     FL_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -143,29 +143,50 @@ bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t nacc,
     return true;
 }
 
-void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t align_px, HostStrip &out)
+void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t lanes, uint32_t ppl, HostStrip &out)
 {
     out = HostStrip();
     out.x0 = x0;
     out.x1 = x1;
-    uint32_t lo = UINT32_MAX, hi = 0, hmax = 0;
+    uint32_t lo = UINT32_MAX, hi = 0;
     for (uint32_t x = x0; x < x1; ++x) {
         lo = std::min(lo, h.left[x]);
         hi = std::max(hi, h.left[x] + h.count[x]);
-        hmax = std::max(hmax, h.count[x]);
     }
-    out.sx0 = lo - (lo % align_px);
+    out.sx0 = lo - (lo % ppl);
     out.sx1 = hi;
-    out.hmax = (hmax + 3u) & ~3u;
     const uint32_t n = x1 - x0;
-    out.left_rel.resize(n);
-    out.w4.assign((size_t)out.hmax * n, 0.0f);
+    // first / last contributing lane of every column
+    std::vector<uint32_t> ta(n), tb(n);
     for (uint32_t x = x0; x < x1; ++x) {
-        const uint32_t xl = x - x0;
-        out.left_rel[xl] = h.left[x] - out.sx0;
-        for (uint32_t i = 0; i < h.count[x]; ++i)
-            out.w4[((size_t)(i >> 2) * n + xl) * 4 + (i & 3)] = h.weights[h.woff[x] + i];
+        ta[x - x0] = (h.left[x] - out.sx0) / ppl;
+        tb[x - x0] = (h.left[x] + h.count[x] - 1 - out.sx0) / ppl;
+        out.kmax = std::max(out.kmax, tb[x - x0] - ta[x - x0] + 1);
     }
+    out.ks = out.kmax | 1u;
+    // columns touched by every lane (windows are monotone, so they form a contiguous range)
+    std::vector<uint32_t> xa(lanes, 0), cnt(lanes, 0);
+    for (uint32_t t = 0; t < lanes; ++t) {
+        uint32_t first = UINT32_MAX, last = 0;
+        for (uint32_t xl = 0; xl < n; ++xl)
+            if (ta[xl] <= t && t <= tb[xl]) { first = std::min(first, xl); last = xl; }
+        if (first != UINT32_MAX) { xa[t] = first; cnt[t] = last - first + 1; }
+        out.jmax = std::max(out.jmax, cnt[t]);
+    }
+    out.jmax = std::max(4u, (out.jmax + 3u) & ~3u); // the kernel unrolls its column loop by 4
+    const uint32_t dummy = n * out.ks * 16u;
+    out.wt.assign((size_t)out.jmax * lanes * 4, 0.0f);
+    out.po.assign((size_t)out.jmax * lanes, dummy);
+    for (uint32_t t = 0; t < lanes; ++t)
+        for (uint32_t j = 0; j < cnt[t]; ++j) {
+            const uint32_t xl = xa[t] + j, x = x0 + xl;
+            if (!(ta[xl] <= t && t <= tb[xl])) continue; // cannot happen for monotone windows
+            for (uint32_t p = 0; p < ppl && p < 4; ++p) {
+                const int64_t i = (int64_t)out.sx0 + (int64_t)t * ppl + p - (int64_t)h.left[x];
+                if (i >= 0 && i < (int64_t)h.count[x]) out.wt[((size_t)j * lanes + t) * 4 + p] = h.weights[h.woff[x] + (uint32_t)i];
+            }
+            out.po[(size_t)j * lanes + t] = (xl * out.ks + (t - ta[xl])) * 16u;
+        }
 }
 
 void build_webp_gamma(std::vector<uint32_t> &out)

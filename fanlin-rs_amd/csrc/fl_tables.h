@@ -36,14 +36,20 @@ void resize_dimensions(uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, bool fi
 bool build_row_sched(const HostAxis &v, uint32_t y0, uint32_t y1, uint32_t nacc, uint32_t block, uint32_t &r0,
                      uint32_t &r1, std::vector<RowSched> &out);
 
-// Horizontal tile of output columns [x0,x1): left[] relative to sx0 and
-// weights laid out [hmax/4][x1-x0][4] (tap-major float4, zero padded).
+// Horizontal tile of output columns [x0,x1) for the streaming kernel.  The kernel's horizontal pass is
+// input-stationary: lane t owns source pixels sx0 + 4t .. +3 of the finished f32 row (they are still in
+// its registers), multiplies them into one partial sum per output column whose window they touch, and a
+// second step adds each column's partial sums in ascending pixel order.  So the tables are per lane:
+//   wt[j][t] = the 4 weights of lane t's pixels towards its j-th column (0 outside the window),
+//   po[j][t] = LDS byte offset of that partial sum: ((x - x0) * ks + k) * 16 with k = ordinal of lane t
+//              among the lanes contributing to column x; unused entries point at a dummy slot.
 struct HostStrip {
-    uint32_t x0 = 0, x1 = 0, sx0 = 0, sx1 = 0, hmax = 0;
-    std::vector<uint32_t> left_rel;
-    std::vector<float> w4;
+    uint32_t x0 = 0, x1 = 0, sx0 = 0, sx1 = 0;
+    uint32_t jmax = 0, kmax = 0, ks = 0;
+    std::vector<float> wt;     // [jmax][lanes][4]
+    std::vector<uint32_t> po;  // [jmax][lanes]
 };
-void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t align_px, HostStrip &out);
+void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t lanes, uint32_t px_per_lane, HostStrip &out);
 
 // libwebp picture_csp_enc.c InitGammaTables: kGammaToLinearTab[256] then kLinearToGammaTab[33], as int32.
 void build_webp_gamma(std::vector<uint32_t> &out);

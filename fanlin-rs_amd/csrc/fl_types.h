@@ -68,11 +68,13 @@ struct alignas(16) StreamItem {
     uint32_t r0, r1;     // source rows walked [r0,r1)
     uint32_t sx0;        // source pixel column of lane 0
     uint32_t sched_off;  // arena word offset: RowSched[r1-r0]
-    uint32_t hleft_off;  // arena word offset: left[x1-x0], relative to sx0
-    uint32_t hw_off;     // arena word offset: weights, tap-major [hmax][x1-x0], zero padded
-    uint32_t hmax;       // taps per output column in this strip (max)
+    uint32_t wt_off;     // arena word offset: float4 WT[jmax][256] - lane t's 4 pixel weights towards its j-th output column
+    uint32_t po_off;     // arena word offset: uint32 PO[jmax][256] - LDS byte offset of that partial sum (dummy slot if unused)
+    uint32_t jmax;       // output columns one lane contributes to (max over lanes)
+    uint32_t kmax;       // lanes contributing to one output column (max over columns)
+    uint32_t ks;         // odd slot stride per output column in the partial-sum buffer (>= kmax)
     uint32_t flags;      // ITEM_* letterbox duties
-    uint32_t pad0, pad1, pad2;
+    uint32_t pad0;
 };
 enum : uint32_t { ITEM_FIRST_BAND = 1, ITEM_LAST_BAND = 2, ITEM_FIRST_STRIP = 4, ITEM_LAST_STRIP = 8 };
 

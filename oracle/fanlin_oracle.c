@@ -250,13 +250,27 @@ static uint8_t *horizontal_sample_f32(const float *img, uint32_t width, uint32_t
         uint32_t n = right - left;
         for (uint32_t y = 0; y < height; ++y) {
             float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (uint32_t i = 0; i < n; ++i) {
-                const float *p = img + ((size_t)y * width + left + i) * 4;
-                float w = ws[i];
-                t[0] = acc_step(t[0], p[0], w, arith);
-                t[1] = acc_step(t[1], p[1], w, arith);
-                t[2] = acc_step(t[2], p[2], w, arith);
-                t[3] = acc_step(t[3], p[3], w, arith);
+            if (arith == FO_ARITH_FMA) {
+                /* The HIP kernels' horizontal order: taps grouped by aligned blocks of 4 source
+                 * pixels, one fused multiply-add per tap inside a block (from 0), block sums
+                 * added in ascending order. */
+                float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (uint32_t i = 0; i < n; ++i) {
+                    if (i != 0 && ((left + i) & 3u) == 0u)
+                        for (int k = 0; k < 4; ++k) { t[k] = t[k] + part[k]; part[k] = 0.0f; }
+                    const float *p = img + ((size_t)y * width + left + i) * 4;
+                    for (int k = 0; k < 4; ++k) part[k] = fmaf(p[k], ws[i], part[k]);
+                }
+                for (int k = 0; k < 4; ++k) t[k] = t[k] + part[k];
+            } else {
+                for (uint32_t i = 0; i < n; ++i) {
+                    const float *p = img + ((size_t)y * width + left + i) * 4;
+                    float w = ws[i];
+                    t[0] = acc_step(t[0], p[0], w, arith);
+                    t[1] = acc_step(t[1], p[1], w, arith);
+                    t[2] = acc_step(t[2], p[2], w, arith);
+                    t[3] = acc_step(t[3], p[3], w, arith);
+                }
             }
             uint8_t *o = out + ((size_t)y * new_w + outx) * c;
             for (uint32_t k = 0; k < c; ++k) o[k] = to_u8_nearest(t[k]);

@@ -34,9 +34,11 @@ typedef struct fo_image {
 /* How t += v * w is evaluated in the resample loops.
  * FO_ARITH_REF: separate f32 multiply then f32 add -- what rustc emits for the
  *               reference (no contraction).  This is THE reference arithmetic.
- * FO_ARITH_FMA: one fused fmaf per tap, same tap order -- the arithmetic of the
- *               HIP kernels, used to prove the kernels bit-exact against a CPU
- *               restatement; differs from FO_ARITH_REF by <= 1 LSB. */
+ * FO_ARITH_FMA: the arithmetic of the HIP kernels, used to prove the kernels
+ *               bit-exact against a CPU restatement: one fused fmaf per tap; the
+ *               vertical pass in tap order, the horizontal pass grouped by aligned
+ *               blocks of 4 source pixels (block sums added in ascending order).
+ *               Differs from FO_ARITH_REF by <= 1 LSB. */
 enum { FO_ARITH_REF = 0, FO_ARITH_FMA = 1 };
 
 enum { FO_FILTER_LANCZOS3 = 0, FO_FILTER_GAUSSIAN = 1, FO_FILTER_NEAREST = 2, FO_FILTER_TRIANGLE = 3 };
