@@ -45,7 +45,7 @@ def shard_batches(global_images: int, world: int):
     return [(r * per, (r + 1) * per) for r in range(world)]
 
 
-def cpu_baseline(n_images: int, workload: dict):
+def cpu_baseline(n_images: int, workload: dict, max_threads: int = 16):
     """Times the CPU oracle (reference arithmetic, one image per thread, like one request per
     tokio worker) on a bounded sample of the same workload.  Reported, never a target."""
     import numpy as np
@@ -54,7 +54,8 @@ def cpu_baseline(n_images: int, workload: dict):
     import oracle_lib
     import synth
     oracle = oracle_lib.load()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, max_threads))  # a 1-GPU box's CPU share is 16 cores, whatever the host exposes
     imgs = [synth.uniform(SRC_H, SRC_W, SRC_C, index=1000 + i) for i in range(min(n_images, 8))]
 
     def one(i):
@@ -85,7 +86,8 @@ def main():
     ap.add_argument("--grayscale", action="store_true")
     ap.add_argument("--crop", action="store_true")
     ap.add_argument("--frontend", choices=["none", "jfif444", "webp420"], default="none")
-    ap.add_argument("--cpu-images", type=int, default=128, help="CPU-baseline sample size (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=1024, help="CPU-baseline sample size (0 = skip); ~14 ms of CPU work per image")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (one image per thread)")
     args = ap.parse_args()
 
     import torch
@@ -190,7 +192,7 @@ def main():
                                   "frontend": stats["frontend_ms"] / args.steps},
         }
         if args.cpu_images > 0 and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_images, workload)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_images, workload, args.cpu_threads)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -1,0 +1,88 @@
+"""The C-ABI shared library loads on a machine without a GPU, exports every symbol include/fanlin_gpu.h
+declares, agrees with the ctypes mirrors on struct layout, and refuses to run without a device (no CPU
+fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fanlin_gpu.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(flgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(fl):
+    lib = fl.load_library()
+    names = declared_functions()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(fl.EXPORTED_SYMBOLS) == names, "python binding list is out of date with the header"
+    assert lib.flgpu_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(fl):
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "fanlin_gpu.h"
+int main(void) {
+  printf("flgpu_image %zu %zu %zu\n", sizeof(flgpu_image), offsetof(flgpu_image, width), offsetof(flgpu_image, flags));
+  printf("flgpu_query %zu %zu %zu\n", sizeof(flgpu_query), offsetof(flgpu_query, w), offsetof(flgpu_query, rgb));
+  printf("flgpu_params %zu %zu %zu\n", sizeof(flgpu_params), offsetof(flgpu_params, blur_sigma), offsetof(flgpu_params, front_end));
+  printf("flgpu_plan %zu %zu %zu\n", sizeof(flgpu_plan), offsetof(flgpu_plan, out_w), offsetof(flgpu_plan, out_bytes));
+  printf("flgpu_config %zu %zu %zu\n", sizeof(flgpu_config), offsetof(flgpu_config, profile), offsetof(flgpu_config, reserved));
+  printf("flgpu_stats %zu %zu %zu\n", sizeof(flgpu_stats), offsetof(flgpu_stats, resample_ms), offsetof(flgpu_stats, frontend_ms));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)  # header must be plain C
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    got = {l.split()[0]: tuple(int(x) for x in l.split()[1:]) for l in out.strip().splitlines()}
+    S = fl
+    want = {
+        "flgpu_image": (C.sizeof(S.flgpu_image), S.flgpu_image.width.offset, S.flgpu_image.flags.offset),
+        "flgpu_query": (C.sizeof(S.flgpu_query), S.flgpu_query.w.offset, S.flgpu_query.rgb.offset),
+        "flgpu_params": (C.sizeof(S.flgpu_params), S.flgpu_params.blur_sigma.offset, S.flgpu_params.front_end.offset),
+        "flgpu_plan": (C.sizeof(S.flgpu_plan), S.flgpu_plan.out_w.offset, S.flgpu_plan.out_bytes.offset),
+        "flgpu_config": (C.sizeof(S.flgpu_config), S.flgpu_config.profile.offset, S.flgpu_config.reserved.offset),
+        "flgpu_stats": (C.sizeof(S.flgpu_stats), S.flgpu_stats.resample_ms.offset, S.flgpu_stats.frontend_ms.offset),
+    }
+    assert got == want
+
+
+def test_no_cpu_fallback_without_a_device(fl):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(fl.FanlinError) as e:
+        fl.State()
+    assert e.value.status == 3  # FLGPU_ERR_NO_DEVICE
+
+
+def test_product_library_does_not_link_the_oracle(fl):
+    out = subprocess.run(["ldd", fl.LIB_PATH], capture_output=True, text=True).stdout
+    assert "fanlin_oracle" not in out
+    syms = subprocess.run(["nm", "-D", fl.LIB_PATH], capture_output=True, text=True).stdout
+    assert " fo_" not in syms
+
+
+def test_error_strings(fl):
+    lib = fl.load_library()
+    seen = set()
+    for code in range(0, 9):
+        s = lib.flgpu_strerror(code).decode()
+        assert s and s != "unknown status"
+        seen.add(s)
+    assert len(seen) == 9 and lib.flgpu_strerror(99).decode() == "unknown status"
