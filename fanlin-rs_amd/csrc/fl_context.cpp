@@ -487,7 +487,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::vector<Job> jobs;
     std::vector<StreamItem> items;
     std::vector<FrontendJob> fjobs;
-    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc; LaunchGeneric g; size_t lds; size_t mid_floats; };
+    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc; LaunchGeneric g; size_t lds; size_t mid_floats; uint32_t blur_grid_x; bool blur_tiled; };
     std::vector<S1Launch> s1_launches, blur_launches;
     struct FeLaunch { uint32_t kind, base, n, mw, mh; };
     std::vector<FeLaunch> fe_launches;
@@ -497,7 +497,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     auto new_launch = [&](const GroupKey &k) {
         S1Launch L{};
         L.k = k; L.job_base = (uint32_t)jobs.size(); L.item_base = (uint32_t)items.size();
-        L.g.cs = k.cs; L.g.pre = k.pre; L.g.letterbox = k.lb;
+        L.g.cs = k.cs; L.g.pre = k.pre; L.g.letterbox = k.lb; L.g.grouped = 1;
         return L;
     };
     for (auto &kv : s1_groups) {
@@ -544,6 +544,15 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             j.htab = get_axis(c, pl.out_w, pl.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, nullptr, nullptr);
             const size_t mid = (size_t)pl.out_w * pl.out_h * pl.out_c;
             if (L.njobs && L.mid_floats + mid > kMidCapFloats) { blur_launches.push_back(L); L = new_launch(k); }
+            {
+                const AxisTable *vh = reinterpret_cast<const AxisTable *>(c->h_arena.data() + j.vtab);
+                const AxisTable *hh = reinterpret_cast<const AxisTable *>(c->h_arena.data() + j.htab);
+                if (L.njobs == 0) L.blur_tiled = true;
+                const size_t lds = blur_lds_bytes(pl.out_w, pl.out_c, vh->max_taps, hh->max_taps);
+                if (!blur_tile_supported(hh->max_taps) || !blur_tile_supported(vh->max_taps) || lds > 150 * 1024) L.blur_tiled = false;
+                L.lds = std::max(L.lds, lds);
+                L.blur_grid_x = std::max(L.blur_grid_x, blur_grid_x(pl.out_w, pl.out_h, hh->max_taps));
+            }
             j.mid_off = (uint32_t)L.mid_floats;
             L.mid_floats += mid;
             mid_floats_max = std::max(mid_floats_max, L.mid_floats);
@@ -630,9 +639,14 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     for (auto &L : blur_launches) {
         L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
         L.g.job_base = L.job_base; L.g.njobs = L.njobs; L.g.pre = PRE_NONE; L.g.letterbox = 0;
+        L.g.grouped = 0;
         ProfileScope ps(c, st, 1);
-        FL_HIP(c, launch_vpass_generic(L.g, st), "blur vertical pass");
-        FL_HIP(c, launch_hpass_generic(L.g, st), "blur horizontal pass");
+        if (L.blur_tiled && !force_generic) {
+            FL_HIP(c, launch_blur_tile(L.g, L.blur_grid_x, L.lds, st), "blur kernel");
+        } else {
+            FL_HIP(c, launch_vpass_generic(L.g, st), "blur vertical pass");
+            FL_HIP(c, launch_hpass_generic(L.g, st), "blur horizontal pass");
+        }
         c->stats.blur_launches++;
     }
     for (auto &F : fe_launches) {

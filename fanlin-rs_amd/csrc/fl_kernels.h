@@ -28,6 +28,7 @@ struct LaunchGeneric {
     uint32_t njobs;
     uint32_t cs, pre;       // source channels, PreOp
     uint32_t letterbox;     // destination is Rgba8 over the fill colour
+    uint32_t grouped;       // horizontal pass sums by aligned 4-pixel blocks (Lanczos3 resize) instead of tap by tap (blur)
     uint32_t max_sw, max_rh;  // vertical pass grid
     uint32_t max_cw, max_ch;  // horizontal pass grid
     uint32_t max_dw, max_dh;  // placement grid
@@ -46,6 +47,12 @@ struct LaunchStream {
 hipError_t launch_vpass_generic(const LaunchGeneric &g, hipStream_t st);
 hipError_t launch_hpass_generic(const LaunchGeneric &g, hipStream_t st);
 hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st);
+
+// fused LDS-tiled Gaussian blur (g.cs = channels of the blurred image; g.jobs[i].vtab/htab = Gaussian tables)
+bool blur_tile_supported(uint32_t htaps);
+size_t blur_lds_bytes(uint32_t w, uint32_t channels, uint32_t vtaps, uint32_t htaps);
+uint32_t blur_grid_x(uint32_t w, uint32_t h, uint32_t htaps);
+hipError_t launch_blur_tile(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st);
 
 bool stream_supported(uint32_t cs, uint32_t pre);
 uint32_t stream_block_rows(); // source rows per block of the streaming kernel (emits are deferred to block ends)

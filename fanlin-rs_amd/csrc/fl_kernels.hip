@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void vpass_generic_kernel(const Job *__restric
     for (int k = 0; k < MC; ++k) o[k] = acc[k];
 }
 
-template <int MC, bool LB>
+template <int MC, bool LB, bool GROUPED>
 __global__ __launch_bounds__(256) void hpass_generic_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ arena,
                                                             const float *__restrict__ mid, uint32_t job_base)
 {
@@ -178,14 +178,15 @@ __global__ __launch_bounds__(256) void hpass_generic_kernel(const Job *__restric
     const uint32_t n = arena[tab->count_off + x];
     const float *w = reinterpret_cast<const float *>(arena + tab->weights_off + arena[tab->woff_off + x]);
     const float *p = mid + (size_t)jb.mid_off + ((size_t)y * jb.sw + left) * MC;
-    // Horizontal summation order of every kernel in this file (and of the oracle's FO_ARITH_FMA mode):
-    // taps are grouped by aligned blocks of 4 source pixels; inside a block one fused multiply-add per
-    // tap in ascending order starting from 0, then the block sums are added in ascending order.
+    // Horizontal summation order (also the oracle's FO_ARITH_FMA mode).  Lanczos3 resize (GROUPED): taps are
+    // grouped by aligned blocks of 4 source pixels; inside a block one fused multiply-add per tap in
+    // ascending order starting from 0, then the block sums are added in ascending order.  Gaussian blur:
+    // one fused multiply-add per tap in tap order.
     float acc[MC], part[MC];
 #pragma unroll
     for (int k = 0; k < MC; ++k) { acc[k] = 0.0f; part[k] = 0.0f; }
     for (uint32_t i = 0; i < n; ++i) {
-        if (i != 0 && ((left + i) & 3u) == 0u) {
+        if (GROUPED && i != 0 && ((left + i) & 3u) == 0u) {
 #pragma unroll
             for (int k = 0; k < MC; ++k) { acc[k] = acc[k] + part[k]; part[k] = 0.0f; }
         }
@@ -510,6 +511,148 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
 }
 
 // ---------------------------------------------------------------------------
+// Separable Gaussian blur (image 0.25.6 imageops::blur = the same two-pass machinery with ratio 1 and
+// support 2*sigma: 41..81 taps, windows truncated and renormalised at the borders).
+//
+// One workgroup = one image x a band of BLUR_TY output rows x a tile of <= T - (taps-1) output columns.
+//   vertical pass   lane <-> source column (tile + halo).  Every source row of the band's window is loaded
+//                   once (u8 -> f32 once) and accumulated into the BLUR_TY output rows in registers; the
+//                   weights are wave-uniform (dense [row][BLUR_TY] table staged in LDS, broadcast reads).
+//   hand-off        the BLUR_TY unrounded f32 rows go to LDS, lane-contiguous.
+//   horizontal pass lane <-> output column.  Neighbouring lanes read neighbouring pixels (ratio 1), so the
+//                   LDS reads are conflict free; one weight read feeds BLUR_TY rows x C channels of FMAs.
+// ---------------------------------------------------------------------------
+
+constexpr int BLUR_TY = 8;
+constexpr uint32_t BLUR_T = 256;
+
+__host__ __device__ inline uint32_t blur_tiles(uint32_t w, uint32_t taps) { const uint32_t cap = BLUR_T - (taps - 1); return (w + cap - 1) / cap; }
+
+template <int C>
+__global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ arena,
+                                                        uint32_t job_base)
+{
+    constexpr int MS = C == 3 ? 4 : C; // floats per pixel in LDS
+    constexpr uint32_t T = BLUR_T;
+    const Job jb = jobs[job_base + blockIdx.y];
+    const uint32_t w = jb.sw, h = jb.sh;
+    const AxisTable *vt = reinterpret_cast<const AxisTable *>(arena + jb.vtab);
+    const AxisTable *ht = reinterpret_cast<const AxisTable *>(arena + jb.htab);
+    const uint32_t htaps = ht->max_taps, vtaps = vt->max_taps;
+    const uint32_t nt = blur_tiles(w, htaps), nb = (h + BLUR_TY - 1) / BLUR_TY;
+    if (blockIdx.x >= nt * nb) return;
+    const uint32_t band = blockIdx.x / nt, tile = blockIdx.x % nt;
+    const uint32_t tw_full = (w + nt - 1) / nt;
+    const uint32_t x0 = tile * tw_full, tw = min(tw_full, w - x0);
+    const uint32_t y0 = band * BLUR_TY, ty = min((uint32_t)BLUR_TY, h - y0);
+    const uint32_t tid = threadIdx.x;
+
+    // source column window of the tile and source row window of the band (from the tables: monotone)
+    const uint32_t cl = arena[ht->left_off + x0];
+    const uint32_t cr = arena[ht->left_off + x0 + tw - 1] + arena[ht->count_off + x0 + tw - 1];
+    const uint32_t top = arena[vt->left_off + y0];
+    const uint32_t bot = arena[vt->left_off + y0 + ty - 1] + arena[vt->count_off + y0 + ty - 1];
+    const uint32_t ncols = cr - cl, nrows = bot - top;   // ncols <= T by construction of the tiling
+
+    // LDS: [ wv: (BLUR_TY + vtaps) x BLUR_TY | mid: BLUR_TY x (T + htaps) x MS | wh: htaps x tw ]
+    float *wv = fl_lds;
+    const uint32_t wv_floats = ((BLUR_TY + vtaps) * BLUR_TY + 3u) & ~3u;
+    const uint32_t midw = T + htaps;
+    float *mid = fl_lds + wv_floats;
+    float *wh = mid + (size_t)BLUR_TY * midw * MS;
+
+    for (uint32_t i = tid; i < wv_floats; i += T) wv[i] = 0.0f;
+    for (uint32_t i = tid; i < BLUR_TY * midw * MS; i += T) mid[i] = 0.0f;
+    __syncthreads();
+    for (uint32_t o = 0; o < ty; ++o) {
+        const uint32_t l = arena[vt->left_off + y0 + o], n = arena[vt->count_off + y0 + o];
+        const float *src = reinterpret_cast<const float *>(arena + vt->weights_off + arena[vt->woff_off + y0 + o]);
+        for (uint32_t i = tid; i < n; i += T) wv[(l + i - top) * BLUR_TY + o] = src[i];
+    }
+    uint32_t hleft = 0;
+    if (tid < tw) {
+        const uint32_t x = x0 + tid;
+        const uint32_t l = arena[ht->left_off + x], n = arena[ht->count_off + x];
+        const float *src = reinterpret_cast<const float *>(arena + ht->weights_off + arena[ht->woff_off + x]);
+        hleft = l - cl;
+        for (uint32_t i = 0; i < htaps; ++i) wh[i * tw + tid] = i < n ? src[i] : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- vertical pass ----
+    float acc[BLUR_TY][C];
+#pragma unroll
+    for (int o = 0; o < BLUR_TY; ++o)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[o][c] = 0.0f;
+    if (tid < ncols) {
+        const uint8_t *p = jb.src + ((size_t)top * w + cl + tid) * C;
+        const size_t pitch = (size_t)w * C;
+        for (uint32_t r = 0; r < nrows; ++r) {
+            float v[C];
+            if constexpr (C == 4) {
+                const uint32_t d = *reinterpret_cast<const uint32_t *>(p);
+                v[0] = (float)(d & 255u); v[1] = (float)((d >> 8) & 255u); v[2] = (float)((d >> 16) & 255u); v[3] = (float)(d >> 24);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[c] = (float)p[c];
+            }
+            const f32x4 wa = *reinterpret_cast<const f32x4 *>(wv + r * BLUR_TY);
+            const f32x4 wb = *reinterpret_cast<const f32x4 *>(wv + r * BLUR_TY + 4);
+#pragma unroll
+            for (int o = 0; o < BLUR_TY; ++o) {
+                const float wo = o == 0 ? wa.x : o == 1 ? wa.y : o == 2 ? wa.z : o == 3 ? wa.w : o == 4 ? wb.x : o == 5 ? wb.y : o == 6 ? wb.z : wb.w;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[o][c] = __builtin_fmaf(v[c], wo, acc[o][c]);
+            }
+            p += pitch;
+        }
+#pragma unroll
+        for (int o = 0; o < BLUR_TY; ++o) {
+            float *m = mid + ((size_t)o * midw + tid) * MS;
+#pragma unroll
+            for (int c = 0; c < C; ++c) m[c] = acc[o][c];
+        }
+    }
+    __syncthreads();
+
+    // ---- horizontal pass (tap order: one fused multiply-add per tap) ----
+    if (tid < tw) {
+#pragma unroll
+        for (int o = 0; o < BLUR_TY; ++o)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[o][c] = 0.0f;
+        const float *m0 = mid + (size_t)hleft * MS;
+        for (uint32_t i = 0; i < htaps; ++i) {
+            const float wi = wh[i * tw + tid];
+#pragma unroll
+            for (int o = 0; o < BLUR_TY; ++o) {
+                const float *px = m0 + ((size_t)o * midw + i) * MS;
+                if constexpr (MS == 4) {
+                    const f32x4 q = *reinterpret_cast<const f32x4 *>(px);
+                    acc[o][0] = __builtin_fmaf(q.x, wi, acc[o][0]);
+                    if constexpr (C > 1) acc[o][1] = __builtin_fmaf(q.y, wi, acc[o][1]);
+                    if constexpr (C > 2) acc[o][2] = __builtin_fmaf(q.z, wi, acc[o][2]);
+                    if constexpr (C > 3) acc[o][3] = __builtin_fmaf(q.w, wi, acc[o][3]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[o][c] = __builtin_fmaf(px[c], wi, acc[o][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < BLUR_TY; ++o) {
+            if ((uint32_t)o < ty) {
+                uint32_t c8[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) c8[c] = round_u8(acc[o][c]);
+                store_pixel<C, false>(jb.dst, (y0 + o) * w + x0 + tid, c8, 0u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Encoder colour front ends
 // ---------------------------------------------------------------------------
 
@@ -632,7 +775,8 @@ template <int MC, bool LB>
 static hipError_t launch_hpass_t(const LaunchGeneric &g, hipStream_t st)
 {
     dim3 grid((g.max_cw + 255u) / 256u, g.max_ch, g.njobs);
-    hipLaunchKernelGGL((hpass_generic_kernel<MC, LB>), grid, dim3(256), 0, st, g.jobs, g.arena, g.mid, g.job_base);
+    if (g.grouped) hipLaunchKernelGGL((hpass_generic_kernel<MC, LB, true>), grid, dim3(256), 0, st, g.jobs, g.arena, g.mid, g.job_base);
+    else hipLaunchKernelGGL((hpass_generic_kernel<MC, LB, false>), grid, dim3(256), 0, st, g.jobs, g.arena, g.mid, g.job_base);
     FL_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -669,6 +813,42 @@ hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st
     FL_CASE(3, PRE_NONE); FL_CASE(3, PRE_GRAY); FL_CASE(3, PRE_INVERT);
     FL_CASE(4, PRE_NONE); FL_CASE(4, PRE_GRAY); FL_CASE(4, PRE_INVERT);
 #undef FL_CASE
+    return hipErrorInvalidValue;
+}
+
+size_t blur_lds_bytes(uint32_t w, uint32_t channels, uint32_t vtaps, uint32_t htaps)
+{
+    const uint32_t ms = channels == 3 ? 4 : channels;
+    const uint32_t nt = blur_tiles(w, htaps), tw = (w + nt - 1) / nt;
+    const size_t wv = (((size_t)(BLUR_TY + vtaps) * BLUR_TY + 3) & ~(size_t)3);
+    return (wv + (size_t)BLUR_TY * (BLUR_T + htaps) * ms + (size_t)htaps * tw) * sizeof(float);
+}
+
+uint32_t blur_grid_x(uint32_t w, uint32_t h, uint32_t htaps) { return blur_tiles(w, htaps) * ((h + BLUR_TY - 1) / BLUR_TY); }
+
+bool blur_tile_supported(uint32_t htaps) { return htaps >= 1 && htaps <= 128; }
+
+template <int C>
+static hipError_t launch_blur_t(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st)
+{
+    auto k = blur_tile_kernel<C>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid_x, g.njobs), dim3(BLUR_T), lds, st, g.jobs, g.arena, g.job_base);
+    FL_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_blur_tile(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st)
+{
+    switch (g.cs) {
+    case 1: return launch_blur_t<1>(g, grid_x, lds, st);
+    case 2: return launch_blur_t<2>(g, grid_x, lds, st);
+    case 3: return launch_blur_t<3>(g, grid_x, lds, st);
+    case 4: return launch_blur_t<4>(g, grid_x, lds, st);
+    }
     return hipErrorInvalidValue;
 }
 

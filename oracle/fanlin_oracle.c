@@ -236,7 +236,7 @@ static inline uint8_t to_u8_nearest(float t)
 
 /* sample.rs::horizontal_sample: Rgba32F -> u8, first c channels kept. */
 static uint8_t *horizontal_sample_f32(const float *img, uint32_t width, uint32_t height, uint32_t c,
-                                      uint32_t new_w, const fo_filter *f, int arith)
+                                      uint32_t new_w, const fo_filter *f, int arith, int grouped)
 {
     uint8_t *out = (uint8_t *)malloc((size_t)new_w * height * c + 16);
     float *ws = (float *)malloc(sizeof(float) * (size_t)width);
@@ -250,8 +250,8 @@ static uint8_t *horizontal_sample_f32(const float *img, uint32_t width, uint32_t
         uint32_t n = right - left;
         for (uint32_t y = 0; y < height; ++y) {
             float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (arith == FO_ARITH_FMA) {
-                /* The HIP kernels' horizontal order: taps grouped by aligned blocks of 4 source
+            if (arith == FO_ARITH_FMA && grouped) {
+                /* The HIP kernels' horizontal order for the Lanczos3 resize: taps grouped by aligned blocks of 4 source
                  * pixels, one fused multiply-add per tap inside a block (from 0), block sums
                  * added in ascending order. */
                 float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -290,11 +290,13 @@ static int clone_image(const fo_image *src, fo_image *dst)
     return 0;
 }
 
-static int sample_two_pass(const fo_image *src, uint32_t nw, uint32_t nh, const fo_filter *f, int arith, fo_image *dst)
+/* grouped: FO_ARITH_FMA sums the horizontal taps by aligned blocks of 4 source pixels (resize kernels);
+ * the blur kernels accumulate tap by tap. */
+static int sample_two_pass(const fo_image *src, uint32_t nw, uint32_t nh, const fo_filter *f, int arith, int grouped, fo_image *dst)
 {
     float *tmp = vertical_sample_u8(src, nh, f, arith);
     if (!tmp) return -1;
-    uint8_t *out = horizontal_sample_f32(tmp, src->w, nh, src->c, nw, f, arith);
+    uint8_t *out = horizontal_sample_f32(tmp, src->w, nh, src->c, nw, f, arith, grouped);
     free(tmp);
     if (!out) return -1;
     dst->w = nw; dst->h = nh; dst->c = src->c; dst->px = out;
@@ -312,7 +314,7 @@ int fo_resize_exact(const fo_image *src, uint32_t nw, uint32_t nh, int filter, i
         return dst->px ? 0 : -1;
     }
     if (nw == src->w && nh == src->h) return clone_image(src, dst);
-    return sample_two_pass(src, nw, nh, &f, arith, dst);
+    return sample_two_pass(src, nw, nh, &f, arith, 1, dst);
 }
 
 /* DynamicImage::resize */
@@ -362,7 +364,7 @@ int fo_blur(const fo_image *src, float sigma, int arith, fo_image *dst)
     if (sigma <= 0.0f) sigma = 1.0f;
     make_filter(FO_FILTER_GAUSSIAN, sigma, &f);
     if (src->w == 0 || src->h == 0) return clone_image(src, dst);
-    return sample_two_pass(src, src->w, src->h, &f, arith, dst);
+    return sample_two_pass(src, src->w, src->h, &f, arith, 0, dst);
 }
 
 /* ----------------------------------------------------------- letterbox -- */

@@ -36,8 +36,9 @@ typedef struct fo_image {
  *               reference (no contraction).  This is THE reference arithmetic.
  * FO_ARITH_FMA: the arithmetic of the HIP kernels, used to prove the kernels
  *               bit-exact against a CPU restatement: one fused fmaf per tap; the
- *               vertical pass in tap order, the horizontal pass grouped by aligned
- *               blocks of 4 source pixels (block sums added in ascending order).
+ *               vertical pass in tap order; the horizontal pass of the Lanczos3 resize
+ *               grouped by aligned blocks of 4 source pixels (block sums added in
+ *               ascending order), the horizontal pass of the blur in tap order.
  *               Differs from FO_ARITH_REF by <= 1 LSB. */
 enum { FO_ARITH_REF = 0, FO_ARITH_FMA = 1 };
 
