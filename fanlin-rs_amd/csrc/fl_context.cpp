@@ -625,8 +625,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             FL_HIP(c, launch_hpass_generic(L.g, st), "generic horizontal pass");
             c->stats.generic_launches++;
         } else {
-            if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
-            LaunchStream s{};
+            LaunchStream s{}; // (the streaming kernel paints the letterbox frame itself)
             s.jobs = d_jobs; s.items = d_items + L.item_base; s.arena = c->d_arena; s.nitems = L.nitems;
             s.cs = L.k.cs; s.pre = L.k.pre; s.letterbox = L.k.lb; s.lds_bytes = L.lds; s.nacc = L.nacc;
             {

@@ -363,6 +363,33 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
     const uint32_t voff = (it.sx0 + tid * PXL) * CS + it.r0 * pitch;
     const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (it.x0 - jb.cx);
 
+    // Letterbox border: every workgroup paints the part of the fill frame that lies next to its own band
+    // and strip (first/last band own the rows above/below the picture, first/last strip the side margins),
+    // so no separate fill kernel runs over the destination.
+    if (LB) {
+        const uint32_t dx0 = it.x0 == jb.cx ? 0u : jb.ox + it.x0 - jb.cx;
+        const uint32_t dx1 = it.x1 == jb.cx + jb.cw ? jb.dw : jb.ox + it.x1 - jb.cx;
+        const uint32_t dy0 = it.y0 == jb.cy ? 0u : jb.oy + it.y0 - jb.cy;
+        const uint32_t dy1 = it.y1 == jb.cy + jb.ch ? jb.dh : jb.oy + it.y1 - jb.cy;
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(jb.dst);
+        // (hidden stores, like every store of this kernel: see load_row)
+        // rows above and below the placed picture
+        const uint32_t wcols = dx1 - dx0;
+        const uint32_t top_rows = dy0 < jb.oy ? min(dy1, jb.oy) - dy0 : 0u;
+        for (uint32_t i = tid; i < top_rows * wcols; i += T) store_hidden_b32(d32 + (dy0 + i / wcols) * jb.dw + dx0 + i % wcols, jb.fill);
+        const uint32_t by0 = max(dy0, jb.oy + jb.ch);
+        const uint32_t bot_rows = dy1 > by0 ? dy1 - by0 : 0u;
+        for (uint32_t i = tid; i < bot_rows * wcols; i += T) store_hidden_b32(d32 + (by0 + i / wcols) * jb.dw + dx0 + i % wcols, jb.fill);
+        // side margins of the rows that hold the picture
+        const uint32_t my0 = max(dy0, jb.oy), my1 = min(dy1, jb.oy + jb.ch);
+        const uint32_t mrows = my1 > my0 ? my1 - my0 : 0u;
+        const uint32_t lcols = dx0 < jb.ox ? min(dx1, jb.ox) - dx0 : 0u;
+        for (uint32_t i = tid; i < mrows * lcols; i += T) store_hidden_b32(d32 + (my0 + i / lcols) * jb.dw + dx0 + i % lcols, jb.fill);
+        const uint32_t rx0 = max(dx0, jb.ox + jb.cw);
+        const uint32_t rcols = dx1 > rx0 ? dx1 - rx0 : 0u;
+        for (uint32_t i = tid; i < mrows * rcols; i += T) store_hidden_b32(d32 + (my0 + i / rcols) * jb.dw + rx0 + i % rcols, jb.fill);
+    }
+
     float acc[NA][NV];
 #pragma unroll
     for (int s = 0; s < NA; ++s)
