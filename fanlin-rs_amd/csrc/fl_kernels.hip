@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
             case 6: take_slot<NV>(acc[NA > 6 ? 6 : 0], e); break;
             default: take_slot<NV>(acc[NA > 7 ? 7 : 0], e); break;
             }
-            if (!(ablate & 1u)) {
+            if (!(ablate & 1u) && !(ablate & 16u)) {
                 // Horizontal pass, step 1 (all lanes): this lane's 4 pixels -> one partial sum per output
                 // column whose window they touch.  Weights and target slots come from per-lane tables, so
                 // every LDS access is lane-contiguous (no bank conflicts).
@@ -512,26 +512,53 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
                 }
             }
             // LDS-only hand-off (no vmcnt drain: the prefetched rows and the pixel stores stay in flight)
-            lds_barrier();
-            if (!(ablate & 1u) && tid < nxs) {
-                // step 2 (one lane per output column): add the partial sums in ascending pixel order
-                float sum[MC];
+            if (!(ablate & 8u)) lds_barrier();
+            // step 2 (one lane per output column): add the partial sums in ascending pixel order.  The partial
+            // sums are fetched into registers first and the second barrier sits right behind the fetch, so
+            // the other waves go back to the vertical pass while the additions, rounding and store run.
+            constexpr uint32_t KREG = 12; // partial sums held in registers across the barrier
+            f32x4 q[KREG];
+            const f32x4 *pp = pbuf + tid * ks;
+            const bool reducer = !(ablate & 1u) && !(ablate & 32u) && tid < nxs;
+            if (reducer) {
 #pragma unroll
-                for (int c = 0; c < MC; ++c) sum[c] = 0.0f;
-                const f32x4 *pp = pbuf + tid * ks;
-                for (uint32_t k = 0; k < kmax; ++k) {
-                    const f32x4 q = pp[k];
-                    sum[0] = sum[0] + q.x;
-                    if constexpr (MC > 1) sum[1] = sum[1] + q.y;
-                    if constexpr (MC > 2) sum[2] = sum[2] + q.z;
-                    if constexpr (MC > 3) sum[3] = sum[3] + q.w;
+                for (uint32_t k = 0; k < KREG; ++k) q[k] = k < kmax ? pp[k] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            float sum[MC];
+#pragma unroll
+            for (int c = 0; c < MC; ++c) sum[c] = 0.0f;
+            if (reducer && kmax > KREG) { // long windows (ratio > ~7): finish the fetch before releasing the buffer
+#pragma unroll
+                for (uint32_t k = 0; k < KREG; ++k) {
+                    sum[0] = sum[0] + q[k].x;
+                    if constexpr (MC > 1) sum[1] = sum[1] + q[k].y;
+                    if constexpr (MC > 2) sum[2] = sum[2] + q[k].z;
+                    if constexpr (MC > 3) sum[3] = sum[3] + q[k].w;
+                }
+                for (uint32_t k = KREG; k < kmax; ++k) {
+                    const f32x4 r = pp[k];
+                    sum[0] = sum[0] + r.x;
+                    if constexpr (MC > 1) sum[1] = sum[1] + r.y;
+                    if constexpr (MC > 2) sum[2] = sum[2] + r.z;
+                    if constexpr (MC > 3) sum[3] = sum[3] + r.w;
+                }
+            }
+            if (!(ablate & 8u)) lds_barrier();
+            if (reducer) {
+                if (kmax <= KREG) {
+#pragma unroll
+                    for (uint32_t k = 0; k < KREG; ++k) { // slots past kmax hold +0: adding them changes nothing
+                        sum[0] = sum[0] + q[k].x;
+                        if constexpr (MC > 1) sum[1] = sum[1] + q[k].y;
+                        if constexpr (MC > 2) sum[2] = sum[2] + q[k].z;
+                        if constexpr (MC > 3) sum[3] = sum[3] + q[k].w;
+                    }
                 }
                 uint32_t c8[MC];
 #pragma unroll
                 for (int c = 0; c < MC; ++c) c8[c] = round_u8(sum[c]);
                 store_pixel<MC, LB, true>(jb.dst, pix_base + oy * jb.dw + tid, c8, jb.fill);
             }
-            lds_barrier();
             ++oy;
         }
     }
