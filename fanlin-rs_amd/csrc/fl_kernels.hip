@@ -30,6 +30,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------
 // small device helpers
@@ -308,11 +309,11 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // Takes the finished vertical row out of one accumulator slot (registers) and re-arms the slot.
-template <int NV>
-__device__ __forceinline__ void take_slot(float *acc, float *e)
+template <int NH>
+__device__ __forceinline__ void take_slot(f32x2 *acc, float *e)
 {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) { e[j] = acc[j]; acc[j] = 0.0f; }
+    for (int j = 0; j < NH; ++j) { e[2 * j] = acc[j].x; e[2 * j + 1] = acc[j].y; acc[j] = f32x2{0.0f, 0.0f}; }
 }
 
 // NA = accumulator slots (output rows alive per source row; the host picks the smallest that fits),
@@ -390,11 +391,14 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
         for (uint32_t i = tid; i < mrows * rcols; i += T) store_hidden_b32(d32 + (my0 + i / rcols) * jb.dw + rx0 + i % rcols, jb.fill);
     }
 
-    float acc[NA][NV];
+    // accumulators live as register PAIRS so that every tap is one v_pk_fma_f32 (two fused multiply-adds)
+    static_assert(NV % 2 == 0, "PXL is even");
+    constexpr int NH = NV / 2;
+    f32x2 acc[NA][NH];
 #pragma unroll
     for (int s = 0; s < NA; ++s)
 #pragma unroll
-        for (int k = 0; k < NV; ++k) acc[s][k] = 0.0f;
+        for (int k = 0; k < NH; ++k) acc[s][k] = f32x2{0.0f, 0.0f};
 
     // whole byte offset goes through voffset: rows past the image end are range-checked by the buffer descriptor and read 0
     RowRaw<CS> ring[D];
@@ -454,8 +458,10 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
                 for (int s = 0; s < NA; ++s) {
                     const float w = s == 0 ? w03.x : s == 1 ? w03.y : s == 2 ? w03.z : s == 3 ? w03.w
                                   : s == 4 ? w47.x : s == 5 ? w47.y : s == 6 ? w47.z : w47.w;
+                    const f32x2 ww = {w, w};
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) acc[s][j] = __builtin_fmaf(v[j], w, acc[s][j]);
+                    for (int j = 0; j < NH; ++j)
+                        acc[s][j] = __builtin_elementwise_fma(f32x2{v[2 * j], v[2 * j + 1]}, ww, acc[s][j]);
                 }
             }
             // One row at a time: left alone, hipcc converts all D rows and reads all D weight sets up front
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
 #pragma unroll
             for (int s = 0; s < NA; ++s)
 #pragma unroll
-                for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(acc[s][j]));
+                for (int j = 0; j < NH; ++j) asm volatile("" : "+v"(acc[s][j])); // pinned as pairs: keeps v_pk_fma_f32
             __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t em = __builtin_amdgcn_readfirstlane(meta.y); // outputs complete in order: first_out, first_out + 1, ...
@@ -482,14 +488,14 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
             em &= ~(1u << s);
             float e[NV]; // the finished f32 row: this lane's PXL pixels x MC channels
             switch (s) {
-            case 0: take_slot<NV>(acc[0], e); break;
-            case 1: take_slot<NV>(acc[NA > 1 ? 1 : 0], e); break;
-            case 2: take_slot<NV>(acc[NA > 2 ? 2 : 0], e); break;
-            case 3: take_slot<NV>(acc[NA > 3 ? 3 : 0], e); break;
-            case 4: take_slot<NV>(acc[NA > 4 ? 4 : 0], e); break;
-            case 5: take_slot<NV>(acc[NA > 5 ? 5 : 0], e); break;
-            case 6: take_slot<NV>(acc[NA > 6 ? 6 : 0], e); break;
-            default: take_slot<NV>(acc[NA > 7 ? 7 : 0], e); break;
+            case 0: take_slot<NH>(acc[0], e); break;
+            case 1: take_slot<NH>(acc[NA > 1 ? 1 : 0], e); break;
+            case 2: take_slot<NH>(acc[NA > 2 ? 2 : 0], e); break;
+            case 3: take_slot<NH>(acc[NA > 3 ? 3 : 0], e); break;
+            case 4: take_slot<NH>(acc[NA > 4 ? 4 : 0], e); break;
+            case 5: take_slot<NH>(acc[NA > 5 ? 5 : 0], e); break;
+            case 6: take_slot<NH>(acc[NA > 6 ? 6 : 0], e); break;
+            default: take_slot<NH>(acc[NA > 7 ? 7 : 0], e); break;
             }
             if (!(ablate & 1u) && !(ablate & 16u)) {
                 // Horizontal pass, step 1 (all lanes): this lane's 4 pixels -> one partial sum per output
