@@ -76,6 +76,57 @@ def cpu_baseline(n_images: int, workload: dict, max_threads: int = 16):
                       f"(C restatement of image 0.25.6, reference arithmetic), one image per thread on {cores} threads"}
 
 
+def measured_traffic(workload: str):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    bench.py cannot run under the profiler and time itself at once, so the committed summary of the last
+    profiled run of this workload is reported, or null if there is none."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    return rec.get(workload, {}).get("hbm_bytes_per_launch")
+
+
+def latency_probe(fl, st, params, n_requests: int, n_threads: int):
+    """Per-image latency of the drop-in entry point: concurrent callers of flgpu_transform with HOST buffers
+    (PCIe in both directions included), packed into shared launches by the library's request queue."""
+    import threading
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    imgs = [synth.uniform(SRC_H, SRC_W, SRC_C, index=2000 + i) for i in range(8)]
+    lat = [0.0] * n_requests
+    nxt = [0]
+    lock = threading.Lock()
+    st.process_pixels(imgs[0], params)  # warm up (tables, staging buffers)
+    before = st.stats()
+
+    def worker():
+        while True:
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= n_requests:
+                return
+            t0 = time.perf_counter()
+            st.process_pixels(imgs[i % len(imgs)], params)
+            lat[i] = (time.perf_counter() - t0) * 1e3
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=worker) for _ in range(n_threads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    wall = time.perf_counter() - t0
+    after = st.stats()
+    a = np.sort(np.array(lat))
+    return {"p50_ms": float(a[len(a) // 2]), "p99_ms": float(a[min(len(a) - 1, int(len(a) * 0.99))]),
+            "requests": n_requests, "caller_threads": n_threads, "images_per_s": n_requests / wall,
+            "queue_flushes": int(after["queue_flushes"] - before["queue_flushes"]),
+            "path": "flgpu_transform, host buffers (H2D + kernels + D2H), request-batching queue"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +139,11 @@ def main():
     ap.add_argument("--frontend", choices=["none", "jfif444", "webp420"], default="none")
     ap.add_argument("--cpu-images", type=int, default=1024, help="CPU-baseline sample size (0 = skip); ~14 ms of CPU work per image")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (one image per thread)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal: several ranks may share one GPU)")
+    ap.add_argument("--latency-requests", type=int, default=256,
+                    help="requests of the per-image latency probe through flgpu_transform (0 = skip)")
+    ap.add_argument("--latency-threads", type=int, default=64, help="concurrent caller threads of the latency probe")
     args = ap.parse_args()
 
     import torch
@@ -103,11 +159,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % max(ndev, 1)  # gloo rehearsal: ranks may share a GPU
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collectives run
 
     fl = load_package()
     fe = {"none": fl.FE_NONE, "jfif444": fl.FE_JFIF444, "webp420": fl.FE_WEBP420}[args.frontend]
@@ -125,7 +187,7 @@ def main():
     out_stride = (int(plan.out_bytes) + 255) // 256 * 256
     dst = torch.zeros((n, out_stride), dtype=torch.uint8, device=dev)
 
-    st = fl.State(device=local_rank, profile=True)
+    st = fl.State(device=local_dev, profile=True)
     run = st.prepared_batch([src.data_ptr() + i * src_bytes for i in range(n)], [(SRC_H, SRC_W, SRC_C)] * n, params,
                             [dst.data_ptr() + i * out_stride for i in range(n)], [out_stride] * n)
     stream = torch.cuda.current_stream().cuda_stream
@@ -136,12 +198,15 @@ def main():
     if world > 1:
         blob = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
         nbytes = st.copy_tables(blob.data_ptr(), blob.numel())
-        size_t = torch.tensor([nbytes], dtype=torch.int64, device=dev)
+        size_t = torch.tensor([nbytes], dtype=torch.int64, device=cdev)
         dist.broadcast(size_t, src=0)
         assert int(size_t.item()) == nbytes, "ranks planned different tables"
-        dist.broadcast(blob[:nbytes], src=0)
+        payload = blob[:nbytes].to(cdev)           # nccl: stays on the device (xGMI); gloo rehearsal: staged through the host
+        dist.broadcast(payload, src=0)
+        blob[:nbytes] = payload.to(dev)
+        torch.cuda.synchronize()
         st.import_tables(blob.data_ptr(), nbytes)
-        del blob
+        del blob, payload
 
     for _ in range(args.warmup):
         run(stream)
@@ -159,7 +224,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = st.stats()
@@ -191,6 +256,9 @@ def main():
             "stage_ms_per_step": {"resample": stats["resample_ms"] / args.steps, "blur": stats["blur_ms"] / args.steps,
                                   "frontend": stats["frontend_ms"] / args.steps},
         }
+        line["roofline"]["traffic"] = measured_traffic(line["config"]["workload"])
+        if args.latency_requests > 0 and world == 1:
+            line["latency"] = latency_probe(fl, st, params, args.latency_requests, args.latency_threads)
         if args.cpu_images > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_images, workload, args.cpu_threads)
         else:

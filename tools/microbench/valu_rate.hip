@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, float w_in, unsig
     float w = w_in;
     f32x2 w2 = f32x2{w_in, w_in};
     unsigned hw = 0x3c003c00u; // two f16 1.0
+    f32x2 wv2 = f32x2{w_in + threadIdx.x * 0.0f, w_in};
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int k = 0; k < NACC; ++k) {
@@ -37,6 +38,9 @@ __global__ __launch_bounds__(256) void valu_kernel(float* out, float w_in, unsig
             if (OP == 5) asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(u[k]) : "v"(u[(k + 1) % NACC]), "s"(hw));
             if (OP == 6) asm volatile("v_mul_f32 %0, %1, %2\n\tv_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(a[(k + 1) % NACC]), "s"(w));
             if (OP == 7) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a[k]) : "v"(u[k]), "v"(u[(k + 1) % NACC]));
+            if (OP == 8) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p[k]) : "v"(p[(k + 1) % NACC]), "v"(wv2));
+            if (OP == 9) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[k]) : "v"(p[(k + 1) % NACC]), "v"(p[(k + 2) % NACC]));
+            if (OP == 10) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[k]) : "v"(a[(k + 1) % NACC]), "v"(a[(k + 2) % NACC]));
         }
     }
     float s = 0;
@@ -113,6 +117,9 @@ int main()
     run_valu<4>("v_perm_b32", 1);
     run_valu<5>("v_dot4_i32_i8", 8);
     run_valu<6>("v_mul_f32+v_add_f32", 1);
+    run_valu<8>("v_pk_fma_f32 (vgpr w, op_sel)", 4);
+    run_valu<9>("v_pk_fma_f32 (3 vgpr pairs)", 4);
+    run_valu<10>("v_fmac_f32 (vgpr)", 2);
     run_stream<12>("stream b96 512thr", 1024, 512);
     run_stream<16>("stream b128 384thr", 1024, 384);
     run_stream<12>("stream b96 512thr", 2048, 512);
