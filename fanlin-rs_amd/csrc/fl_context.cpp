@@ -89,10 +89,17 @@ struct StreamPlan {
     size_t lds_bytes = 0;
 };
 
+struct PinBlock {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
 struct Request {
     const flgpu_image *src;
     const flgpu_params *p;
     flgpu_image *dst;
+    PinBlock in, out;      // pinned staging filled / drained by the CALLER thread (parallel memcpy)
+    uint64_t src_bytes = 0, out_bytes = 0;
     int status = 0;
     bool done = false;
 };
@@ -132,6 +139,10 @@ struct flgpu_ctx {
     std::vector<hipEvent_t> event_pool;
 
     std::string last_error;
+
+    // pinned staging blocks recycled between requests (power-of-two size classes)
+    std::mutex pin_mu;
+    std::multimap<size_t, void *> pin_free;
 
     // request queue
     std::thread worker;
@@ -722,6 +733,64 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
 
 // ---- request queue ---------------------------------------------------------
 
+PinBlock pin_acquire(flgpu_ctx *c, size_t bytes)
+{
+    size_t cap = 64 * 1024;
+    while (cap < bytes) cap <<= 1;
+    {
+        std::lock_guard<std::mutex> g(c->pin_mu);
+        auto it = c->pin_free.find(cap);
+        if (it != c->pin_free.end()) { PinBlock b{it->second, cap}; c->pin_free.erase(it); return b; }
+    }
+    PinBlock b;
+    (void)hipSetDevice(c->device);
+    if (hipHostMalloc(&b.p, cap, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return b; }
+    b.cap = cap;
+    return b;
+}
+
+void pin_release(flgpu_ctx *c, PinBlock &b)
+{
+    if (!b.p) return;
+    std::lock_guard<std::mutex> g(c->pin_mu);
+    c->pin_free.emplace(b.cap, b.p);
+    b.p = nullptr;
+}
+
+// One flushed batch of queued requests: sources already sit in pinned blocks (copied there by the
+// calling threads), results are left in pinned blocks for the callers to copy out.
+int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
+{
+    const size_t n = batch.size();
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    std::vector<flgpu_image> dsrc(n), ddst(n);
+    std::vector<flgpu_params> ps(n);
+    size_t in_b = 0, out_b = 0;
+    for (size_t i = 0; i < n; ++i) {
+        dsrc[i] = *batch[i]->src; ddst[i] = *batch[i]->dst; ps[i] = *batch[i]->p;
+        dsrc[i].data = reinterpret_cast<uint8_t *>(in_b); dsrc[i].capacity = batch[i]->src_bytes; in_b += align_up(batch[i]->src_bytes, 256);
+        ddst[i].data = reinterpret_cast<uint8_t *>(out_b); ddst[i].capacity = batch[i]->out_bytes; out_b += align_up(batch[i]->out_bytes, 256);
+    }
+    FL_HIP(c, c->d_in.reserve(in_b), "device input staging");
+    FL_HIP(c, c->d_out.reserve(out_b), "device output staging");
+    hipStream_t st = c->stream;
+    for (size_t i = 0; i < n; ++i) {
+        dsrc[i].data = static_cast<uint8_t *>(c->d_in.p) + reinterpret_cast<size_t>(dsrc[i].data);
+        ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
+        FL_HIP(c, hipMemcpyAsync(dsrc[i].data, batch[i]->in.p, batch[i]->src_bytes, hipMemcpyHostToDevice, st), "H2D");
+    }
+    int rc = run_batch_device(c, n, dsrc.data(), ps.data(), false, ddst.data(), st);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i)
+        FL_HIP(c, hipMemcpyAsync(batch[i]->out.p, ddst[i].data, batch[i]->out_bytes, hipMemcpyDeviceToHost, st), "D2H");
+    FL_HIP(c, hipStreamSynchronize(st), "batch sync");
+    for (size_t i = 0; i < n; ++i) {
+        batch[i]->dst->width = ddst[i].width; batch[i]->dst->height = ddst[i].height;
+        batch[i]->dst->channels = ddst[i].channels; batch[i]->dst->flags = ddst[i].flags;
+    }
+    return FLGPU_OK;
+}
+
 void worker_main(flgpu_ctx *c)
 {
     const size_t max_batch = c->cfg.max_batch ? c->cfg.max_batch : 256;
@@ -739,22 +808,15 @@ void worker_main(flgpu_ctx *c)
             }
             while (!c->queue.empty() && batch.size() < max_batch) { batch.push_back(c->queue.front()); c->queue.pop_front(); }
         }
-        std::vector<flgpu_image> srcs(batch.size()), dsts(batch.size());
-        std::vector<flgpu_params> ps(batch.size());
-        for (size_t i = 0; i < batch.size(); ++i) { srcs[i] = *batch[i]->src; dsts[i] = *batch[i]->dst; ps[i] = *batch[i]->p; }
         int rc;
         {
             std::lock_guard<std::mutex> g(c->mu);
-            rc = run_batch_host(c, batch.size(), srcs.data(), ps.data(), dsts.data());
+            rc = run_batch_queued(c, batch);
             c->stats.queue_flushes++;
         }
         {
             std::lock_guard<std::mutex> lk(c->qmu);
-            for (size_t i = 0; i < batch.size(); ++i) {
-                if (!rc) { batch[i]->dst->width = dsts[i].width; batch[i]->dst->height = dsts[i].height; batch[i]->dst->channels = dsts[i].channels; batch[i]->dst->flags = dsts[i].flags; }
-                batch[i]->status = rc;
-                batch[i]->done = true;
-            }
+            for (Request *r : batch) { r->status = rc; r->done = true; }
         }
         c->qdone.notify_all();
     }
@@ -807,6 +869,7 @@ void flgpu_destroy(flgpu_ctx *c)
     if (c->last_done) (void)hipEventDestroy(c->last_done);
     c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_status.release(); c->d_in.release(); c->d_out.release();
     c->h_stage_in.release(); c->h_stage_out.release();
+    for (auto &kv : c->pin_free) (void)hipHostFree(kv.second);
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -836,10 +899,17 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
     if (rc) return rc;
     if (src->capacity < (uint64_t)src->width * src->height * src->channels) return FLGPU_ERR_INVALID_ARG;
     if (dst->capacity < plan.out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
-    Request r{src, p, dst};
+    Request r{};
+    r.src = src; r.p = p; r.dst = dst;
+    r.src_bytes = (uint64_t)src->width * src->height * src->channels;
+    r.out_bytes = plan.out_bytes;
+    r.in = pin_acquire(c, r.src_bytes);
+    r.out = pin_acquire(c, r.out_bytes);
+    if (!r.in.p || !r.out.p) { pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_OOM; }
+    memcpy(r.in.p, src->data, r.src_bytes); // on the caller's thread: concurrent callers stage in parallel
     {
         std::unique_lock<std::mutex> lk(c->qmu);
-        if (c->stop) return FLGPU_ERR_SHUTDOWN;
+        if (c->stop) { lk.unlock(); pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_SHUTDOWN; }
         if (!c->worker_started) { c->worker = std::thread(worker_main, c); c->worker_started = true; }
         c->queue.push_back(&r);
     }
@@ -848,6 +918,9 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
         std::unique_lock<std::mutex> lk(c->qmu);
         c->qdone.wait(lk, [&] { return r.done; });
     }
+    if (r.status == FLGPU_OK) memcpy(dst->data, r.out.p, r.out_bytes);
+    pin_release(c, r.in);
+    pin_release(c, r.out);
     return r.status;
 }
 
