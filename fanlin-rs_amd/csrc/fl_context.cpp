@@ -123,6 +123,7 @@ struct flgpu_ctx {
     std::map<AxisKey, uint32_t> axis_off;
     std::map<AxisKey, HostAxis> axis_host;
     std::map<StreamPlanKey, StreamPlan> stream_plans;
+    std::map<std::pair<AxisKey, AxisKey>, uint32_t> blur_plans; // blur kernel table blocks per (vertical, horizontal) Gaussian axis
     uint32_t gamma_off = 0;
 
     DescSlot slots[4];
@@ -187,6 +188,7 @@ void arena_reset(flgpu_ctx *c)
     c->axis_off.clear();
     c->axis_host.clear();
     c->stream_plans.clear();
+    c->blur_plans.clear();
     std::vector<uint32_t> g;
     build_webp_gamma(g);
     c->gamma_off = arena_append(c, g.data(), g.size());
@@ -475,8 +477,15 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if (full) break;
             if (w.p->blur_sigma > 0.0f) {
                 AxisKey k; const HostAxis *h;
-                if (!get_axis(c, w.plan.out_h, w.plan.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h) ||
+                AxisKey kv; const HostAxis *hv;
+                if (!get_axis(c, w.plan.out_h, w.plan.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &kv, &hv) ||
                     !get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h)) full = true;
+                else if (blur_tile_supported(h->max_taps) && blur_tile_supported(hv->max_taps) && !c->blur_plans.count({kv, k})) {
+                    std::vector<uint32_t> blk;
+                    build_blur_plan(*hv, *h, blur_tile_count(w.plan.out_w, h->max_taps), blur_band_rows(), blk);
+                    const uint32_t off = arena_append(c, blk.data(), blk.size());
+                    if (!off) full = true; else c->blur_plans[{kv, k}] = off;
+                }
             }
         }
         if (!full) break;
@@ -492,7 +501,16 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
         if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
-        if (w.p->blur_sigma > 0.0f) blur_groups[{0, w.plan.out_c, 0, 0}].push_back(i);
+        if (w.p->blur_sigma > 0.0f) {
+            // channels that really need filtering: a letterboxed picture of an opaque source has alpha == 255
+            // everywhere, and a grey one on a grey fill has R == G == B (see blur_tile_kernel)
+            uint32_t ce = w.plan.out_c;
+            if (w.plan.letterboxed && (w.cs == 1 || w.cs == 3)) {
+                const bool grey = mid_channels(w.cs, w.pre) == 1 && w.p->fill_r == w.p->fill_g && w.p->fill_g == w.p->fill_b;
+                ce = grey ? 1u : 3u;
+            }
+            blur_groups[{0, w.plan.out_c, ce, 0}].push_back(i);
+        }
         if (w.p->front_end != FLGPU_FE_NONE) fe_groups[{w.p->front_end, 0, 0, 0}].push_back(i);
     }
     std::vector<Job> jobs;
@@ -551,16 +569,21 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             j.src = w.s1_dst; j.dst = w.blur_dst; j.src_bytes = (uint32_t)pl.pixel_bytes;
             j.sw = pl.out_w; j.sh = pl.out_h; j.rw = pl.out_w; j.rh = pl.out_h; j.cw = pl.out_w; j.ch = pl.out_h;
             j.dw = pl.out_w; j.dh = pl.out_h;
-            j.vtab = get_axis(c, pl.out_h, pl.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, nullptr, nullptr);
-            j.htab = get_axis(c, pl.out_w, pl.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, nullptr, nullptr);
+            AxisKey vkey, hkey;
+            j.vtab = get_axis(c, pl.out_h, pl.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &vkey, nullptr);
+            j.htab = get_axis(c, pl.out_w, pl.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &hkey, nullptr);
+            {
+                auto bt = c->blur_plans.find({vkey, hkey});
+                j.pad0 = bt != c->blur_plans.end() ? bt->second : 0u; // table block of the blur kernel
+            }
             const size_t mid = (size_t)pl.out_w * pl.out_h * pl.out_c;
             if (L.njobs && L.mid_floats + mid > kMidCapFloats) { blur_launches.push_back(L); L = new_launch(k); }
             {
                 const AxisTable *vh = reinterpret_cast<const AxisTable *>(c->h_arena.data() + j.vtab);
                 const AxisTable *hh = reinterpret_cast<const AxisTable *>(c->h_arena.data() + j.htab);
                 if (L.njobs == 0) L.blur_tiled = true;
-                const size_t lds = blur_lds_bytes(pl.out_w, pl.out_c, vh->max_taps, hh->max_taps);
-                if (!blur_tile_supported(hh->max_taps) || !blur_tile_supported(vh->max_taps) || lds > 150 * 1024) L.blur_tiled = false;
+                const size_t lds = blur_lds_bytes(pl.out_w, k.pre ? k.pre : pl.out_c, vh->max_taps, hh->max_taps); // k.pre = channels filtered
+                if (!blur_tile_supported(hh->max_taps) || !blur_tile_supported(vh->max_taps) || lds > 150 * 1024 || !j.pad0) L.blur_tiled = false;
                 L.lds = std::max(L.lds, lds);
                 L.blur_grid_x = std::max(L.blur_grid_x, blur_grid_x(pl.out_w, pl.out_h, hh->max_taps));
             }
@@ -648,12 +671,14 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     }
     for (auto &L : blur_launches) {
         L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
-        L.g.job_base = L.job_base; L.g.njobs = L.njobs; L.g.pre = PRE_NONE; L.g.letterbox = 0;
+        L.g.job_base = L.job_base; L.g.njobs = L.njobs; L.g.letterbox = 0;
         L.g.grouped = 0;
         ProfileScope ps(c, st, 1);
         if (L.blur_tiled && !force_generic) {
+            L.g.pre = L.k.pre; // channels to filter (group key), see blur_tile_kernel
             FL_HIP(c, launch_blur_tile(L.g, L.blur_grid_x, L.lds, st), "blur kernel");
         } else {
+            L.g.pre = PRE_NONE;
             FL_HIP(c, launch_vpass_generic(L.g, st), "blur vertical pass");
             FL_HIP(c, launch_hpass_generic(L.g, st), "blur horizontal pass");
         }

@@ -52,6 +52,8 @@ hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st
 bool blur_tile_supported(uint32_t htaps);
 size_t blur_lds_bytes(uint32_t w, uint32_t channels, uint32_t vtaps, uint32_t htaps);
 uint32_t blur_grid_x(uint32_t w, uint32_t h, uint32_t htaps);
+uint32_t blur_tile_count(uint32_t w, uint32_t htaps);
+uint32_t blur_band_rows(); // output rows per workgroup of the blur kernel // column tiles per image; tile width = ceil(w / count)
 hipError_t launch_blur_tile(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st);
 
 bool stream_supported(uint32_t cs, uint32_t pre);

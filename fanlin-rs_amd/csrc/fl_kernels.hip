@@ -585,10 +585,16 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
 
 constexpr int BLUR_TY = 8;
 constexpr uint32_t BLUR_T = 256;
+constexpr uint32_t BLUR_MAXTAPS = 128;            // sigma <= 20 gives 81 taps
+constexpr uint32_t BLUR_MIDW = BLUR_T + BLUR_MAXTAPS; // columns of the f32 hand-off rows in LDS
 
 __host__ __device__ inline uint32_t blur_tiles(uint32_t w, uint32_t taps) { const uint32_t cap = BLUR_T - (taps - 1); return (w + cap - 1) / cap; }
 
-template <int C>
+// CS = channels stored per pixel, C = channels filtered.  C < CS only for opaque Rgba8 pictures (every
+// letterboxed output of an opaque source): the alpha plane is the constant 255 (any normalised filter
+// maps it to 255 again, far from a rounding boundary) and, for a grey picture on a grey fill, R = G = B, so
+// one channel is filtered and replicated -- identical arithmetic on identical inputs, bit-identical output.
+template <int CS, int C>
 __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ arena,
                                                         uint32_t job_base)
 {
@@ -596,46 +602,44 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
     constexpr uint32_t T = BLUR_T;
     const Job jb = jobs[job_base + blockIdx.y];
     const uint32_t w = jb.sw, h = jb.sh;
-    const AxisTable *vt = reinterpret_cast<const AxisTable *>(arena + jb.vtab);
-    const AxisTable *ht = reinterpret_cast<const AxisTable *>(arena + jb.htab);
-    const uint32_t htaps = ht->max_taps, vtaps = vt->max_taps;
-    const uint32_t nt = blur_tiles(w, htaps), nb = (h + BLUR_TY - 1) / BLUR_TY;
-    if (blockIdx.x >= nt * nb) return;
+    // one table block per (w, h, sigma): header -> this workgroup's tile and band records -> bulk copies
+    const uint32_t *blk = arena + jb.pad0;
+    const BlurPlanHeader hd = *reinterpret_cast<const BlurPlanHeader *>(blk);
+    const uint32_t nt = hd.nt, htaps = hd.htaps, tw_full = hd.tw_full;
+    if (blockIdx.x >= nt * hd.nb) return;
     const uint32_t band = blockIdx.x / nt, tile = blockIdx.x % nt;
-    const uint32_t tw_full = (w + nt - 1) / nt;
     const uint32_t x0 = tile * tw_full, tw = min(tw_full, w - x0);
     const uint32_t y0 = band * BLUR_TY, ty = min((uint32_t)BLUR_TY, h - y0);
     const uint32_t tid = threadIdx.x;
+    const uint32_t cl = blk[hd.tiles_off + 2 * tile], ncols = blk[hd.tiles_off + 2 * tile + 1]; // ncols <= T by construction
+    const uint32_t top = blk[hd.bands_off + 2 * band], nrows = blk[hd.bands_off + 2 * band + 1];
 
-    // source column window of the tile and source row window of the band (from the tables: monotone)
-    const uint32_t cl = arena[ht->left_off + x0];
-    const uint32_t cr = arena[ht->left_off + x0 + tw - 1] + arena[ht->count_off + x0 + tw - 1];
-    const uint32_t top = arena[vt->left_off + y0];
-    const uint32_t bot = arena[vt->left_off + y0 + ty - 1] + arena[vt->count_off + y0 + ty - 1];
-    const uint32_t ncols = cr - cl, nrows = bot - top;   // ncols <= T by construction of the tiling
-
-    // LDS: [ wv: (BLUR_TY + vtaps) x BLUR_TY | mid: BLUR_TY x (T + htaps) x MS | wh: htaps x tw ]
+    // LDS: [ wv: rv x BLUR_TY | mid: BLUR_TY x (T + htaps) x MS | wh: htaps x tw ]
     float *wv = fl_lds;
-    const uint32_t wv_floats = ((BLUR_TY + vtaps) * BLUR_TY + 3u) & ~3u;
-    const uint32_t midw = T + htaps;
+    const uint32_t wv_floats = (hd.rv * BLUR_TY + 3u) & ~3u;
+    constexpr uint32_t midw = BLUR_MIDW; // compile-time row pitch: row offsets fold into the ds_read immediates
     float *mid = fl_lds + wv_floats;
-    float *wh = mid + (size_t)BLUR_TY * midw * MS;
+    float *wh = mid + BLUR_TY * midw * MS;
 
-    for (uint32_t i = tid; i < wv_floats; i += T) wv[i] = 0.0f;
-    for (uint32_t i = tid; i < BLUR_TY * midw * MS; i += T) mid[i] = 0.0f;
-    __syncthreads();
-    for (uint32_t o = 0; o < ty; ++o) {
-        const uint32_t l = arena[vt->left_off + y0 + o], n = arena[vt->count_off + y0 + o];
-        const float *src = reinterpret_cast<const float *>(arena + vt->weights_off + arena[vt->woff_off + y0 + o]);
-        for (uint32_t i = tid; i < n; i += T) wv[(l + i - top) * BLUR_TY + o] = src[i];
+    {
+        const float *vsrc = reinterpret_cast<const float *>(blk + hd.vdense_off) + (size_t)band * hd.rv * BLUR_TY;
+        for (uint32_t i = tid; i < hd.rv * BLUR_TY; i += T) wv[i] = vsrc[i];
     }
-    uint32_t hleft = 0;
-    if (tid < tw) {
-        const uint32_t x = x0 + tid;
-        const uint32_t l = arena[ht->left_off + x], n = arena[ht->count_off + x];
-        const float *src = reinterpret_cast<const float *>(arena + ht->weights_off + arena[ht->woff_off + x]);
-        hleft = l - cl;
-        for (uint32_t i = 0; i < htaps; ++i) wh[i * tw + tid] = i < n ? src[i] : 0.0f;
+    // columns past the tile's source window are only ever read with zero weights, but must hold finite values
+    // (loops are written without integer division: it costs ~40 instructions per element on this ISA)
+#pragma unroll
+    for (int o = 0; o < BLUR_TY; ++o)
+        for (uint32_t cidx = ncols + tid; cidx < midw; cidx += T) {
+#pragma unroll
+            for (int c = 0; c < MS; ++c) mid[(o * midw + cidx) * MS + c] = 0.0f;
+        }
+    // horizontal weights of this tile: tap-major [htaps][tw_full] behind hleft[tw_full] (coalesced copy)
+    const uint32_t *tt = blk + hd.htiles_off + (size_t)tile * (tw_full * (htaps + 1));
+    const uint32_t hleft = tid < tw ? tt[tid] : 0u;
+    {
+        const float *src = reinterpret_cast<const float *>(tt + tw_full);
+        if (tid < tw)
+            for (uint32_t tap = 0; tap < htaps; ++tap) wh[tap * tw + tid] = src[tap * tw_full + tid];
     }
     __syncthreads();
 
@@ -646,30 +650,52 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[o][c] = 0.0f;
     if (tid < ncols) {
-        const uint8_t *p = jb.src + ((size_t)top * w + cl + tid) * C;
-        const size_t pitch = (size_t)w * C;
-        for (uint32_t r = 0; r < nrows; ++r) {
-            float v[C];
-            if constexpr (C == 4) {
-                const uint32_t d = *reinterpret_cast<const uint32_t *>(p);
-                v[0] = (float)(d & 255u); v[1] = (float)((d >> 8) & 255u); v[2] = (float)((d >> 16) & 255u); v[3] = (float)(d >> 24);
-            } else {
+        // raw buffer loads: a pointer read from a descriptor is "generic" to hipcc and would become flat_load,
+        // which also counts on lgkmcnt and so serialises against every LDS weight read
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(jb.src), 0, (int)jb.src_bytes, 0x00020000);
+        const uint32_t off0 = (top * w + cl + tid) * CS, pitch = w * CS;
+        // the image is L2/MALL resident but a load is still ~1 us away: keep PF rows in flight per lane
+        constexpr int PF = 12;
+        uint32_t ring[PF][CS == 4 ? 1 : C];
+        auto fetch = [&](uint32_t r, uint32_t *d) {
+            const uint32_t o = off0 + r * pitch; // rows past the image end are range-checked and read 0 (never used)
+            if constexpr (CS == 4) d[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0);
+            else {
 #pragma unroll
-                for (int c = 0; c < C; ++c) v[c] = (float)p[c];
+                for (int c = 0; c < C; ++c) d[c] = __builtin_amdgcn_raw_buffer_load_b8(rs, o + c, 0, 0);
             }
-            const f32x4 wa = *reinterpret_cast<const f32x4 *>(wv + r * BLUR_TY);
-            const f32x4 wb = *reinterpret_cast<const f32x4 *>(wv + r * BLUR_TY + 4);
+        };
 #pragma unroll
-            for (int o = 0; o < BLUR_TY; ++o) {
-                const float wo = o == 0 ? wa.x : o == 1 ? wa.y : o == 2 ? wa.z : o == 3 ? wa.w : o == 4 ? wb.x : o == 5 ? wb.y : o == 6 ? wb.z : wb.w;
+        for (int k = 0; k < PF; ++k) fetch(k, ring[k]);
+        for (uint32_t rb = 0; rb < nrows; rb += PF) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[o][c] = __builtin_fmaf(v[c], wo, acc[o][c]);
+            for (int k = 0; k < PF; ++k) {
+                const uint32_t r = rb + k;
+                float v[C];
+                if constexpr (CS == 4) {
+                    const uint32_t d = ring[k][0];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) v[c] = (float)((d >> (8 * c)) & 255u);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) v[c] = (float)ring[k][c];
+                }
+                fetch(r + PF, ring[k]);
+                if (r < nrows) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(wv + r * BLUR_TY);
+                    const f32x4 wb = *reinterpret_cast<const f32x4 *>(wv + r * BLUR_TY + 4);
+#pragma unroll
+                    for (int o = 0; o < BLUR_TY; ++o) {
+                        const float wo = o == 0 ? wa.x : o == 1 ? wa.y : o == 2 ? wa.z : o == 3 ? wa.w : o == 4 ? wb.x : o == 5 ? wb.y : o == 6 ? wb.z : wb.w;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[o][c] = __builtin_fmaf(v[c], wo, acc[o][c]);
+                    }
+                }
             }
-            p += pitch;
         }
 #pragma unroll
         for (int o = 0; o < BLUR_TY; ++o) {
-            float *m = mid + ((size_t)o * midw + tid) * MS;
+            float *m = mid + (o * midw + tid) * MS;
 #pragma unroll
             for (int c = 0; c < C; ++c) m[c] = acc[o][c];
         }
@@ -682,12 +708,13 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
         for (int o = 0; o < BLUR_TY; ++o)
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[o][c] = 0.0f;
-        const float *m0 = mid + (size_t)hleft * MS;
+        const float *m0 = mid + hleft * MS;
+#pragma unroll 4
         for (uint32_t i = 0; i < htaps; ++i) {
             const float wi = wh[i * tw + tid];
 #pragma unroll
             for (int o = 0; o < BLUR_TY; ++o) {
-                const float *px = m0 + ((size_t)o * midw + i) * MS;
+                const float *px = m0 + (o * midw + i) * MS;
                 if constexpr (MS == 4) {
                     const f32x4 q = *reinterpret_cast<const f32x4 *>(px);
                     acc[o][0] = __builtin_fmaf(q.x, wi, acc[o][0]);
@@ -703,10 +730,12 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
 #pragma unroll
         for (int o = 0; o < BLUR_TY; ++o) {
             if ((uint32_t)o < ty) {
-                uint32_t c8[C];
+                uint32_t c8[CS];
 #pragma unroll
                 for (int c = 0; c < C; ++c) c8[c] = round_u8(acc[o][c]);
-                store_pixel<C, false>(jb.dst, (y0 + o) * w + x0 + tid, c8, 0u);
+                if constexpr (CS == 4 && C == 1) { c8[1] = c8[0]; c8[2] = c8[0]; c8[3] = 255u; }
+                if constexpr (CS == 4 && C == 3) c8[3] = 255u;
+                store_pixel<CS, false>(jb.dst, (y0 + o) * w + x0 + tid, c8, 0u);
             }
         }
     }
@@ -880,18 +909,21 @@ size_t blur_lds_bytes(uint32_t w, uint32_t channels, uint32_t vtaps, uint32_t ht
 {
     const uint32_t ms = channels == 3 ? 4 : channels;
     const uint32_t nt = blur_tiles(w, htaps), tw = (w + nt - 1) / nt;
-    const size_t wv = (((size_t)(BLUR_TY + vtaps) * BLUR_TY + 3) & ~(size_t)3);
-    return (wv + (size_t)BLUR_TY * (BLUR_T + htaps) * ms + (size_t)htaps * tw) * sizeof(float);
+    const size_t wv = (((size_t)(BLUR_TY + vtaps) * BLUR_TY + 3) & ~(size_t)3); // rv <= BLUR_TY + vtaps - 1
+    return (wv + (size_t)BLUR_TY * BLUR_MIDW * ms + (size_t)htaps * tw) * sizeof(float);
 }
+
+uint32_t blur_tile_count(uint32_t w, uint32_t htaps) { return blur_tiles(w, htaps); }
+uint32_t blur_band_rows() { return BLUR_TY; }
 
 uint32_t blur_grid_x(uint32_t w, uint32_t h, uint32_t htaps) { return blur_tiles(w, htaps) * ((h + BLUR_TY - 1) / BLUR_TY); }
 
-bool blur_tile_supported(uint32_t htaps) { return htaps >= 1 && htaps <= 128; }
+bool blur_tile_supported(uint32_t htaps) { return htaps >= 1 && htaps <= BLUR_MAXTAPS; }
 
-template <int C>
+template <int CS, int C>
 static hipError_t launch_blur_t(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st)
 {
-    auto k = blur_tile_kernel<C>;
+    auto k = blur_tile_kernel<CS, C>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -901,13 +933,16 @@ static hipError_t launch_blur_t(const LaunchGeneric &g, uint32_t grid_x, size_t 
     return hipSuccess;
 }
 
+// g.cs = channels stored, g.pre = channels filtered (see blur_tile_kernel)
 hipError_t launch_blur_tile(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st)
 {
+    if (g.cs == 4 && g.pre == 1) return launch_blur_t<4, 1>(g, grid_x, lds, st);
+    if (g.cs == 4 && g.pre == 3) return launch_blur_t<4, 3>(g, grid_x, lds, st);
     switch (g.cs) {
-    case 1: return launch_blur_t<1>(g, grid_x, lds, st);
-    case 2: return launch_blur_t<2>(g, grid_x, lds, st);
-    case 3: return launch_blur_t<3>(g, grid_x, lds, st);
-    case 4: return launch_blur_t<4>(g, grid_x, lds, st);
+    case 1: return launch_blur_t<1, 1>(g, grid_x, lds, st);
+    case 2: return launch_blur_t<2, 2>(g, grid_x, lds, st);
+    case 3: return launch_blur_t<3, 3>(g, grid_x, lds, st);
+    case 4: return launch_blur_t<4, 4>(g, grid_x, lds, st);
     }
     return hipErrorInvalidValue;
 }

@@ -189,6 +189,59 @@ void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t lanes, ui
         }
 }
 
+void build_blur_plan(const HostAxis &v, const HostAxis &h, uint32_t nt, uint32_t ty, std::vector<uint32_t> &out)
+{
+    const uint32_t w = h.out_size, hh = v.out_size, htaps = h.max_taps;
+    const uint32_t tw_full = (w + nt - 1) / nt, nb = (hh + ty - 1) / ty;
+    uint32_t rv = 0;
+    std::vector<uint32_t> tiles(2 * nt, 0u), bands(2 * nb, 0u);
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t x0 = t * tw_full;
+        if (x0 >= w) continue;
+        const uint32_t x1 = std::min(w, x0 + tw_full) - 1;
+        tiles[2 * t] = h.left[x0];
+        tiles[2 * t + 1] = h.left[x1] + h.count[x1] - h.left[x0];
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t y0 = b * ty, y1 = std::min(hh, y0 + ty) - 1;
+        bands[2 * b] = v.left[y0];
+        bands[2 * b + 1] = v.left[y1] + v.count[y1] - v.left[y0];
+        rv = std::max(rv, bands[2 * b + 1]);
+    }
+    BlurPlanHeader hd{};
+    hd.nt = nt; hd.nb = nb; hd.tw_full = tw_full; hd.htaps = htaps; hd.rv = rv;
+    const uint32_t hw = sizeof(BlurPlanHeader) / 4;
+    hd.tiles_off = hw;
+    hd.bands_off = hd.tiles_off + 2 * nt;
+    hd.vdense_off = (hd.bands_off + 2 * nb + 3u) & ~3u;
+    hd.htiles_off = hd.vdense_off + nb * rv * ty;
+    out.assign((size_t)hd.htiles_off + (size_t)nt * tw_full * (htaps + 1), 0u);
+    memcpy(out.data(), &hd, sizeof(hd));
+    memcpy(out.data() + hd.tiles_off, tiles.data(), tiles.size() * 4);
+    memcpy(out.data() + hd.bands_off, bands.data(), bands.size() * 4);
+    float *vd = reinterpret_cast<float *>(out.data() + hd.vdense_off);
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t y0 = b * ty, top = bands[2 * b];
+        for (uint32_t o = 0; o < ty && y0 + o < hh; ++o) {
+            const uint32_t y = y0 + o;
+            for (uint32_t i = 0; i < v.count[y]; ++i)
+                vd[((size_t)b * rv + (v.left[y] + i - top)) * ty + o] = v.weights[v.woff[y] + i];
+        }
+    }
+    for (uint32_t t = 0; t < nt; ++t) {
+        uint32_t *base = out.data() + hd.htiles_off + (size_t)t * tw_full * (htaps + 1);
+        const uint32_t x0 = t * tw_full;
+        if (x0 >= w) break;
+        const uint32_t cl = h.left[x0];
+        float *wh = reinterpret_cast<float *>(base + tw_full);
+        for (uint32_t j = 0; j < tw_full && x0 + j < w; ++j) {
+            const uint32_t x = x0 + j;
+            base[j] = h.left[x] - cl;
+            for (uint32_t i = 0; i < h.count[x]; ++i) wh[(size_t)i * tw_full + j] = h.weights[h.woff[x] + i];
+        }
+    }
+}
+
 void build_webp_gamma(std::vector<uint32_t> &out)
 {
     // libwebp src/enc/picture_csp_enc.c: kGamma = 0.80, GAMMA_FIX = 12, GAMMA_TAB_FIX = 7

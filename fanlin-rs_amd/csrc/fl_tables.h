@@ -51,6 +51,15 @@ struct HostStrip {
 };
 void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t lanes, uint32_t px_per_lane, HostStrip &out);
 
+// Everything the blur kernel needs for one (width, height, sigma), as one arena block so that a workgroup
+// reaches its tables with two dependent loads instead of a chain through the generic axis tables:
+//   header  : nt, nb, tw_full, htaps, rv (rows of a dense vertical table), tiles_off, bands_off, vdense_off, htiles_off (relative words)
+//   tiles   : per column tile  { first source column, number of source columns }
+//   bands   : per row band     { first source row, number of source rows }
+//   vdense  : per band, rv x ty floats: weight of source row (top + r) in output row (y0 + o), 0 outside the window
+//   htiles  : per tile, hleft[tw_full] then weights tap-major [htaps][tw_full]
+void build_blur_plan(const HostAxis &v, const HostAxis &h, uint32_t nt, uint32_t ty, std::vector<uint32_t> &out);
+
 // libwebp picture_csp_enc.c InitGammaTables: kGammaToLinearTab[256] then kLinearToGammaTab[33], as int32.
 void build_webp_gamma(std::vector<uint32_t> &out);
 

@@ -32,7 +32,8 @@ struct alignas(16) Job {
     uint32_t fill;          // r | g<<8 | b<<16 | 255<<24
     uint32_t vtab, htab;    // arena word offsets of the AxisTable headers (vertical, horizontal)
     uint32_t mid_off;       // generic path: float offset of this job's f32 intermediate
-    uint32_t pad0, pad1;
+    uint32_t pad0;          // blur jobs: arena word offset of the horizontal weight tiles
+    uint32_t pad1;
 };
 
 // Output-major weight table of one axis (image 0.25.6 sample.rs index maths).
@@ -76,6 +77,9 @@ struct alignas(16) StreamItem {
     uint32_t flags;      // ITEM_* letterbox duties
     uint32_t pad0;
 };
+// Header of the blur kernel's table block (fl_tables.h build_blur_plan); offsets are words relative to the header.
+struct BlurPlanHeader { uint32_t nt, nb, tw_full, htaps, rv, tiles_off, bands_off, vdense_off, htiles_off, pad[3]; };
+
 enum : uint32_t { ITEM_FIRST_BAND = 1, ITEM_LAST_BAND = 2, ITEM_FIRST_STRIP = 4, ITEM_LAST_STRIP = 8 };
 
 } // namespace fl

@@ -161,6 +161,27 @@ def test_config2_gray_resize_blur(fl, gpu_state, oracle):
     assert got.shape == (200, 300, 4) and (got[..., 3] == 255).all()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(w=300, h=200, blur_sigma=10.0),                                      # colour, letterboxed: 3 of 4 channels filtered
+    dict(w=300, h=200, blur_sigma=20.0, grayscale=True, fill=(9, 9, 9)),       # grey on grey fill: 1 channel filtered
+    dict(w=300, h=200, blur_sigma=12.0, grayscale=True, fill=(200, 10, 10)),   # grey picture, coloured fill: 3 channels
+    dict(w=300, h=200, blur_sigma=10.0, crop=True),                            # Rgb8 output, no letterbox
+    dict(w=640, h=360, blur_sigma=15.0),                                       # same size: blur of the source itself
+])
+def test_blur_channel_shortcuts_are_exact(fl, gpu_state, oracle, kw):
+    img = synth.photo(360, 640, 3, index=22)
+    check_resample(fl, gpu_state, oracle, img, **kw)
+
+
+def test_blur_wide_image_tiles(fl, gpu_state, oracle):
+    img = synth.uniform(90, 700, 3, index=23)       # several column tiles, halo across tile borders
+    got = gpu_state.process_pixels(img, fl.make_params(blur_sigma=20.0))
+    assert np.array_equal(got, oracle.blur(img, 20.0, arith=oracle_lib.ARITH_FMA))
+    tiny = synth.uniform(5, 7, 4, index=24)         # window larger than the image on both axes
+    got = gpu_state.process_pixels(tiny, fl.make_params(blur_sigma=10.0))
+    assert np.array_equal(got, oracle.blur(tiny, 10.0, arith=oracle_lib.ARITH_FMA))
+
+
 # ---------------------------------------------------------------- encoder front ends --
 
 def test_jfif444_front_end(fl, gpu_state, oracle):
