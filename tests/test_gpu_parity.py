@@ -244,6 +244,50 @@ def test_request_queue_concurrent_callers(fl, gpu_state, oracle):
     assert after["queue_flushes"] - before["queue_flushes"] < len(imgs)
 
 
+def test_device_resident_batch_properties(fl, gpu_state, oracle):
+    """BASELINE configs 1/3 shape (many 1080p images, HBM-resident, one call): size-independent checks --
+    duplicates of an image anywhere in the batch give identical bytes, constant images stay constant, and a
+    sample of the batch matches the oracle."""
+    import torch
+    n, h, w, c = 96, 1080, 1920, 3
+    base = [torch.from_numpy(synth.uniform(h, w, c, index=70 + i)) for i in range(4)]
+    src = torch.empty((n, h, w, c), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        src[i] = base[i % 4].cuda() if i % 8 != 7 else torch.full((h, w, c), (i * 37) % 256, dtype=torch.uint8, device="cuda")
+    params = fl.make_params(300, 200, fill=(5, 6, 7))
+    plan = fl.plan_output(params, w, h, c)
+    stride = (int(plan.out_bytes) + 255) // 256 * 256
+    dst = torch.zeros((n, stride), dtype=torch.uint8, device="cuda")
+    gpu_state.process_batch_device([src.data_ptr() + i * h * w * c for i in range(n)], [(h, w, c)] * n, params,
+                                   [dst.data_ptr() + i * stride for i in range(n)], [stride] * n,
+                                   stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = dst[:, :plan.out_bytes].cpu().numpy().reshape(n, 200, 300, 4)
+    for i in range(n):
+        if i % 8 == 7:
+            assert (out[i, 15:184, :, :3] == (i * 37) % 256).all() and (out[i, :15, :, :3] == np.array([5, 6, 7])).all()
+        else:
+            assert np.array_equal(out[i], out[i % 4]), i
+    for i in range(4):
+        assert np.array_equal(out[i], oracle.process_pixels(base[i].numpy(), 300, 200, fill=(5, 6, 7), arith=oracle_lib.ARITH_FMA))
+
+
+def test_mixed_size_batch_with_webp_front_end(fl, gpu_state, oracle):
+    """BASELINE config 4 shape: 4K / 1080p / thumbnail sources in one batch (1:6:3), webp=true quality=85."""
+    shapes = [(2160, 3840)] * 1 + [(1080, 1920)] * 6 + [(120, 160)] * 3
+    order = [3, 0, 7, 9, 1, 4, 8, 2, 5, 6]                      # seed-shuffled
+    imgs = [synth.photo(*shapes[k], 3, index=80 + k) for k in order]
+    q = fl.Query.parse("w=300&h=200&webp=true&quality=85")
+    p, fmt = q.to_params(fl.Format(fl.ACCEPT_WEBP), input_is_jpeg=True)
+    assert fmt == fl.OUT_WEBP and p.front_end == fl.FE_WEBP420
+    outs = gpu_state.process_batch(imgs, [p] * len(imgs))
+    for img, planes in zip(imgs, outs):
+        pix = oracle.process_pixels(img, 300, 200, arith=oracle_lib.ARITH_FMA)
+        y, u, v, has_alpha = oracle.webp_yuv420(pix)
+        assert not has_alpha and planes.y.shape == (200, 300) and planes.u.shape == (100, 150)
+        assert np.array_equal(planes.y, y) and np.array_equal(planes.u, u) and np.array_equal(planes.v, v)
+
+
 def test_band_split_small_batch_matches(fl, gpu_state, oracle, monkeypatch):
     img = synth.uniform(1080, 1920, 3, index=60)
     want = oracle.process_pixels(img, 300, 200, arith=oracle_lib.ARITH_FMA)
