@@ -20,6 +20,10 @@
 
 #include "fl_kernels.h"
 
+#ifndef FL_WPREFETCH
+#define FL_WPREFETCH 0 // 1 = fetch a row's weights from LDS one row ahead (measured: no gain)
+#endif
+
 #ifndef FL_STREAM_DEPTH
 #define FL_STREAM_DEPTH 4 // source rows in flight per lane in the streaming kernel
 #endif
@@ -430,18 +434,34 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
         // block summary (row 0 of the block): which slots complete inside this block, first completed output row
         const u32x4 meta = *reinterpret_cast<const u32x4 *>(schc + 8);
         const uint32_t sch_base = (uint32_t)(schc - sch); // dword offset of this block's first row inside the dynamic LDS block
+        // Row weights: wave-uniform LDS reads (broadcast), fetched ONE row ahead so that a row's FMAs never
+        // wait for LDS.  Dead slots carry weight 0, so the accumulate below is branch free: acc + v * 0
+        // leaves a finished or not yet started slot untouched, and skipping it with scalar branches costs
+        // more than the idle v_pk_fma_f32 it saves.  (The opaque offsets stop hipcc from hoisting all D rows'
+        // reads to the top of the block, which costs 8 VGPRs per row of look-ahead.)
+        f32x4 wr03[D], wr47[D];
+        {
+            uint32_t so = sch_base;
+            asm volatile("" : "+v"(so));
+            wr03[0] = *reinterpret_cast<const f32x4 *>(fl_lds + so);
+            wr47[0] = *reinterpret_cast<const f32x4 *>(fl_lds + so + 4);
+        }
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const uint32_t ri = rb + k;
-            // wave-uniform LDS reads (broadcast).  Dead slots carry weight 0, so the accumulate below is
-            // branch free: acc + v * 0 leaves a finished or not yet started slot untouched, and skipping
-            // it with scalar branches costs more than the idle v_pk_fma_f32 it saves.
-            // (the opaque offset stops hipcc from hoisting all D rows' weight reads to the top of the block,
-            // which costs 8 VGPRs per row of look-ahead)
-            uint32_t so = sch_base + k * 12;
-            asm volatile("" : "+v"(so));
-            const f32x4 w03 = *reinterpret_cast<const f32x4 *>(fl_lds + so);
-            const f32x4 w47 = *reinterpret_cast<const f32x4 *>(fl_lds + so + 4);
+            if (k + 1 < D && FL_WPREFETCH) {
+                uint32_t so = sch_base + (k + 1) * 12;
+                asm volatile("" : "+v"(so));
+                wr03[k + 1 < D ? k + 1 : 0] = *reinterpret_cast<const f32x4 *>(fl_lds + so);
+                wr47[k + 1 < D ? k + 1 : 0] = *reinterpret_cast<const f32x4 *>(fl_lds + so + 4);
+            }
+            if (k > 0 && !FL_WPREFETCH) {
+                uint32_t so = sch_base + k * 12;
+                asm volatile("" : "+v"(so));
+                wr03[k] = *reinterpret_cast<const f32x4 *>(fl_lds + so);
+                wr47[k] = *reinterpret_cast<const f32x4 *>(fl_lds + so + 4);
+            }
+            const f32x4 w03 = wr03[k], w47 = wr47[k];
             // unconditional refill: rows past the band are harmless extra reads, rows past the image read 0
             // (convert first, refill second: the slot's registers are dead by then, so the refill lands in place)
             float v[NV];
