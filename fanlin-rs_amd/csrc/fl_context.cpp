@@ -359,6 +359,7 @@ struct Work {
     const HostAxis *va = nullptr, *ha = nullptr;
     uint32_t vtab = 0, htab = 0;
     const StreamPlan *splan = nullptr;
+    bool unaligned = false;
 };
 
 struct GroupKey {
@@ -456,8 +457,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if (!w.vtab || !w.htab) { full = true; break; }
             // fused streaming kernel if the geometry allows it
             w.s1 = S1_GENERIC;
-            const bool aligned = ((w.sw * w.cs) % 4u == 0) && ((uintptr_t)w.src % 4u == 0) &&
-                                 (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
+            // rows that are not dword aligned: Rgb8 has a funnel-shift variant of the kernel, others use the generic path
+            w.unaligned = ((w.sw * w.cs) % 4u != 0) || ((uintptr_t)w.src % 4u != 0);
+            const bool aligned = (!w.unaligned || w.cs == 3) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
             if (stream_supported(w.cs, w.pre) && aligned && !force_generic) {
                 Job jtmp; fill_job(w, jtmp);
                 uint32_t nbands = 1;
@@ -500,7 +502,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
-        if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         if (w.p->blur_sigma > 0.0f) {
             // channels that really need filtering: a letterboxed picture of an opaque source has alpha == 255
             // everywhere, and a grey one on a grey fill has R == G == B (see blur_tile_kernel)
@@ -661,7 +663,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         } else {
             LaunchStream s{}; // (the streaming kernel paints the letterbox frame itself)
             s.jobs = d_jobs; s.items = d_items + L.item_base; s.arena = c->d_arena; s.nitems = L.nitems;
-            s.cs = L.k.cs; s.pre = L.k.pre; s.letterbox = L.k.lb; s.lds_bytes = L.lds; s.nacc = L.nacc;
+            s.cs = L.k.cs; s.pre = L.k.pre; s.letterbox = L.k.lb; s.lds_bytes = L.lds; s.nacc = L.nacc; s.unaligned = (L.k.kind >> 16) & 1u;
             {
                 ProfileScope ps(c, st, 0);
                 FL_HIP(c, launch_stream(s, st), "streaming resample kernel");

@@ -41,6 +41,7 @@ struct LaunchStream {
     uint32_t nitems;
     uint32_t cs, pre, letterbox;
     uint32_t nacc;           // accumulator slots the row schedules were built for (7 or 8)
+    uint32_t unaligned;      // Rgb8 sources whose rows are not dword aligned (odd pitch or base): funnel-shift variant
     size_t lds_bytes;
 };
 

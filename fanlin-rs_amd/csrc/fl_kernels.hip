@@ -322,7 +322,11 @@ __device__ __forceinline__ void take_slot(f32x2 *acc, float *e)
 
 // NA = accumulator slots (output rows alive per source row; the host picks the smallest that fits),
 // D  = source rows kept in flight per lane.
-template <int CS, int PRE, bool LB, int NA, int D>
+// UA (Rgb8 only): source rows that are not dword aligned (pitch or base pointer not a multiple of 4).  Dword
+// buffer loads ignore the two low address bits, so each lane loads the 16 aligned bytes that cover its 12 and
+// funnel-shifts them by the row's byte phase (v_alignbyte_b32; the phase is wave-uniform because a lane's
+// own offset, 12 * lane, is a multiple of 4).
+template <int CS, int PRE, bool LB, int NA, int D, bool UA>
 __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restrict__ jobs,
                                                               const StreamItem *__restrict__ items,
                                                               const uint32_t *__restrict__ arena
@@ -363,9 +367,13 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
     }
 
     // raw buffer descriptor (stride 0): num_records = image bytes, so the hardware range-checks every lane
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(jb.src), 0, (int)jb.src_bytes, 0x00020000);
+    const uint32_t base_phase = UA ? (uint32_t)(reinterpret_cast<uintptr_t>(jb.src) & 3u) : 0u;
+    // (UA: the range is rounded up to whole dwords, otherwise the hardware zeroes the last, partly valid dword;
+    //  an aligned dword that holds one valid byte lies in the same page as that byte, so this cannot fault)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(jb.src) - base_phase, 0,
+                                                                        (int)(UA ? ((jb.src_bytes + base_phase + 3u) & ~3u) : jb.src_bytes), 0x00020000);
     const uint32_t pitch = jb.sw * CS;
-    const uint32_t voff = (it.sx0 + tid * PXL) * CS + it.r0 * pitch;
+    const uint32_t voff = (it.sx0 + tid * PXL) * CS + it.r0 * pitch + base_phase;
     const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (it.x0 - jb.cx);
 
     // Letterbox border: every workgroup paints the part of the fill frame that lies next to its own band
@@ -405,9 +413,10 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
         for (int k = 0; k < NH; ++k) acc[s][k] = f32x2{0.0f, 0.0f};
 
     // whole byte offset goes through voffset: rows past the image end are range-checked by the buffer descriptor and read 0
-    RowRaw<CS> ring[D];
+    constexpr int LW = UA ? 4 : CS; // dwords loaded per lane and row
+    RowRaw<LW> ring[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) load_row<CS>(ring[k], rs, voff + k * pitch);
+    for (int k = 0; k < D; ++k) load_row<LW>(ring[k], rs, UA ? ((voff + k * pitch) & ~3u) : voff + k * pitch);
 
     __syncthreads();
 
@@ -465,14 +474,23 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
             // unconditional refill: rows past the band are harmless extra reads, rows past the image read 0
             // (convert first, refill second: the slot's registers are dead by then, so the refill lands in place)
             float v[NV];
-            convert_row<CS, PRE>(ring[k], v); // hipcc waits for this row only: the D - 1 younger rows stay in flight
+            if constexpr (UA) {
+                const uint32_t ph = __builtin_amdgcn_readfirstlane((voff + ri * pitch) & 3u); // same in every lane
+                RowRaw<CS> al;
+                al.v.x = __builtin_amdgcn_alignbyte(ring[k].v.y, ring[k].v.x, ph);
+                al.v.y = __builtin_amdgcn_alignbyte(ring[k].v.z, ring[k].v.y, ph);
+                al.v.z = __builtin_amdgcn_alignbyte(ring[k].v.w, ring[k].v.z, ph);
+                convert_row<CS, PRE>(al, v);
+            } else {
+                convert_row<CS, PRE>(ring[k], v); // hipcc waits for this row only: the D - 1 younger rows stay in flight
+            }
             // Keep the refill below the conversion: hoisted above it, the refill needs fresh registers and the
             // ring is then rotated with v_mov behind a vmcnt(0) at the loop end.  The empty asm makes the
             // refill's address depend on every converted value, so all reads of the old row precede it.
             uint32_t roff = voff + (ri + D) * pitch;
 #pragma unroll
             for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(roff) : "v"(v[j]));
-            load_row<CS>(ring[k], rs, roff);
+            load_row<LW>(ring[k], rs, UA ? (roff & ~3u) : roff);
             if (!(ablate & 4u)) {
 #pragma unroll
                 for (int s = 0; s < NA; ++s) {
@@ -983,10 +1001,10 @@ bool stream_supported(uint32_t cs, uint32_t pre)
     return cs == 3 || cs == 4;
 }
 
-template <int CS, int PRE, bool LB, int NA, int D>
+template <int CS, int PRE, bool LB, int NA, int D, bool UA>
 static hipError_t launch_stream_v(const LaunchStream &s, hipStream_t st)
 {
-    auto k = resample_stream_kernel<CS, PRE, LB, NA, D>;
+    auto k = resample_stream_kernel<CS, PRE, LB, NA, D, UA>;
     if (s.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes);
         if (e != hipSuccess) return e;
@@ -1000,8 +1018,14 @@ template <int CS, int PRE>
 static hipError_t launch_stream_t(const LaunchStream &s, hipStream_t st)
 {
     constexpr int D = FL_STREAM_DEPTH;
-    if (s.letterbox) return s.nacc <= 7 ? launch_stream_v<CS, PRE, true, 7, D>(s, st) : launch_stream_v<CS, PRE, true, 8, D>(s, st);
-    return s.nacc <= 7 ? launch_stream_v<CS, PRE, false, 7, D>(s, st) : launch_stream_v<CS, PRE, false, 8, D>(s, st);
+    if constexpr (CS == 3) {
+        if (s.unaligned) {
+            if (s.letterbox) return s.nacc <= 7 ? launch_stream_v<CS, PRE, true, 7, D, true>(s, st) : launch_stream_v<CS, PRE, true, 8, D, true>(s, st);
+            return s.nacc <= 7 ? launch_stream_v<CS, PRE, false, 7, D, true>(s, st) : launch_stream_v<CS, PRE, false, 8, D, true>(s, st);
+        }
+    }
+    if (s.letterbox) return s.nacc <= 7 ? launch_stream_v<CS, PRE, true, 7, D, false>(s, st) : launch_stream_v<CS, PRE, true, 8, D, false>(s, st);
+    return s.nacc <= 7 ? launch_stream_v<CS, PRE, false, 7, D, false>(s, st) : launch_stream_v<CS, PRE, false, 8, D, false>(s, st);
 }
 
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st)

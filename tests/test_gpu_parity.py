@@ -133,6 +133,22 @@ def test_fill_colour_and_crop_geometry(fl, gpu_state, oracle, crop):
     check_resample(fl, gpu_state, oracle, img, w=333, h=222, crop=crop, fill=(255, 0, 128))
 
 
+@pytest.mark.parametrize("w", [1919, 1366, 1001, 513])
+def test_unaligned_row_pitch_uses_the_fused_kernel(fl, gpu_state, oracle, w):
+    # Rgb8 rows whose byte pitch is not a multiple of 4 (3 * w): funnel-shift variant of the streaming kernel
+    img = synth.uniform(540, w, 3, index=w)
+    before = gpu_state.stats()
+    check_resample(fl, gpu_state, oracle, img, w=300, h=200)
+    after = gpu_state.stats()
+    assert after["resample_launches"] == before["resample_launches"] + 1 and after["generic_launches"] == before["generic_launches"]
+    # an unaligned base pointer as well (a view one byte into a buffer)
+    buf = np.zeros(img.size + 1, np.uint8)
+    view = buf[1:].reshape(img.shape)
+    view[...] = img
+    got = gpu_state.process_batch([view], [fl.make_params(300, 200)])[0]
+    assert np.array_equal(got, oracle.process_pixels(img, 300, 200, arith=oracle_lib.ARITH_FMA))
+
+
 def test_constant_image_stays_constant(fl, gpu_state):
     for v in (0, 1, 127, 255):
         img = np.full((1080, 1920, 3), v, np.uint8)
