@@ -998,7 +998,7 @@ static_assert(SCHED_CHUNK % FL_STREAM_DEPTH == 0, "schedule chunks must hold who
 bool stream_supported(uint32_t cs, uint32_t pre)
 {
     (void)pre;
-    return cs == 3 || cs == 4;
+    return cs >= 1 && cs <= 4;
 }
 
 template <int CS, int PRE, bool LB, int NA, int D, bool UA>
@@ -1031,6 +1031,8 @@ static hipError_t launch_stream_t(const LaunchStream &s, hipStream_t st)
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st)
 {
 #define FL_CASE(C_, P_) if (s.cs == C_ && s.pre == P_) return launch_stream_t<C_, P_>(s, st)
+    FL_CASE(1, PRE_NONE); FL_CASE(1, PRE_INVERT);   // (grayscale of Luma / LumaA is the identity: the host maps it to PRE_NONE)
+    FL_CASE(2, PRE_NONE); FL_CASE(2, PRE_INVERT);
     FL_CASE(3, PRE_NONE); FL_CASE(3, PRE_GRAY); FL_CASE(3, PRE_INVERT);
     FL_CASE(4, PRE_NONE); FL_CASE(4, PRE_GRAY); FL_CASE(4, PRE_INVERT);
 #undef FL_CASE

@@ -149,6 +149,15 @@ def test_unaligned_row_pitch_uses_the_fused_kernel(fl, gpu_state, oracle, w):
     assert np.array_equal(got, oracle.process_pixels(img, 300, 200, arith=oracle_lib.ARITH_FMA))
 
 
+@pytest.mark.parametrize("c,kw", [(1, {}), (1, dict(inverse=True)), (2, {}), (2, dict(inverse=True)), (1, dict(grayscale=True))])
+def test_luma_sources_use_the_fused_kernel(fl, gpu_state, oracle, c, kw):
+    img = synth.uniform(720, 1280, c, index=90 + c)
+    before = gpu_state.stats()
+    check_resample(fl, gpu_state, oracle, img, w=300, h=200, **kw)
+    after = gpu_state.stats()
+    assert after["resample_launches"] == before["resample_launches"] + 1
+
+
 def test_constant_image_stays_constant(fl, gpu_state):
     for v in (0, 1, 127, 255):
         img = np.full((1080, 1920, 3), v, np.uint8)
