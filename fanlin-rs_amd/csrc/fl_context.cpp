@@ -520,7 +520,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::vector<FrontendJob> fjobs;
     struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc; LaunchGeneric g; size_t lds; size_t mid_floats; uint32_t blur_grid_x; bool blur_tiled; };
     std::vector<S1Launch> s1_launches, blur_launches;
-    struct FeLaunch { uint32_t kind, base, n, mw, mh; };
+    struct FeLaunch { uint32_t kind, base, n, mw, mh; bool rgba; };
     std::vector<FeLaunch> fe_launches;
     size_t mid_floats_max = 0;
     const size_t kMidCapFloats = (size_t)256 << 20; // 1 GiB of f32 intermediate per launch group
@@ -601,7 +601,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     }
     size_t n_status = 0;
     for (auto &kv : fe_groups) {
-        FeLaunch F{kv.first.kind, (uint32_t)fjobs.size(), 0, 0, 0};
+        FeLaunch F{kv.first.kind, (uint32_t)fjobs.size(), 0, 0, 0, true};
         for (size_t idx : kv.second) {
             const Work &w = work[idx];
             const flgpu_plan &pl = w.plan;
@@ -611,6 +611,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             f.status = reinterpret_cast<uint32_t *>(n_status++ * 4 + 4); // patched below
             f.w = pl.out_w; f.h = pl.out_h; f.c = pl.out_c;
             f.plane_w = pl.plane_w; f.plane_h = pl.plane_h; f.chroma_w = pl.chroma_w; f.chroma_h = pl.chroma_h;
+            if (f.c != 4 || ((uintptr_t)f.src & 3u) || ((uintptr_t)f.dst & 3u)) F.rgba = false;
             if (F.kind == FLGPU_FE_JFIF444) { F.mw = std::max(F.mw, f.plane_w); F.mh = std::max(F.mh, f.plane_h); }
             else { F.mw = std::max(F.mw, f.chroma_w); F.mh = std::max(F.mh, f.chroma_h); }
             fjobs.push_back(f);
@@ -688,8 +689,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     }
     for (auto &F : fe_launches) {
         ProfileScope ps(c, st, 2);
-        if (F.kind == FLGPU_FE_JFIF444) FL_HIP(c, launch_jfif444(d_fjobs, F.base, F.n, F.mw, F.mh, st), "jfif front end");
-        else FL_HIP(c, launch_webp420(d_fjobs, c->d_arena, c->gamma_off, F.base, F.n, F.mw, F.mh, st), "webp front end");
+        if (F.kind == FLGPU_FE_JFIF444) FL_HIP(c, launch_jfif444(d_fjobs, F.base, F.n, F.mw, F.mh, F.rgba, st), "jfif front end");
+        else FL_HIP(c, launch_webp420(d_fjobs, c->d_arena, c->gamma_off, F.base, F.n, F.mw, F.mh, F.rgba, st), "webp front end");
         c->stats.frontend_launches++;
     }
     // plain copies for requests that change nothing

@@ -872,6 +872,77 @@ __global__ __launch_bounds__(256) void webp420_kernel(const FrontendJob *__restr
     if (any_alpha && fj.status) atomicOr(fj.status, 1u);
 }
 
+// Rgba8 fast paths of the front ends (every letterboxed output is Rgba8): 4 pixels per thread, dword loads,
+// dword stores per plane.  Same arithmetic as the generic kernels above.
+__device__ __forceinline__ void jfif_px(uint32_t d, uint32_t &y, uint32_t &cb, uint32_t &cr)
+{
+    const float max = 255.0f;
+    const float r = (float)(d & 255u), g = (float)((d >> 8) & 255u), b = (float)((d >> 16) & 255u);
+    y = sat_u8(76.245f / max * r + 149.685f / max * g + 29.07f / max * b);
+    cb = sat_u8(-43.0185f / max * r - 84.4815f / max * g + 127.5f / max * b + 128.0f);
+    cr = sat_u8(127.5f / max * r - 106.7685f / max * g - 20.7315f / max * b + 128.0f);
+}
+
+__global__ __launch_bounds__(256) void jfif444_rgba_kernel(const FrontendJob *__restrict__ fjobs, uint32_t job_base)
+{
+    const FrontendJob fj = fjobs[job_base + blockIdx.y];
+    const uint32_t q = fj.plane_w >> 2;                        // 4-pixel groups per plane row (plane_w is a multiple of 8)
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;      // flat over rows x groups: narrow planes still fill the waves
+    if (idx >= q * fj.plane_h) return;
+    const uint32_t y = idx / q, x = (idx - y * q) * 4u;
+    const uint32_t sy = y < fj.h ? y : fj.h - 1u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fj.src), 0, (int)(fj.w * fj.h * 4u), 0x00020000);
+    uint32_t yy = 0, cb = 0, cr = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sx = x + k < fj.w ? x + k : fj.w - 1u; // replicate the last column into the padding
+        const uint32_t d = __builtin_amdgcn_raw_buffer_load_b32(rs, (sy * fj.w + sx) * 4u, 0, 0);
+        uint32_t a, b, c;
+        jfif_px(d, a, b, c);
+        yy |= a << (8 * k); cb |= b << (8 * k); cr |= c << (8 * k);
+    }
+    const size_t plane = (size_t)fj.plane_w * fj.plane_h, o = (size_t)y * fj.plane_w + x;
+    uint8_t *dst = fj.dst;
+    *reinterpret_cast<uint32_t *>(dst + o) = yy;
+    *reinterpret_cast<uint32_t *>(dst + plane + o) = cb;
+    *reinterpret_cast<uint32_t *>(dst + 2 * plane + o) = cr;
+}
+
+__global__ __launch_bounds__(256) void webp420_rgba_kernel(const FrontendJob *__restrict__ fjobs, const uint32_t *__restrict__ arena,
+                                                           uint32_t gamma_off, uint32_t job_base)
+{
+    const FrontendJob fj = fjobs[job_base + blockIdx.y];
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x; // flat over chroma samples
+    if (idx >= fj.chroma_w * fj.chroma_h) return;
+    const uint32_t by = idx / fj.chroma_w, bx = idx - by * fj.chroma_w;
+    const int32_t *gam2lin = reinterpret_cast<const int32_t *>(arena + gamma_off);
+    const int32_t *lin2gam = gam2lin + 256;
+    const uint32_t w = fj.w, h = fj.h;
+    const uint32_t x0 = 2u * bx, y0 = 2u * by;
+    const uint32_t x1 = x0 + 1u < w ? x0 + 1u : x0;
+    const uint32_t y1 = y0 + 1u < h ? y0 + 1u : y0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fj.src), 0, (int)(w * h * 4u), 0x00020000);
+    uint8_t *Y = fj.dst, *U = fj.dst + (size_t)w * h, *V = U + (size_t)fj.chroma_w * fj.chroma_h;
+    uint32_t sr = 0, sg = 0, sb = 0, any_alpha = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t px = (k & 1) ? x1 : x0, py = (k & 2) ? y1 : y0;
+        const uint32_t d = __builtin_amdgcn_raw_buffer_load_b32(rs, (py * w + px) * 4u, 0, 0);
+        const uint32_t r = d & 255u, g = (d >> 8) & 255u, b = (d >> 16) & 255u;
+        any_alpha |= ((d >> 24) != 255u);
+        const int luma = 16839 * (int)r + 33059 * (int)g + 6420 * (int)b;
+        Y[(size_t)py * w + px] = (uint8_t)((luma + (1 << 15) + (16 << 16)) >> 16);
+        if (x1 != x0 || !(k & 1)) { sr += (uint32_t)gam2lin[r]; sg += (uint32_t)gam2lin[g]; sb += (uint32_t)gam2lin[b]; }
+    }
+    const int shift = (x1 == x0) ? 1 : 0;
+    const int r = webp_linear_to_gamma(lin2gam, sr, shift);
+    const int g = webp_linear_to_gamma(lin2gam, sg, shift);
+    const int b = webp_linear_to_gamma(lin2gam, sb, shift);
+    U[(size_t)by * fj.chroma_w + bx] = (uint8_t)webp_clip_uv(-9719 * r - 19081 * g + 28800 * b, 1 << 17);
+    V[(size_t)by * fj.chroma_w + bx] = (uint8_t)webp_clip_uv(+28800 * r - 24116 * g - 4684 * b, 1 << 17);
+    if (any_alpha && fj.status) atomicOr(fj.status, 1u);
+}
+
 // ---------------------------------------------------------------------------
 // launch wrappers (called from the host runtime; all asynchronous on `stream`)
 // ---------------------------------------------------------------------------
@@ -1039,8 +1110,15 @@ hipError_t launch_stream(const LaunchStream &s, hipStream_t st)
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_jfif444(const FrontendJob *fjobs, uint32_t job_base, uint32_t njobs, uint32_t max_pw, uint32_t max_ph, hipStream_t st)
+hipError_t launch_jfif444(const FrontendJob *fjobs, uint32_t job_base, uint32_t njobs, uint32_t max_pw, uint32_t max_ph,
+                          bool all_rgba_aligned, hipStream_t st)
 {
+    if (all_rgba_aligned) {
+        dim3 grid4(((max_pw / 4u) * max_ph + 255u) / 256u, njobs);
+        hipLaunchKernelGGL(jfif444_rgba_kernel, grid4, dim3(256), 0, st, fjobs, job_base);
+        FL_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     dim3 grid((max_pw + 255u) / 256u, max_ph, njobs);
     hipLaunchKernelGGL(jfif444_kernel, grid, dim3(256), 0, st, fjobs, job_base);
     FL_LAUNCH_CHECK();
@@ -1048,8 +1126,14 @@ hipError_t launch_jfif444(const FrontendJob *fjobs, uint32_t job_base, uint32_t 
 }
 
 hipError_t launch_webp420(const FrontendJob *fjobs, const uint32_t *arena, uint32_t gamma_off, uint32_t job_base,
-                          uint32_t njobs, uint32_t max_cw, uint32_t max_ch, hipStream_t st)
+                          uint32_t njobs, uint32_t max_cw, uint32_t max_ch, bool all_rgba_aligned, hipStream_t st)
 {
+    if (all_rgba_aligned) {
+        dim3 gridf((max_cw * max_ch + 255u) / 256u, njobs);
+        hipLaunchKernelGGL(webp420_rgba_kernel, gridf, dim3(256), 0, st, fjobs, arena, gamma_off, job_base);
+        FL_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     dim3 grid((max_cw + 255u) / 256u, max_ch, njobs);
     hipLaunchKernelGGL(webp420_kernel, grid, dim3(256), 0, st, fjobs, arena, gamma_off, job_base);
     FL_LAUNCH_CHECK();
