@@ -85,7 +85,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_cropping", "flgpu_query_blur", "flgpu_query_grayscale", "flgpu_query_inverse",
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
     "flgpu_params_from_query", "flgpu_plan_output", "flgpu_create", "flgpu_destroy", "flgpu_transform",
-    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_export_tables", "flgpu_copy_tables",
+    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_ycck_to_cmyk", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
     "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version",
     "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable",
@@ -134,6 +134,7 @@ def load_library() -> C.CDLL:
     lib.flgpu_transform_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params), C.POINTER(flgpu_image)]
     lib.flgpu_transform_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params),
                                                  C.POINTER(flgpu_image), C.c_void_p, C.c_uint32]
+    lib.flgpu_ycck_to_cmyk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.flgpu_export_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.flgpu_copy_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.flgpu_import_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -416,6 +417,14 @@ class State:
             _check(lib.flgpu_transform_batch_device(ctx, n, srcs, ps, dsts, C.c_void_p(stream), flags), ctx)
         run._keep = (srcs, dsts, ps)
         return run
+
+    def ycck_to_cmyk(self, raw: np.ndarray) -> np.ndarray:
+        """handler.rs:423-438 on an (..., 4) uint8 array of (Y, Cb, Cr, K) pixels; returns a converted copy."""
+        a = np.ascontiguousarray(raw, dtype=np.uint8).copy()
+        if a.size % 4:
+            raise ValueError("expected 4 bytes per pixel")
+        _check(self._lib.flgpu_ycck_to_cmyk(self._ctx, a.ctypes.data, a.size // 4), self._ctx)
+        return a
 
     def export_tables(self) -> Tuple[int, int]:
         ptr, nbytes = C.c_void_p(), C.c_uint64()

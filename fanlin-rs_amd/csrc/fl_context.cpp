@@ -872,6 +872,10 @@ flgpu_ctx *flgpu_create(const flgpu_config *cfg, int *status)
         delete c; set(FLGPU_ERR_NO_DEVICE); return nullptr;
     }
     c->arena_cap_words = kArenaWords;
+    if (const char *aw = getenv("FLGPU_ARENA_WORDS")) { // tests: a small arena exercises the overflow -> reset path
+        const long v = atol(aw);
+        if (v >= 65536 && (size_t)v <= kArenaWords) c->arena_cap_words = (size_t)v;
+    }
     if (hipMalloc(reinterpret_cast<void **>(&c->d_arena), kArenaWords * 4) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; set(FLGPU_ERR_OOM); return nullptr;
     }
@@ -950,6 +954,22 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
     pin_release(c, r.in);
     pin_release(c, r.out);
     return r.status;
+}
+
+int flgpu_ycck_to_cmyk(flgpu_ctx *c, uint8_t *raw, uint64_t n_pixels)
+{
+    if (!c || (!raw && n_pixels)) return FLGPU_ERR_INVALID_ARG;
+    if (n_pixels == 0) return FLGPU_OK;
+    if (n_pixels >= (1ull << 30)) return FLGPU_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> g(c->mu);
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    const size_t bytes = (size_t)n_pixels * 4;
+    FL_HIP(c, c->d_in.reserve(bytes), "device staging");
+    FL_HIP(c, hipMemcpyAsync(c->d_in.p, raw, bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    FL_HIP(c, launch_ycck_to_cmyk(static_cast<uint32_t *>(c->d_in.p), n_pixels, c->stream), "ycck kernel");
+    FL_HIP(c, hipMemcpyAsync(raw, c->d_in.p, bytes, hipMemcpyDeviceToHost, c->stream), "D2H");
+    FL_HIP(c, hipStreamSynchronize(c->stream), "sync");
+    return FLGPU_OK;
 }
 
 int flgpu_export_tables(flgpu_ctx *c, void **device_ptr, uint64_t *bytes)

@@ -63,6 +63,8 @@ size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks);
 uint32_t stream_lanes(); // lanes (threads) per workgroup of the streaming kernel
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st);
 
+hipError_t launch_ycck_to_cmyk(uint32_t *px, uint64_t n_pixels, hipStream_t st);
+
 // all_rgba_aligned: every job of the group is Rgba8 with dword-aligned source and destination (4 pixels per thread)
 hipError_t launch_jfif444(const FrontendJob *fjobs, uint32_t job_base, uint32_t njobs, uint32_t max_pw, uint32_t max_ph,
                           bool all_rgba_aligned, hipStream_t st);

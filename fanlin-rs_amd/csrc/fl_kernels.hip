@@ -943,6 +943,23 @@ __global__ __launch_bounds__(256) void webp420_rgba_kernel(const FrontendJob *__
     if (any_alpha && fj.status) atomicOr(fj.status, 1u);
 }
 
+// reference src/handler.rs:423-438: per pixel (Y, Cb, Cr, K) -> (clamp(R), clamp(G), clamp(B), 255 - K), f32 with
+// truncating casts, evaluated in the reference's operation order (this file is built with -ffp-contract=off)
+__global__ __launch_bounds__(256) void ycck_to_cmyk_kernel(uint32_t *__restrict__ px, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t d = px[i];
+    const float y = (float)(d & 255u), cb = (float)((d >> 8) & 255u), cr = (float)((d >> 16) & 255u);
+    float r = y + 1.40200f * cr - 179.456f;
+    float g = y - 0.34414f * cb - 0.71414f * cr + 135.45984f;
+    float b = y + 1.77200f * cb - 226.816f;
+    r = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+    g = g < 0.0f ? 0.0f : (g > 255.0f ? 255.0f : g);
+    b = b < 0.0f ? 0.0f : (b > 255.0f ? 255.0f : b);
+    px[i] = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | ((255u - (d >> 24)) << 24);
+}
+
 // ---------------------------------------------------------------------------
 // launch wrappers (called from the host runtime; all asynchronous on `stream`)
 // ---------------------------------------------------------------------------
@@ -1108,6 +1125,14 @@ hipError_t launch_stream(const LaunchStream &s, hipStream_t st)
     FL_CASE(4, PRE_NONE); FL_CASE(4, PRE_GRAY); FL_CASE(4, PRE_INVERT);
 #undef FL_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_ycck_to_cmyk(uint32_t *px, uint64_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(ycck_to_cmyk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, px, n);
+    FL_LAUNCH_CHECK();
+    return hipSuccess;
 }
 
 hipError_t launch_jfif444(const FrontendJob *fjobs, uint32_t job_base, uint32_t njobs, uint32_t max_pw, uint32_t max_ph,

@@ -24,6 +24,7 @@
  *                                       src/handler.rs:274-278
  *   front_end = FLGPU_FE_WEBP420        WebPPictureImportRGBA + ARGB->YUV420 inside
  *                                       webp::Encoder::encode, src/handler.rs:295-297
+ *   flgpu_ycck_to_cmyk                  the YCCK loop of convert_jpeg_color_if_needed, src/handler.rs:423-438
  *   flgpu_create / flgpu_destroy        lifetime of handler::State, src/handler.rs:14-21,36-52
  */
 #ifndef FANLIN_GPU_H
@@ -189,6 +190,10 @@ int flgpu_transform_batch(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, con
 #define FLGPU_BATCH_SAME_PARAMS 1u
 int flgpu_transform_batch_device(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, const flgpu_params *ps,
                                  flgpu_image *dsts, void *hip_stream, uint32_t flags);
+
+/* In-place YCCK -> "CMYK with inverted K" on n_pixels x 4 host bytes: the pointwise loop of
+ * convert_jpeg_color_if_needed (src/handler.rs:423-438) that precedes the lcms2 transform.  Blocking. */
+int flgpu_ycck_to_cmyk(flgpu_ctx *ctx, uint8_t *raw, uint64_t n_pixels);
 
 /* Read-only device tables (weight tables, row schedules, gamma LUTs) as one blob.
  * Multi-GPU runs build them on rank 0, broadcast the blob over RCCL/xGMI and install

@@ -235,6 +235,29 @@ def test_webp420_front_end(fl, gpu_state, oracle, shape):
     assert np.array_equal(planes.y, y) and np.array_equal(planes.u, u) and np.array_equal(planes.v, v)
 
 
+def test_ycck_loop_bit_exact(fl, gpu_state, oracle):
+    # every (Y, Cb, Cr) combination on a coarse grid plus random pixels; K inverted
+    g = np.arange(0, 256, 5, dtype=np.uint8)
+    y, cb, cr = np.meshgrid(g, g, g, indexing="ij")
+    grid = np.stack([y.ravel(), cb.ravel(), cr.ravel(), (y.ravel() * 7 + 3).astype(np.uint8)], axis=1)
+    rnd = synth.uniform(1, 100003, 4, index=99)[0]
+    raw = np.concatenate([grid, rnd], axis=0)
+    assert np.array_equal(gpu_state.ycck_to_cmyk(raw), oracle.ycck_to_cmyk(raw).reshape(raw.shape))
+
+
+def test_many_geometries_overflow_the_table_arena(fl, oracle, monkeypatch):
+    # a deliberately tiny arena: planning 40 different geometries must reset and rebuild the table cache, not fail
+    monkeypatch.setenv("FLGPU_ARENA_WORDS", "262144")  # 1 MiB
+    with fl.State(device=0) as st:
+        for i in range(40):
+            h, w = 200 + 13 * i, 320 + 17 * i
+            img = synth.uniform(h, w, 3, index=300 + i)
+            got = st.process_pixels(img, fl.make_params(120 + i, 90, blur_sigma=10.0 if i % 7 == 0 else 0.0))
+            want = oracle.process_pixels(img, 120 + i, 90, blur_sigma=10.0 if i % 7 == 0 else 0.0, arith=oracle_lib.ARITH_FMA)
+            assert np.array_equal(got, want), i
+        assert st.stats()["tables_built"] > 80
+
+
 # ----------------------------------------------------------------- batch + queue paths --
 
 def test_batch_mixed_requests(fl, gpu_state, oracle):
