@@ -56,11 +56,12 @@ class flgpu_params(C.Structure):
     _fields_ = [("has_dims", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32),
                 ("fill_r", C.c_uint8), ("fill_g", C.c_uint8), ("fill_b", C.c_uint8), ("crop", C.c_uint8),
                 ("blur_sigma", C.c_float),
-                ("grayscale", C.c_uint8), ("inverse", C.c_uint8), ("quality", C.c_uint8), ("front_end", C.c_uint8)]
+                ("grayscale", C.c_uint8), ("inverse", C.c_uint8), ("quality", C.c_uint8), ("front_end", C.c_uint8),
+                ("orientation", C.c_uint8), ("reserved", C.c_uint8 * 3)]
 
 
 class flgpu_plan(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("mid_c", "resampled", "resized_w", "resized_h", "crop_x", "crop_y",
+    _fields_ = [(n, C.c_uint32) for n in ("src_w", "src_h", "mid_c", "resampled", "resized_w", "resized_h", "crop_x", "crop_y",
                                            "letterboxed", "place_x", "place_y", "out_w", "out_h", "out_c",
                                            "plane_w", "plane_h", "chroma_w", "chroma_h")] + \
                [("pixel_bytes", C.c_uint64), ("out_bytes", C.c_uint64)]
@@ -262,7 +263,7 @@ class Query:
 
 
 def make_params(w: Optional[int] = None, h: Optional[int] = None, fill=(32, 32, 32), crop=False, blur_sigma=0.0,
-                grayscale=False, inverse=False, quality=75, front_end=FE_NONE) -> flgpu_params:
+                grayscale=False, inverse=False, quality=75, front_end=FE_NONE, orientation=1) -> flgpu_params:
     p = flgpu_params()
     p.has_dims = 1 if (w is not None and h is not None) else 0
     p.w, p.h = (w or 0), (h or 0)
@@ -271,6 +272,7 @@ def make_params(w: Optional[int] = None, h: Optional[int] = None, fill=(32, 32, 
     p.blur_sigma = blur_sigma
     p.grayscale, p.inverse = int(grayscale), int(inverse)
     p.quality, p.front_end = quality, front_end
+    p.orientation = orientation
     return p
 
 

@@ -128,7 +128,7 @@ struct flgpu_ctx {
 
     DescSlot slots[4];
     int next_slot = 0;
-    DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_status;
+    DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_tmp_o, d_status;
     DeviceBuf d_in, d_out;
     PinnedBuf h_stage_in, h_stage_out;
     hipStream_t last_stream = nullptr;
@@ -360,6 +360,9 @@ struct Work {
     uint32_t vtab = 0, htab = 0;
     const StreamPlan *splan = nullptr;
     bool unaligned = false;
+    uint32_t orient = 0, raw_w = 0, raw_h = 0; // EXIF orientation pre-pass (2..8), source size before it
+    size_t orient_off = 0;
+    const uint8_t *raw_src = nullptr;
 };
 
 struct GroupKey {
@@ -400,7 +403,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
 
     // ---- plan every image ------------------------------------------------
     std::vector<Work> work(n);
-    size_t tmp_a_bytes = 0, tmp_b_bytes = 0;
+    size_t tmp_a_bytes = 0, tmp_b_bytes = 0, tmp_o_bytes = 0;
     for (size_t i = 0; i < n; ++i) {
         Work &w = work[i];
         const flgpu_image &s = srcs[i];
@@ -410,7 +413,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (rc) return rc;
         if (s.capacity < (uint64_t)s.width * s.height * s.channels) return FLGPU_ERR_INVALID_ARG;
         if (dsts[i].capacity < w.plan.out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
-        w.cs = s.channels; w.sw = s.width; w.sh = s.height;
+        w.cs = s.channels; w.sw = w.plan.src_w; w.sh = w.plan.src_h; // size after apply_orientation
+        w.raw_w = s.width; w.raw_h = s.height;
+        w.orient = w.p->orientation >= 2 ? w.p->orientation : 0;
+        if (w.orient) { w.orient_off = tmp_o_bytes; tmp_o_bytes += align_up((size_t)s.width * s.height * s.channels, 256); }
         w.pre = w.p->grayscale ? PRE_GRAY : (w.p->inverse ? PRE_INVERT : PRE_NONE);
         w.src = s.data;
         w.final_dst = dsts[i].data;
@@ -433,10 +439,14 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             else { w.blur_dst = reinterpret_cast<uint8_t *>(tmp_b_bytes); tmp_b_bytes += align_up(pl.pixel_bytes, 256); }
         } else w.blur_dst = nullptr;
     }
+    FL_HIP(c, c->d_tmp_o.reserve(tmp_o_bytes), "orientation scratch");
+    for (auto &w : work)
+        if (w.orient) { w.raw_src = w.src; w.src = static_cast<uint8_t *>(c->d_tmp_o.p) + w.orient_off; }
     FL_HIP(c, c->d_tmp_a.reserve(tmp_a_bytes), "scratch A");
     FL_HIP(c, c->d_tmp_b.reserve(tmp_b_bytes), "scratch B");
     for (auto &w : work) {
         const bool blur = w.p->blur_sigma > 0.0f, fe = w.p->front_end != FLGPU_FE_NONE;
+        if (w.s1 == S1_NONE) w.s1_dst = const_cast<uint8_t *>(w.src);
         if (w.s1 != S1_NONE && (blur || fe)) w.s1_dst = static_cast<uint8_t *>(c->d_tmp_a.p) + reinterpret_cast<size_t>(w.s1_dst);
         if (blur && fe) w.blur_dst = static_cast<uint8_t *>(c->d_tmp_b.p) + reinterpret_cast<size_t>(w.blur_dst);
     }
@@ -518,6 +528,22 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::vector<Job> jobs;
     std::vector<StreamItem> items;
     std::vector<FrontendJob> fjobs;
+    // EXIF orientation pre-pass jobs, grouped by channel count
+    struct OrientLaunch { uint32_t cs, base, n, mw, mh; };
+    std::vector<OrientLaunch> orient_launches;
+    for (uint32_t cs = 1; cs <= 4; ++cs) {
+        OrientLaunch O{cs, (uint32_t)jobs.size(), 0, 0, 0};
+        for (auto &w : work) {
+            if (!w.orient || w.cs != cs) continue;
+            Job j; memset(&j, 0, sizeof(j));
+            j.src = w.raw_src; j.dst = const_cast<uint8_t *>(w.src);
+            j.sw = w.raw_w; j.sh = w.raw_h; j.dw = w.sw; j.dh = w.sh; j.fill = w.orient;
+            O.mw = std::max(O.mw, j.dw); O.mh = std::max(O.mh, j.dh);
+            jobs.push_back(j);
+            O.n++;
+        }
+        if (O.n) orient_launches.push_back(O);
+    }
     struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc; LaunchGeneric g; size_t lds; size_t mid_floats; uint32_t blur_grid_x; bool blur_tiled; };
     std::vector<S1Launch> s1_launches, blur_launches;
     struct FeLaunch { uint32_t kind, base, n, mw, mh; bool rgba; };
@@ -651,6 +677,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     }
 
     // ---- launches --------------------------------------------------------------
+    for (auto &O : orient_launches) {
+        LaunchGeneric g{};
+        g.jobs = d_jobs; g.job_base = O.base; g.njobs = O.n; g.cs = O.cs; g.max_dw = O.mw; g.max_dh = O.mh;
+        FL_HIP(c, launch_orient(g, st), "orientation kernel");
+    }
     for (auto &L : s1_launches) {
         L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
         L.g.job_base = L.job_base; L.g.njobs = L.njobs;
@@ -899,7 +930,7 @@ void flgpu_destroy(flgpu_ctx *c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto &s : c->slots) { s.host.release(); s.dev.release(); if (s.done) (void)hipEventDestroy(s.done); }
     if (c->last_done) (void)hipEventDestroy(c->last_done);
-    c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_status.release(); c->d_in.release(); c->d_out.release();
+    c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_tmp_o.release(); c->d_status.release(); c->d_in.release(); c->d_out.release();
     c->h_stage_in.release(); c->h_stage_out.release();
     for (auto &kv : c->pin_free) (void)hipHostFree(kv.second);
     if (c->d_arena) (void)hipFree(c->d_arena);

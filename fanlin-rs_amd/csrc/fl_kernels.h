@@ -63,6 +63,8 @@ size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks);
 uint32_t stream_lanes(); // lanes (threads) per workgroup of the streaming kernel
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st);
 
+// EXIF orientation pre-pass: g.cs = channels, jobs[i].fill = EXIF code, sw/sh source size, dw/dh oriented size
+hipError_t launch_orient(const LaunchGeneric &g, hipStream_t st);
 hipError_t launch_ycck_to_cmyk(uint32_t *px, uint64_t n_pixels, hipStream_t st);
 
 // all_rgba_aligned: every job of the group is Rgba8 with dword-aligned source and destination (4 pixels per thread)

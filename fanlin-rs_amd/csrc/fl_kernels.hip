@@ -242,6 +242,35 @@ __global__ __launch_bounds__(256) void place_kernel(const Job *__restrict__ jobs
 }
 
 // ---------------------------------------------------------------------------
+// EXIF orientation (DynamicImage::apply_orientation, image 0.25.6 metadata::Orientation + imageops::rotate90 /
+// rotate180 / rotate270 / flip_horizontal / flip_vertical): a pure pixel permutation, one thread per
+// destination pixel.  jb.sw x jb.sh = SOURCE size, jb.dw x jb.dh = oriented size, jb.fill = EXIF code 2..8.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void orient_kernel(const Job *__restrict__ jobs, uint32_t job_base)
+{
+    const Job jb = jobs[job_base + blockIdx.z];
+    const uint32_t y = blockIdx.y, x = blockIdx.x * 256u + threadIdx.x;
+    if (y >= jb.dh || x >= jb.dw) return;
+    const uint32_t W = jb.sw, H = jb.sh;
+    uint32_t sx, sy;
+    switch (jb.fill) {
+    case 2: sx = W - 1u - x; sy = y; break;              // FlipHorizontal
+    case 3: sx = W - 1u - x; sy = H - 1u - y; break;     // Rotate180
+    case 4: sx = x; sy = H - 1u - y; break;              // FlipVertical
+    case 5: sx = y; sy = x; break;                       // Rotate90FlipH (transpose)
+    case 6: sx = y; sy = H - 1u - x; break;              // Rotate90
+    case 7: sx = W - 1u - y; sy = H - 1u - x; break;     // Rotate270FlipH (transverse)
+    case 8: sx = W - 1u - y; sy = x; break;              // Rotate270
+    default: sx = x; sy = y; break;
+    }
+    const uint8_t *p = jb.src + ((size_t)sy * W + sx) * C;
+    uint8_t *o = jb.dst + ((size_t)y * jb.dw + x) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = p[c];
+}
+
+// ---------------------------------------------------------------------------
 // Fused streaming Lanczos3 down-scale: the hot kernel.
 // ---------------------------------------------------------------------------
 
@@ -1125,6 +1154,20 @@ hipError_t launch_stream(const LaunchStream &s, hipStream_t st)
     FL_CASE(4, PRE_NONE); FL_CASE(4, PRE_GRAY); FL_CASE(4, PRE_INVERT);
 #undef FL_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_orient(const LaunchGeneric &g, hipStream_t st)
+{
+    dim3 grid((g.max_dw + 255u) / 256u, g.max_dh, g.njobs);
+    switch (g.cs) {
+    case 1: hipLaunchKernelGGL(orient_kernel<1>, grid, dim3(256), 0, st, g.jobs, g.job_base); break;
+    case 2: hipLaunchKernelGGL(orient_kernel<2>, grid, dim3(256), 0, st, g.jobs, g.job_base); break;
+    case 3: hipLaunchKernelGGL(orient_kernel<3>, grid, dim3(256), 0, st, g.jobs, g.job_base); break;
+    case 4: hipLaunchKernelGGL(orient_kernel<4>, grid, dim3(256), 0, st, g.jobs, g.job_base); break;
+    default: return hipErrorInvalidValue;
+    }
+    FL_LAUNCH_CHECK();
+    return hipSuccess;
 }
 
 hipError_t launch_ycck_to_cmyk(uint32_t *px, uint64_t n, hipStream_t st)

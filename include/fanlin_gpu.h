@@ -17,7 +17,8 @@
  *   flgpu_plan_output                   image::math::utils::resize_dimensions +
  *                                       DynamicImage::resize / resize_to_fill geometry +
  *                                       the letterbox rule at src/handler.rs:229-249
- *   flgpu_transform*                    the image-crate calls at src/handler.rs:225,227,233,
+ *   flgpu_transform*                    img.apply_orientation (src/handler.rs:221-223) and the image-crate calls at
+ *                                       src/handler.rs:225,227,233,
  *                                       235,240-247,253 (grayscale, invert, resize,
  *                                       resize_to_fill, from_pixel + overlay, blur)
  *   front_end = FLGPU_FE_JFIF444        colour front end of jpeg::JpegEncoder::encode_image,
@@ -96,10 +97,13 @@ typedef struct flgpu_params {
     uint8_t grayscale, inverse;        /* Query::grayscale(), Query::inverse() */
     uint8_t quality;                   /* Query::quality() (carried for the host encoder) */
     uint8_t front_end;                 /* flgpu_front_end */
+    uint8_t orientation;               /* EXIF orientation 1..8 from decoder.orientation() (src/handler.rs:206,221-223); 0 or 1 = none */
+    uint8_t reserved[3];
 } flgpu_params;
 
 /* Geometry decided on the host before any pixel is touched. */
 typedef struct flgpu_plan {
+    uint32_t src_w, src_h;             /* source size after img.apply_orientation() (swapped for EXIF 5..8) */
     uint32_t mid_c;                    /* channels after grayscale/invert */
     uint32_t resampled;                /* 1 if a Lanczos3 pass runs */
     uint32_t resized_w, resized_h;     /* resize_exact target */

@@ -181,6 +181,59 @@ void fo_invert(fo_image *img)
         for (uint32_t k = 0; k < nc; ++k) img->px[i * c + k] = (uint8_t)(255 - img->px[i * c + k]);
 }
 
+/* image 0.25.6 metadata::Orientation::from_exif + DynamicImage::apply_orientation, written as the
+ * imageops loops it calls: rotate90 puts (x,y) at (h-1-y, x), rotate270 at (y, w-1-x), rotate180 at
+ * (w-1-x, h-1-y); the two "FlipH" variants rotate first and mirror afterwards. */
+static void put_px(fo_image *d, uint32_t x, uint32_t y, const uint8_t *p) { memcpy(d->px + ((size_t)y * d->w + x) * d->c, p, d->c); }
+static int rotate_into(const fo_image *s, int quarter_turns, fo_image *d)
+{
+    d->c = s->c;
+    d->w = (quarter_turns & 1) ? s->h : s->w;
+    d->h = (quarter_turns & 1) ? s->w : s->h;
+    d->px = (uint8_t *)malloc((size_t)d->w * d->h * d->c + 1);
+    if (!d->px) return -1;
+    for (uint32_t y = 0; y < s->h; ++y)
+        for (uint32_t x = 0; x < s->w; ++x) {
+            const uint8_t *p = s->px + ((size_t)y * s->w + x) * s->c;
+            if (quarter_turns == 1) put_px(d, s->h - y - 1, x, p);
+            else if (quarter_turns == 2) put_px(d, s->w - x - 1, s->h - y - 1, p);
+            else if (quarter_turns == 3) put_px(d, y, s->w - x - 1, p);
+            else put_px(d, x, y, p);
+        }
+    return 0;
+}
+static void flip_h_in_place(fo_image *m)
+{
+    uint8_t t[4];
+    for (uint32_t y = 0; y < m->h; ++y)
+        for (uint32_t x = 0; x < m->w / 2; ++x) {
+            uint8_t *a = m->px + ((size_t)y * m->w + x) * m->c, *b = m->px + ((size_t)y * m->w + (m->w - 1 - x)) * m->c;
+            memcpy(t, a, m->c); memcpy(a, b, m->c); memcpy(b, t, m->c);
+        }
+}
+static void flip_v_in_place(fo_image *m)
+{
+    uint8_t t[4];
+    for (uint32_t y = 0; y < m->h / 2; ++y)
+        for (uint32_t x = 0; x < m->w; ++x) {
+            uint8_t *a = m->px + ((size_t)y * m->w + x) * m->c, *b = m->px + ((size_t)(m->h - 1 - y) * m->w + x) * m->c;
+            memcpy(t, a, m->c); memcpy(a, b, m->c); memcpy(b, t, m->c);
+        }
+}
+int fo_apply_orientation(const fo_image *src, int exif, fo_image *dst)
+{
+    switch (exif) {
+    case 2: if (rotate_into(src, 0, dst)) return -1; flip_h_in_place(dst); return 0;   /* FlipHorizontal */
+    case 3: return rotate_into(src, 2, dst);                                           /* Rotate180 */
+    case 4: if (rotate_into(src, 0, dst)) return -1; flip_v_in_place(dst); return 0;   /* FlipVertical */
+    case 5: if (rotate_into(src, 1, dst)) return -1; flip_h_in_place(dst); return 0;   /* Rotate90FlipH */
+    case 6: return rotate_into(src, 1, dst);                                           /* Rotate90 */
+    case 7: if (rotate_into(src, 3, dst)) return -1; flip_h_in_place(dst); return 0;   /* Rotate270FlipH */
+    case 8: return rotate_into(src, 3, dst);                                           /* Rotate270 */
+    default: return rotate_into(src, 0, dst);                                          /* NoTransforms */
+    }
+}
+
 /* ------------------------------------------------------------ resample -- */
 
 static inline float acc_step(float t, float v, float w, int arith)
@@ -430,12 +483,16 @@ int fo_letterbox(const fo_image *top, uint32_t w, uint32_t h, const uint8_t fill
 
 int fo_process_pixels(const fo_image *src, const fo_params *p, int arith, fo_image *dst)
 {
-    fo_image img;
+    fo_image img, oriented;
+    /* handler.rs:221-223 */
+    if (fo_apply_orientation(src, p->orientation, &oriented)) return -1;
     /* handler.rs:224-228: grayscale XOR invert, grayscale wins */
     if (p->grayscale) {
-        if (fo_grayscale(src, &img)) return -1;
+        int rc = fo_grayscale(&oriented, &img);
+        free(oriented.px);
+        if (rc) return -1;
     } else {
-        if (clone_image(src, &img)) return -1;
+        img = oriented;
         if (p->inverse) fo_invert(&img);
     }
     /* handler.rs:229-249 */

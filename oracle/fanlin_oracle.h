@@ -53,6 +53,7 @@ typedef struct fo_params {
     float blur_sigma;   /* Query::blur(): 0.0 or clamp(v,10,20)     query.rs:59-62 */
     int grayscale;      /* Query::grayscale()                       query.rs:64-66 */
     int inverse;        /* Query::inverse()                         query.rs:68-70 */
+    int orientation;    /* EXIF orientation 1..8 (decoder.orientation(), handler.rs:206); 0 = none */
 } fo_params;
 
 void fo_free(void *p);
@@ -69,6 +70,9 @@ void fo_resize_dimensions(uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, int 
 long fo_build_weights(uint32_t in_size, uint32_t out_size, int filter, float sigma,
                       uint32_t *left, uint32_t *count, uint32_t *offset,
                       float *weights, size_t cap);
+
+/* DynamicImage::apply_orientation(Orientation::from_exif(code)) (handler.rs:221-223) */
+int fo_apply_orientation(const fo_image *src, int exif, fo_image *dst);
 
 /* image::imageops::colorops::grayscale / grayscale_alpha (color.rs rgb_to_luma). */
 int fo_grayscale(const fo_image *src, fo_image *dst);

@@ -19,7 +19,7 @@ class fo_image(C.Structure):
 
 class fo_params(C.Structure):
     _fields_ = [("has_dims", C.c_int), ("w", C.c_uint32), ("h", C.c_uint32), ("fill", C.c_uint8 * 3),
-                ("crop", C.c_int), ("blur_sigma", C.c_float), ("grayscale", C.c_int), ("inverse", C.c_int)]
+                ("crop", C.c_int), ("blur_sigma", C.c_float), ("grayscale", C.c_int), ("inverse", C.c_int), ("orientation", C.c_int)]
 
 
 class Oracle:
@@ -61,13 +61,14 @@ class Oracle:
                 np.array(w[:n], dtype=np.float32))
 
     def process_pixels(self, image, w=None, h=None, fill=(32, 32, 32), crop=False, blur_sigma=0.0, grayscale=False,
-                       inverse=False, arith=ARITH_REF):
+                       inverse=False, orientation=0, arith=ARITH_REF):
         im, keep = self._img(image)
         p = fo_params()
         p.has_dims = int(w is not None and h is not None)
         p.w, p.h = (w or 0), (h or 0)
         p.fill[0], p.fill[1], p.fill[2] = fill
         p.crop, p.blur_sigma, p.grayscale, p.inverse = int(crop), blur_sigma, int(grayscale), int(inverse)
+        p.orientation = orientation
         out = fo_image()
         rc = self.lib.fo_process_pixels(C.byref(im), C.byref(p), arith, C.byref(out))
         assert rc == 0
@@ -84,6 +85,12 @@ class Oracle:
         out = fo_image()
         assert self.lib.fo_blur(C.byref(im), C.c_float(sigma), arith, C.byref(out)) == 0
         return self._take(out)
+
+    def apply_orientation(self, image, exif):
+        src, keep = self._img(image)
+        dst = fo_image()
+        assert self.lib.fo_apply_orientation(C.byref(src), int(exif), C.byref(dst)) == 0
+        return self._take(dst)
 
     def grayscale(self, image):
         im, keep = self._img(image)

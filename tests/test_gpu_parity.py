@@ -28,7 +28,8 @@ def check_resample(fl, st, oracle, img, **kw):
     p = fl.make_params(**fe_kw)
     got = st.process_pixels(img, p)
     okw = dict(w=kw.get("w"), h=kw.get("h"), fill=kw.get("fill", (32, 32, 32)), crop=kw.get("crop", False),
-               blur_sigma=kw.get("blur_sigma", 0.0), grayscale=kw.get("grayscale", False), inverse=kw.get("inverse", False))
+               blur_sigma=kw.get("blur_sigma", 0.0), grayscale=kw.get("grayscale", False), inverse=kw.get("inverse", False),
+               orientation=kw.get("orientation", 0))
     want_fma = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **okw)
     want_ref = oracle.process_pixels(img, arith=oracle_lib.ARITH_REF, **okw)
     assert got.shape == want_ref.shape
@@ -64,6 +65,24 @@ def test_grayscale_wins_over_inverse(fl, gpu_state, oracle):
     img = synth.uniform(16, 16, 3)
     got = gpu_state.process_pixels(img, fl.make_params(grayscale=True, inverse=True))
     assert np.array_equal(got, oracle.grayscale(img))
+
+
+@pytest.mark.parametrize("exif", range(1, 9))
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+def test_exif_orientation_bit_exact(fl, gpu_state, oracle, exif, c):
+    # handler.rs:221-223 img.apply_orientation(): a pure permutation, odd sizes so that every edge is hit
+    img = synth.uniform(37, 301, c, index=exif * 4 + c)
+    got = gpu_state.process_pixels(img, fl.make_params(orientation=exif))
+    assert np.array_equal(got, oracle.apply_orientation(img, exif))
+
+
+@pytest.mark.parametrize("exif", [3, 6, 7])
+def test_exif_orientation_then_pipeline(fl, gpu_state, oracle, exif):
+    # portrait-stored 1080p photo: orientation first, then the config-1 resize + letterbox
+    img = synth.photo(1920, 1080, 3, index=exif)
+    check_resample(fl, gpu_state, oracle, img, w=300, h=200, orientation=exif)
+    small = synth.photo(333, 250, 4, index=exif)
+    check_resample(fl, gpu_state, oracle, small, w=120, h=90, crop=True, grayscale=True, blur_sigma=10.0, orientation=exif)
 
 
 def test_identity_copy(fl, gpu_state):

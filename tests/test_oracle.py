@@ -39,6 +39,45 @@ def test_invert_keeps_alpha(oracle):
     assert np.array_equal(out[..., 0], 255 - la[..., 0]) and np.array_equal(out[..., 1], la[..., 1])
 
 
+# EXIF orientation (handler.rs:206,221-223): image 0.25.6 Orientation::from_exif maps 1..8 onto
+# NoTransforms, FlipHorizontal, Rotate180, FlipVertical, Rotate90FlipH, Rotate90, Rotate270FlipH, Rotate270;
+# the numpy forms below are the same permutations stated independently (rot90 with k=-1 is clockwise).
+NP_ORIENT = {
+    1: lambda a: a,
+    2: lambda a: a[:, ::-1],
+    3: lambda a: a[::-1, ::-1],
+    4: lambda a: a[::-1],
+    5: lambda a: np.rot90(a, -1)[:, ::-1],
+    6: lambda a: np.rot90(a, -1),
+    7: lambda a: np.rot90(a, 1)[:, ::-1],
+    8: lambda a: np.rot90(a, 1),
+}
+
+
+@pytest.mark.parametrize("exif", range(0, 9))
+@pytest.mark.parametrize("c", [1, 3, 4])
+def test_apply_orientation_permutations(oracle, exif, c):
+    img = synth.uniform(7, 11, c, index=exif)
+    want = np.ascontiguousarray(NP_ORIENT.get(exif, NP_ORIENT[1])(img))
+    assert np.array_equal(oracle.apply_orientation(img, exif), want)
+
+
+def test_orientation_known_answer(oracle):
+    # a camera held in portrait stores EXIF 6: the stored top-left pixel ends up top-right
+    img = np.arange(6, dtype=np.uint8).reshape(2, 3, 1)          # rows [0 1 2] / [3 4 5]
+    assert oracle.apply_orientation(img, 6)[:, :, 0].tolist() == [[3, 0], [4, 1], [5, 2]]
+    assert oracle.apply_orientation(img, 8)[:, :, 0].tolist() == [[2, 5], [1, 4], [0, 3]]
+    assert oracle.apply_orientation(img, 5)[:, :, 0].tolist() == [[0, 3], [1, 4], [2, 5]]
+    assert oracle.apply_orientation(img, 7)[:, :, 0].tolist() == [[5, 2], [4, 1], [3, 0]]
+
+
+def test_orientation_runs_before_everything_else(oracle):
+    img = synth.photo(60, 90, 3)
+    got = oracle.process_pixels(img, 40, 40, orientation=6, grayscale=True)
+    want = oracle.process_pixels(np.ascontiguousarray(np.rot90(img, -1)), 40, 40, grayscale=True)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("args,want", [
     ((1920, 1080, 300, 200, False), (300, 169)), ((1920, 1080, 300, 200, True), (356, 200)),
     ((512, 512, 300, 200, False), (200, 200)), ((512, 512, 300, 200, True), (300, 300)),

@@ -56,6 +56,11 @@ def test_plan_matches_oracle_geometry(fl, oracle):
 def test_plan_known_geometry(fl):
     p = fl.plan_output(fl.make_params(300, 200), 1920, 1080, 3)
     assert (p.resized_w, p.resized_h, p.letterboxed, p.place_x, p.place_y, p.out_w, p.out_h, p.out_c) == (300, 169, 1, 0, 15, 300, 200, 4)
+    # EXIF 5..8 swap the source size before anything is planned (handler.rs:221-223)
+    q = fl.plan_output(fl.make_params(300, 200, orientation=6), 1080, 1920, 3)
+    assert (q.src_w, q.src_h, q.resized_w, q.resized_h) == (1920, 1080, 300, 169)
+    q = fl.plan_output(fl.make_params(300, 200, orientation=3), 1080, 1920, 3)
+    assert (q.src_w, q.src_h, q.resized_w, q.resized_h) == (1080, 1920, 113, 200)
     p = fl.plan_output(fl.make_params(300, 200, crop=True), 1920, 1080, 3)
     assert (p.resized_w, p.resized_h, p.crop_x, p.crop_y, p.letterboxed, p.out_w, p.out_h, p.out_c) == (356, 200, 28, 0, 0, 300, 200, 3)
     p = fl.plan_output(fl.make_params(300, 200), 512, 512, 3)
