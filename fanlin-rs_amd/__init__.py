@@ -57,7 +57,7 @@ class flgpu_params(C.Structure):
                 ("fill_r", C.c_uint8), ("fill_g", C.c_uint8), ("fill_b", C.c_uint8), ("crop", C.c_uint8),
                 ("blur_sigma", C.c_float),
                 ("grayscale", C.c_uint8), ("inverse", C.c_uint8), ("quality", C.c_uint8), ("front_end", C.c_uint8),
-                ("orientation", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+                ("orientation", C.c_uint8), ("filter", C.c_uint8), ("reserved", C.c_uint8 * 2)]
 
 
 class flgpu_plan(C.Structure):
@@ -262,8 +262,11 @@ class Query:
         return p, fmt.value
 
 
+FILTER_LANCZOS3, FILTER_NEAREST = 0, 1
+
+
 def make_params(w: Optional[int] = None, h: Optional[int] = None, fill=(32, 32, 32), crop=False, blur_sigma=0.0,
-                grayscale=False, inverse=False, quality=75, front_end=FE_NONE, orientation=1) -> flgpu_params:
+                grayscale=False, inverse=False, quality=75, front_end=FE_NONE, orientation=1, filter=FILTER_LANCZOS3) -> flgpu_params:
     p = flgpu_params()
     p.has_dims = 1 if (w is not None and h is not None) else 0
     p.w, p.h = (w or 0), (h or 0)
@@ -273,6 +276,7 @@ def make_params(w: Optional[int] = None, h: Optional[int] = None, fill=(32, 32, 
     p.grayscale, p.inverse = int(grayscale), int(inverse)
     p.quality, p.front_end = quality, front_end
     p.orientation = orientation
+    p.filter = filter
     return p
 
 

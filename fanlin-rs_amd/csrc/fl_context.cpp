@@ -344,7 +344,7 @@ struct ProfileScope {
 
 // ---- batch execution -------------------------------------------------------
 
-enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3 };
+enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3, S1_NEAREST = 4 };
 
 struct Work {
     flgpu_plan plan;
@@ -390,6 +390,11 @@ void fill_job(const Work &w, Job &j)
     j.ox = pl.place_x; j.oy = pl.place_y;
     j.fill = (uint32_t)w.p->fill_r | ((uint32_t)w.p->fill_g << 8) | ((uint32_t)w.p->fill_b << 16) | (255u << 24);
     j.vtab = w.vtab; j.htab = w.htab;
+    if (w.s1 == S1_NEAREST) {
+        // sample.rs: ratio = in as f32 / out as f32, carried as bits where the Lanczos3 jobs carry table offsets
+        const float ry = (float)w.sh / (float)pl.resized_h, rx = (float)w.sw / (float)pl.resized_w;
+        memcpy(&j.vtab, &ry, 4); memcpy(&j.htab, &rx, 4);
+    }
 }
 
 int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, bool same_params,
@@ -425,7 +430,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         // grayscale of Luma/LumaA and "no-op" pre-ops change nothing
         const bool pre_changes = (w.pre == PRE_INVERT) || (w.pre == PRE_GRAY && w.cs >= 3);
         if (!pre_changes) w.pre = PRE_NONE;
-        if (pl.resampled) w.s1 = S1_GENERIC;
+        if (pl.resampled) w.s1 = w.p->filter == FLGPU_FILTER_NEAREST ? S1_NEAREST : S1_GENERIC;
         else if (pre_changes || pl.letterboxed || cropped) w.s1 = S1_PLACE;
         else w.s1 = S1_NONE;
         const bool blur = w.p->blur_sigma > 0.0f;
@@ -459,9 +464,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool full = false;
         size_t n_resample = 0;
-        for (auto &w : work) n_resample += w.plan.resampled ? 1 : 0;
+        for (auto &w : work) n_resample += (w.plan.resampled && w.s1 != S1_NEAREST) ? 1 : 0;
         for (auto &w : work) {
-            if (!w.plan.resampled) continue;
+            if (!w.plan.resampled || w.s1 == S1_NEAREST) continue;
             w.vtab = get_axis(c, w.sh, w.plan.resized_h, FILTER_LANCZOS3, 0.0f, &w.vk, &w.va);
             w.htab = get_axis(c, w.sw, w.plan.resized_w, FILTER_LANCZOS3, 0.0f, &w.hk, &w.ha);
             if (!w.vtab || !w.htab) { full = true; break; }
@@ -685,7 +690,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     for (auto &L : s1_launches) {
         L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
         L.g.job_base = L.job_base; L.g.njobs = L.njobs;
-        if ((L.k.kind & 255u) == S1_PLACE) {
+        if ((L.k.kind & 255u) == S1_NEAREST) {
+            L.g.nearest = 1;
+            FL_HIP(c, launch_place(L.g, false, st), "nearest kernel");
+        } else if ((L.k.kind & 255u) == S1_PLACE) {
             FL_HIP(c, launch_place(L.g, false, st), "place kernel");
         } else if ((L.k.kind & 255u) == S1_GENERIC) {
             if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");

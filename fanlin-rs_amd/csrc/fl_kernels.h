@@ -32,6 +32,7 @@ struct LaunchGeneric {
     uint32_t max_sw, max_rh;  // vertical pass grid
     uint32_t max_cw, max_ch;  // horizontal pass grid
     uint32_t max_dw, max_dh;  // placement grid
+    uint32_t nearest;         // place kernel: FilterType::Nearest gather (jobs carry the f32 ratios in vtab/htab)
 };
 
 struct LaunchStream {

@@ -215,7 +215,17 @@ __global__ __launch_bounds__(256) void hpass_generic_kernel(const Job *__restric
 // the border fill of resampled letterboxed images (BORDER_ONLY).
 // ---------------------------------------------------------------------------
 
-template <int CS, int PRE, bool LB, bool BORDER_ONLY>
+// FilterType::Nearest through image 0.25.6 sample.rs (support 0.0, box kernel): one tap of weight 1 at
+// clamp(floor((o + 0.5) * ratio), 0, in - 1), ratio = in as f32 / out as f32 computed on the host
+// (animated-GIF frames, reference handler.rs:336-341).
+__device__ __forceinline__ uint32_t nearest_tap(uint32_t o, uint32_t ratio_bits, uint32_t in_size)
+{
+    const float c = ((float)o + 0.5f) * __uint_as_float(ratio_bits);
+    const int left = (int)floorf(c);
+    return (uint32_t)min(max(left, 0), (int)in_size - 1);
+}
+
+template <int CS, int PRE, bool LB, bool BORDER_ONLY, bool NEAREST = false>
 __global__ __launch_bounds__(256) void place_kernel(const Job *__restrict__ jobs, uint32_t job_base)
 {
     constexpr int MC = mid_channels(CS, PRE);
@@ -229,7 +239,9 @@ __global__ __launch_bounds__(256) void place_kernel(const Job *__restrict__ jobs
         return;
     }
     if (BORDER_ONLY) return;
-    const uint8_t *p = jb.src + ((size_t)(y - jb.oy + jb.cy) * jb.sw + (x - jb.ox + jb.cx)) * CS;
+    uint32_t sy = y - jb.oy + jb.cy, sx = x - jb.ox + jb.cx;
+    if (NEAREST) { sy = nearest_tap(sy, jb.vtab, jb.sh); sx = nearest_tap(sx, jb.htab, jb.sw); }
+    const uint8_t *p = jb.src + ((size_t)sy * jb.sw + sx) * CS;
     uint32_t s[CS];
 #pragma unroll
     for (int k = 0; k < CS; ++k) s[k] = p[k];
@@ -1038,7 +1050,10 @@ template <int CS, int PRE>
 static hipError_t launch_place_t(const LaunchGeneric &g, bool border_only, hipStream_t st)
 {
     dim3 grid((g.max_dw + 255u) / 256u, g.max_dh, g.njobs);
-    if (g.letterbox) {
+    if (g.nearest) {
+        if (g.letterbox) hipLaunchKernelGGL((place_kernel<CS, PRE, true, false, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
+        else hipLaunchKernelGGL((place_kernel<CS, PRE, false, false, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
+    } else if (g.letterbox) {
         if (border_only) hipLaunchKernelGGL((place_kernel<CS, PRE, true, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
         else hipLaunchKernelGGL((place_kernel<CS, PRE, true, false>), grid, dim3(256), 0, st, g.jobs, g.job_base);
     } else {

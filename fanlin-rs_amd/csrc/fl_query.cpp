@@ -193,7 +193,7 @@ int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t 
     if (!p || !plan) return FLGPU_ERR_INVALID_ARG;
     if (sw == 0 || sh == 0 || sc < 1 || sc > 4) return FLGPU_ERR_INVALID_ARG;
     if ((uint64_t)sw * sh * sc >= (1ull << 31)) return FLGPU_ERR_UNSUPPORTED;
-    if (p->front_end > FLGPU_FE_WEBP420 || p->orientation > 8) return FLGPU_ERR_INVALID_ARG;
+    if (p->front_end > FLGPU_FE_WEBP420 || p->orientation > 8 || p->filter > FLGPU_FILTER_NEAREST) return FLGPU_ERR_INVALID_ARG;
     memset(plan, 0, sizeof(*plan));
     /* handler.rs:221-223: EXIF orientations 5..8 contain a quarter turn: width and height swap */
     if (p->orientation >= 5) { const uint32_t t = sw; sw = sh; sh = t; }

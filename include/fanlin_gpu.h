@@ -88,6 +88,8 @@ typedef struct flgpu_query {
 } flgpu_query;
 
 /* Exactly the accessor outputs of query::Query that the pixel pipeline consumes. */
+enum flgpu_filter { FLGPU_FILTER_LANCZOS3 = 0, FLGPU_FILTER_NEAREST = 1 };
+
 typedef struct flgpu_params {
     uint32_t has_dims;                 /* Query::dimensions().is_some() */
     uint32_t w, h;
@@ -98,7 +100,8 @@ typedef struct flgpu_params {
     uint8_t quality;                   /* Query::quality() (carried for the host encoder) */
     uint8_t front_end;                 /* flgpu_front_end */
     uint8_t orientation;               /* EXIF orientation 1..8 from decoder.orientation() (src/handler.rs:206,221-223); 0 or 1 = none */
-    uint8_t reserved[3];
+    uint8_t filter;                    /* flgpu_filter: Lanczos3 for stills (handler.rs:233,235), Nearest for GIF frames (handler.rs:338,340) */
+    uint8_t reserved[2];
 } flgpu_params;
 
 /* Geometry decided on the host before any pixel is touched. */

@@ -500,8 +500,9 @@ int fo_process_pixels(const fo_image *src, const fo_params *p, int arith, fo_ima
         uint32_t width = p->w, height = p->h;
         if (width != img.w || height != img.h) {
             fo_image r;
-            int rc = p->crop ? fo_resize_to_fill(&img, width, height, FO_FILTER_LANCZOS3, arith, &r)
-                             : fo_resize(&img, width, height, FO_FILTER_LANCZOS3, arith, &r);
+            const int filter = p->filter == FO_FILTER_NEAREST ? FO_FILTER_NEAREST : FO_FILTER_LANCZOS3;
+            int rc = p->crop ? fo_resize_to_fill(&img, width, height, filter, arith, &r)
+                             : fo_resize(&img, width, height, filter, arith, &r);
             free(img.px);
             if (rc) return -1;
             img = r;

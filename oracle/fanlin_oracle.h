@@ -54,6 +54,7 @@ typedef struct fo_params {
     int grayscale;      /* Query::grayscale()                       query.rs:64-66 */
     int inverse;        /* Query::inverse()                         query.rs:68-70 */
     int orientation;    /* EXIF orientation 1..8 (decoder.orientation(), handler.rs:206); 0 = none */
+    int filter;         /* FO_FILTER_LANCZOS3 (process_image, handler.rs:233,235) or FO_FILTER_NEAREST (process_gif, 338,340) */
 } fo_params;
 
 void fo_free(void *p);

@@ -10,7 +10,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "libfanlin_oracle.so")
 
 ARITH_REF, ARITH_FMA = 0, 1
-FILTER_LANCZOS3, FILTER_GAUSSIAN = 0, 1
+FILTER_LANCZOS3, FILTER_GAUSSIAN, FILTER_NEAREST, FILTER_TRIANGLE = 0, 1, 2, 3
 
 
 class fo_image(C.Structure):
@@ -19,7 +19,7 @@ class fo_image(C.Structure):
 
 class fo_params(C.Structure):
     _fields_ = [("has_dims", C.c_int), ("w", C.c_uint32), ("h", C.c_uint32), ("fill", C.c_uint8 * 3),
-                ("crop", C.c_int), ("blur_sigma", C.c_float), ("grayscale", C.c_int), ("inverse", C.c_int), ("orientation", C.c_int)]
+                ("crop", C.c_int), ("blur_sigma", C.c_float), ("grayscale", C.c_int), ("inverse", C.c_int), ("orientation", C.c_int), ("filter", C.c_int)]
 
 
 class Oracle:
@@ -61,7 +61,7 @@ class Oracle:
                 np.array(w[:n], dtype=np.float32))
 
     def process_pixels(self, image, w=None, h=None, fill=(32, 32, 32), crop=False, blur_sigma=0.0, grayscale=False,
-                       inverse=False, orientation=0, arith=ARITH_REF):
+                       inverse=False, orientation=0, filter=FILTER_LANCZOS3, arith=ARITH_REF):
         im, keep = self._img(image)
         p = fo_params()
         p.has_dims = int(w is not None and h is not None)
@@ -69,6 +69,7 @@ class Oracle:
         p.fill[0], p.fill[1], p.fill[2] = fill
         p.crop, p.blur_sigma, p.grayscale, p.inverse = int(crop), blur_sigma, int(grayscale), int(inverse)
         p.orientation = orientation
+        p.filter = filter
         out = fo_image()
         rc = self.lib.fo_process_pixels(C.byref(im), C.byref(p), arith, C.byref(out))
         assert rc == 0

@@ -85,6 +85,26 @@ def test_exif_orientation_then_pipeline(fl, gpu_state, oracle, exif):
     check_resample(fl, gpu_state, oracle, small, w=120, h=90, crop=True, grayscale=True, blur_sigma=10.0, orientation=exif)
 
 
+@pytest.mark.parametrize("shape,req,kw", [
+    ((120, 160), (300, 200), {}),                              # small GIF scaled up, letterboxed
+    ((480, 640), (300, 200), {}),                              # scaled down
+    ((480, 640), (300, 200), dict(crop=True)),
+    ((333, 517), (120, 90), dict(grayscale=True)),             # LumaA frames over the fill colour
+    ((97, 61), (64, 64), dict(inverse=True, crop=True)),
+    ((50, 50), (20, 1000), dict(fill=(255, 0, 7))),
+])
+def test_gif_frame_nearest_bit_exact(fl, gpu_state, oracle, shape, req, kw):
+    # process_gif (handler.rs:327-353): frames are Rgba8 (alpha from the palette's transparent index),
+    # FilterType::Nearest; one tap of weight 1.0, so REF and FMA arithmetic coincide and the bar is bit-exact
+    img = synth.uniform(shape[0], shape[1], 4, index=shape[0])
+    img[::3, ::5, 3] = 0            # transparent pixels keep the fill colour under overlay
+    img[1::3, 1::5, 3] = 255
+    got = gpu_state.process_pixels(img, fl.make_params(req[0], req[1], filter=fl.FILTER_NEAREST, **kw))
+    want = oracle.process_pixels(img, req[0], req[1], filter=oracle_lib.FILTER_NEAREST, **kw)
+    assert np.array_equal(got, want)
+    assert np.array_equal(want, oracle.process_pixels(img, req[0], req[1], filter=oracle_lib.FILTER_NEAREST, arith=oracle_lib.ARITH_FMA, **kw))
+
+
 def test_identity_copy(fl, gpu_state):
     img = synth.uniform(33, 17, 3)
     assert np.array_equal(gpu_state.process_pixels(img, fl.make_params()), img)

@@ -62,6 +62,17 @@ def test_apply_orientation_permutations(oracle, exif, c):
     assert np.array_equal(oracle.apply_orientation(img, exif), want)
 
 
+def test_nearest_filter_picks_source_pixels(oracle):
+    # process_gif (handler.rs:338-340): FilterType::Nearest = support 0, one tap of weight 1 at floor((o + 0.5) * in / out)
+    img = synth.uniform(40, 64, 4)
+    got = oracle.process_pixels(img, 20, 20, crop=True, filter=oracle_lib.FILTER_NEAREST)      # covering size 32x20, crop x = 6
+    ys = np.minimum(np.floor((np.arange(20, dtype=np.float32) + np.float32(0.5)) * np.float32(40 / 20)).astype(int), 39)
+    xs = np.minimum(np.floor((np.arange(32, dtype=np.float32) + np.float32(0.5)) * np.float32(64 / 32)).astype(int), 63)
+    assert np.array_equal(got, img[ys][:, xs][:, 6:26])
+    up = oracle.process_pixels(img[:5, :7], 14, 10, crop=True, filter=oracle_lib.FILTER_NEAREST)
+    assert np.array_equal(up, np.repeat(np.repeat(img[:5, :7], 2, axis=0), 2, axis=1))
+
+
 def test_orientation_known_answer(oracle):
     # a camera held in portrait stores EXIF 6: the stored top-left pixel ends up top-right
     img = np.arange(6, dtype=np.uint8).reshape(2, 3, 1)          # rows [0 1 2] / [3 4 5]
