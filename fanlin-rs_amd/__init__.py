@@ -32,6 +32,8 @@ ACCEPT_WEBP, ACCEPT_AVIF = 1, 2
 OUT_KEEP, OUT_WEBP, OUT_AVIF = 0, 1, 2
 IMG_FRONTEND_PLANES, IMG_HAS_ALPHA = 1, 2
 BATCH_SAME_PARAMS = 1
+(OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_OOM, ERR_DEVICE, ERR_PARSE, ERR_BUFFER_TOO_SMALL,
+ ERR_SHUTDOWN) = range(9)
 
 
 class FanlinError(RuntimeError):
@@ -77,7 +79,8 @@ class flgpu_stats(C.Structure):
                 ("tables_built", C.c_uint64), ("resample_launches", C.c_uint64), ("resample_ms", C.c_double),
                 ("resample_src_bytes", C.c_uint64), ("resample_dst_bytes", C.c_uint64),
                 ("generic_launches", C.c_uint64), ("blur_launches", C.c_uint64), ("blur_ms", C.c_double),
-                ("frontend_launches", C.c_uint64), ("frontend_ms", C.c_double)]
+                ("frontend_launches", C.c_uint64), ("frontend_ms", C.c_double),
+                ("cmyk_pixels", C.c_uint64), ("cmyk_tables_baked", C.c_uint64)]
 
 
 # every symbol include/fanlin_gpu.h declares
@@ -86,7 +89,9 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_cropping", "flgpu_query_blur", "flgpu_query_grayscale", "flgpu_query_inverse",
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
     "flgpu_params_from_query", "flgpu_plan_output", "flgpu_create", "flgpu_destroy", "flgpu_transform",
-    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_ycck_to_cmyk", "flgpu_export_tables", "flgpu_copy_tables",
+    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_ycck_to_cmyk",
+    "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
+    "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
     "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version",
     "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable",
@@ -136,6 +141,11 @@ def load_library() -> C.CDLL:
     lib.flgpu_transform_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params),
                                                  C.POINTER(flgpu_image), C.c_void_p, C.c_uint32]
     lib.flgpu_ycck_to_cmyk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.flgpu_set_cmyk_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    lib.flgpu_set_cmyk_clut.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.flgpu_get_cmyk_clut.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.flgpu_cmyk_to_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32]
+    lib.flgpu_cmyk_to_rgb_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
     lib.flgpu_export_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.flgpu_copy_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.flgpu_import_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -263,6 +273,7 @@ class Query:
 
 
 FILTER_LANCZOS3, FILTER_NEAREST = 0, 1
+CMYK_GRID, CMYK_INPUT_YCCK = 17, 1
 
 
 def make_params(w: Optional[int] = None, h: Optional[int] = None, fill=(32, 32, 32), crop=False, blur_sigma=0.0,
@@ -431,6 +442,38 @@ class State:
             raise ValueError("expected 4 bytes per pixel")
         _check(self._lib.flgpu_ycck_to_cmyk(self._ctx, a.ctypes.data, a.size // 4), self._ctx)
         return a
+
+    # ---- CMYK / YCCK JPEG sources (handler.rs:398-493) ----
+    def set_cmyk_profile(self, icc: bytes) -> None:
+        """create_cmyk_to_rgb_converter (main.rs:74-76): bakes the profile's CMYK_8 -> sRGB device-link table."""
+        _check(self._lib.flgpu_set_cmyk_profile(self._ctx, icc, len(icc)), self._ctx)
+
+    def set_cmyk_clut(self, rgb_nodes: np.ndarray) -> None:
+        a = np.ascontiguousarray(rgb_nodes, dtype=np.uint16)
+        if a.size != CMYK_GRID ** 4 * 3:
+            raise ValueError("expected a 17^4 x 3 table")
+        _check(self._lib.flgpu_set_cmyk_clut(self._ctx, CMYK_GRID, a.ctypes.data), self._ctx)
+
+    def get_cmyk_clut(self) -> np.ndarray:
+        a = np.zeros((CMYK_GRID,) * 4 + (3,), np.uint16)
+        grid = C.c_uint32()
+        _check(self._lib.flgpu_get_cmyk_clut(self._ctx, a.ctypes.data, a.size, C.byref(grid)), self._ctx)
+        return a
+
+    def cmyk_to_rgb(self, cmyk: np.ndarray, embedded_icc: Optional[bytes] = None, ycck: bool = False) -> np.ndarray:
+        """CMYK2RGB::convert (handler.rs:490-492) on an (..., 4) uint8 array; returns (..., 3)."""
+        a = np.ascontiguousarray(cmyk, dtype=np.uint8)
+        if a.ndim < 1 or a.shape[-1] != 4:
+            raise ValueError("expected 4 bytes per pixel")
+        out = np.empty(a.shape[:-1] + (3,), np.uint8)
+        n = a.size // 4
+        _check(self._lib.flgpu_cmyk_to_rgb(self._ctx, a.ctypes.data, n, out.ctypes.data, embedded_icc,
+                                           len(embedded_icc) if embedded_icc else 0, CMYK_INPUT_YCCK if ycck else 0), self._ctx)
+        return out
+
+    def cmyk_to_rgb_device(self, d_cmyk: int, d_rgb: int, n_pixels: int, ycck: bool = False, stream: int = 0) -> None:
+        _check(self._lib.flgpu_cmyk_to_rgb_device(self._ctx, C.c_void_p(d_cmyk), C.c_void_p(d_rgb), n_pixels,
+                                                  CMYK_INPUT_YCCK if ycck else 0, C.c_void_p(stream)), self._ctx)
 
     def export_tables(self) -> Tuple[int, int]:
         ptr, nbytes = C.c_void_p(), C.c_uint64()

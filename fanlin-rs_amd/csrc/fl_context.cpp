@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/fanlin_gpu.h"
+#include "fl_cmyk.h"
 #include "fl_kernels.h"
 #include "fl_tables.h"
 
@@ -140,6 +141,15 @@ struct flgpu_ctx {
     std::vector<hipEvent_t> event_pool;
 
     std::string last_error;
+
+    // CMYK -> sRGB device-link tables (kCmykGrid^4 nodes of 4 x u16): the boot-time default (main.rs:74-76) and a
+    // small cache of tables baked from embedded profiles, keyed by a hash of the profile bytes (handler.rs:446-458
+    // rebuilds the lcms2 transform, 40 ms, on every such request)
+    struct Clut { DeviceBuf dev; std::vector<uint16_t> host; uint64_t stamp = 0; };
+    Clut cmyk_default;
+    bool has_cmyk_default = false;
+    std::map<uint64_t, Clut> cmyk_embedded;
+    uint64_t cmyk_stamp = 0;
 
     // pinned staging blocks recycled between requests (power-of-two size classes)
     std::mutex pin_mu;
@@ -939,6 +949,8 @@ void flgpu_destroy(flgpu_ctx *c)
     for (auto &s : c->slots) { s.host.release(); s.dev.release(); if (s.done) (void)hipEventDestroy(s.done); }
     if (c->last_done) (void)hipEventDestroy(c->last_done);
     c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_tmp_o.release(); c->d_status.release(); c->d_in.release(); c->d_out.release();
+    c->cmyk_default.dev.release();
+    for (auto &kv : c->cmyk_embedded) kv.second.dev.release();
     c->h_stage_in.release(); c->h_stage_out.release();
     for (auto &kv : c->pin_free) (void)hipHostFree(kv.second);
     if (c->d_arena) (void)hipFree(c->d_arena);
@@ -1010,6 +1022,141 @@ int flgpu_ycck_to_cmyk(flgpu_ctx *c, uint8_t *raw, uint64_t n_pixels)
     FL_HIP(c, hipStreamSynchronize(c->stream), "sync");
     return FLGPU_OK;
 }
+
+// ---- CMYK -> RGB (reference src/handler.rs:398-493) ----------------------------------------
+
+namespace {
+
+int upload_clut(flgpu_ctx *c, flgpu_ctx::Clut &t)
+{
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    FL_HIP(c, t.dev.reserve(t.host.size() * sizeof(uint16_t)), "CLUT alloc");
+    FL_HIP(c, hipMemcpyAsync(t.dev.p, t.host.data(), t.host.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream), "CLUT upload");
+    FL_HIP(c, hipStreamSynchronize(c->stream), "CLUT sync");
+    return FLGPU_OK;
+}
+
+constexpr size_t kClutNodes = (size_t)kCmykGrid * kCmykGrid * kCmykGrid * kCmykGrid;
+
+// picks the table for one conversion: the embedded profile's if it can be baked (cached), else the default
+int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev)
+{
+    if (icc && icc_len) {
+        const uint64_t h = hash_bytes(icc, icc_len);
+        auto it = c->cmyk_embedded.find(h);
+        if (it == c->cmyk_embedded.end()) {
+            std::vector<uint16_t> nodes;
+            if (bake_cmyk_clut(icc, icc_len, nodes) == 0) {
+                if (c->cmyk_embedded.size() >= 8) { // evict the least recently used table
+                    auto old = c->cmyk_embedded.begin();
+                    for (auto i2 = c->cmyk_embedded.begin(); i2 != c->cmyk_embedded.end(); ++i2) if (i2->second.stamp < old->second.stamp) old = i2;
+                    FL_HIP(c, hipStreamSynchronize(c->stream), "CLUT evict sync");
+                    old->second.dev.release();
+                    c->cmyk_embedded.erase(old);
+                }
+                flgpu_ctx::Clut &t = c->cmyk_embedded[h];
+                t.host.swap(nodes);
+                int rc = upload_clut(c, t);
+                if (rc) { c->cmyk_embedded.erase(h); return rc; }
+                c->stats.cmyk_tables_baked++;
+                it = c->cmyk_embedded.find(h);
+            }
+        }
+        if (it != c->cmyk_embedded.end()) { it->second.stamp = ++c->cmyk_stamp; *dev = it->second.dev.p; return FLGPU_OK; }
+        // handler.rs:449-455: an embedded profile that cannot be used falls back to the configured one
+    }
+    if (!c->has_cmyk_default) { c->last_error = "no CMYK profile configured"; return FLGPU_ERR_UNSUPPORTED; }
+    *dev = c->cmyk_default.dev.p;
+    return FLGPU_OK;
+}
+
+} // namespace
+
+int flgpu_set_cmyk_profile(flgpu_ctx *c, const uint8_t *icc, uint64_t n)
+{
+    if (!c || !icc || !n) return FLGPU_ERR_INVALID_ARG;
+    std::vector<uint16_t> nodes;
+    const int rc = bake_cmyk_clut(icc, n, nodes);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (rc == -2) { c->last_error = "liblcms2.so.2 could not be loaded; bake the table elsewhere and use flgpu_set_cmyk_clut"; return FLGPU_ERR_UNSUPPORTED; }
+    if (rc) { c->last_error = "not a usable CMYK ICC profile"; return FLGPU_ERR_INVALID_ARG; }
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    FL_HIP(c, hipStreamSynchronize(c->stream), "CLUT swap sync");
+    c->cmyk_default.host.swap(nodes);
+    const int u = upload_clut(c, c->cmyk_default);
+    c->has_cmyk_default = (u == FLGPU_OK);
+    if (u == FLGPU_OK) c->stats.cmyk_tables_baked++;
+    return u;
+}
+
+int flgpu_set_cmyk_clut(flgpu_ctx *c, uint32_t grid, const uint16_t *rgb_nodes)
+{
+    if (!c || !rgb_nodes) return FLGPU_ERR_INVALID_ARG;
+    if (grid != kCmykGrid) return FLGPU_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> g(c->mu);
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    FL_HIP(c, hipStreamSynchronize(c->stream), "CLUT swap sync");
+    c->cmyk_default.host.assign(kClutNodes * 4, 0);
+    for (size_t i = 0; i < kClutNodes; ++i)
+        for (int k = 0; k < 3; ++k) c->cmyk_default.host[i * 4 + k] = rgb_nodes[i * 3 + k];
+    const int u = upload_clut(c, c->cmyk_default);
+    c->has_cmyk_default = (u == FLGPU_OK);
+    return u;
+}
+
+int flgpu_get_cmyk_clut(flgpu_ctx *c, uint16_t *rgb_nodes, uint64_t capacity_entries, uint32_t *grid)
+{
+    if (!c || !grid) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->has_cmyk_default) { c->last_error = "no CMYK profile configured"; return FLGPU_ERR_UNSUPPORTED; }
+    *grid = kCmykGrid;
+    if (!rgb_nodes) return FLGPU_OK;
+    if (capacity_entries < kClutNodes * 3) return FLGPU_ERR_BUFFER_TOO_SMALL;
+    for (size_t i = 0; i < kClutNodes; ++i)
+        for (int k = 0; k < 3; ++k) rgb_nodes[i * 3 + k] = c->cmyk_default.host[i * 4 + k];
+    return FLGPU_OK;
+}
+
+int flgpu_cmyk_to_rgb_device(flgpu_ctx *c, const void *d_cmyk, void *d_rgb, uint64_t n_pixels, uint32_t flags, void *hip_stream)
+{
+    if (!c || ((!d_cmyk || !d_rgb) && n_pixels)) return FLGPU_ERR_INVALID_ARG;
+    if (n_pixels == 0) return FLGPU_OK;
+    if (n_pixels >= (1ull << 32)) return FLGPU_ERR_UNSUPPORTED;
+    if (((uintptr_t)d_cmyk & 15u) || ((uintptr_t)d_rgb & 3u)) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    const void *clut = nullptr;
+    const int rc = select_clut(c, nullptr, 0, &clut);
+    if (rc) return rc;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    FL_HIP(c, launch_cmyk_clut(d_cmyk, d_rgb, clut, kCmykGrid, n_pixels, (flags & FLGPU_CMYK_INPUT_YCCK) != 0, st), "CMYK kernel");
+    c->stats.cmyk_pixels += n_pixels;
+    return FLGPU_OK;
+}
+
+int flgpu_cmyk_to_rgb(flgpu_ctx *c, const uint8_t *cmyk, uint64_t n_pixels, uint8_t *rgb, const uint8_t *embedded_icc,
+                      uint64_t icc_len, uint32_t flags)
+{
+    if (!c || ((!cmyk || !rgb) && n_pixels)) return FLGPU_ERR_INVALID_ARG;
+    if (n_pixels == 0) return FLGPU_OK;
+    if (n_pixels >= (1ull << 30)) return FLGPU_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> g(c->mu);
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    const void *clut = nullptr;
+    const int rc = select_clut(c, embedded_icc, icc_len, &clut);
+    if (rc) return rc;
+    const size_t n4 = (size_t)(n_pixels + 3) / 4;
+    FL_HIP(c, c->d_in.reserve(n4 * 16), "device staging");
+    FL_HIP(c, c->d_out.reserve(n4 * 12), "device staging");
+    FL_HIP(c, hipMemcpyAsync(c->d_in.p, cmyk, (size_t)n_pixels * 4, hipMemcpyHostToDevice, c->stream), "H2D");
+    FL_HIP(c, launch_cmyk_clut(c->d_in.p, c->d_out.p, clut, kCmykGrid, n_pixels, (flags & FLGPU_CMYK_INPUT_YCCK) != 0, c->stream), "CMYK kernel");
+    FL_HIP(c, hipMemcpyAsync(rgb, c->d_out.p, (size_t)n_pixels * 3, hipMemcpyDeviceToHost, c->stream), "D2H");
+    FL_HIP(c, hipStreamSynchronize(c->stream), "sync");
+    c->stats.cmyk_pixels += n_pixels;
+    return FLGPU_OK;
+}
+
+int flgpu_cmyk_bake_available(void) { return cmyk_bake_available() ? 1 : 0; }
 
 int flgpu_export_tables(flgpu_ctx *c, void **device_ptr, uint64_t *bytes)
 {

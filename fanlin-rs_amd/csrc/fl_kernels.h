@@ -66,6 +66,9 @@ hipError_t launch_stream(const LaunchStream &s, hipStream_t st);
 
 // EXIF orientation pre-pass: g.cs = channels, jobs[i].fill = EXIF code, sw/sh source size, dw/dh oriented size
 hipError_t launch_orient(const LaunchGeneric &g, hipStream_t st);
+// CMYK_8 (or YCCK, converted first) -> RGB_8 through a baked lcms2 device-link table; clut = grid^4 nodes of 4 x u16,
+// src / dst padded to a multiple of 4 pixels
+hipError_t launch_cmyk_clut(const void *src, void *dst, const void *clut, uint32_t grid, uint64_t n_pixels, bool ycck, hipStream_t st);
 hipError_t launch_ycck_to_cmyk(uint32_t *px, uint64_t n_pixels, hipStream_t st);
 
 // all_rgba_aligned: every job of the group is Rgba8 with dword-aligned source and destination (4 pixels per thread)

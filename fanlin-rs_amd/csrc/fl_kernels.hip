@@ -986,11 +986,8 @@ __global__ __launch_bounds__(256) void webp420_rgba_kernel(const FrontendJob *__
 
 // reference src/handler.rs:423-438: per pixel (Y, Cb, Cr, K) -> (clamp(R), clamp(G), clamp(B), 255 - K), f32 with
 // truncating casts, evaluated in the reference's operation order (this file is built with -ffp-contract=off)
-__global__ __launch_bounds__(256) void ycck_to_cmyk_kernel(uint32_t *__restrict__ px, uint64_t n)
+__device__ __forceinline__ uint32_t ycck_pixel(uint32_t d)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t d = px[i];
     const float y = (float)(d & 255u), cb = (float)((d >> 8) & 255u), cr = (float)((d >> 16) & 255u);
     float r = y + 1.40200f * cr - 179.456f;
     float g = y - 0.34414f * cb - 0.71414f * cr + 135.45984f;
@@ -998,8 +995,112 @@ __global__ __launch_bounds__(256) void ycck_to_cmyk_kernel(uint32_t *__restrict_
     r = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
     g = g < 0.0f ? 0.0f : (g > 255.0f ? 255.0f : g);
     b = b < 0.0f ? 0.0f : (b > 255.0f ? 255.0f : b);
-    px[i] = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | ((255u - (d >> 24)) << 24);
+    return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | ((255u - (d >> 24)) << 24);
 }
+
+__global__ __launch_bounds__(256) void ycck_to_cmyk_kernel(uint32_t *__restrict__ px, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    px[i] = ycck_pixel(px[i]);
+}
+
+// ---------------------------------------------------------------------------
+// CMYK_8 -> RGB_8 through a baked device-link CLUT: what lcms2's transform_pixels does for the transform the
+// reference builds (src/handler.rs:469-493: CMYK profile -> sRGB, Perceptual, NO_CACHE).  Little CMS 2 optimises
+// that transform into ONE 17^4 x 3 u16 table (cmsopt.c OptimizeByResampling) and evaluates every pixel with
+// cmsintrp.c Eval4Inputs: tetrahedral interpolation over inputs 1..3 on the two table slices that bracket
+// input 0, then a linear blend, all in 16.16 fixed point with 32-bit wrap-around.  This kernel is that
+// arithmetic (formatters Unroll4Bytes / Pack3Bytes included); the table is baked on the host
+// (fl_cmyk.cpp).  Table nodes are padded to 4 x u16 so that a node is one 8-byte load.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int32_t lcms_to_fixed_domain(int32_t a)
+{
+    return (int32_t)((uint32_t)a + (uint32_t)((int32_t)((uint32_t)a + 0x7fffu) / 0xffff));
+}
+
+struct ClutNode { int32_t c[3]; };
+__device__ __forceinline__ ClutNode clut_load(const uint2 *__restrict__ t, uint32_t idx)
+{
+    const uint2 v = t[idx];
+    return ClutNode{{(int32_t)(v.x & 0xffffu), (int32_t)(v.x >> 16), (int32_t)(v.y & 0xffffu)}};
+}
+
+// tetrahedral interpolation inside slice `base`: the six cases of Eval4Inputs collapse to "walk the cube
+// from (0,0,0) to (1,1,1) along the axes in descending order of their fractions" (ties give equal sums)
+__device__ __forceinline__ void clut_tetra(const uint2 *__restrict__ t, uint32_t base, uint32_t X0, uint32_t X1, uint32_t Y0,
+                                           uint32_t Y1, uint32_t Z0, uint32_t Z1, int32_t rx, int32_t ry, int32_t rz, uint32_t out[3])
+{
+    uint32_t a1, a2; // the two intermediate vertices
+    int32_t r1, r2, r3;
+    if (rx >= ry && ry >= rz)      { a1 = X1 + Y0 + Z0; a2 = X1 + Y1 + Z0; r1 = rx; r2 = ry; r3 = rz; }
+    else if (rx >= rz && rz >= ry) { a1 = X1 + Y0 + Z0; a2 = X1 + Y0 + Z1; r1 = rx; r2 = rz; r3 = ry; }
+    else if (rz >= rx && rx >= ry) { a1 = X0 + Y0 + Z1; a2 = X1 + Y0 + Z1; r1 = rz; r2 = rx; r3 = ry; }
+    else if (ry >= rx && rx >= rz) { a1 = X0 + Y1 + Z0; a2 = X1 + Y1 + Z0; r1 = ry; r2 = rx; r3 = rz; }
+    else if (ry >= rz && rz >= rx) { a1 = X0 + Y1 + Z0; a2 = X0 + Y1 + Z1; r1 = ry; r2 = rz; r3 = rx; }
+    else                           { a1 = X0 + Y0 + Z1; a2 = X0 + Y1 + Z1; r1 = rz; r2 = ry; r3 = rx; }
+    const ClutNode v0 = clut_load(t, base + X0 + Y0 + Z0), v1 = clut_load(t, base + a1), v2 = clut_load(t, base + a2),
+                   v3 = clut_load(t, base + X1 + Y1 + Z1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t rest = (uint32_t)(v1.c[k] - v0.c[k]) * (uint32_t)r1 + (uint32_t)(v2.c[k] - v1.c[k]) * (uint32_t)r2 +
+                              (uint32_t)(v3.c[k] - v2.c[k]) * (uint32_t)r3;
+        const int32_t f = lcms_to_fixed_domain((int32_t)rest);
+        out[k] = (uint32_t)(v0.c[k] + (((int32_t)((uint32_t)f + 0x8000u)) >> 16)) & 0xffffu;
+    }
+}
+
+__device__ __forceinline__ uint32_t cmyk_clut_pixel(const uint2 *__restrict__ t, uint32_t grid, uint32_t d)
+{
+    const uint32_t domain = grid - 1u;
+    const uint32_t sz = 1u, sy = grid, sx = grid * grid, sk = grid * grid * grid; // node strides of inputs 3, 2, 1, 0
+    uint32_t i0[4], step[4];
+    int32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = (d >> (8 * k)) & 255u;
+        const uint32_t in16 = b * 257u;                                  // FROM_8_TO_16
+        const int32_t f = lcms_to_fixed_domain((int32_t)(in16 * domain));
+        i0[k] = (uint32_t)f >> 16;
+        r[k] = f & 0xffff;
+        step[k] = b == 255u ? 0u : 1u;                                   // Input == 0xFFFF: no upper neighbour
+    }
+    const uint32_t K0 = sk * i0[0], K1 = K0 + sk * step[0];
+    const uint32_t X0 = sx * i0[1], X1 = X0 + sx * step[1];
+    const uint32_t Y0 = sy * i0[2], Y1 = Y0 + sy * step[2];
+    const uint32_t Z0 = sz * i0[3], Z1 = Z0 + sz * step[3];
+    uint32_t t1[3], t2[3];
+    clut_tetra(t, K0, X0, X1, Y0, Y1, Z0, Z1, r[1], r[2], r[3], t1);
+    clut_tetra(t, K1, X0, X1, Y0, Y1, Z0, Z1, r[1], r[2], r[3], t2);
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t dif = (t2[k] - t1[k]) * (uint32_t)r[0] + 0x8000u;      // LinearInterp
+        dif = ((dif >> 16) + t1[k]) & 0xffffu;
+        o |= ((dif * 65281u + 8388608u) >> 24) << (8 * k);              // FROM_16_TO_8
+    }
+    return o;
+}
+
+// 4 pixels per thread: one 16-byte load, three dword stores.  n4 = ceil(n / 4); the buffers are padded to that.
+template <bool YCCK>
+__global__ __launch_bounds__(256) void cmyk_clut_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ dst,
+                                                        const uint2 *__restrict__ clut, uint32_t grid, uint64_t n4)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const uint4 q = src[i];
+    uint32_t p[4] = {q.x, q.y, q.z, q.w}, o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (YCCK) p[k] = ycck_pixel(p[k]);
+        o[k] = cmyk_clut_pixel(clut, grid, p[k]);
+    }
+    dst[i * 3 + 0] = o[0] | (o[1] << 24);
+    dst[i * 3 + 1] = (o[1] >> 8) | (o[2] << 16);
+    dst[i * 3 + 2] = (o[2] >> 16) | (o[3] << 8);
+}
+
 
 // ---------------------------------------------------------------------------
 // launch wrappers (called from the host runtime; all asynchronous on `stream`)
@@ -1181,6 +1282,19 @@ hipError_t launch_orient(const LaunchGeneric &g, hipStream_t st)
     case 4: hipLaunchKernelGGL(orient_kernel<4>, grid, dim3(256), 0, st, g.jobs, g.job_base); break;
     default: return hipErrorInvalidValue;
     }
+    FL_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_cmyk_clut(const void *src, void *dst, const void *clut, uint32_t grid, uint64_t n_pixels, bool ycck, hipStream_t st)
+{
+    const uint64_t n4 = (n_pixels + 3) / 4;
+    if (n4 == 0) return hipSuccess;
+    const dim3 g((unsigned)((n4 + 255) / 256));
+    if (ycck) hipLaunchKernelGGL(cmyk_clut_kernel<true>, g, dim3(256), 0, st, static_cast<const uint4 *>(src), static_cast<uint32_t *>(dst),
+                                 static_cast<const uint2 *>(clut), grid, n4);
+    else hipLaunchKernelGGL(cmyk_clut_kernel<false>, g, dim3(256), 0, st, static_cast<const uint4 *>(src), static_cast<uint32_t *>(dst),
+                            static_cast<const uint2 *>(clut), grid, n4);
     FL_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -142,6 +142,8 @@ typedef struct flgpu_stats {
     double blur_ms;
     uint64_t frontend_launches;
     double frontend_ms;
+    uint64_t cmyk_pixels;         /* pixels converted CMYK -> RGB */
+    uint64_t cmyk_tables_baked;   /* device-link tables baked from ICC profiles */
 } flgpu_stats;
 
 typedef struct flgpu_ctx flgpu_ctx;
@@ -174,6 +176,33 @@ int flgpu_params_from_query(const flgpu_query *q, uint32_t accept_flags, int inp
 
 /* Pure function: output geometry for a source of sw x sh x sc. */
 int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t sc, flgpu_plan *plan);
+
+/* ---- CMYK / YCCK JPEG sources (reference src/handler.rs:398-493) ------------- */
+
+#define FLGPU_CMYK_GRID 17u          /* nodes per axis of the device-link table (Little CMS default for 4 inputs) */
+#define FLGPU_CMYK_INPUT_YCCK 1u     /* pixels are (Y, Cb, Cr, K): run the loop of handler.rs:423-438 first */
+
+/* Replaces create_cmyk_to_rgb_converter / CMYK2RGB::with_icc_profile (src/main.rs:74-76, src/handler.rs:469-488):
+ * bakes the CMYK_8 -> sRGB RGB_8, Intent::Perceptual transform of `icc` into the 17^4 table Little CMS itself
+ * interpolates, using the system's liblcms2 (dlopen).  FLGPU_ERR_INVALID_ARG = not a usable CMYK profile (the
+ * reference's `None`), FLGPU_ERR_UNSUPPORTED = liblcms2 missing on this host. */
+int flgpu_set_cmyk_profile(flgpu_ctx *ctx, const uint8_t *icc, uint64_t icc_len);
+int flgpu_cmyk_bake_available(void); /* 1 if liblcms2 could be loaded */
+/* The same table handed over / read back as grid^4 x 3 u16 (R, G, B), node index ((c*grid + m)*grid + y)*grid + k:
+ * for hosts that bake it themselves and for copying rank 0's table to the other GPUs. */
+int flgpu_set_cmyk_clut(flgpu_ctx *ctx, uint32_t grid, const uint16_t *rgb_nodes);
+int flgpu_get_cmyk_clut(flgpu_ctx *ctx, uint16_t *rgb_nodes, uint64_t capacity_entries, uint32_t *grid);
+/* Replaces CMYK2RGB::convert = lcms2 transform_pixels (src/handler.rs:490-492) and, with
+ * FLGPU_CMYK_INPUT_YCCK, the YCCK loop in front of it (423-438).  n_pixels x 4 bytes in, n_pixels x 3 bytes out.
+ * `embedded_icc` (may be NULL) is the JPEG's own profile when use_embedded_profile is set: it is baked once and
+ * cached by content; if it cannot be used the configured profile is (handler.rs:446-458).  With no usable
+ * profile at all: FLGPU_ERR_UNSUPPORTED (the reference returns None and decodes the JPEG the ordinary way). */
+int flgpu_cmyk_to_rgb(flgpu_ctx *ctx, const uint8_t *cmyk, uint64_t n_pixels, uint8_t *rgb,
+                      const uint8_t *embedded_icc, uint64_t icc_len, uint32_t flags);
+/* Device-resident variant with the configured profile: d_cmyk 16-byte aligned and readable up to a multiple of 4
+ * pixels, d_rgb 4-byte aligned and writable up to a multiple of 4 pixels; returns after enqueueing. */
+int flgpu_cmyk_to_rgb_device(flgpu_ctx *ctx, const void *d_cmyk, void *d_rgb, uint64_t n_pixels, uint32_t flags,
+                             void *hip_stream);
 
 /* ---- device context ---------------------------------------------------- */
 

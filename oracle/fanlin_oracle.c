@@ -666,3 +666,62 @@ void fo_ycck_to_cmyk(uint8_t *raw, size_t n_pixels)
         raw[i + 3] = (uint8_t)(255 - raw[i + 3]);
     }
 }
+
+/* ------------------------------------------------------------ CMYK CLUT -- */
+/* Little CMS 2 (2.12 .. 2.16 share this code) cmsintrp.c: _cmsToFixedDomain, Eval4Inputs, LinearInterp; lcms2_internal.h
+ * FROM_8_TO_16 / FROM_16_TO_8.  cmsS15Fixed16Number is int32 and the library relies on wrap-around, so the sums
+ * are formed in uint32 here. */
+static int32_t to_fixed_domain(int32_t a) { return (int32_t)((uint32_t)a + (uint32_t)((int32_t)((uint32_t)a + 0x7fffu) / 0xffff)); }
+
+static void eval3_tetra(const uint16_t *t, uint32_t nout, int32_t X0, int32_t X1, int32_t Y0, int32_t Y1, int32_t Z0, int32_t Z1,
+                        int32_t rx, int32_t ry, int32_t rz, uint16_t *out)
+{
+#define DENS(i, j, k) ((int32_t)t[(i) + (j) + (k) + ch])
+    for (uint32_t ch = 0; ch < nout; ++ch) {
+        int32_t c0 = DENS(X0, Y0, Z0), c1, c2, c3;
+        if (rx >= ry && ry >= rz) {
+            c1 = DENS(X1, Y0, Z0) - c0; c2 = DENS(X1, Y1, Z0) - DENS(X1, Y0, Z0); c3 = DENS(X1, Y1, Z1) - DENS(X1, Y1, Z0);
+        } else if (rx >= rz && rz >= ry) {
+            c1 = DENS(X1, Y0, Z0) - c0; c2 = DENS(X1, Y1, Z1) - DENS(X1, Y0, Z1); c3 = DENS(X1, Y0, Z1) - DENS(X1, Y0, Z0);
+        } else if (rz >= rx && rx >= ry) {
+            c1 = DENS(X1, Y0, Z1) - DENS(X0, Y0, Z1); c2 = DENS(X1, Y1, Z1) - DENS(X1, Y0, Z1); c3 = DENS(X0, Y0, Z1) - c0;
+        } else if (ry >= rx && rx >= rz) {
+            c1 = DENS(X1, Y1, Z0) - DENS(X0, Y1, Z0); c2 = DENS(X0, Y1, Z0) - c0; c3 = DENS(X1, Y1, Z1) - DENS(X1, Y1, Z0);
+        } else if (ry >= rz && rz >= rx) {
+            c1 = DENS(X1, Y1, Z1) - DENS(X0, Y1, Z1); c2 = DENS(X0, Y1, Z0) - c0; c3 = DENS(X0, Y1, Z1) - DENS(X0, Y1, Z0);
+        } else if (rz >= ry && ry >= rx) {
+            c1 = DENS(X1, Y1, Z1) - DENS(X0, Y1, Z1); c2 = DENS(X0, Y1, Z1) - DENS(X0, Y0, Z1); c3 = DENS(X0, Y0, Z1) - c0;
+        } else {
+            c1 = c2 = c3 = 0;
+        }
+        const int32_t rest = (int32_t)((uint32_t)c1 * (uint32_t)rx + (uint32_t)c2 * (uint32_t)ry + (uint32_t)c3 * (uint32_t)rz);
+        out[ch] = (uint16_t)(c0 + (((int32_t)((uint32_t)to_fixed_domain(rest) + 0x8000u)) >> 16));
+    }
+#undef DENS
+}
+
+void fo_cmyk_to_rgb(const uint8_t *cmyk, size_t n_pixels, const uint16_t *clut, uint32_t grid, uint8_t *rgb)
+{
+    const int32_t domain = (int32_t)grid - 1;
+    const int32_t opta0 = 3, opta1 = 3 * (int32_t)grid, opta2 = opta1 * (int32_t)grid, opta3 = opta2 * (int32_t)grid;
+    for (size_t p = 0; p < n_pixels; ++p) {
+        uint16_t in[4], t1[3], t2[3];
+        for (int k = 0; k < 4; ++k) in[k] = (uint16_t)((cmyk[p * 4 + k] << 8) | cmyk[p * 4 + k]); /* FROM_8_TO_16 */
+        const int32_t fk = to_fixed_domain((int32_t)in[0] * domain), fx = to_fixed_domain((int32_t)in[1] * domain),
+                      fy = to_fixed_domain((int32_t)in[2] * domain), fz = to_fixed_domain((int32_t)in[3] * domain);
+        const int32_t k0 = fk >> 16, x0 = fx >> 16, y0 = fy >> 16, z0 = fz >> 16;
+        const int32_t rk = fk & 0xffff, rx = fx & 0xffff, ry = fy & 0xffff, rz = fz & 0xffff;
+        const int32_t K0 = opta3 * k0, K1 = K0 + (in[0] == 0xffff ? 0 : opta3);
+        const int32_t X0 = opta2 * x0, X1 = X0 + (in[1] == 0xffff ? 0 : opta2);
+        const int32_t Y0 = opta1 * y0, Y1 = Y0 + (in[2] == 0xffff ? 0 : opta1);
+        const int32_t Z0 = opta0 * z0, Z1 = Z0 + (in[3] == 0xffff ? 0 : opta0);
+        eval3_tetra(clut + K0, 3, X0, X1, Y0, Y1, Z0, Z1, rx, ry, rz, t1);
+        eval3_tetra(clut + K1, 3, X0, X1, Y0, Y1, Z0, Z1, rx, ry, rz, t2);
+        for (int k = 0; k < 3; ++k) {
+            uint32_t dif = (uint32_t)((int32_t)t2[k] - (int32_t)t1[k]) * (uint32_t)rk + 0x8000u; /* LinearInterp */
+            dif = (dif >> 16) + t1[k];
+            const uint16_t o16 = (uint16_t)dif;
+            rgb[p * 3 + k] = (uint8_t)(((uint32_t)o16 * 65281u + 8388608u) >> 24);               /* FROM_16_TO_8 */
+        }
+    }
+}

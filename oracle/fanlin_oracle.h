@@ -106,6 +106,13 @@ int fo_webp_yuv420(const fo_image *src, uint8_t *out);
 /* handler.rs:423-438, YCCK -> "CMYK with inverted K" pointwise loop, in place on n pixels x 4. */
 void fo_ycck_to_cmyk(uint8_t *raw, size_t n_pixels);
 
+/* lcms2 transform_pixels for the transform of handler.rs:469-488 (CMYK_8 -> RGB_8), given the 17^4 device-link
+ * table Little CMS precomputes for it (cmsopt.c OptimizeByResampling): formatters Unroll4Bytes / Pack3Bytes and
+ * cmsintrp.c Eval4Inputs, in its 16.16 fixed point.  clut = grid^4 x 3 u16, node index ((c*grid+m)*grid+y)*grid+k.
+ * PINNED: tests compare this function with the system's liblcms2 itself (tests/golden/cmyk_lcms2.npz and, where
+ * the library is present, live). */
+void fo_cmyk_to_rgb(const uint8_t *cmyk, size_t n_pixels, const uint16_t *clut, uint32_t grid, uint8_t *rgb);
+
 #ifdef __cplusplus
 }
 #endif

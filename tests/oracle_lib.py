@@ -87,6 +87,16 @@ class Oracle:
         assert self.lib.fo_blur(C.byref(im), C.c_float(sigma), arith, C.byref(out)) == 0
         return self._take(out)
 
+    def cmyk_to_rgb(self, cmyk, clut):
+        a = np.ascontiguousarray(cmyk, dtype=np.uint8)
+        t = np.ascontiguousarray(clut, dtype=np.uint16)
+        grid = t.shape[0]
+        assert t.shape == (grid,) * 4 + (3,) and a.shape[-1] == 4
+        out = np.empty(a.shape[:-1] + (3,), np.uint8)
+        self.lib.fo_cmyk_to_rgb(a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size // 4), t.ctypes.data_as(C.c_void_p), C.c_uint32(grid),
+                                out.ctypes.data_as(C.c_void_p))
+        return out
+
     def apply_orientation(self, image, exif):
         src, keep = self._img(image)
         dst = fo_image()
