@@ -27,10 +27,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FLGPU_LIB") or os.path.join(_HERE, "libfanlin_gpu.so")
 
-FE_NONE, FE_JFIF444, FE_WEBP420 = 0, 1, 2
+FE_NONE, FE_JFIF444, FE_WEBP420, FE_JPEG = 0, 1, 2, 3
 ACCEPT_WEBP, ACCEPT_AVIF = 1, 2
 OUT_KEEP, OUT_WEBP, OUT_AVIF = 0, 1, 2
-IMG_FRONTEND_PLANES, IMG_HAS_ALPHA = 1, 2
+IMG_FRONTEND_PLANES, IMG_HAS_ALPHA, IMG_ENCODED = 1, 2, 4
 BATCH_SAME_PARAMS = 1
 (OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_OOM, ERR_DEVICE, ERR_PARSE, ERR_BUFFER_TOO_SMALL,
  ERR_SHUTDOWN) = range(9)
@@ -44,7 +44,7 @@ class FanlinError(RuntimeError):
 
 class flgpu_image(C.Structure):
     _fields_ = [("data", C.c_void_p), ("capacity", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32),
-                ("channels", C.c_uint32), ("flags", C.c_uint32)]
+                ("channels", C.c_uint32), ("flags", C.c_uint32), ("bytes", C.c_uint64)]
 
 
 class flgpu_query(C.Structure):
@@ -89,7 +89,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_cropping", "flgpu_query_blur", "flgpu_query_grayscale", "flgpu_query_inverse",
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
     "flgpu_params_from_query", "flgpu_plan_output", "flgpu_create", "flgpu_destroy", "flgpu_transform",
-    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_ycck_to_cmyk",
+    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_batch_results", "flgpu_ycck_to_cmyk",
     "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
@@ -140,6 +140,7 @@ def load_library() -> C.CDLL:
     lib.flgpu_transform_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params), C.POINTER(flgpu_image)]
     lib.flgpu_transform_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params),
                                                  C.POINTER(flgpu_image), C.c_void_p, C.c_uint32]
+    lib.flgpu_batch_results.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image)]
     lib.flgpu_ycck_to_cmyk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.flgpu_set_cmyk_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     lib.flgpu_set_cmyk_clut.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
@@ -334,9 +335,11 @@ def _as_image_array(a: np.ndarray) -> np.ndarray:
     return a
 
 
-def _split_output(buf: np.ndarray, plan: flgpu_plan, front_end: int, flags: int):
+def _split_output(buf: np.ndarray, plan: flgpu_plan, front_end: int, flags: int, nbytes: int = 0):
     if front_end == FE_NONE:
         return buf[: plan.pixel_bytes].reshape(plan.out_h, plan.out_w, plan.out_c)
+    if front_end == FE_JPEG:
+        return buf[:nbytes].tobytes()
     ny = plan.plane_w * plan.plane_h
     nc = plan.chroma_w * plan.chroma_h
     return Planes(y=buf[:ny].reshape(plan.plane_h, plan.plane_w),
@@ -382,14 +385,14 @@ class State:
         self.close()
 
     # -- host memory ---------------------------------------------------------
-    def process_pixels(self, image: np.ndarray, params: flgpu_params):
+    def process_pixels(self, image: np.ndarray, params: flgpu_params, capacity: int = 0):
         img = _as_image_array(image)
         plan = plan_output(params, img.shape[1], img.shape[0], img.shape[2])
-        out = np.empty(max(int(plan.out_bytes), 1), dtype=np.uint8)
+        out = np.empty(max(int(plan.out_bytes), capacity, 1), dtype=np.uint8)
         src = flgpu_image(img.ctypes.data, img.nbytes, img.shape[1], img.shape[0], img.shape[2], 0)
         dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
         _check(self._lib.flgpu_transform(self._ctx, C.byref(src), C.byref(params), C.byref(dst)), self._ctx)
-        return _split_output(out, plan, params.front_end, dst.flags)
+        return _split_output(out, plan, params.front_end, dst.flags, dst.bytes)
 
     def process_batch(self, images: Sequence[np.ndarray], params: Sequence[flgpu_params]) -> List:
         n = len(images)
@@ -400,7 +403,7 @@ class State:
         dsts = (flgpu_image * n)(*[flgpu_image(o.ctypes.data, o.nbytes, 0, 0, 0, 0) for o in outs])
         ps = (flgpu_params * n)(*params)
         _check(self._lib.flgpu_transform_batch(self._ctx, n, srcs, ps, dsts), self._ctx)
-        return [_split_output(outs[i], plans[i], params[i].front_end, dsts[i].flags) for i in range(n)]
+        return [_split_output(outs[i], plans[i], params[i].front_end, dsts[i].flags, dsts[i].bytes) for i in range(n)]
 
     # -- device memory -------------------------------------------------------
     def process_batch_device(self, src_ptrs: Sequence[int], shapes: Sequence[Tuple[int, int, int]],
@@ -417,6 +420,12 @@ class State:
             ps, flags = (flgpu_params * n)(*params), 0
         self._keep = (srcs, dsts, ps)
         _check(self._lib.flgpu_transform_batch_device(self._ctx, n, srcs, ps, dsts, C.c_void_p(stream), flags), self._ctx)
+
+    def batch_results(self) -> List[Tuple[int, int]]:
+        """(flags, bytes) of every image of the last ``process_batch_device`` call; waits for it."""
+        srcs, dsts, ps = self._keep
+        _check(self._lib.flgpu_batch_results(self._ctx, len(dsts), dsts), self._ctx)
+        return [(d.flags, d.bytes) for d in dsts]
 
     def prepared_batch(self, src_ptrs, shapes, params, dst_ptrs, dst_caps):
         """Pre-marshals a device batch so that the timed loop only pays for the C call."""

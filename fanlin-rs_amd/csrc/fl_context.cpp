@@ -23,6 +23,7 @@
 
 #include "../../include/fanlin_gpu.h"
 #include "fl_cmyk.h"
+#include "fl_jpeg_tables.h"
 #include "fl_kernels.h"
 #include "fl_tables.h"
 
@@ -131,6 +132,14 @@ struct flgpu_ctx {
     int next_slot = 0;
     DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_tmp_o, d_status;
     DeviceBuf d_in, d_out;
+    DeviceBuf d_jpeg_coef, d_jpeg_off, d_jpeg_raw; // JPEG encode scratch (fl_jpeg.hip)
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> jpeg_tables; // (w, h, quality) -> arena offset of header + q tables
+    // per-image result words of the most recent device batch: [2i] flags (bit 0: non-opaque alpha seen by the WebP front
+    // end, FL_JPEG_RESULT_OVERFLOW), [2i + 1] bytes of an encoded stream
+    size_t last_n = 0;
+    bool last_has_results = false;
+    std::vector<uint8_t> last_fe;
+    PinnedBuf h_results;
     PinnedBuf h_stage_in, h_stage_out;
     hipStream_t last_stream = nullptr;
     hipEvent_t last_done = nullptr;
@@ -199,6 +208,7 @@ void arena_reset(flgpu_ctx *c)
     c->axis_host.clear();
     c->stream_plans.clear();
     c->blur_plans.clear();
+    c->jpeg_tables.clear();
     std::vector<uint32_t> g;
     build_webp_gamma(g);
     c->gamma_off = arena_append(c, g.data(), g.size());
@@ -370,6 +380,8 @@ struct Work {
     uint32_t vtab = 0, htab = 0;
     const StreamPlan *splan = nullptr;
     bool unaligned = false;
+    size_t jpeg_coef_off = 0, jpeg_off_off = 0, jpeg_raw_off = 0; // FE_JPEG scratch (bytes)
+    uint32_t jpeg_tab = 0;
     uint32_t orient = 0, raw_w = 0, raw_h = 0; // EXIF orientation pre-pass (2..8), source size before it
     size_t orient_off = 0;
     const uint8_t *raw_src = nullptr;
@@ -418,7 +430,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
 
     // ---- plan every image ------------------------------------------------
     std::vector<Work> work(n);
-    size_t tmp_a_bytes = 0, tmp_b_bytes = 0, tmp_o_bytes = 0;
+    size_t tmp_a_bytes = 0, tmp_b_bytes = 0, tmp_o_bytes = 0, jpeg_coef_bytes = 0, jpeg_off_bytes = 0, jpeg_raw_bytes = 0;
     for (size_t i = 0; i < n; ++i) {
         Work &w = work[i];
         const flgpu_image &s = srcs[i];
@@ -453,7 +465,18 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if (!fe) w.blur_dst = w.final_dst;
             else { w.blur_dst = reinterpret_cast<uint8_t *>(tmp_b_bytes); tmp_b_bytes += align_up(pl.pixel_bytes, 256); }
         } else w.blur_dst = nullptr;
+        if (w.p->front_end == FLGPU_FE_JPEG) {
+            if (pl.out_w > 65535u || pl.out_h > 65535u) return FLGPU_ERR_UNSUPPORTED; // SOF0 carries u16 dimensions
+            const size_t units = (size_t)(pl.plane_w / 8u) * (pl.plane_h / 8u) * 3u;
+            if (units * kJpegMaxUnitBytes + 64 >= ((size_t)1 << 32)) return FLGPU_ERR_UNSUPPORTED;
+            w.jpeg_coef_off = jpeg_coef_bytes; jpeg_coef_bytes += align_up(units * 64 * sizeof(int16_t), 256);
+            w.jpeg_off_off = jpeg_off_bytes; jpeg_off_bytes += align_up((units + 1) * sizeof(uint32_t), 256);
+            w.jpeg_raw_off = jpeg_raw_bytes; jpeg_raw_bytes += align_up(units * kJpegMaxUnitBytes + 64, 256);
+        }
     }
+    FL_HIP(c, c->d_jpeg_coef.reserve(jpeg_coef_bytes), "JPEG coefficient scratch");
+    FL_HIP(c, c->d_jpeg_off.reserve(jpeg_off_bytes), "JPEG offset scratch");
+    FL_HIP(c, c->d_jpeg_raw.reserve(jpeg_raw_bytes), "JPEG bit-stream scratch");
     FL_HIP(c, c->d_tmp_o.reserve(tmp_o_bytes), "orientation scratch");
     for (auto &w : work)
         if (w.orient) { w.raw_src = w.src; w.src = static_cast<uint8_t *>(c->d_tmp_o.p) + w.orient_off; }
@@ -514,6 +537,21 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                     if (!off) full = true; else c->blur_plans[{kv, k}] = off;
                 }
             }
+        }
+        for (auto &w : work) {
+            if (full) break;
+            if (w.p->front_end != FLGPU_FE_JPEG) continue;
+            const uint32_t q = std::min<uint32_t>(std::max<uint32_t>(w.p->quality, 1u), 100u); // handler.rs:275 quality().clamp(1, 100)
+            const auto key = std::make_tuple(w.plan.out_w, w.plan.out_h, q);
+            auto it = c->jpeg_tables.find(key);
+            if (it == c->jpeg_tables.end()) {
+                std::vector<uint32_t> blk;
+                build_jpeg_tables(w.plan.out_w, w.plan.out_h, q, blk);
+                const uint32_t off = arena_append(c, blk.data(), blk.size());
+                if (!off) { full = true; break; }
+                it = c->jpeg_tables.emplace(key, off).first;
+            }
+            w.jpeg_tab = it->second;
         }
         if (!full) break;
         if (attempt == 1) return FLGPU_ERR_OOM;
@@ -640,8 +678,36 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         }
         blur_launches.push_back(L);
     }
-    size_t n_status = 0;
+    // result words: two per image of the batch, see flgpu_ctx::last_fe
+    const bool has_results = !fe_groups.empty();
+    if (has_results) {
+        FL_HIP(c, c->d_status.reserve(n * 8), "result words");
+        FL_HIP(c, hipMemsetAsync(c->d_status.p, 0, n * 8, st), "result clear");
+    }
+    std::vector<JpegJob> jjobs;
+    uint32_t jpeg_max_blocks = 0;
     for (auto &kv : fe_groups) {
+        if (kv.first.kind == FLGPU_FE_JPEG) {
+            for (size_t idx : kv.second) {
+                const Work &w = work[idx];
+                const flgpu_plan &pl = w.plan;
+                JpegJob j; memset(&j, 0, sizeof(j));
+                j.src = w.blur_dst ? w.blur_dst : w.s1_dst;
+                j.dst = w.final_dst;
+                j.coef = reinterpret_cast<int16_t *>(static_cast<char *>(c->d_jpeg_coef.p) + w.jpeg_coef_off);
+                j.unit_off = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_off.p) + w.jpeg_off_off);
+                j.raw = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_raw.p) + w.jpeg_raw_off);
+                j.result = static_cast<uint32_t *>(c->d_status.p) + 2 * idx;
+                j.w = pl.out_w; j.h = pl.out_h; j.c = pl.out_c;
+                j.bx = pl.plane_w / 8u; j.by = pl.plane_h / 8u;
+                j.tab_off = w.jpeg_tab;
+                j.raw_cap = (uint32_t)((size_t)j.bx * j.by * 3u * kJpegMaxUnitBytes + 64);
+                j.dst_cap = (uint32_t)std::min<uint64_t>(dsts[idx].capacity, 0xffffffffull);
+                jpeg_max_blocks = std::max(jpeg_max_blocks, j.bx * j.by);
+                jjobs.push_back(j);
+            }
+            continue;
+        }
         FeLaunch F{kv.first.kind, (uint32_t)fjobs.size(), 0, 0, 0, true};
         for (size_t idx : kv.second) {
             const Work &w = work[idx];
@@ -649,7 +715,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             FrontendJob f; memset(&f, 0, sizeof(f));
             f.src = w.blur_dst ? w.blur_dst : w.s1_dst;
             f.dst = w.final_dst;
-            f.status = reinterpret_cast<uint32_t *>(n_status++ * 4 + 4); // patched below
+            f.status = static_cast<uint32_t *>(c->d_status.p) + 2 * idx;
             f.w = pl.out_w; f.h = pl.out_h; f.c = pl.out_c;
             f.plane_w = pl.plane_w; f.plane_h = pl.plane_h; f.chroma_w = pl.chroma_w; f.chroma_h = pl.chroma_h;
             if (f.c != 4 || ((uintptr_t)f.src & 3u) || ((uintptr_t)f.dst & 3u)) F.rgba = false;
@@ -660,18 +726,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         }
         fe_launches.push_back(F);
     }
-    if (n_status) {
-        FL_HIP(c, c->d_status.reserve(n_status * 4), "status words");
-        FL_HIP(c, hipMemsetAsync(c->d_status.p, 0, n_status * 4, st), "status clear");
-        for (auto &f : fjobs) f.status = static_cast<uint32_t *>(c->d_status.p) + (reinterpret_cast<size_t>(f.status) / 4 - 1);
-    }
     FL_HIP(c, c->d_mid.reserve(mid_floats_max * 4), "f32 intermediate");
 
-    // one staging slot: [jobs][items][fjobs]
+    // one staging slot: [jobs][items][fjobs][jjobs]
     const size_t jobs_b = align_up(jobs.size() * sizeof(Job), 256), items_b = align_up(items.size() * sizeof(StreamItem), 256),
-                 fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256);
-    const size_t desc_b = jobs_b + items_b + fjobs_b;
-    const Job *d_jobs = nullptr; const StreamItem *d_items = nullptr; const FrontendJob *d_fjobs = nullptr;
+                 fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256), jjobs_b = align_up(jjobs.size() * sizeof(JpegJob), 256);
+    const size_t desc_b = jobs_b + items_b + fjobs_b + jjobs_b;
+    const Job *d_jobs = nullptr; const StreamItem *d_items = nullptr; const FrontendJob *d_fjobs = nullptr; const JpegJob *d_jjobs = nullptr;
     DescSlot *slot = nullptr;
     if (desc_b) {
         slot = &c->slots[c->next_slot];
@@ -684,11 +745,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (!jobs.empty()) memcpy(hp, jobs.data(), jobs.size() * sizeof(Job));
         if (!items.empty()) memcpy(hp + jobs_b, items.data(), items.size() * sizeof(StreamItem));
         if (!fjobs.empty()) memcpy(hp + jobs_b + items_b, fjobs.data(), fjobs.size() * sizeof(FrontendJob));
+        if (!jjobs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b, jjobs.data(), jjobs.size() * sizeof(JpegJob));
         FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, st), "descriptor upload");
         char *dp = static_cast<char *>(slot->dev.p);
         d_jobs = reinterpret_cast<const Job *>(dp);
         d_items = reinterpret_cast<const StreamItem *>(dp + jobs_b);
         d_fjobs = reinterpret_cast<const FrontendJob *>(dp + jobs_b + items_b);
+        d_jjobs = reinterpret_cast<const JpegJob *>(dp + jobs_b + items_b + fjobs_b);
     }
 
     // ---- launches --------------------------------------------------------------
@@ -742,6 +805,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         else FL_HIP(c, launch_webp420(d_fjobs, c->d_arena, c->gamma_off, F.base, F.n, F.mw, F.mh, F.rgba, st), "webp front end");
         c->stats.frontend_launches++;
     }
+    if (!jjobs.empty()) {
+        ProfileScope ps(c, st, 2);
+        FL_HIP(c, launch_jpeg_encode(d_jjobs, c->d_arena, 0, (uint32_t)jjobs.size(), jpeg_max_blocks, st), "JPEG encode");
+        c->stats.frontend_launches++;
+    }
     // plain copies for requests that change nothing
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
@@ -756,11 +824,37 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     for (size_t i = 0; i < n; ++i) {
         const flgpu_plan &pl = work[i].plan;
         dsts[i].width = pl.out_w; dsts[i].height = pl.out_h; dsts[i].channels = pl.out_c;
-        dsts[i].flags = work[i].p->front_end != FLGPU_FE_NONE ? FLGPU_IMG_FRONTEND_PLANES : 0u;
+        const uint32_t fe = work[i].p->front_end;
+        dsts[i].flags = fe == FLGPU_FE_JPEG ? FLGPU_IMG_ENCODED : (fe != FLGPU_FE_NONE ? FLGPU_IMG_FRONTEND_PLANES : 0u);
+        dsts[i].bytes = fe == FLGPU_FE_JPEG ? 0 : pl.out_bytes; // an encoded stream's length is a result word: flgpu_batch_results
     }
+    c->last_n = n;
+    c->last_has_results = has_results;
+    c->last_fe.resize(n);
+    for (size_t i = 0; i < n; ++i) c->last_fe[i] = work[i].p->front_end;
     c->stats.images += n;
     c->stats.batches++;
     return FLGPU_OK;
+}
+
+// Reads the result words of the batch that was just enqueued on `st` (synchronises) and completes dsts[]:
+// the alpha flag of the WebP front end, the length of an encoded stream.
+int collect_results(flgpu_ctx *c, size_t n, flgpu_image *dsts, hipStream_t st)
+{
+    if (!c->last_has_results || n != c->last_n) { FL_HIP(c, hipStreamSynchronize(st), "batch sync"); return FLGPU_OK; }
+    FL_HIP(c, c->h_results.reserve(n * 8), "pinned result words");
+    FL_HIP(c, hipMemcpyAsync(c->h_results.p, c->d_status.p, n * 8, hipMemcpyDeviceToHost, st), "result words D2H");
+    FL_HIP(c, hipStreamSynchronize(st), "batch sync");
+    const uint32_t *r = static_cast<const uint32_t *>(c->h_results.p);
+    int rc = FLGPU_OK;
+    for (size_t i = 0; i < n; ++i) {
+        if (c->last_fe[i] == FLGPU_FE_WEBP420 && (r[2 * i] & 1u)) dsts[i].flags |= FLGPU_IMG_HAS_ALPHA;
+        if (c->last_fe[i] == FLGPU_FE_JPEG) {
+            dsts[i].bytes = r[2 * i + 1];
+            if (!r[2 * i + 1]) { c->last_error = "encoded stream does not fit the destination"; rc = FLGPU_ERR_BUFFER_TOO_SMALL; }
+        }
+    }
+    return rc;
 }
 
 // Host-memory batch: stage in, run, stage out, wait.
@@ -781,7 +875,12 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
         if (dsts[i].capacity < plans[i].out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
         dsrc[i] = srcs[i]; ddst[i] = dsts[i];
         dsrc[i].data = reinterpret_cast<uint8_t *>(in_b); dsrc[i].capacity = sb; in_b += align_up(sb, 256);
-        ddst[i].data = reinterpret_cast<uint8_t *>(out_b); ddst[i].capacity = plans[i].out_bytes; out_b += align_up(plans[i].out_bytes, 256);
+        uint64_t ob = plans[i].out_bytes;
+        if (ps[i].front_end == FLGPU_FE_JPEG) {
+            const uint64_t worst = 1024ull + 2ull * kJpegMaxUnitBytes * 3ull * (plans[i].plane_w / 8u) * (plans[i].plane_h / 8u);
+            ob = std::max<uint64_t>(ob, std::min<uint64_t>(dsts[i].capacity, worst));
+        }
+        ddst[i].data = reinterpret_cast<uint8_t *>(out_b); ddst[i].capacity = ob; out_b += align_up(ob, 256);
     }
     FL_HIP(c, c->d_in.reserve(in_b), "device input staging");
     FL_HIP(c, c->d_out.reserve(out_b), "device output staging");
@@ -798,14 +897,14 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
     int rc = run_batch_device(c, n, dsrc.data(), ps, false, ddst.data(), st);
     if (rc) return rc;
     FL_HIP(c, hipMemcpyAsync(c->h_stage_out.p, c->d_out.p, out_b, hipMemcpyDeviceToHost, st), "D2H");
-    std::vector<uint32_t> status_words;
-    FL_HIP(c, hipStreamSynchronize(st), "batch sync");
+    rc = collect_results(c, n, ddst.data(), st);
     for (size_t i = 0; i < n; ++i) {
         const size_t off = static_cast<uint8_t *>(ddst[i].data) - static_cast<uint8_t *>(c->d_out.p);
-        memcpy(dsts[i].data, static_cast<char *>(c->h_stage_out.p) + off, plans[i].out_bytes);
+        memcpy(dsts[i].data, static_cast<char *>(c->h_stage_out.p) + off, std::min<uint64_t>(ddst[i].bytes, ddst[i].capacity));
         dsts[i].width = ddst[i].width; dsts[i].height = ddst[i].height; dsts[i].channels = ddst[i].channels; dsts[i].flags = ddst[i].flags;
+        dsts[i].bytes = ddst[i].bytes;
     }
-    return FLGPU_OK;
+    return rc;
 }
 
 // ---- request queue ---------------------------------------------------------
@@ -858,13 +957,24 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
     }
     int rc = run_batch_device(c, n, dsrc.data(), ps.data(), false, ddst.data(), st);
     if (rc) return rc;
-    for (size_t i = 0; i < n; ++i)
-        FL_HIP(c, hipMemcpyAsync(batch[i]->out.p, ddst[i].data, batch[i]->out_bytes, hipMemcpyDeviceToHost, st), "D2H");
-    FL_HIP(c, hipStreamSynchronize(st), "batch sync");
+    // encoded streams: learn their lengths first, then fetch exactly those bytes (a 300x200 JPEG is ~16 KB of a 183 KB bound)
+    bool encoded = false;
+    for (size_t i = 0; i < n; ++i) encoded |= ps[i].front_end == FLGPU_FE_JPEG;
+    int rrc = FLGPU_OK;
+    if (encoded) rrc = collect_results(c, n, ddst.data(), st);
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t nb = ps[i].front_end == FLGPU_FE_JPEG ? ddst[i].bytes : batch[i]->out_bytes;
+        if (nb) FL_HIP(c, hipMemcpyAsync(batch[i]->out.p, ddst[i].data, nb, hipMemcpyDeviceToHost, st), "D2H");
+    }
+    if (!encoded) rrc = collect_results(c, n, ddst.data(), st);
+    else FL_HIP(c, hipStreamSynchronize(st), "batch sync");
     for (size_t i = 0; i < n; ++i) {
         batch[i]->dst->width = ddst[i].width; batch[i]->dst->height = ddst[i].height;
         batch[i]->dst->channels = ddst[i].channels; batch[i]->dst->flags = ddst[i].flags;
+        batch[i]->dst->bytes = ddst[i].bytes;
+        if (ps[i].front_end == FLGPU_FE_JPEG && !ddst[i].bytes) batch[i]->status = FLGPU_ERR_BUFFER_TOO_SMALL;
     }
+    (void)rrc; // per-request status above: one oversized stream must not fail its batch mates
     return FLGPU_OK;
 }
 
@@ -893,7 +1003,7 @@ void worker_main(flgpu_ctx *c)
         }
         {
             std::lock_guard<std::mutex> lk(c->qmu);
-            for (Request *r : batch) { r->status = rc; r->done = true; }
+            for (Request *r : batch) { if (rc) r->status = rc; r->done = true; }
         }
         c->qdone.notify_all();
     }
@@ -949,6 +1059,7 @@ void flgpu_destroy(flgpu_ctx *c)
     for (auto &s : c->slots) { s.host.release(); s.dev.release(); if (s.done) (void)hipEventDestroy(s.done); }
     if (c->last_done) (void)hipEventDestroy(c->last_done);
     c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_tmp_o.release(); c->d_status.release(); c->d_in.release(); c->d_out.release();
+    c->d_jpeg_coef.release(); c->d_jpeg_off.release(); c->d_jpeg_raw.release();
     c->cmyk_default.dev.release();
     for (auto &kv : c->cmyk_embedded) kv.second.dev.release();
     c->h_stage_in.release(); c->h_stage_out.release();
@@ -986,6 +1097,11 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
     r.src = src; r.p = p; r.dst = dst;
     r.src_bytes = (uint64_t)src->width * src->height * src->channels;
     r.out_bytes = plan.out_bytes;
+    if (p->front_end == FLGPU_FE_JPEG) {
+        // a caller that offers more room than the planning bound gets it, up to the worst case of the format
+        const uint64_t worst = 1024ull + 2ull * kJpegMaxUnitBytes * 3ull * (plan.plane_w / 8u) * (plan.plane_h / 8u);
+        r.out_bytes = std::max<uint64_t>(plan.out_bytes, std::min<uint64_t>(dst->capacity, worst));
+    }
     r.in = pin_acquire(c, r.src_bytes);
     r.out = pin_acquire(c, r.out_bytes);
     if (!r.in.p || !r.out.p) { pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_OOM; }
@@ -1001,10 +1117,19 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
         std::unique_lock<std::mutex> lk(c->qmu);
         c->qdone.wait(lk, [&] { return r.done; });
     }
-    if (r.status == FLGPU_OK) memcpy(dst->data, r.out.p, r.out_bytes);
+    if (r.status == FLGPU_OK) memcpy(dst->data, r.out.p, std::min<uint64_t>(dst->bytes, r.out_bytes));
     pin_release(c, r.in);
     pin_release(c, r.out);
     return r.status;
+}
+
+int flgpu_batch_results(flgpu_ctx *c, size_t n, flgpu_image *dsts)
+{
+    if (!c || (!dsts && n)) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n != c->last_n) { c->last_error = "flgpu_batch_results: n differs from the last device batch"; return FLGPU_ERR_INVALID_ARG; }
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    return collect_results(c, n, dsts, c->last_stream ? c->last_stream : c->stream);
 }
 
 int flgpu_ycck_to_cmyk(flgpu_ctx *c, uint8_t *raw, uint64_t n_pixels)

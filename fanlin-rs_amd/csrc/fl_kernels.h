@@ -19,6 +19,22 @@ struct alignas(16) FrontendJob {
     uint32_t pad;
 };
 
+// One image of a JPEG-encode launch (fl_jpeg.hip).
+#define FL_JPEG_RESULT_OVERFLOW 4u
+struct alignas(16) JpegJob {
+    const uint8_t *src;   // interleaved pixels, w x h x c
+    uint8_t *dst;         // the JFIF stream
+    int16_t *coef;        // scratch: quantised coefficients, [unit][64] in zig-zag order, unit = block * 3 + component
+    uint32_t *unit_off;   // scratch: units + 1 bit offsets
+    uint32_t *raw;        // scratch: entropy-coded bits before byte stuffing
+    uint32_t *result;     // [0] |= flags (FL_JPEG_RESULT_OVERFLOW), [1] = stream bytes (0 if it did not fit dst_cap)
+    uint32_t w, h, c;
+    uint32_t bx, by;      // blocks per row / column
+    uint32_t tab_off;     // arena word offset of the header + quantisation tables block (fl_jpeg_tables.h)
+    uint32_t raw_cap;     // bytes available at raw
+    uint32_t dst_cap;     // bytes available at dst
+};
+
 // A group of jobs sharing source channels / pre-op / letterbox flag.
 struct LaunchGeneric {
     const Job *jobs;        // device array
@@ -76,5 +92,9 @@ hipError_t launch_jfif444(const FrontendJob *fjobs, uint32_t job_base, uint32_t 
                           bool all_rgba_aligned, hipStream_t st);
 hipError_t launch_webp420(const FrontendJob *fjobs, const uint32_t *arena, uint32_t gamma_off, uint32_t job_base,
                           uint32_t njobs, uint32_t max_cw, uint32_t max_ch, bool all_rgba_aligned, hipStream_t st);
+
+// JPEG encode of njobs pictures: colour + FDCT + quantise (one wave per block), then entropy coding (one workgroup per picture)
+hipError_t launch_jpeg_encode(const JpegJob *jobs, const uint32_t *arena, uint32_t job_base, uint32_t njobs, uint32_t max_blocks,
+                              hipStream_t st);
 
 } // namespace fl

@@ -193,7 +193,7 @@ int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t 
     if (!p || !plan) return FLGPU_ERR_INVALID_ARG;
     if (sw == 0 || sh == 0 || sc < 1 || sc > 4) return FLGPU_ERR_INVALID_ARG;
     if ((uint64_t)sw * sh * sc >= (1ull << 31)) return FLGPU_ERR_UNSUPPORTED;
-    if (p->front_end > FLGPU_FE_WEBP420 || p->orientation > 8 || p->filter > FLGPU_FILTER_NEAREST) return FLGPU_ERR_INVALID_ARG;
+    if (p->front_end > FLGPU_FE_JPEG || p->orientation > 8 || p->filter > FLGPU_FILTER_NEAREST) return FLGPU_ERR_INVALID_ARG;
     memset(plan, 0, sizeof(*plan));
     /* handler.rs:221-223: EXIF orientations 5..8 contain a quarter turn: width and height swap */
     if (p->orientation >= 5) { const uint32_t t = sw; sw = sh; sh = t; }
@@ -251,6 +251,16 @@ int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t 
         plan->chroma_w = plan->plane_w;
         plan->chroma_h = plan->plane_h;
         plan->out_bytes = 3ull * plan->plane_w * plan->plane_h;
+        break;
+    case FLGPU_FE_JPEG:
+        // capacity bound of the stream, not its length: header + one byte per sample (quantised photographs stay
+        // far below; if a stream does not fit, the call reports FLGPU_ERR_BUFFER_TOO_SMALL and may be retried
+        // with a larger dst->capacity, at most 623 + 2 + 2 * 208 bytes per 8x8 block and component)
+        plan->plane_w = (plan->out_w + 7u) & ~7u;
+        plan->plane_h = (plan->out_h + 7u) & ~7u;
+        plan->chroma_w = plan->plane_w;
+        plan->chroma_h = plan->plane_h;
+        plan->out_bytes = 3ull * plan->plane_w * plan->plane_h + 1024ull;
         break;
     case FLGPU_FE_WEBP420:
         plan->plane_w = plan->out_w;

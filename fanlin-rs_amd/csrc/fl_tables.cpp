@@ -2,6 +2,7 @@
 // window bounds depend on exact f32 evaluation order (floor/ceil of
 // (o + 0.5) * ratio -/+ support), as in image 0.25.6 imageops/sample.rs.
 #include "fl_tables.h"
+#include "fl_jpeg_tables.h"
 
 #include <math.h>
 #include <string.h>
@@ -253,6 +254,49 @@ void build_webp_gamma(std::vector<uint32_t> &out)
     out.clear();
     for (int v = 0; v <= 255; ++v) out.push_back((uint32_t)(uint16_t)(pow(norm * v, kGamma) * kGammaScale + .5));
     for (int v = 0; v <= kGammaTabSize; ++v) out.push_back((uint32_t)(int)(255. * pow(scale * v, 1. / kGamma) + .5));
+}
+
+void build_jpeg_tables(uint32_t width, uint32_t height, uint32_t quality, std::vector<uint32_t> &out)
+{
+    std::vector<uint8_t> b;
+    b.reserve(kJpegTableBlockBytes);
+    uint8_t q[2][64];
+    // "Derive our quantization table scaling value using the libjpeg algorithm"
+    uint32_t scale = std::min(std::max(quality, 1u), 100u);
+    scale = scale < 50 ? 5000 / scale : 200 - scale * 2;
+    for (int i = 0; i < 64; ++i) {
+        q[0][i] = (uint8_t)std::min(std::max(((uint32_t)kStdLumaQ[i] * scale + 50) / 100, 1u), 255u);
+        q[1][i] = (uint8_t)std::min(std::max(((uint32_t)kStdChromaQ[i] * scale + 50) / 100, 1u), 255u);
+    }
+    auto segment = [&](uint8_t marker, const std::vector<uint8_t> &d) {
+        b.push_back(0xFF); b.push_back(marker);
+        b.push_back((uint8_t)((d.size() + 2) >> 8)); b.push_back((uint8_t)(d.size() + 2));
+        b.insert(b.end(), d.begin(), d.end());
+    };
+    b.push_back(0xFF); b.push_back(0xD8);                                                      // SOI
+    segment(0xE0, {'J', 'F', 'I', 'F', 0, 1, 2, 0, 0, 1, 0, 1, 0, 0});                         // JFIF 1.2, PixelDensity::default() = 1:1 aspect
+    std::vector<uint8_t> d = {8, (uint8_t)(height >> 8), (uint8_t)height, (uint8_t)(width >> 8), (uint8_t)width, 3};
+    for (int c = 0; c < 3; ++c) { d.push_back((uint8_t)(c + 1)); d.push_back(0x11); d.push_back((uint8_t)(c ? 1 : 0)); }
+    segment(0xC0, d);                                                                          // SOF0
+    for (int t = 0; t < 2; ++t) {                                                              // DQT, zig-zag order
+        d.assign(1, (uint8_t)t);
+        for (int k = 0; k < 64; ++k) d.push_back(q[t][kUnzigzag[k]]);
+        segment(0xDB, d);
+    }
+    const struct { uint8_t cls, dest; const HuffSpec *s; } hts[4] = {{0, 0, &kDcLuma}, {1, 0, &kAcLuma}, {0, 1, &kDcChroma}, {1, 1, &kAcChroma}};
+    for (const auto &h : hts) {                                                                // DHT
+        d.assign(1, (uint8_t)((h.cls << 4) | h.dest));
+        d.insert(d.end(), h.s->len, h.s->len + 16);
+        d.insert(d.end(), h.s->val, h.s->val + h.s->n);
+        segment(0xC4, d);
+    }
+    d = {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0};                                              // SOS
+    segment(0xDA, d);
+    b.resize(624, 0);
+    b.insert(b.end(), q[0], q[0] + 64);
+    b.insert(b.end(), q[1], q[1] + 64);
+    out.assign(kJpegTableBlockBytes / 4, 0);
+    memcpy(out.data(), b.data(), kJpegTableBlockBytes);
 }
 
 } // namespace fl

@@ -59,16 +59,20 @@ typedef struct flgpu_image {
     uint64_t capacity;  /* src: bytes valid at data; dst: bytes writable at data */
     uint32_t width, height, channels;
     uint32_t flags;     /* out: FLGPU_IMG_* */
+    uint64_t bytes;     /* out: bytes produced at data (pixels, planes or an encoded stream) */
 } flgpu_image;
 
 #define FLGPU_IMG_FRONTEND_PLANES 1u  /* dst->data holds encoder planes, not interleaved pixels */
+#define FLGPU_IMG_ENCODED         4u  /* JPEG: data holds an encoded stream of `bytes` bytes */
 #define FLGPU_IMG_HAS_ALPHA       2u  /* WEBP420: picture has non-opaque alpha; planes were NOT produced */
 
 /* Encoder colour front end to run after the pixel pipeline. */
 typedef enum flgpu_front_end {
     FLGPU_FE_NONE = 0,     /* dst = interleaved pixels, out_c channels */
     FLGPU_FE_JFIF444 = 1,  /* dst = Y | Cb | Cr, each plane_w x plane_h (multiples of 8, edge replicated) */
-    FLGPU_FE_WEBP420 = 2   /* dst = Y (w x h) | U | V (each ceil(w/2) x ceil(h/2)), BT.601 limited range */
+    FLGPU_FE_WEBP420 = 2,  /* dst = Y (w x h) | U | V (each ceil(w/2) x ceil(h/2)), BT.601 limited range */
+    FLGPU_FE_JPEG = 3      /* dst = the finished JFIF stream of JpegEncoder::new_with_quality(q).encode_image(&img)
+                              (src/handler.rs:274-278): baseline, 3 components, 4:4:4; dst->bytes long */
 } flgpu_front_end;
 
 /* content::Format bits (src/content.rs:15-16). */
@@ -226,6 +230,11 @@ int flgpu_transform_batch(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, con
 #define FLGPU_BATCH_SAME_PARAMS 1u
 int flgpu_transform_batch_device(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, const flgpu_params *ps,
                                  flgpu_image *dsts, void *hip_stream, uint32_t flags);
+/* What only the device knows when flgpu_transform_batch_device returns -- the length of an encoded stream
+ * (FLGPU_FE_JPEG: dsts[i].bytes, 0 + FLGPU_ERR_BUFFER_TOO_SMALL if it did not fit dsts[i].capacity) and
+ * FLGPU_IMG_HAS_ALPHA of the WebP front end: waits for the most recent device batch of this context and completes
+ * the same dsts[] array.  The host-memory entry points do this themselves. */
+int flgpu_batch_results(flgpu_ctx *ctx, size_t n, flgpu_image *dsts);
 
 /* In-place YCCK -> "CMYK with inverted K" on n_pixels x 4 host bytes: the pointwise loop of
  * convert_jpeg_color_if_needed (src/handler.rs:423-438) that precedes the lcms2 transform.  Blocking. */

@@ -106,6 +106,14 @@ int fo_webp_yuv420(const fo_image *src, uint8_t *out);
 /* handler.rs:423-438, YCCK -> "CMYK with inverted K" pointwise loop, in place on n pixels x 4. */
 void fo_ycck_to_cmyk(uint8_t *raw, size_t n_pixels);
 
+/* JPEG encoder back half (fanlin_oracle_jpeg.c): image 0.25.6 codecs/jpeg/encoder.rs + transform.rs as called at
+ * handler.rs:274-278.  Coefficients are quantised, zig-zag ordered, unit = (block_row*blocks_x + block_col)*3 + comp. */
+void fo_jpeg_qtables(int quality, uint8_t luma[64], uint8_t chroma[64]);
+void fo_jpeg_fdct(const uint8_t samples[64], int32_t coeffs[64]);
+int fo_jpeg_coefficients(const fo_image *src, int quality, int16_t *out);
+size_t fo_jpeg_header(uint32_t width, uint32_t height, int quality, uint8_t *out, size_t cap);
+size_t fo_jpeg_encode(const fo_image *src, int quality, uint8_t *out, size_t cap);
+
 /* lcms2 transform_pixels for the transform of handler.rs:469-488 (CMYK_8 -> RGB_8), given the 17^4 device-link
  * table Little CMS precomputes for it (cmsopt.c OptimizeByResampling): formatters Unroll4Bytes / Pack3Bytes and
  * cmsintrp.c Eval4Inputs, in its 16.16 fixed point.  clut = grid^4 x 3 u16, node index ((c*grid+m)*grid+y)*grid+k.

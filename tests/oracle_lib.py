@@ -87,6 +87,40 @@ class Oracle:
         assert self.lib.fo_blur(C.byref(im), C.c_float(sigma), arith, C.byref(out)) == 0
         return self._take(out)
 
+    # ---- JPEG encoder back half (fanlin_oracle_jpeg.c) ----
+    def jpeg_qtables(self, quality):
+        a, b = (C.c_uint8 * 64)(), (C.c_uint8 * 64)()
+        self.lib.fo_jpeg_qtables(int(quality), a, b)
+        return np.array(a, np.uint8), np.array(b, np.uint8)
+
+    def jpeg_fdct(self, samples):
+        s = np.ascontiguousarray(samples, dtype=np.uint8).reshape(64)
+        out = np.zeros(64, np.int32)
+        self.lib.fo_jpeg_fdct(s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out.reshape(8, 8)
+
+    def jpeg_coefficients(self, image, quality):
+        im, keep = self._img(image)
+        bx, by = (im.w + 7) // 8, (im.h + 7) // 8
+        out = np.zeros((by * bx * 3, 64), np.int16)
+        assert self.lib.fo_jpeg_coefficients(C.byref(im), int(quality), out.ctypes.data_as(C.c_void_p)) == 0
+        return out
+
+    def jpeg_header(self, w, h, quality):
+        buf = np.zeros(1024, np.uint8)
+        self.lib.fo_jpeg_header.restype = C.c_size_t
+        n = self.lib.fo_jpeg_header(C.c_uint32(w), C.c_uint32(h), int(quality), buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
+        return buf[:n].tobytes()
+
+    def jpeg_encode(self, image, quality):
+        im, keep = self._img(image)
+        cap = 1024 + im.w * im.h * 8 + 4096
+        buf = np.zeros(cap, np.uint8)
+        self.lib.fo_jpeg_encode.restype = C.c_size_t
+        n = self.lib.fo_jpeg_encode(C.byref(im), int(quality), buf.ctypes.data_as(C.c_void_p), C.c_size_t(cap))
+        assert 0 < n <= cap
+        return buf[:n].tobytes()
+
     def cmyk_to_rgb(self, cmyk, clut):
         a = np.ascontiguousarray(cmyk, dtype=np.uint8)
         t = np.ascontiguousarray(clut, dtype=np.uint16)
