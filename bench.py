@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--blur", type=float, default=0.0, help="blur sigma (config 2 uses 10)")
     ap.add_argument("--grayscale", action="store_true")
     ap.add_argument("--crop", action="store_true")
-    ap.add_argument("--frontend", choices=["none", "jfif444", "webp420"], default="none")
+    ap.add_argument("--frontend", choices=["none", "jfif444", "webp420", "jpeg"], default="none")
     ap.add_argument("--cpu-images", type=int, default=1024, help="CPU-baseline sample size (0 = skip); ~14 ms of CPU work per image")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (one image per thread)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -172,7 +172,7 @@ def main():
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collectives run
 
     fl = load_package()
-    fe = {"none": fl.FE_NONE, "jfif444": fl.FE_JFIF444, "webp420": fl.FE_WEBP420}[args.frontend]
+    fe = {"none": fl.FE_NONE, "jfif444": fl.FE_JFIF444, "webp420": fl.FE_WEBP420, "jpeg": fl.FE_JPEG}[args.frontend]
     params = fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fe)
     plan = fl.plan_output(params, SRC_W, SRC_H, SRC_C)
     n = args.batch
