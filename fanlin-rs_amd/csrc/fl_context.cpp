@@ -132,7 +132,7 @@ struct flgpu_ctx {
     int next_slot = 0;
     DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_tmp_o, d_status;
     DeviceBuf d_in, d_out;
-    DeviceBuf d_jpeg_coef, d_jpeg_off, d_jpeg_raw; // JPEG encode scratch (fl_jpeg.hip)
+    DeviceBuf d_jpeg_coef, d_jpeg_off, d_jpeg_raw; // JPEG encode scratch (fl_jpeg.hip): block meta words, bit offsets, AC bits
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> jpeg_tables; // (w, h, quality) -> arena offset of header + q tables
     // per-image result words of the most recent device batch: [2i] flags (bit 0: non-opaque alpha seen by the WebP front
     // end, FL_JPEG_RESULT_OVERFLOW), [2i + 1] bytes of an encoded stream
@@ -468,10 +468,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (w.p->front_end == FLGPU_FE_JPEG) {
             if (pl.out_w > 65535u || pl.out_h > 65535u) return FLGPU_ERR_UNSUPPORTED; // SOF0 carries u16 dimensions
             const size_t units = (size_t)(pl.plane_w / 8u) * (pl.plane_h / 8u) * 3u;
-            if (units * kJpegMaxUnitBytes + 64 >= ((size_t)1 << 32)) return FLGPU_ERR_UNSUPPORTED;
-            w.jpeg_coef_off = jpeg_coef_bytes; jpeg_coef_bytes += align_up(units * 64 * sizeof(int16_t), 256);
+            if (units * kJpegMaxUnitBytes * 8 >= ((size_t)1 << 32)) return FLGPU_ERR_UNSUPPORTED; // bit offsets are 32-bit
+            w.jpeg_coef_off = jpeg_coef_bytes; jpeg_coef_bytes += align_up(units * sizeof(uint32_t), 256);
             w.jpeg_off_off = jpeg_off_bytes; jpeg_off_bytes += align_up((units + 1) * sizeof(uint32_t), 256);
-            w.jpeg_raw_off = jpeg_raw_bytes; jpeg_raw_bytes += align_up(units * kJpegMaxUnitBytes + 64, 256);
+            w.jpeg_raw_off = jpeg_raw_bytes; jpeg_raw_bytes += align_up(units * kAcWordsPerUnit * sizeof(uint32_t), 256);
         }
     }
     FL_HIP(c, c->d_jpeg_coef.reserve(jpeg_coef_bytes), "JPEG coefficient scratch");
@@ -694,14 +694,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 JpegJob j; memset(&j, 0, sizeof(j));
                 j.src = w.blur_dst ? w.blur_dst : w.s1_dst;
                 j.dst = w.final_dst;
-                j.coef = reinterpret_cast<int16_t *>(static_cast<char *>(c->d_jpeg_coef.p) + w.jpeg_coef_off);
+                j.meta = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_coef.p) + w.jpeg_coef_off);
                 j.unit_off = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_off.p) + w.jpeg_off_off);
-                j.raw = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_raw.p) + w.jpeg_raw_off);
+                j.acbits = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_raw.p) + w.jpeg_raw_off);
                 j.result = static_cast<uint32_t *>(c->d_status.p) + 2 * idx;
                 j.w = pl.out_w; j.h = pl.out_h; j.c = pl.out_c;
                 j.bx = pl.plane_w / 8u; j.by = pl.plane_h / 8u;
                 j.tab_off = w.jpeg_tab;
-                j.raw_cap = (uint32_t)((size_t)j.bx * j.by * 3u * kJpegMaxUnitBytes + 64);
                 j.dst_cap = (uint32_t)std::min<uint64_t>(dsts[idx].capacity, 0xffffffffull);
                 jpeg_max_blocks = std::max(jpeg_max_blocks, j.bx * j.by);
                 jjobs.push_back(j);

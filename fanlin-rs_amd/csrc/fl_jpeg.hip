@@ -6,19 +6,19 @@
 // huffman_encode, build_* header helpers) and src/codecs/jpeg/transform.rs (fdct): baseline, three components,
 // all sampling factors 1x1, Annex K quantisation tables scaled by quality, Annex K Huffman tables.
 //
-// Four kernels per batch:
-//   jpeg_dct_quant_kernel   one wave per 8x8 block: the wave's 64 lanes are the 64 samples / coefficients.  The
-//                           integer DCT of transform.rs (IJG jfdctint) is linear up to its final shift of each pass,
-//                           so a lane computes ITS coefficient as an 8-term integer dot product with a constant
-//                           matrix derived at compile time from the butterfly itself (int32 wrap-around arithmetic
-//                           is a ring: the sums are identical bit for bit).
-//                           The same wave also sizes the block's AC code (lane k = zig-zag coefficient k; zero runs
-//                           come from a ballot).
-//   jpeg_scan_kernel        one workgroup per picture: adds the DC code sizes (they need the previous block) and scans
-//                           the block sizes into bit offsets; clears the bit-stream scratch; writes the header.
-//   jpeg_emit_kernel        one wave per block again: every lane forms its code word(s), a wave prefix sum places them,
-//                           LDS atomics assemble the block, word stores (atomic at the two shared edges) write it.
-//   jpeg_stuff_kernel       one workgroup per picture: pad_byte, 0xFF -> 0xFF00 stuffing by a second scan, EOI, length.
+// Two kernels per batch:
+//   jpeg_dct_quant_kernel   one wave per 8x8 block (a wave walks through 8 consecutive blocks): the 64 lanes are the
+//                           64 samples / coefficients.  The integer DCT of transform.rs (IJG jfdctint) is linear up
+//                           to the final shift of each pass, so a lane computes ITS coefficient as an 8-term integer
+//                           dot product with a constant matrix derived at compile time from the butterfly itself
+//                           (int32 wrap-around arithmetic is a ring: the sums are identical bit for bit).  The same
+//                           wave then Huffman-codes the block's AC coefficients: lane k = zig-zag coefficient k, a
+//                           ballot gives every lane its zero run, a DPP prefix sum places the code words, LDS
+//                           atomics assemble them.  Out: quantised DC, AC bit count, AC bits (from bit 0).
+//   jpeg_pack_kernel        one workgroup per picture: DC code sizes (they need the previous block) + AC sizes ->
+//                           exclusive scan -> bit offset of every block; the blocks' bits are shifted into place in an
+//                           LDS window of the stream (atomics), then pad_byte, 0xFF -> 0xFF00 stuffing by a second
+//                           scan, header, EOI, length.  Long streams are handled window after window.
 // HBM traffic is the pixels once (the input is the 240 KB picture the resample kernel just wrote, L2 resident) plus
 // the coefficient scratch; the kernels are VALU / LDS bound, not bandwidth bound.
 #include <hip/hip_runtime.h>
@@ -105,21 +105,24 @@ __constant__ HuffAll kHuff = make_all();
 
 // ---------------------------------------------------------------- wave helpers --
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    // lane i receives lane i - N of its row of 16; lanes without a source get 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, false);
 }
 
+// Inclusive prefix sum over the 64 lanes: four DPP steps inside the rows of 16, then the three row totals
+// (VALU latency only; ds_bpermute based shuffles cost an LDS round trip per step).
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= (uint32_t)o) v += t;
-    }
-    return v;
+    v += dpp_row_shr<1>(v);
+    v += dpp_row_shr<2>(v);
+    v += dpp_row_shr<4>(v);
+    v += dpp_row_shr<8>(v);
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), s1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                   s2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    return v + (lane >= 16u ? s0 : 0u) + (lane >= 32u ? s1 : 0u) + (lane >= 48u ? s2 : 0u);
 }
 
 // LDS traffic that stays inside one wave needs no hardware barrier (a wave's DS instructions execute in order);
@@ -151,34 +154,70 @@ __device__ __forceinline__ uint32_t coef_size(int32_t v) // encode_coefficient: 
     return mag ? 32u - (uint32_t)__clz(mag) : 0u;
 }
 
-// What lane k >= 1 of a wave contributes to the bit stream of one block (BitWriter::write_block): a non-zero AC
-// coefficient (zig-zag position k) with the zero run in front of it, ZRL codes included; lane 63 the end-of-block
-// code when coefficient 63 is zero.  v is meaningful for lanes >= 1 only (lane 0 = DC, coded separately).
-// ac = the component's 256-entry AC look-up table in LDS.  Returns the bit count, bits right-aligned in *bits.
-__device__ __forceinline__ uint32_t ac_lane_code(int32_t v, uint32_t lane, const uint32_t *ac, uint64_t *bits)
+// Huffman coding of one block's AC coefficients by one wave (BitWriter::write_block without the DC term): lane k
+// holds zig-zag coefficient k (lane 0, the DC term, does not take part).  A non-zero lane emits its (run, size)
+// code and value bits, preceded by ZRL codes when the zero run in front of it exceeds 15; lane 63 emits the
+// end-of-block code when coefficient 63 is zero.  The code words are OR-ed into `tu` (LDS, zero on entry) from
+// bit 0, most significant bit first.  Returns the number of bits.  ac = the component's 256-entry table in LDS;
+// lt_lo / lt_hi = mask of the lanes below this one.
+__device__ __forceinline__ uint32_t code_ac_block(int32_t zv, uint32_t lane, uint32_t lt_lo, uint32_t lt_hi, const uint32_t *ac,
+                                                  uint32_t *tu)
 {
-    const uint64_t nzmask = __ballot(v != 0 && lane != 0u);
-    uint32_t nb = 0;
-    uint64_t b = 0;
-    if (lane != 0u && v != 0) {
-        const uint32_t size = coef_size(v);
-        const uint32_t value = (uint32_t)(v < 0 ? v - 1 : v) & ((1u << size) - 1u);
-        const uint64_t lower = nzmask & ((1ull << lane) - 1ull);
-        const uint32_t prev = lower ? 63u - (uint32_t)__clzll(lower) : 0u;     // position of the previous coded coefficient
-        const uint32_t run = lane - prev - 1u;
-        const uint32_t zrl = ac[0xF0], e = ac[((run & 15u) << 4) | size];
-        const uint32_t zl = zrl >> 16, zc = zrl & 0xffffu;
-        for (uint32_t i = 0; i < (run >> 4); ++i) { b = (b << zl) | zc; nb += zl; }  // while zero_run > 15 { 0xF0 }
-        b = (b << (e >> 16)) | (e & 0xffffu);
-        b = (b << size) | value;
-        nb += (e >> 16) + size;
-    } else if (lane == 63u) {
-        const uint32_t e = ac[0]; // EOB
-        nb = e >> 16;
-        b = e & 0xffffu;
+    const bool nz = zv != 0 && lane != 0u;
+    const uint64_t mask = __ballot(nz);
+    const uint32_t eob = ac[0];
+    if (mask == 0ull) { // DC-only block (wave-uniform): just the end-of-block code
+        if (lane == 0u) tu[0] = (eob & 0xffffu) << (32u - (eob >> 16));
+        return eob >> 16;
     }
-    *bits = b;
-    return nb;
+    const uint32_t mag = (uint32_t)(zv < 0 ? -zv : zv);
+    const uint32_t size = mag ? 32u - (uint32_t)__clz(mag) : 0u;               // encode_coefficient
+    const uint32_t value = (uint32_t)(zv + (zv >> 31)) & ((1u << size) - 1u);  // negative: (v - 1) & mask
+    const uint32_t lo = (uint32_t)mask & lt_lo, hi = (uint32_t)(mask >> 32) & lt_hi;
+    const uint32_t prev = hi ? 63u - (uint32_t)__clz(hi) : (lo ? 31u - (uint32_t)__clz(lo) : 0u); // previous coded coefficient
+    const uint32_t run = lane - prev - 1u;
+    uint32_t nb = 0, code = 0;
+    if (nz) {
+        const uint32_t e = ac[((run & 15u) << 4) | size];
+        nb = (e >> 16) + size;                       // <= 16 + 10
+        code = ((e & 0xffffu) << size) | value;
+    } else if (lane == 63u) {
+        nb = eob >> 16;
+        code = eob & 0xffffu;
+    }
+    if (__ballot(nz && run > 15u) == 0ull) {
+        // common case, no ZRL anywhere in the block: every lane's code fits one 32-bit word
+        const uint32_t inc = wave_inclusive_scan(nb, lane);
+        if (nb) {
+            const uint32_t p = inc - nb, wi = p >> 5, sh = p & 31u;
+            const uint32_t left = code << (32u - nb);
+            const uint32_t w1 = (left << 1) << (31u - sh);
+            atomicOr(&tu[wi], left >> sh);
+            if (w1) atomicOr(&tu[wi + 1u], w1);
+        }
+        return (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    // "while zero_run > 15 { huffman_encode(0xF0) }": up to three ZRL codes in front, 59 bits in all
+    uint64_t bits = code;
+    if (nz) {
+        const uint32_t zrl = ac[0xF0], zl = zrl >> 16, zc = zrl & 0xffffu;
+        uint64_t pre = 0;
+        uint32_t pl = 0;
+        for (uint32_t i = 0; i < (run >> 4); ++i) { pre = (pre << zl) | zc; pl += zl; }
+        bits |= pre << nb;
+        nb += pl;
+    }
+    const uint32_t inc = wave_inclusive_scan(nb, lane);
+    if (nb) {
+        const uint32_t p = inc - nb, wi = p >> 5, sh = p & 31u;
+        const uint64_t left = bits << (64u - nb);
+        const uint64_t a = left >> sh;
+        const uint32_t w0 = (uint32_t)(a >> 32), w1 = (uint32_t)a, w2 = sh ? (uint32_t)((left << (64u - sh)) >> 32) : 0u;
+        if (w0) atomicOr(&tu[wi], w0);
+        if (w1) atomicOr(&tu[wi + 1u], w1);
+        if (w2) atomicOr(&tu[wi + 2u], w2);
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
 }
 
 // ---------------------------------------------------------------- kernel 1: colour + FDCT + quantise (+ AC bit count) --
@@ -199,6 +238,8 @@ __device__ __forceinline__ uint32_t block_pixel(const JpegJob &jb, uint32_t blk,
     uint32_t px = bcol * 8u + c, py = brow * 8u + r;
     px = px < jb.w ? px : jb.w - 1u;
     py = py < jb.h ? py : jb.h - 1u;
+    if (jb.c == 4u && (reinterpret_cast<uintptr_t>(jb.src) & 3u) == 0u) // every letterboxed picture: one dword per pixel
+        return reinterpret_cast<const uint32_t *>(jb.src)[(size_t)py * jb.w + px] & 0xffffffu;
     uint32_t pr, pg, pb, pa;
     load_rgba(jb.src + ((size_t)py * jb.w + px) * jb.c, jb.c, pr, pg, pb, pa);
     return pr | (pg << 8) | (pb << 16);
@@ -208,11 +249,12 @@ __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__re
                                                              uint32_t job_base)
 {
     __shared__ int32_t s_a[4][64], s_b[4][64];
-    __shared__ uint32_t s_ac[512];
+    __shared__ uint32_t s_ac[512], s_u[4][64];
     const JpegJob jb = jobs[job_base + blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, r = lane >> 3, c = lane & 7u;
     const uint32_t nblocks = jb.bx * jb.by;
     if (blockIdx.x * kBlocksPerWg >= nblocks) return; // whole workgroup idle (uniform)
+    s_u[wave][lane] = 0u;
     stage_ac_luts(s_ac);
     const uint32_t first = blockIdx.x * kBlocksPerWg + wave * kBlocksPerWave;
     if (first >= nblocks) return;                      // wave-uniform; from here on waves never synchronise with each other
@@ -221,9 +263,13 @@ __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__re
 #pragma unroll
     for (int j = 0; j < 8; ++j) { m1[j] = kFdct.a[c][j]; m2[j] = kFdct.a[r][j]; }
     const uint8_t *qt = reinterpret_cast<const uint8_t *>(arena + jb.tab_off) + 624;
-    const float ql = (float)qt[lane], qc = (float)qt[64 + lane];
+    const uint32_t ql = qt[lane], qc = qt[64 + lane];
+    const uint32_t *magic = reinterpret_cast<const uint32_t *>(qt + 128);
+    const uint32_t ml = magic[lane], mc = magic[64 + lane];
+    const uint32_t lt_lo = lane >= 32u ? 0xffffffffu : (1u << lane) - 1u, lt_hi = lane >= 32u ? (1u << (lane - 32u)) - 1u : 0u;
     const uint32_t zz = kZigzagPos[lane];
     int32_t *ta = s_a[wave], *tb = s_b[wave];
+    uint32_t *tu = s_u[wave];
     uint32_t rgb = block_pixel(jb, first, r, c);
     for (uint32_t blk = first; blk < last; ++blk) {
         uint32_t smp[3];
@@ -236,60 +282,91 @@ __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__re
             // Pass 1 (rows): lane (r, c) produces horizontal frequency c of row r
             int32_t p = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) p += m1[j] * ta[r * 8 + j];
+            for (int j = 0; j < 8; ++j) p += __mul24(m1[j], ta[r * 8 + j]);   // |matrix| < 2^16, samples < 2^8: 24-bit multiplies are exact and full rate
             int32_t v1;
             if (c == 0) v1 = (p - 8 * 128) << 2;          // level shift folded in, scaled by 2^PASS1_BITS
             else if (c == 4) v1 = p << 2;
             else v1 = (p + (1 << 10)) >> 11;              // CONST_BITS - PASS1_BITS
-            tb[lane] = v1;
+            tb[c * 8 + r] = v1;                              // transposed: the column pass reads 8 consecutive words
             wave_lds_sync();
             // Pass 2 (columns): lane (r, c) produces vertical frequency r of column c
             int32_t p2 = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) p2 += m2[j] * tb[j * 8 + c];
+            for (int j = 0; j < 8; ++j) p2 += __mul24(m2[j], tb[c * 8 + j]);  // |pass-1 output| <= 255 * 8 * 4 < 2^14
             int32_t d;
             if (r == 0 || r == 4) d = (p2 + 2) >> 2;
             else d = (p2 + (1 << 14)) >> 15;              // CONST_BITS + PASS1_BITS
-            // encode_rgb "Quantization": ((d / 8) as f32 / f32::from(q)).round() as i32
-            const int32_t qv = (int32_t)roundf(__fdiv_rn((float)(d / 8), comp ? qc : ql));
+            // encode_rgb "Quantization": ((d / 8) as f32 / f32::from(q)).round() as i32.  |d / 8| <= 2048 and q <= 255,
+            // so the f32 quotient cannot round onto or across a half (nearest miss: 1 / (2q) >= 2^-9 away, f32 error
+            // <= 2^-14): it equals the exact round-half-away  sign(n) * floor((2|n| + q) / 2q), taken with the
+            // per-coefficient reciprocal ceil(2^32 / 2q) from the table block (exact for 2|n| + q < 2^13).
+            const int32_t n = (d + ((d >> 31) & 7)) >> 3;                       // i32 division truncates toward zero
+            const uint32_t an = (uint32_t)(n < 0 ? -n : n);
+            const uint32_t rq = __umulhi(2u * an + (comp ? qc : ql), comp ? mc : ml);
+            const int32_t qv = n < 0 ? -(int32_t)rq : (int32_t)rq;
             // natural -> zig-zag order through LDS: lane k then owns zig-zag coefficient k
             ta[zz] = qv;
             wave_lds_sync();
             const int32_t zv = ta[lane];
             wave_lds_sync();
             const uint32_t unit = blk * 3u + comp;
-            jb.coef[(size_t)unit * 64 + lane] = (int16_t)zv;
-            uint64_t bits;
-            const uint32_t nb = ac_lane_code(zv, lane, s_ac + (comp ? 256 : 0), &bits);
-            const uint32_t ac_bits = wave_sum(nb);
-            if (lane == 0u) jb.unit_off[unit] = ac_bits;   // the DC code is added by the scan (it needs the previous block)
+            // the block's AC code, assembled from bit 0 of a private buffer: the pack kernel shifts it into place
+            const uint32_t ac_bits = code_ac_block(zv, lane, lt_lo, lt_hi, s_ac + (comp ? 256 : 0), tu);
+            wave_lds_sync();
+            const uint32_t nw = (ac_bits + 31u) >> 5;                // <= 52 words: 63 * 26 bits
+            if (lane < nw) { jb.acbits[(size_t)unit * kAcWordsPerUnit + lane] = tu[lane]; tu[lane] = 0u; }
+            if (lane == 0u) jb.meta[unit] = ((uint32_t)zv & 0xffffu) | (ac_bits << 16); // quantised DC, AC bit count
+            wave_lds_sync();
         }
     }
 }
 
-// ---------------------------------------------------------------- kernel 2: bit offsets of all blocks --
+// ---------------------------------------------------------------- kernel 2: offsets, assembly, stuffing, framing --
 
-__device__ __forceinline__ int32_t dc_diff(const JpegJob &jb, uint32_t u)
+constexpr uint32_t kWinWords = 8192; // LDS window of the bit stream: 32 KB = 262,144 bits
+
+// ORs the 32-bit word `val`, whose most significant bit sits at stream bit g, into the window [wbase, wbase + kWinWords)
+__device__ __forceinline__ void win_or(uint32_t *win, uint32_t wbase, uint64_t g, uint32_t val)
 {
-    // differential DC against the same component's previous block (encode_rgb: y_dcprev / cb_dcprev / cr_dcprev)
-    return (int32_t)jb.coef[(size_t)u * 64] - (u >= 3u ? (int32_t)jb.coef[(size_t)(u - 3u) * 64] : 0);
+    const uint64_t W = g >> 5;
+    const uint32_t sh = (uint32_t)g & 31u;
+    const uint32_t hi = val >> sh, lo = sh ? val << (32u - sh) : 0u;
+    if (hi && W >= wbase && W < (uint64_t)wbase + kWinWords) atomicOr(&win[W - wbase], hi);
+    if (lo && W + 1 >= wbase && W + 1 < (uint64_t)wbase + kWinWords) atomicOr(&win[W + 1 - wbase], lo);
 }
 
-__global__ __launch_bounds__(256) void jpeg_scan_kernel(const JpegJob *__restrict__ jobs, const uint32_t *__restrict__ arena,
+__device__ __forceinline__ uint32_t dc_code(const JpegJob &jb, uint32_t u, uint32_t meta, uint32_t *len)
+{
+    // differential DC against the same component's previous block (encode_rgb: y_dcprev / cb_dcprev / cr_dcprev)
+    const int32_t dc = (int16_t)(meta & 0xffffu), prev = u >= 3u ? (int32_t)(int16_t)(jb.meta[u - 3u] & 0xffffu) : 0;
+    const int32_t diff = dc - prev;
+    const uint32_t size = coef_size(diff);
+    const uint32_t value = (uint32_t)(diff < 0 ? diff - 1 : diff) & ((1u << size) - 1u);
+    const uint32_t e = kHuff.dc[(u % 3u) ? 1 : 0].e[size];
+    *len = (e >> 16) + size;                                   // <= 9 + 11 or 11 + 11 bits
+    return (((e & 0xffffu) << size) | value) << (32u - *len);  // left-aligned
+}
+
+__global__ __launch_bounds__(256) void jpeg_pack_kernel(const JpegJob *__restrict__ jobs, const uint32_t *__restrict__ arena,
                                                         uint32_t job_base)
 {
-    __shared__ uint32_t s_w[4], s_carry;
+    __shared__ uint32_t s_win[kWinWords];
+    __shared__ uint32_t s_w[4], s_carry, s_lo, s_hi;
     const JpegJob jb = jobs[job_base + blockIdx.x];
     const uint32_t tid = threadIdx.x;
     const uint32_t nunits = jb.bx * jb.by * 3u;
+
+    // ---- bit offset of every block: DC code size (needs the previous block) + AC size, exclusive scan ----
     if (tid == 0u) s_carry = 0u;
     __syncthreads();
     for (uint32_t base = 0; base < nunits; base += 256u) {
         const uint32_t u = base + tid;
         uint32_t len = 0;
         if (u < nunits) {
-            const uint32_t size = coef_size(dc_diff(jb, u));
-            len = jb.unit_off[u] + (kHuff.dc[(u % 3u) ? 1 : 0].e[size] >> 16) + size;
+            const uint32_t m = jb.meta[u];
+            uint32_t dl;
+            (void)dc_code(jb, u, m, &dl);
+            len = dl + (m >> 16);
         }
         uint32_t chunk;
         const uint32_t ex = wg_exclusive_scan(len, s_w, &chunk);
@@ -300,133 +377,83 @@ __global__ __launch_bounds__(256) void jpeg_scan_kernel(const JpegJob *__restric
         __syncthreads();
     }
     const uint32_t total_bits = s_carry;
-    const uint32_t nbytes = (total_bits + 7u) >> 3;
-    if ((uint64_t)nbytes + 16u > jb.raw_cap) { // cannot happen with the scratch the host sizes; never write out of bounds
-        if (tid == 0u) { jb.unit_off[nunits] = 0u; jb.result[1] = 0u; atomicOr(&jb.result[0], FL_JPEG_RESULT_OVERFLOW); }
-        return;
-    }
     if (tid == 0u) jb.unit_off[nunits] = total_bits;
-    const uint32_t nwords = (total_bits + 31u) / 32u + 1u;
-    for (uint32_t i = tid; i < nwords; i += 256u) jb.raw[i] = 0u;
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t nbytes = (total_bits + 7u) >> 3, limit = jb.dst_cap;
     // everything in front of the scan data
     const uint8_t *hdr = reinterpret_cast<const uint8_t *>(arena + jb.tab_off);
-    for (uint32_t i = tid; i < kJpegHeaderBytes; i += 256u) if (i < jb.dst_cap) jb.dst[i] = hdr[i];
-}
+    for (uint32_t i = tid; i < kJpegHeaderBytes; i += 256u) if (i < limit) jb.dst[i] = hdr[i];
 
-// ---------------------------------------------------------------- kernel 3: emit the code words --
-
-constexpr int kUnitsPerWave = 8;
-
-__global__ __launch_bounds__(256) void jpeg_emit_kernel(const JpegJob *__restrict__ jobs, uint32_t job_base)
-{
-    __shared__ uint32_t s_unit[4][64];
-    __shared__ uint32_t s_ac[512];
-    const JpegJob jb = jobs[job_base + blockIdx.y];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t nunits = jb.bx * jb.by * 3u;
-    if (blockIdx.x * (4u * kUnitsPerWave) >= nunits) return; // whole workgroup idle (uniform)
-    stage_ac_luts(s_ac);
-    const uint32_t first = blockIdx.x * (4u * kUnitsPerWave) + wave * kUnitsPerWave;
-    if (first >= nunits) return;
-    if (jb.unit_off[nunits] == 0u) return; // the scan refused this picture
-    uint32_t *buf = s_unit[wave];
-    buf[lane] = 0u;
-    // everything this wave will read, requested up front: the block loop below then runs out of registers
-    int32_t v[kUnitsPerWave], dcp[kUnitsPerWave];
-    uint32_t off[kUnitsPerWave + 1];
-#pragma unroll
-    for (int k = 0; k < kUnitsPerWave; ++k) {
-        const uint32_t u = min(first + (uint32_t)k, nunits - 1u);
-        v[k] = jb.coef[(size_t)u * 64 + lane];
-        dcp[k] = u >= 3u ? (int32_t)jb.coef[(size_t)(u - 3u) * 64] : 0; // same component, previous block
-    }
-#pragma unroll
-    for (int k = 0; k <= kUnitsPerWave; ++k) off[k] = jb.unit_off[min(first + (uint32_t)k, nunits)]; // nunits + 1 entries
-#pragma unroll
-    for (int k = 0; k < kUnitsPerWave; ++k) {
-        const uint32_t u = first + (uint32_t)k;
-        if (u >= nunits) break;
-        const uint32_t table = (u % 3u) ? 1u : 0u;
-        uint64_t bits;
-        uint32_t nb = ac_lane_code(v[k], lane, s_ac + table * 256u, &bits);
-        if (lane == 0u) {
-            const int32_t diff = v[k] - dcp[k];
-            const uint32_t size = coef_size(diff);
-            const uint32_t value = (uint32_t)(diff < 0 ? diff - 1 : diff) & ((1u << size) - 1u);
-            const uint32_t e = kHuff.dc[table].e[size];
-            nb = (e >> 16) + size;
-            bits = ((uint64_t)(e & 0xffffu) << size) | value;
+    uint32_t ff_before = 0; // stuffed bytes emitted by earlier windows (same value in every thread)
+    for (uint32_t wbase = 0; wbase * 32ull < total_bits; wbase += kWinWords) {
+        const uint64_t wb = (uint64_t)wbase * 32u, we = wb + (uint64_t)kWinWords * 32u;
+        for (uint32_t i = tid; i < kWinWords; i += 256u) s_win[i] = 0u;
+        // blocks that touch this window: offsets are ascending, so two binary searches bound them
+        if (tid == 0u) {
+            uint32_t lo = 0, hi = nunits;            // first u with unit_off[u + 1] > wb
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (jb.unit_off[mid + 1u] > wb) hi = mid; else lo = mid + 1u; }
+            s_lo = lo;
+            uint32_t lo2 = lo, hi2 = nunits;         // first u with unit_off[u] >= we
+            while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (jb.unit_off[mid] >= we) hi2 = mid; else lo2 = mid + 1u; }
+            s_hi = lo2;
         }
-        const uint32_t inc = wave_inclusive_scan(nb, lane);
-        const uint32_t unit_bits = off[k + 1] - off[k];
-        wave_lds_sync();
-        if (nb) {
-            const uint32_t p = (off[k] & 31u) + (inc - nb);
-            const uint32_t wi = p >> 5, sh = p & 31u;
-            const uint64_t left = bits << (64u - nb);            // left-aligned code word(s), at most 59 bits
-            const uint64_t a = left >> sh;
-            const uint32_t w0 = (uint32_t)(a >> 32), w1 = (uint32_t)a, w2 = sh ? (uint32_t)((left << (64u - sh)) >> 32) : 0u;
-            if (w0) atomicOr(&buf[wi], w0);
-            if (w1) atomicOr(&buf[wi + 1u], w1);
-            if (w2) atomicOr(&buf[wi + 2u], w2);
-        }
-        wave_lds_sync();
-        const uint32_t nw = ((off[k] & 31u) + unit_bits + 31u) >> 5; // <= 54: a block codes to at most 22 + 63 * 26 bits
-        if (lane < nw) {
-            const uint32_t word = __builtin_bswap32(buf[lane]);  // memory order = stream order
-            buf[lane] = 0u;
-            uint32_t *g = jb.raw + (off[k] >> 5) + lane;
-            if (lane == 0u || lane == nw - 1u) atomicOr(g, word); // boundary words are shared with the neighbouring blocks
-            else *g = word;
-        }
-    }
-}
-
-// ---------------------------------------------------------------- kernel 4: pad_byte, 0xFF stuffing, EOI --
-
-__global__ __launch_bounds__(256) void jpeg_stuff_kernel(const JpegJob *__restrict__ jobs, uint32_t job_base)
-{
-    __shared__ uint32_t s_w[4], s_carry;
-    const JpegJob jb = jobs[job_base + blockIdx.x];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t nunits = jb.bx * jb.by * 3u;
-    const uint32_t total_bits = jb.unit_off[nunits];
-    if (total_bits == 0u) return; // refused by the scan (result words already say so)
-    const uint32_t nbytes = (total_bits + 7u) >> 3, limit = jb.dst_cap;
-    // BitWriter::pad_byte = write_bits(0x7F, 7): the last partial byte is filled with ones
-    const uint32_t pad_word = (total_bits & 7u) ? (0xFFu >> (total_bits & 7u)) << (8u * ((total_bits >> 3) & 3u)) : 0u;
-    if (tid == 0u) s_carry = 0u;
-    __syncthreads();
-    for (uint32_t base = 0; base < nbytes; base += 1024u) {
-        const uint32_t i = base + tid * 4u;
-        uint32_t word = i < nbytes ? jb.raw[i >> 2] : 0u;
-        if ((i >> 2) == (total_bits >> 5)) word |= pad_word;
-        const uint32_t valid = i < nbytes ? (nbytes - i < 4u ? nbytes - i : 4u) : 0u;
-        uint32_t ff = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) ff += (k < valid && ((word >> (8u * k)) & 255u) == 255u) ? 1u : 0u;
-        uint32_t chunk;
-        const uint32_t ex = wg_exclusive_scan(ff, s_w, &chunk);
-        const uint32_t carry = s_carry;
-        uint32_t o = kJpegHeaderBytes + i + carry + ex;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            if (k < valid) {
-                const uint32_t b = (word >> (8u * k)) & 255u;
-                if (o < limit) jb.dst[o] = (uint8_t)b;
-                ++o;
-                if (b == 255u) { if (o < limit) jb.dst[o] = 0u; ++o; }
+        __syncthreads();
+        const uint32_t u_lo = s_lo, u_hi = s_hi;
+        // 8 lanes per block: lane 0 of the group also places the DC code, all of them shift AC words into place
+        for (uint32_t ub = u_lo; ub < u_hi; ub += 32u) {
+            const uint32_t u = ub + (tid >> 3), j = tid & 7u;
+            if (u < u_hi) {
+                const uint32_t m = jb.meta[u], off = jb.unit_off[u];
+                uint32_t dl;
+                const uint32_t dcw = dc_code(jb, u, m, &dl);
+                if (j == 0u) win_or(s_win, wbase, off, dcw);
+                const uint32_t nw = ((m >> 16) + 31u) >> 5;
+                for (uint32_t w = j; w < nw; w += 8u)
+                    win_or(s_win, wbase, (uint64_t)off + dl + 32u * w, jb.acbits[(size_t)u * kAcWordsPerUnit + w]);
             }
         }
         __syncthreads();
-        if (tid == 0u) s_carry = carry + chunk;
+        // BitWriter::pad_byte = write_bits(0x7F, 7): the last partial byte is filled with ones
+        if (tid == 0u && (total_bits & 7u) && (total_bits >> 5) >= wbase && (total_bits >> 5) < wbase + kWinWords)
+            s_win[(total_bits >> 5) - wbase] |= (0xFFu >> (total_bits & 7u)) << (24u - 8u * ((total_bits >> 3) & 3u));
+        __syncthreads();
+        // 0xFF -> 0xFF 0x00 stuffing: scan of the 0xFF counts, then every thread writes its four bytes
+        const uint32_t win_bytes = (uint32_t)min((uint64_t)kWinWords * 4u, (uint64_t)nbytes - (uint64_t)wbase * 4u);
+        if (tid == 0u) s_carry = 0u;
+        __syncthreads();
+        for (uint32_t base = 0; base < win_bytes; base += 1024u) {
+            const uint32_t i = base + tid * 4u;
+            const uint32_t word = i < win_bytes ? s_win[i >> 2] : 0u;     // stream order = most significant byte first
+            const uint32_t valid = i < win_bytes ? (win_bytes - i < 4u ? win_bytes - i : 4u) : 0u;
+            uint32_t ff = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) ff += (k < valid && ((word >> (24u - 8u * k)) & 255u) == 255u) ? 1u : 0u;
+            uint32_t chunk;
+            const uint32_t ex = wg_exclusive_scan(ff, s_w, &chunk);
+            const uint32_t carry = s_carry;
+            uint64_t o = (uint64_t)kJpegHeaderBytes + (uint64_t)wbase * 4u + i + ff_before + carry + ex;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k < valid) {
+                    const uint32_t b = (word >> (24u - 8u * k)) & 255u;
+                    if (o < limit) jb.dst[o] = (uint8_t)b;
+                    ++o;
+                    if (b == 255u) { if (o < limit) jb.dst[o] = 0u; ++o; }
+                }
+            }
+            __syncthreads();
+            if (tid == 0u) s_carry = carry + chunk;
+            __syncthreads();
+        }
+        ff_before += s_carry;
         __syncthreads();
     }
     if (tid == 0u) {
-        const uint32_t end = kJpegHeaderBytes + nbytes + s_carry;
-        if ((uint64_t)end + 2u <= limit) {
+        const uint64_t end = (uint64_t)kJpegHeaderBytes + nbytes + ff_before;
+        if (end + 2u <= limit) {
             jb.dst[end] = 0xFF; jb.dst[end + 1u] = 0xD9; // EOI
-            jb.result[1] = end + 2u;
+            jb.result[1] = (uint32_t)(end + 2u);
         } else {
             jb.result[1] = 0u;
             atomicOr(&jb.result[0], FL_JPEG_RESULT_OVERFLOW);
@@ -444,11 +471,7 @@ hipError_t launch_jpeg_encode(const JpegJob *jobs, const uint32_t *arena, uint32
     if (!njobs || !max_blocks) return hipSuccess;
     hipLaunchKernelGGL(jpeg_dct_quant_kernel, dim3((max_blocks + kBlocksPerWg - 1) / kBlocksPerWg, njobs), dim3(256), 0, st, jobs, arena, job_base);
     FL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jpeg_scan_kernel, dim3(njobs), dim3(256), 0, st, jobs, arena, job_base);
-    FL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jpeg_emit_kernel, dim3((max_blocks * 3u + 4u * kUnitsPerWave - 1u) / (4u * kUnitsPerWave), njobs), dim3(256), 0, st, jobs, job_base);
-    FL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jpeg_stuff_kernel, dim3(njobs), dim3(256), 0, st, jobs, job_base);
+    hipLaunchKernelGGL(jpeg_pack_kernel, dim3(njobs), dim3(256), 0, st, jobs, arena, job_base);
     FL_LAUNCH_CHECK();
     return hipSuccess;
 }

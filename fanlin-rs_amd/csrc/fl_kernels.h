@@ -21,17 +21,18 @@ struct alignas(16) FrontendJob {
 
 // One image of a JPEG-encode launch (fl_jpeg.hip).
 #define FL_JPEG_RESULT_OVERFLOW 4u
+constexpr uint32_t kAcWordsPerUnit = 52; // 63 coefficients x (16-bit code + 10 value bits) = 1638 bits
 struct alignas(16) JpegJob {
     const uint8_t *src;   // interleaved pixels, w x h x c
     uint8_t *dst;         // the JFIF stream
-    int16_t *coef;        // scratch: quantised coefficients, [unit][64] in zig-zag order, unit = block * 3 + component
+    uint32_t *meta;       // scratch: [unit] quantised DC (low 16 bits, i16) | AC code bits << 16; unit = block * 3 + component
     uint32_t *unit_off;   // scratch: units + 1 bit offsets
-    uint32_t *raw;        // scratch: entropy-coded bits before byte stuffing
+    uint32_t *acbits;     // scratch: [unit][kAcWordsPerUnit] the block's AC code from bit 0, most significant bit first
     uint32_t *result;     // [0] |= flags (FL_JPEG_RESULT_OVERFLOW), [1] = stream bytes (0 if it did not fit dst_cap)
     uint32_t w, h, c;
     uint32_t bx, by;      // blocks per row / column
     uint32_t tab_off;     // arena word offset of the header + quantisation tables block (fl_jpeg_tables.h)
-    uint32_t raw_cap;     // bytes available at raw
+    uint32_t pad0;
     uint32_t dst_cap;     // bytes available at dst
 };
 

@@ -295,6 +295,14 @@ void build_jpeg_tables(uint32_t width, uint32_t height, uint32_t quality, std::v
     b.resize(624, 0);
     b.insert(b.end(), q[0], q[0] + 64);
     b.insert(b.end(), q[1], q[1] + 64);
+    for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < 64; ++i) {
+            // reciprocal of 2q for the kernel's exact round-half-away division (see jpeg_dct_quant_kernel)
+            const uint64_t d2 = 2ull * q[t][i];
+            const uint32_t m = (uint32_t)((((uint64_t)1 << 32) + d2 - 1) / d2);
+            const uint8_t *mb = reinterpret_cast<const uint8_t *>(&m);
+            b.insert(b.end(), mb, mb + 4);
+        }
     out.assign(kJpegTableBlockBytes / 4, 0);
     memcpy(out.data(), b.data(), kJpegTableBlockBytes);
 }

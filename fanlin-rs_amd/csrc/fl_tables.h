@@ -64,7 +64,7 @@ void build_blur_plan(const HostAxis &v, const HostAxis &h, uint32_t nt, uint32_t
 void build_webp_gamma(std::vector<uint32_t> &out);
 
 // JPEG: everything in front of the entropy-coded data (SOI, APP0, SOF0, DQT x2, DHT x4, SOS = 623 bytes, padded to
-// 624) followed by the two quality-scaled quantisation tables in natural order (64 + 64 bytes).
+// 624) followed by the two quality-scaled quantisation tables in natural order (64 + 64 bytes) and ceil(2^32 / 2q) of each.
 // image 0.25.6 codecs/jpeg/encoder.rs: JpegEncoder::new_with_quality (table scaling), encode_image (segment order),
 // build_jfif_header / build_frame_header / build_quantization_segment / build_huffman_segment / build_scan_header.
 void build_jpeg_tables(uint32_t width, uint32_t height, uint32_t quality, std::vector<uint32_t> &out);
