@@ -1,10 +1,21 @@
 #!/bin/bash
-# builds tools/libfanlin_gpu_ablate_<mask>.so for each mask given (experiment variants of the kernels)
+# builds tools/libfanlin_gpu_ablate_<name>.so for each "name[:mask[:extra compiler flags]]" given
+# (experiment variants of fl_kernels.hip; FL_ABLATE masks are documented there)
 set -e
 cd "$(dirname "$0")/../fanlin-rs_amd/csrc"
 mkdir -p /tmp/abl
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math"
-for f in fl_context.cpp fl_tables.cpp fl_query.cpp; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o /tmp/abl/$f.o & done
-for m in "$@"; do /opt/rocm/bin/hipcc $FLAGS -DFL_ABLATE=$m ${EXTRA} -x hip -c fl_kernels.hip -o /tmp/abl/k_$m.o & done
+OTHERS="fl_context.cpp fl_tables.cpp fl_query.cpp fl_cmyk.cpp fl_jpeg.hip"
+for f in $OTHERS; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o /tmp/abl/$f.o & done
+for v in "$@"; do
+  IFS=: read -r name mask extra <<< "$v"
+  /opt/rocm/bin/hipcc $FLAGS -DFL_ABLATE=${mask:-0} ${extra} ${EXTRA} -x hip -c fl_kernels.hip -o /tmp/abl/k_$name.o &
+done
 wait
-for m in "$@"; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libfanlin_gpu_ablate_$m.so /tmp/abl/k_$m.o /tmp/abl/fl_context.cpp.o /tmp/abl/fl_tables.cpp.o /tmp/abl/fl_query.cpp.o; done
+rm -f ../../tools/libfanlin_gpu_ablate_*.so
+for v in "$@"; do
+  name=${v%%:*}
+  objs=""; for f in $OTHERS; do objs="$objs /tmp/abl/$f.o"; done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libfanlin_gpu_ablate_$name.so /tmp/abl/k_$name.o $objs -ldl
+done
+ls -la ../../tools/*.so
