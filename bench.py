@@ -89,6 +89,21 @@ def measured_traffic(workload: str):
     return rec.get(workload, {}).get("hbm_bytes_per_launch")
 
 
+def latency_probe_c(args, query: str, front_end: int):
+    """The same probe from a plain C program (tools/latency/latency_probe.c, built by __graft_entry__.build()):
+    pthread callers instead of Python threads, so the interpreter lock is not part of the measurement."""
+    exe = os.path.join(ROOT, "tools", "latency", "latency_probe")
+    if not os.path.exists(exe):
+        return None
+    import subprocess
+    try:
+        r = subprocess.run([exe, str(args.latency_threads), str(args.latency_requests), str(SRC_W), str(SRC_H), query, str(front_end),
+                            str(args.queue_lanes), str(args.queue_max_batch)], capture_output=True, text=True, timeout=300)
+        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception:
+        return None
+
+
 def latency_probe(fl, st, params, n_requests: int, n_threads: int):
     """Per-image latency of the drop-in entry point: concurrent callers of flgpu_transform with HOST buffers
     (PCIe in both directions included), packed into shared launches by the library's request queue."""
@@ -141,9 +156,11 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (one image per thread)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal: several ranks may share one GPU)")
-    ap.add_argument("--latency-requests", type=int, default=256,
+    ap.add_argument("--latency-requests", type=int, default=1024,
                     help="requests of the per-image latency probe through flgpu_transform (0 = skip)")
     ap.add_argument("--latency-threads", type=int, default=64, help="concurrent caller threads of the latency probe")
+    ap.add_argument("--queue-lanes", type=int, default=0, help="batches the request queue keeps in flight (0 = library default)")
+    ap.add_argument("--queue-max-batch", type=int, default=0, help="largest batch the request queue forms (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -187,7 +204,7 @@ def main():
     out_stride = (int(plan.out_bytes) + 255) // 256 * 256
     dst = torch.zeros((n, out_stride), dtype=torch.uint8, device=dev)
 
-    st = fl.State(device=local_dev, profile=True)
+    st = fl.State(device=local_dev, profile=True, queue_lanes=args.queue_lanes, max_batch=args.queue_max_batch)
     run = st.prepared_batch([src.data_ptr() + i * src_bytes for i in range(n)], [(SRC_H, SRC_W, SRC_C)] * n, params,
                             [dst.data_ptr() + i * out_stride for i in range(n)], [out_stride] * n)
     stream = torch.cuda.current_stream().cuda_stream
@@ -258,7 +275,9 @@ def main():
         }
         line["roofline"]["traffic"] = measured_traffic(line["config"]["workload"])
         if args.latency_requests > 0 and world == 1:
-            line["latency"] = latency_probe(fl, st, params, args.latency_requests, args.latency_threads)
+            query = f"w={REQ_W}&h={REQ_H}" + ("&crop=true" if args.crop else "") + (f"&blur={int(args.blur)}" if args.blur else "") \
+                + ("&grayscale=true" if args.grayscale else "")
+            line["latency"] = latency_probe_c(args, query, fe) or latency_probe(fl, st, params, args.latency_requests, args.latency_threads)
         if args.cpu_images > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_images, workload, args.cpu_threads)
         else:

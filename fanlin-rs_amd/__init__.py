@@ -71,7 +71,7 @@ class flgpu_plan(C.Structure):
 
 class flgpu_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_batch", C.c_uint32), ("flush_timeout_us", C.c_uint32),
-                ("profile", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("profile", C.c_uint32), ("queue_lanes", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class flgpu_stats(C.Structure):
@@ -357,10 +357,12 @@ class State:
     pointers (PyTorch tensors) for HBM-resident batches.
     """
 
-    def __init__(self, device: int = -1, max_batch: int = 0, flush_timeout_us: int = 0, profile: bool = False):
+    def __init__(self, device: int = -1, max_batch: int = 0, flush_timeout_us: int = 0, profile: bool = False,
+                 queue_lanes: int = 0):
         lib = load_library()
         cfg = flgpu_config()
         cfg.device, cfg.max_batch, cfg.flush_timeout_us, cfg.profile = device, max_batch, flush_timeout_us, int(profile)
+        cfg.queue_lanes = queue_lanes
         st = C.c_int()
         self._ctx = lib.flgpu_create(C.byref(cfg), C.byref(st))
         if not self._ctx:

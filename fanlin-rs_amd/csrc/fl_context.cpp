@@ -165,7 +165,12 @@ struct flgpu_ctx {
     std::multimap<size_t, void *> pin_free;
 
     // request queue
-    std::thread worker;
+    // Queued single-image requests are served by `lanes` worker threads, each driving its own child context (own
+    // stream, scratch, table cache): while one lane's batch is on the PCIe link / in kernels, another lane is already
+    // collecting and uploading the next batch.
+    std::vector<std::thread> workers;
+    std::vector<flgpu_ctx *> lanes;
+    bool collecting = false; // a worker is gathering a batch (one collector at a time keeps batches large)
     std::mutex qmu;
     std::condition_variable qcv, qdone;
     std::deque<Request *> queue;
@@ -977,28 +982,33 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
     return FLGPU_OK;
 }
 
-void worker_main(flgpu_ctx *c)
+void worker_main(flgpu_ctx *c, flgpu_ctx *lane)
 {
-    const size_t max_batch = c->cfg.max_batch ? c->cfg.max_batch : 256;
+    const size_t max_batch = c->cfg.max_batch ? c->cfg.max_batch : 32; // measured: 3 lanes x 32 keeps the PCIe link busiest
     const auto flush = std::chrono::microseconds(c->cfg.flush_timeout_us ? c->cfg.flush_timeout_us : 200);
     for (;;) {
         std::vector<Request *> batch;
         {
             std::unique_lock<std::mutex> lk(c->qmu);
-            c->qcv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
-            if (c->stop && c->queue.empty()) return;
+            c->qcv.wait(lk, [&] { return c->stop || (!c->collecting && !c->queue.empty()); });
+            if (c->queue.empty()) { if (c->stop) return; continue; }
+            if (c->collecting) continue;
+            c->collecting = true;
             // a first request arrived: wait for company until the batch is full or the flush timer fires
             const auto deadline = std::chrono::steady_clock::now() + flush;
             while (c->queue.size() < max_batch && !c->stop) {
                 if (c->qcv.wait_until(lk, deadline) == std::cv_status::timeout) break;
             }
             while (!c->queue.empty() && batch.size() < max_batch) { batch.push_back(c->queue.front()); c->queue.pop_front(); }
+            c->collecting = false;
         }
+        c->qcv.notify_all(); // the next batch may be collected while this one is in flight
         int rc;
         {
-            std::lock_guard<std::mutex> g(c->mu);
-            rc = run_batch_queued(c, batch);
-            c->stats.queue_flushes++;
+            std::lock_guard<std::mutex> g(lane->mu);
+            rc = run_batch_queued(lane, batch);
+            lane->stats.queue_flushes++;
+            if (rc) { std::lock_guard<std::mutex> lk(c->qmu); c->last_error = lane->last_error; }
         }
         {
             std::lock_guard<std::mutex> lk(c->qmu);
@@ -1050,7 +1060,8 @@ void flgpu_destroy(flgpu_ctx *c)
         c->stop = true;
     }
     c->qcv.notify_all();
-    if (c->worker_started) c->worker.join();
+    for (auto &t : c->workers) t.join();
+    for (flgpu_ctx *l : c->lanes) flgpu_destroy(l);
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     resolve_pending(c);
@@ -1108,7 +1119,22 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
     {
         std::unique_lock<std::mutex> lk(c->qmu);
         if (c->stop) { lk.unlock(); pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_SHUTDOWN; }
-        if (!c->worker_started) { c->worker = std::thread(worker_main, c); c->worker_started = true; }
+        if (!c->worker_started) {
+            // lanes: child contexts on the same device (cfg.queue_lanes, default 3)
+            const uint32_t nl = std::min<uint32_t>(std::max<uint32_t>(c->cfg.queue_lanes ? c->cfg.queue_lanes : 3u, 1u), 8u);
+            flgpu_config lc = c->cfg;
+            lc.device = c->device;
+            lc.queue_lanes = 1;
+            for (uint32_t i = 0; i < nl; ++i) {
+                int lst = 0;
+                flgpu_ctx *l = flgpu_create(&lc, &lst);
+                if (!l) break;
+                c->lanes.push_back(l);
+            }
+            if (c->lanes.empty()) { lk.unlock(); pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_OOM; }
+            for (flgpu_ctx *l : c->lanes) c->workers.emplace_back(worker_main, c, l);
+            c->worker_started = true;
+        }
         c->queue.push_back(&r);
     }
     c->qcv.notify_all();
@@ -1329,6 +1355,16 @@ int flgpu_get_stats(flgpu_ctx *c, flgpu_stats *out)
     (void)hipSetDevice(c->device);
     resolve_pending(c);
     *out = c->stats;
+    for (flgpu_ctx *l : c->lanes) { // queued requests run on the lanes' child contexts
+        flgpu_stats ls;
+        if (flgpu_get_stats(l, &ls) != FLGPU_OK) continue;
+        out->images += ls.images; out->batches += ls.batches; out->queue_flushes += ls.queue_flushes; out->tables_built += ls.tables_built;
+        out->resample_launches += ls.resample_launches; out->resample_ms += ls.resample_ms;
+        out->resample_src_bytes += ls.resample_src_bytes; out->resample_dst_bytes += ls.resample_dst_bytes;
+        out->generic_launches += ls.generic_launches; out->blur_launches += ls.blur_launches; out->blur_ms += ls.blur_ms;
+        out->frontend_launches += ls.frontend_launches; out->frontend_ms += ls.frontend_ms;
+        out->cmyk_pixels += ls.cmyk_pixels; out->cmyk_tables_baked += ls.cmyk_tables_baked;
+    }
     return FLGPU_OK;
 }
 
@@ -1339,6 +1375,7 @@ int flgpu_reset_stats(flgpu_ctx *c)
     (void)hipSetDevice(c->device);
     resolve_pending(c);
     c->stats = flgpu_stats{};
+    for (flgpu_ctx *l : c->lanes) (void)flgpu_reset_stats(l);
     return FLGPU_OK;
 }
 

@@ -126,10 +126,12 @@ typedef struct flgpu_plan {
 
 typedef struct flgpu_config {
     int32_t device;            /* HIP device ordinal; -1 = current device */
-    uint32_t max_batch;        /* request-queue flush size (0 = default 256) */
+    uint32_t max_batch;        /* request-queue flush size (0 = default 32) */
     uint32_t flush_timeout_us; /* request-queue flush timer (0 = default 200) */
     uint32_t profile;          /* 1 = bracket kernels with HIP events and report them in flgpu_stats */
-    uint32_t reserved[4];
+    uint32_t queue_lanes;      /* flgpu_transform: batches kept in flight at once (each lane has its own stream and
+                                  scratch, so one batch's PCIe transfers overlap another's kernels); 0 = default 3 */
+    uint32_t reserved[3];
 } flgpu_config;
 
 typedef struct flgpu_stats {

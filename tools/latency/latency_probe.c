@@ -1,0 +1,98 @@
+/* Per-image latency of the drop-in entry point, measured without Python in the way: T caller threads (the
+ * reference's tokio workers, src/main.rs:33) call flgpu_transform concurrently with HOST buffers; the library's
+ * request queue packs them into shared launches.  Prints one JSON object.
+ *   latency_probe <threads> <requests> <src_w> <src_h> <query> [front_end] [queue_lanes] [max_batch]            */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "fanlin_gpu.h"
+
+static flgpu_ctx *g_ctx;
+static flgpu_params g_params;
+static flgpu_plan g_plan;
+static uint32_t g_w, g_h;
+static uint8_t *g_src[8];
+static int g_requests, g_next, g_failed;
+static double *g_lat;
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static void *caller(void *arg)
+{
+    (void)arg;
+    uint8_t *dst = (uint8_t *)malloc(g_plan.out_bytes);
+    for (;;) {
+        pthread_mutex_lock(&g_mu);
+        const int i = g_next++;
+        pthread_mutex_unlock(&g_mu);
+        if (i >= g_requests) break;
+        flgpu_image in = {g_src[i % 8], (uint64_t)g_w * g_h * 3, g_w, g_h, 3, 0, 0}, out = {dst, g_plan.out_bytes, 0, 0, 0, 0, 0};
+        const double t0 = now_ms();
+        if (flgpu_transform(g_ctx, &in, &g_params, &out) != FLGPU_OK) { pthread_mutex_lock(&g_mu); g_failed++; pthread_mutex_unlock(&g_mu); }
+        g_lat[i] = now_ms() - t0;
+    }
+    free(dst);
+    return NULL;
+}
+
+static int cmp(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return (x > y) - (x < y); }
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) return 2;
+    const int threads = atoi(argv[1]);
+    g_requests = atoi(argv[2]);
+    g_w = (uint32_t)atoi(argv[3]); g_h = (uint32_t)atoi(argv[4]);
+    flgpu_query q;
+    int fmt = 0;
+    if (flgpu_query_parse(argv[5], &q) != FLGPU_OK || flgpu_params_from_query(&q, 0, 0, &g_params, &fmt) != FLGPU_OK) return 3;
+    g_params.front_end = argc > 6 ? (uint8_t)atoi(argv[6]) : FLGPU_FE_NONE;
+    if (flgpu_plan_output(&g_params, g_w, g_h, 3, &g_plan) != FLGPU_OK) return 4;
+    flgpu_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.device = -1;
+    cfg.queue_lanes = argc > 7 ? (uint32_t)atoi(argv[7]) : 0;
+    cfg.max_batch = argc > 8 ? (uint32_t)atoi(argv[8]) : 0;
+    int st = 0;
+    g_ctx = flgpu_create(&cfg, &st);
+    if (!g_ctx) { fprintf(stderr, "flgpu_create: %s\n", flgpu_strerror(st)); return 5; }
+    const size_t n = (size_t)g_w * g_h * 3;
+    uint32_t s = 0xFA171200u;
+    for (int k = 0; k < 8; ++k) {
+        g_src[k] = (uint8_t *)malloc(n);
+        for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; g_src[k][i] = (uint8_t)(s >> 24); }
+    }
+    g_lat = (double *)calloc((size_t)(g_requests > threads * 2 ? g_requests : threads * 2), sizeof(double));
+    pthread_t *ts = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    /* warm up: tables, pinned blocks, lanes */
+    const int total = g_requests;
+    g_requests = threads * 2; g_next = 0;
+    for (int t = 0; t < threads; ++t) pthread_create(&ts[t], NULL, caller, NULL);
+    for (int t = 0; t < threads; ++t) pthread_join(ts[t], NULL);
+    g_requests = total; g_next = 0;
+    flgpu_reset_stats(g_ctx);
+    const double t0 = now_ms();
+    for (int t = 0; t < threads; ++t) pthread_create(&ts[t], NULL, caller, NULL);
+    for (int t = 0; t < threads; ++t) pthread_join(ts[t], NULL);
+    const double wall = now_ms() - t0;
+    flgpu_stats stats;
+    flgpu_get_stats(g_ctx, &stats);
+    qsort(g_lat, (size_t)g_requests, sizeof(double), cmp);
+    printf("{\"p50_ms\": %.3f, \"p99_ms\": %.3f, \"requests\": %d, \"caller_threads\": %d, \"images_per_s\": %.1f, \"queue_flushes\": %llu, "
+           "\"failed\": %d, \"path\": \"flgpu_transform from C threads, host buffers (H2D + kernels + D2H), request-batching queue\"}\n",
+           g_lat[g_requests / 2], g_lat[(int)(g_requests * 0.99) < g_requests ? (int)(g_requests * 0.99) : g_requests - 1], g_requests, threads,
+           g_requests / wall * 1e3, (unsigned long long)stats.queue_flushes, g_failed);
+    flgpu_destroy(g_ctx);
+    return g_failed ? 6 : 0;
+}
