@@ -25,8 +25,11 @@
 #define FL_WPREFETCH 0 // 1 = fetch a row's weights from LDS one row ahead (measured: no gain)
 #endif
 
+#ifndef FL_RING_MULT
+#define FL_RING_MULT 2    // prefetch ring of the streaming kernel = FL_RING_MULT blocks of FL_STREAM_DEPTH rows
+#endif
 #ifndef FL_STREAM_DEPTH
-#define FL_STREAM_DEPTH 4 // source rows in flight per lane in the streaming kernel
+#define FL_STREAM_DEPTH 4 // source rows per block of the streaming kernel
 #endif
 
 namespace fl {
@@ -456,9 +459,12 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
 
     // whole byte offset goes through voffset: rows past the image end are range-checked by the buffer descriptor and read 0
     constexpr int LW = UA ? 4 : CS; // dwords loaded per lane and row
-    RowRaw<LW> ring[D];
+    // rows in flight per lane: R.  HBM latency under load is longer than one block of FMAs, so the ring holds two blocks
+    // where the register file allows it (Rgba8 accumulators and the unaligned variant's 4-dword rows already fill it)
+    constexpr int RM = (!UA && CS <= 3) ? FL_RING_MULT : 1, R = D * RM;
+    RowRaw<LW> ring[R];
 #pragma unroll
-    for (int k = 0; k < D; ++k) load_row<LW>(ring[k], rs, UA ? ((voff + k * pitch) & ~3u) : voff + k * pitch);
+    for (int k = 0; k < R; ++k) load_row<LW>(ring[k], rs, UA ? ((voff + k * pitch) & ~3u) : voff + k * pitch);
 
     __syncthreads();
 
@@ -473,7 +479,12 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
     // VGPRs at the start of a chunk and written to the other LDS buffer at its end.
     const uint32_t nrows = it.r1 - it.r0; // the host pads the schedule to a whole number of chunks
     uint32_t g0 = 0, g1 = 0;
-    for (uint32_t rb = 0; rb < nrows; rb += D) {
+    // One block of D rows per pass of the inner loop; HALF selects which D registers of the ring the block consumes
+    // and refills.  The inner loop is fully unrolled, so HALF is a constant and the ring stays in fixed registers.
+    for (uint32_t rb0 = 0; rb0 < nrows; rb0 += R) { // nrows is a multiple of SCHED_CHUNK, hence of R
+#pragma unroll
+    for (int HALF = 0; HALF < RM; ++HALF) {
+        const uint32_t rb = rb0 + HALF * D;
         const uint32_t in_chunk = rb % SCHED_CHUNK;
         const uint32_t *schc = sch + ((rb / SCHED_CHUNK) & 1u) * SCH_WORDS + in_chunk * (sizeof(RowSched) / 4);
         const bool fetch_next = in_chunk == 0 && rb + SCHED_CHUNK < nrows;
@@ -519,20 +530,20 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
             if constexpr (UA) {
                 const uint32_t ph = __builtin_amdgcn_readfirstlane((voff + ri * pitch) & 3u); // same in every lane
                 RowRaw<CS> al;
-                al.v.x = __builtin_amdgcn_alignbyte(ring[k].v.y, ring[k].v.x, ph);
-                al.v.y = __builtin_amdgcn_alignbyte(ring[k].v.z, ring[k].v.y, ph);
-                al.v.z = __builtin_amdgcn_alignbyte(ring[k].v.w, ring[k].v.z, ph);
+                al.v.x = __builtin_amdgcn_alignbyte(ring[HALF * D + k].v.y, ring[HALF * D + k].v.x, ph);
+                al.v.y = __builtin_amdgcn_alignbyte(ring[HALF * D + k].v.z, ring[HALF * D + k].v.y, ph);
+                al.v.z = __builtin_amdgcn_alignbyte(ring[HALF * D + k].v.w, ring[HALF * D + k].v.z, ph);
                 convert_row<CS, PRE>(al, v);
             } else {
-                convert_row<CS, PRE>(ring[k], v); // hipcc waits for this row only: the D - 1 younger rows stay in flight
+                convert_row<CS, PRE>(ring[HALF * D + k], v); // hipcc waits for this row only: the R - 1 younger rows stay in flight
             }
             // Keep the refill below the conversion: hoisted above it, the refill needs fresh registers and the
             // ring is then rotated with v_mov behind a vmcnt(0) at the loop end.  The empty asm makes the
             // refill's address depend on every converted value, so all reads of the old row precede it.
-            uint32_t roff = voff + (ri + D) * pitch;
+            uint32_t roff = voff + (ri + R) * pitch;
 #pragma unroll
             for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(roff) : "v"(v[j]));
-            load_row<LW>(ring[k], rs, UA ? (roff & ~3u) : roff);
+            load_row<LW>(ring[HALF * D + k], rs, UA ? (roff & ~3u) : roff);
             if (!(ablate & 4u)) {
 #pragma unroll
                 for (int s = 0; s < NA; ++s) {
@@ -647,6 +658,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
             }
             ++oy;
         }
+    }
     }
 }
 
@@ -1203,7 +1215,7 @@ size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks)
 uint32_t stream_lanes() { return 256; }
 
 uint32_t stream_block_rows() { return FL_STREAM_DEPTH; }
-static_assert(SCHED_CHUNK % FL_STREAM_DEPTH == 0, "schedule chunks must hold whole blocks");
+static_assert(SCHED_CHUNK % (FL_STREAM_DEPTH * FL_RING_MULT) == 0 && FL_RING_MULT >= 1 && FL_RING_MULT <= 2, "schedule chunks must hold whole ring rounds");
 
 bool stream_supported(uint32_t cs, uint32_t pre)
 {
