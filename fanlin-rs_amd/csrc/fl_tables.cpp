@@ -5,6 +5,7 @@
 #include "fl_jpeg_tables.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -174,7 +175,11 @@ void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t lanes, ui
         if (first != UINT32_MAX) { xa[t] = first; cnt[t] = last - first + 1; }
         out.jmax = std::max(out.jmax, cnt[t]);
     }
-    out.jmax = std::max(4u, (out.jmax + 3u) & ~3u); // the kernel unrolls its column loop by 4
+    {   // the kernel unrolls its column loop by 4 and finishes odd counts in a remainder loop
+        const char *pad = getenv("FLGPU_JMAX_PAD"); // experiment knob: 4 restores the padded tables
+        const uint32_t m = pad ? (uint32_t)std::max(1, atoi(pad)) : 1u;
+        out.jmax = std::max(1u, (out.jmax + m - 1u) / m * m);
+    }
     const uint32_t dummy = n * out.ks * 16u;
     out.wt.assign((size_t)out.jmax * lanes * 4, 0.0f);
     out.po.assign((size_t)out.jmax * lanes, dummy);
