@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): collects everything profiles/ is made of into gpurun_out/profiles_raw/.
+#   bash tools/collect_profiles.sh
+# rocprofv3 needs the program itself after `--` and a writable TMPDIR; counters are collected in separate passes.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/profiles_raw
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --cpu-images 0 --latency-requests 0"
+run() { echo "== $*" >&2; timeout -k 10 300 "$@"; }
+# kernel time summaries (the same commands bench.py is judged on, fewer steps)
+run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config1 -o c1 -- $B --steps 5 --warmup 2 > $O/config1.log 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config2 -o c2 -- $B --steps 5 --warmup 2 --blur 10 --grayscale > $O/config2.log 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d $O/jpeg -o jp -- $B --steps 5 --warmup 2 --frontend jpeg > $O/jpeg.log 2>&1
+# HBM traffic and instruction counters of config 1, one pass per counter group
+run rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $B --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
+run rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
+run rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -o p -- $B --steps 2 --warmup 1 > $O/pmc_sq.log 2>&1
+run rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- $B --steps 2 --warmup 1 > $O/pmc_sq2.log 2>&1
+# plain bench lines (no profiler attached)
+cd $R
+for name_args in "config1:" "config1_crop:--crop" "config2_gray_blur:--blur 10 --grayscale" "config1_jfif444:--frontend jfif444" "config1_webp420:--frontend webp420" "config1_jpeg:--frontend jpeg"; do
+  name=${name_args%%:*}; args=${name_args#*:}
+  extra="--cpu-images 0 --latency-requests 0"; [ "$name" = config1 ] && extra=""
+  run python3 bench.py $args $extra > $O/bench_$name.json 2> $O/bench_$name.err
+done
+ls $O

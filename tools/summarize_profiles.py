@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/profiles_raw/ (tools/collect_profiles.sh, run on the GPU box) into the committed summaries
+under profiles/: per-config rocprofv3 kernel statistics, the PMC counter averages of the dominant kernel, the
+measured HBM traffic bench.py reports as roofline.traffic, and the bench lines.   python tools/summarize_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
+OUT = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def kernel_stats(sub, prefix, dst):
+    src = os.path.join(RAW, sub, f"{prefix}_kernel_stats.csv")
+    rows = list(csv.DictReader(open(src)))
+    keep = [r for r in rows if "fl::" in r["Name"]]
+    with open(os.path.join(OUT, dst), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(keep)
+    return keep
+
+
+def counters(sub, kernel):
+    acc, n = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(os.path.join(RAW, sub, "p_counter_collection.csv"))):
+        if kernel in r["Kernel_Name"]:
+            acc[r["Counter_Name"]] += float(r["Counter_Value"])
+            n[r["Counter_Name"]] += 1
+    # one row per dispatch and counter: average over the dispatches
+    return {k: acc[k] / n[k] for k in acc}, (max(n.values()) if n else 0)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    kernel_stats("config1", "c1", f"{tag}_config1_kernel_stats.csv")
+    kernel_stats("config2", "c2", f"{tag}_config2_kernel_stats.csv")
+    kernel_stats("jpeg", "jp", f"{tag}_config1_jpeg_kernel_stats.csv")
+    vals, nd = {}, 0
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+        v, n = counters(sub, "resample_stream_kernel")
+        vals.update(v)
+        nd = max(nd, n)
+    bench = json.load(open(os.path.join(RAW, "bench_config1.json")))
+    workload = bench["config"]["workload"]
+    alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+    # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports half of wide coalesced reads -> FETCH x 2
+    hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    k_ms = bench["roofline"]["kernel_ms"]
+    with open(os.path.join(OUT, f"{tag}_config1_pmc.txt"), "w") as f:
+        f.write("rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-images 0 --latency-requests 0\n")
+        f.write("separate passes: {FETCH_SIZE} {WRITE_SIZE} {SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY} "
+                "{SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE}\n")
+        f.write(f"per-dispatch averages of fl::resample_stream_kernel ({workload}), {nd} dispatches each\n\n")
+        for k in sorted(vals):
+            f.write(f"{k:28s} {vals[k]:16.1f}\n")
+        f.write(f"\nHBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB = {hbm / 1e9:.3f} GB (FETCH_SIZE doubled: gfx950 reports half of wide coalesced reads)\n")
+        f.write(f"algorithmic bytes per launch = {alg / 1e9:.3f} GB -> traffic / algorithmic = {hbm / alg:.3f}\n")
+        if "GRBM_GUI_ACTIVE" in vals and "SQ_INSTS_VALU" in vals:
+            clk = vals["GRBM_GUI_ACTIVE"] / 8.0 / (k_ms * 1e-3) / 1e9
+            f.write(f"effective clock = GRBM_GUI_ACTIVE / 8 / kernel time = {clk:.2f} GHz; VALU issue = "
+                    f"{vals['SQ_INSTS_VALU'] / (k_ms * 1e-3 * clk * 1e9 * 256):.2f} wave-instr/clk/CU\n")
+    traffic = {workload: {"kernel": "resample_stream_kernel", "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"],
+                          "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE as is; separate --pmc passes",
+                          "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
+                          "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-images 0 --latency-requests 0",
+                          "round": int(tag[1:])}}
+    json.dump(traffic, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
+    for p in glob.glob(os.path.join(RAW, "bench_*.json")):
+        line = open(p).read().strip().splitlines()[-1]
+        json.loads(line)
+        open(os.path.join(OUT, f"{tag}_" + os.path.basename(p)), "w").write(line + "\n")
+    print("profiles/ updated:", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
