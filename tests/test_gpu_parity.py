@@ -402,3 +402,39 @@ def test_errors_are_reported_not_swallowed(fl, gpu_state):
 def test_native_kernels_were_used(gpu_state):
     s = gpu_state.stats()
     assert s["resample_launches"] > 0 and s["generic_launches"] > 0 and s["blur_launches"] > 0 and s["frontend_launches"] > 0
+
+
+# ---------------------------------------------------------------- seeded sweep over request space --
+
+def _sweep_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        sh, sw = int(rng.integers(20, 640)), int(rng.integers(20, 900))
+        c = int(rng.choice([1, 2, 3, 3, 3, 4]))
+        w, h = int(rng.integers(20, 500)), int(rng.integers(20, 400))
+        kw = dict(w=w, h=h, crop=bool(rng.integers(0, 2)), grayscale=bool(rng.integers(0, 4) == 0), inverse=bool(rng.integers(0, 4) == 0),
+                  fill=tuple(int(x) for x in rng.integers(0, 256, 3)), orientation=int(rng.choice([1, 1, 1, 3, 6, 8])))
+        if rng.integers(0, 5) == 0:
+            kw["blur_sigma"] = float(rng.choice([10.0, 14.0, 20.0]))
+        cases.append((i, (sh, sw, c), kw))
+    return cases
+
+
+@pytest.mark.parametrize("idx,shape,kw", _sweep_cases(48, 0xFA17), ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_seeded_request_sweep(fl, gpu_state, oracle, idx, shape, kw):
+    # whatever the request, the device path must equal the fused-arithmetic oracle bit for bit and stay within
+    # 1 LSB of the reference arithmetic: exercises up- and down-scales, strips, bands, unaligned rows, all layouts
+    img = synth.photo(*shape, index=3000 + idx) if idx % 2 else synth.uniform(*shape, index=3000 + idx)
+    check_resample(fl, gpu_state, oracle, img, **kw)
+
+
+def test_seeded_sweep_as_one_mixed_batch(fl, gpu_state, oracle):
+    cases = _sweep_cases(24, 0xBA7C)
+    imgs = [synth.uniform(*shape, index=4000 + i) for i, shape, _ in cases]
+    ps = [fl.make_params(**kw) for _, _, kw in cases]
+    outs = gpu_state.process_batch(imgs, ps)
+    for (i, shape, kw), img, got in zip(cases, imgs, outs):
+        okw = {k: v for k, v in kw.items()}
+        want = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **okw)
+        assert np.array_equal(got, want), (i, shape, kw)
