@@ -30,6 +30,9 @@ LIB_PATH = os.environ.get("FLGPU_LIB") or os.path.join(_HERE, "libfanlin_gpu.so"
 FE_NONE, FE_JFIF444, FE_WEBP420, FE_JPEG = 0, 1, 2, 3
 ACCEPT_WEBP, ACCEPT_AVIF = 1, 2
 OUT_KEEP, OUT_WEBP, OUT_AVIF = 0, 1, 2
+IN_OTHER, IN_JPEG, IN_PNG, IN_WEBP, IN_GIF_FRAME = 0, 1, 2, 3, 4
+RESULT_AS_IS, RESULT_JPEG_STREAM, RESULT_WEBP_PLANES, RESULT_PIXELS = 0, 1, 2, 3
+MIME = {IN_JPEG: "image/jpeg", IN_PNG: "image/png", IN_WEBP: "image/webp", IN_GIF_FRAME: "image/gif"}
 IMG_FRONTEND_PLANES, IMG_HAS_ALPHA, IMG_ENCODED = 1, 2, 4
 BATCH_SAME_PARAMS = 1
 (OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_OOM, ERR_DEVICE, ERR_PARSE, ERR_BUFFER_TOO_SMALL,
@@ -88,7 +91,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_parse", "flgpu_query_dimensions", "flgpu_query_fill_color", "flgpu_query_quality",
     "flgpu_query_cropping", "flgpu_query_blur", "flgpu_query_grayscale", "flgpu_query_inverse",
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
-    "flgpu_params_from_query", "flgpu_plan_output", "flgpu_create", "flgpu_destroy", "flgpu_transform",
+    "flgpu_params_from_query", "flgpu_plan_output", "flgpu_process_image", "flgpu_process_image_plan", "flgpu_create", "flgpu_destroy", "flgpu_transform",
     "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_batch_results", "flgpu_ycck_to_cmyk",
     "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
@@ -131,6 +134,9 @@ def load_library() -> C.CDLL:
         f.argtypes = [C.POINTER(flgpu_query)]
         f.restype = C.c_int
     lib.flgpu_params_from_query.argtypes = [C.POINTER(flgpu_query), C.c_uint32, C.c_int, C.POINTER(flgpu_params), C.POINTER(C.c_int)]
+    lib.flgpu_process_image.argtypes = [C.c_void_p, C.POINTER(flgpu_image), C.c_uint8, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(flgpu_image),
+                                        C.POINTER(flgpu_plan), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.flgpu_process_image_plan.argtypes = [C.POINTER(flgpu_image), C.c_uint8, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(flgpu_plan), C.POINTER(C.c_int)]
     lib.flgpu_plan_output.argtypes = [C.POINTER(flgpu_params), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(flgpu_plan)]
     lib.flgpu_create.argtypes = [C.POINTER(flgpu_config), C.POINTER(C.c_int)]
     lib.flgpu_create.restype = C.c_void_p
@@ -395,6 +401,26 @@ class State:
         dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
         _check(self._lib.flgpu_transform(self._ctx, C.byref(src), C.byref(params), C.byref(dst)), self._ctx)
         return _split_output(out, plan, params.front_end, dst.flags, dst.bytes)
+
+    def process_image(self, decoded: np.ndarray, query_string: str, content: "Format" = None, input_format: int = IN_JPEG,
+                      orientation: int = 1):
+        """State::process_image after the decoder (reference src/handler.rs:198-308): returns (mime, kind, payload) where
+        payload is None (AS_IS), the JPEG body (bytes), WebP planes (Planes) or the pixels for a host encoder (ndarray)."""
+        img = _as_image_array(decoded)
+        src = flgpu_image(img.ctypes.data, img.nbytes, img.shape[1], img.shape[0], img.shape[2], 0)
+        plan, kind, fmt = flgpu_plan(), C.c_int(), C.c_int()
+        flags = content.flags if content else 0
+        qs = query_string.encode()
+        _check(self._lib.flgpu_process_image_plan(C.byref(src), orientation, qs, flags, input_format, C.byref(plan), C.byref(kind)))
+        if kind.value == RESULT_AS_IS:
+            return MIME.get(input_format, "application/octet-stream"), RESULT_AS_IS, None
+        out = np.empty(max(int(plan.out_bytes), 1), dtype=np.uint8)
+        dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
+        _check(self._lib.flgpu_process_image(self._ctx, C.byref(src), orientation, qs, flags, input_format, C.byref(dst), C.byref(plan),
+                                             C.byref(kind), C.byref(fmt)), self._ctx)
+        mime = "image/webp" if fmt.value == OUT_WEBP else "image/avif" if fmt.value == OUT_AVIF else MIME.get(input_format, "application/octet-stream")
+        fe = {RESULT_JPEG_STREAM: FE_JPEG, RESULT_WEBP_PLANES: FE_WEBP420, RESULT_PIXELS: FE_NONE}[kind.value]
+        return mime, kind.value, _split_output(out, plan, fe, dst.flags, dst.bytes)
 
     def process_batch(self, images: Sequence[np.ndarray], params: Sequence[flgpu_params]) -> List:
         n = len(images)

@@ -183,9 +183,63 @@ int flgpu_params_from_query(const flgpu_query *q, uint32_t accept_flags, int inp
        lossless WebP, AVIF, PNG, ... take interleaved pixels */
     uint8_t qc = p->quality < 1 ? 1 : (p->quality > 100 ? 100 : p->quality);
     if (fmt == FLGPU_OUT_WEBP) p->front_end = (qc == 100) ? FLGPU_FE_NONE : FLGPU_FE_WEBP420;
-    else if (fmt == FLGPU_OUT_KEEP && input_is_jpeg) p->front_end = FLGPU_FE_JFIF444;
+    else if (fmt == FLGPU_OUT_KEEP && input_is_jpeg) p->front_end = input_is_jpeg == 2 ? FLGPU_FE_JPEG : FLGPU_FE_JFIF444;
     else p->front_end = FLGPU_FE_NONE;
     return FLGPU_OK;
+}
+
+/* Everything State::process_image decides before it touches pixels (handler.rs:198-261). */
+static int plan_request(const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string, uint32_t accept_flags,
+                        int input_format, flgpu_params *p, flgpu_plan *plan, int *result_kind, int *out_format)
+{
+    if (!decoded || !query_string || !plan || !result_kind) return FLGPU_ERR_INVALID_ARG;
+    if (input_format < FLGPU_IN_OTHER || input_format > FLGPU_IN_GIF_FRAME || exif_orientation > 8) return FLGPU_ERR_INVALID_ARG;
+    flgpu_query q;
+    int rc = flgpu_query_parse(query_string, &q);
+    if (rc) return rc;
+    if (flgpu_query_unsupported_scale_size(&q)) return FLGPU_ERR_PARSE;            /* main.rs:134-138: 400 before the handler runs */
+    memset(plan, 0, sizeof(*plan));
+    if (flgpu_query_as_is(&q)) { *result_kind = FLGPU_RESULT_AS_IS; if (out_format) *out_format = FLGPU_OUT_KEEP; return FLGPU_OK; }
+    int fmt = FLGPU_OUT_KEEP;
+    rc = flgpu_params_from_query(&q, accept_flags, input_format == FLGPU_IN_JPEG ? 2 : 0, p, &fmt);
+    if (rc) return rc;
+    if (input_format == FLGPU_IN_GIF_FRAME) {
+        /* process_gif (handler.rs:311-366): Nearest, no blur, no orientation, always re-encoded as GIF by the host */
+        p->filter = FLGPU_FILTER_NEAREST;
+        p->blur_sigma = 0.0f;
+        p->front_end = FLGPU_FE_NONE;
+        fmt = FLGPU_OUT_KEEP;
+    } else {
+        p->orientation = exif_orientation;
+        /* a WebP source that stays WebP goes through the same arm as a negotiated one (handler.rs:286-305) */
+        if (fmt == FLGPU_OUT_KEEP && input_format == FLGPU_IN_WEBP) {
+            const uint8_t qc = p->quality < 1 ? 1 : (p->quality > 100 ? 100 : p->quality);
+            p->front_end = qc == 100 ? FLGPU_FE_NONE : FLGPU_FE_WEBP420;
+        }
+    }
+    if (out_format) *out_format = fmt;
+    *result_kind = p->front_end == FLGPU_FE_JPEG ? FLGPU_RESULT_JPEG_STREAM : p->front_end == FLGPU_FE_WEBP420 ? FLGPU_RESULT_WEBP_PLANES : FLGPU_RESULT_PIXELS;
+    return flgpu_plan_output(p, decoded->width, decoded->height, decoded->channels, plan);
+}
+
+int flgpu_process_image_plan(const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string, uint32_t accept_flags,
+                             int input_format, flgpu_plan *plan, int *result_kind)
+{
+    flgpu_params p;
+    return plan_request(decoded, exif_orientation, query_string, accept_flags, input_format, &p, plan, result_kind, nullptr);
+}
+
+int flgpu_process_image(flgpu_ctx *ctx, const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string,
+                        uint32_t accept_flags, int input_format, flgpu_image *dst, flgpu_plan *plan, int *result_kind, int *out_format)
+{
+    if (!ctx || !dst) return FLGPU_ERR_INVALID_ARG;
+    flgpu_params p;
+    flgpu_plan local;
+    int kind = 0;
+    int rc = plan_request(decoded, exif_orientation, query_string, accept_flags, input_format, &p, plan ? plan : &local, &kind, out_format);
+    if (result_kind) *result_kind = kind;
+    if (rc || kind == FLGPU_RESULT_AS_IS) return rc;
+    return flgpu_transform(ctx, decoded, &p, dst);
 }
 
 int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t sc, flgpu_plan *plan)

@@ -179,6 +179,8 @@ int flgpu_query_unsupported_scale_size(const flgpu_query *q);
  * keeps its own encoder and gets pixels). */
 int flgpu_params_from_query(const flgpu_query *q, uint32_t accept_flags, int input_is_jpeg,
                             flgpu_params *params, int *out_format);
+/* input_is_jpeg: 0 = no, 1 = JPEG and the caller's encoder wants Y/Cb/Cr planes (FLGPU_FE_JFIF444),
+ * 2 = JPEG and the library finishes the stream (FLGPU_FE_JPEG). */
 
 /* Pure function: output geometry for a source of sw x sh x sc. */
 int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t sc, flgpu_plan *plan);
@@ -219,6 +221,25 @@ void flgpu_destroy(flgpu_ctx *ctx);
 /* One image, host memory, blocking.  Thread-safe: concurrent callers are
  * packed into shared kernel launches by the context's request queue. */
 int flgpu_transform(flgpu_ctx *ctx, const flgpu_image *src, const flgpu_params *p, flgpu_image *dst);
+
+/* State::process_image after the decoder, as one call (src/handler.rs:198-308 minus decoding and the host-only
+ * encoders): `decoded` = DynamicImage::from_decoder's pixels, `exif_orientation` = decoder.orientation() (1..8),
+ * `query_string` = the request's query, `accept_flags` = content::Format, `input_format` = what with_guessed_format
+ * said.  The outcome is one of flgpu_result_kind:
+ *   AS_IS         params.as_is() (handler.rs:202-204): nothing was done, serve the original bytes
+ *   JPEG_STREAM   input was JPEG and no other container was negotiated: dst holds the finished "image/jpeg" body
+ *   WEBP_PLANES   lossy WebP was negotiated (handler.rs:286-297): dst holds Y | U | V for WebPEncode
+ *   PIXELS        everything else (PNG, AVIF, lossless WebP, GIF frames, ...): dst holds the DynamicImage pixels for
+ *                 the crate's own encoder; *out_format says which container was negotiated
+ * Errors: FLGPU_ERR_PARSE where axum answers 400 (bad query, or the size gate of src/main.rs:134-138). */
+typedef enum flgpu_input_format { FLGPU_IN_OTHER = 0, FLGPU_IN_JPEG = 1, FLGPU_IN_PNG = 2, FLGPU_IN_WEBP = 3, FLGPU_IN_GIF_FRAME = 4 } flgpu_input_format;
+typedef enum flgpu_result_kind { FLGPU_RESULT_AS_IS = 0, FLGPU_RESULT_JPEG_STREAM = 1, FLGPU_RESULT_WEBP_PLANES = 2, FLGPU_RESULT_PIXELS = 3 } flgpu_result_kind;
+int flgpu_process_image(flgpu_ctx *ctx, const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string,
+                        uint32_t accept_flags, int input_format, flgpu_image *dst, flgpu_plan *plan, int *result_kind,
+                        int *out_format);
+/* Room dst needs for that request (0 for AS_IS); same parsing and errors, no device work. */
+int flgpu_process_image_plan(const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string,
+                             uint32_t accept_flags, int input_format, flgpu_plan *plan, int *result_kind);
 
 /* n images, host memory, blocking: staged through pinned buffers, one set of launches. */
 int flgpu_transform_batch(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, const flgpu_params *ps,
