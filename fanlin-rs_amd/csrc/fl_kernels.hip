@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
     const uint32_t cl = blk[hd.tiles_off + 2 * tile], ncols = blk[hd.tiles_off + 2 * tile + 1]; // ncols <= T by construction
     const uint32_t top = blk[hd.bands_off + 2 * band], nrows = blk[hd.bands_off + 2 * band + 1];
 
-    // LDS: [ wv: rv x BLUR_TY | mid: BLUR_TY x (T + htaps) x MS | wh: htaps x tw ]
+    // LDS: [ wv: rv x BLUR_TY | mid: BLUR_TY x (T + htaps) x MS | wh: htaps x nrows_h (distinct weight vectors) ]
     float *wv = fl_lds;
     const uint32_t wv_floats = (hd.rv * BLUR_TY + 3u) & ~3u;
     constexpr uint32_t midw = BLUR_MIDW; // compile-time row pitch: row offsets fold into the ds_read immediates
@@ -725,13 +725,14 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
 #pragma unroll
             for (int c = 0; c < MS; ++c) mid[(o * midw + cidx) * MS + c] = 0.0f;
         }
-    // horizontal weights of this tile: tap-major [htaps][tw_full] behind hleft[tw_full] (coalesced copy)
-    const uint32_t *tt = blk + hd.htiles_off + (size_t)tile * (tw_full * (htaps + 1));
-    const uint32_t hleft = tid < tw ? tt[tid] : 0u;
+    // horizontal weights: this column's first tap and the id of its weight vector; the distinct vectors (one for all
+    // interior columns, one per column within 2 sigma of a border) are copied tap-major
+    const uint32_t *tt = blk + hd.htiles_off + (size_t)tile * (tw_full * 2);
+    const uint2 hcol = tid < tw ? *reinterpret_cast<const uint2 *>(tt + 2 * tid) : uint2{0u, 0u};
+    const uint32_t hleft = hcol.x, hrow = hcol.y, nrh = hd.nrows_h;
     {
-        const float *src = reinterpret_cast<const float *>(tt + tw_full);
-        if (tid < tw)
-            for (uint32_t tap = 0; tap < htaps; ++tap) wh[tap * tw + tid] = src[tap * tw_full + tid];
+        const float *src = reinterpret_cast<const float *>(blk + hd.hrows_off);
+        for (uint32_t i = tid; i < htaps * nrh; i += T) wh[i] = src[i];
     }
     __syncthreads();
 
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
         const float *m0 = mid + hleft * MS;
 #pragma unroll 4
         for (uint32_t i = 0; i < htaps; ++i) {
-            const float wi = wh[i * tw + tid];
+            const float wi = wh[i * nrh + hrow];
 #pragma unroll
             for (int o = 0; o < BLUR_TY; ++o) {
                 const float *px = m0 + (o * midw + i) * MS;
@@ -1170,7 +1171,9 @@ size_t blur_lds_bytes(uint32_t w, uint32_t channels, uint32_t vtaps, uint32_t ht
     const uint32_t ms = channels == 3 ? 4 : channels;
     const uint32_t nt = blur_tiles(w, htaps), tw = (w + nt - 1) / nt;
     const size_t wv = (((size_t)(BLUR_TY + vtaps) * BLUR_TY + 3) & ~(size_t)3); // rv <= BLUR_TY + vtaps - 1
-    return (wv + (size_t)BLUR_TY * BLUR_MIDW * ms + (size_t)htaps * tw) * sizeof(float);
+    (void)tw;
+    const size_t rows_h = std::min<size_t>(w, 2 * (size_t)htaps); // distinct horizontal weight vectors: <= htaps (borders) + 1 (interior)
+    return (wv + (size_t)BLUR_TY * BLUR_MIDW * ms + (size_t)htaps * rows_h) * sizeof(float);
 }
 
 uint32_t blur_tile_count(uint32_t w, uint32_t htaps) { return blur_tiles(w, htaps); }

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 
 namespace fl {
 
@@ -221,7 +222,20 @@ void build_blur_plan(const HostAxis &v, const HostAxis &h, uint32_t nt, uint32_t
     hd.bands_off = hd.tiles_off + 2 * nt;
     hd.vdense_off = (hd.bands_off + 2 * nb + 3u) & ~3u;
     hd.htiles_off = hd.vdense_off + nb * rv * ty;
-    out.assign((size_t)hd.htiles_off + (size_t)nt * tw_full * (htaps + 1), 0u);
+    // distinct horizontal weight vectors (zero padded to htaps): interior columns all share one
+    std::map<std::vector<uint32_t>, uint32_t> ids;
+    std::vector<uint32_t> col_row(w);
+    std::vector<std::vector<uint32_t>> rows;
+    for (uint32_t x = 0; x < w; ++x) {
+        std::vector<uint32_t> key(htaps, 0u);
+        memcpy(key.data(), h.weights.data() + h.woff[x], h.count[x] * sizeof(float));
+        auto it = ids.find(key);
+        if (it == ids.end()) { it = ids.emplace(key, (uint32_t)rows.size()).first; rows.push_back(key); }
+        col_row[x] = it->second;
+    }
+    hd.nrows_h = (uint32_t)rows.size();
+    hd.hrows_off = hd.htiles_off + nt * tw_full * 2;
+    out.assign((size_t)hd.hrows_off + (size_t)htaps * hd.nrows_h, 0u);
     memcpy(out.data(), &hd, sizeof(hd));
     memcpy(out.data() + hd.tiles_off, tiles.data(), tiles.size() * 4);
     memcpy(out.data() + hd.bands_off, bands.data(), bands.size() * 4);
@@ -235,17 +249,18 @@ void build_blur_plan(const HostAxis &v, const HostAxis &h, uint32_t nt, uint32_t
         }
     }
     for (uint32_t t = 0; t < nt; ++t) {
-        uint32_t *base = out.data() + hd.htiles_off + (size_t)t * tw_full * (htaps + 1);
+        uint32_t *base = out.data() + hd.htiles_off + (size_t)t * tw_full * 2;
         const uint32_t x0 = t * tw_full;
         if (x0 >= w) break;
         const uint32_t cl = h.left[x0];
-        float *wh = reinterpret_cast<float *>(base + tw_full);
         for (uint32_t j = 0; j < tw_full && x0 + j < w; ++j) {
-            const uint32_t x = x0 + j;
-            base[j] = h.left[x] - cl;
-            for (uint32_t i = 0; i < h.count[x]; ++i) wh[(size_t)i * tw_full + j] = h.weights[h.woff[x] + i];
+            base[2 * j] = h.left[x0 + j] - cl;
+            base[2 * j + 1] = col_row[x0 + j];
         }
     }
+    uint32_t *hr = out.data() + hd.hrows_off;
+    for (uint32_t r = 0; r < hd.nrows_h; ++r)
+        for (uint32_t i = 0; i < htaps; ++i) hr[(size_t)i * hd.nrows_h + r] = rows[r][i];
 }
 
 void build_webp_gamma(std::vector<uint32_t> &out)

@@ -78,7 +78,9 @@ struct alignas(16) StreamItem {
     uint32_t pad0;
 };
 // Header of the blur kernel's table block (fl_tables.h build_blur_plan); offsets are words relative to the header.
-struct BlurPlanHeader { uint32_t nt, nb, tw_full, htaps, rv, tiles_off, bands_off, vdense_off, htiles_off, pad[3]; };
+// htiles: per tile tw_full x {hleft, row id}; hrows: the distinct horizontal weight vectors, tap-major [htaps][nrows_h]
+// (all interior columns of a blurred picture share one vector; only the columns within 2 sigma of a border differ)
+struct BlurPlanHeader { uint32_t nt, nb, tw_full, htaps, rv, tiles_off, bands_off, vdense_off, htiles_off, hrows_off, nrows_h, pad; };
 
 enum : uint32_t { ITEM_FIRST_BAND = 1, ITEM_LAST_BAND = 2, ITEM_FIRST_STRIP = 4, ITEM_LAST_STRIP = 8 };
 
