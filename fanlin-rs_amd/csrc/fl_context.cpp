@@ -125,7 +125,7 @@ struct flgpu_ctx {
     std::map<AxisKey, uint32_t> axis_off;
     std::map<AxisKey, HostAxis> axis_host;
     std::map<StreamPlanKey, StreamPlan> stream_plans;
-    std::map<std::pair<AxisKey, AxisKey>, uint32_t> blur_plans; // blur kernel table blocks per (vertical, horizontal) Gaussian axis
+    std::map<std::tuple<AxisKey, AxisKey, uint32_t>, uint32_t> blur_plans; // blur kernel table blocks per (vertical, horizontal) Gaussian axis
     uint32_t gamma_off = 0;
 
     DescSlot slots[4];
@@ -397,6 +397,18 @@ struct GroupKey {
     bool operator<(const GroupKey &o) const { return std::tie(kind, cs, pre, lb) < std::tie(o.kind, o.cs, o.pre, o.lb); }
 };
 
+// Channels the blur really has to filter: a letterboxed picture of an opaque source has alpha == 255 everywhere,
+// and a grey one on a grey fill has R == G == B (see blur_tile_kernel).
+uint32_t blur_channels(const Work &w)
+{
+    uint32_t ce = w.plan.out_c;
+    if (w.plan.letterboxed && (w.cs == 1 || w.cs == 3)) {
+        const bool grey = mid_channels(w.cs, w.pre) == 1 && w.p->fill_r == w.p->fill_g && w.p->fill_g == w.p->fill_b;
+        ce = grey ? 1u : 3u;
+    }
+    return ce;
+}
+
 void fill_job(const Work &w, Job &j)
 {
     memset(&j, 0, sizeof(j));
@@ -535,11 +547,14 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 AxisKey kv; const HostAxis *hv;
                 if (!get_axis(c, w.plan.out_h, w.plan.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &kv, &hv) ||
                     !get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h)) full = true;
-                else if (blur_tile_supported(h->max_taps) && blur_tile_supported(hv->max_taps) && !c->blur_plans.count({kv, k})) {
-                    std::vector<uint32_t> blk;
-                    build_blur_plan(*hv, *h, blur_tile_count(w.plan.out_w, h->max_taps), blur_band_rows(), blk);
-                    const uint32_t off = arena_append(c, blk.data(), blk.size());
-                    if (!off) full = true; else c->blur_plans[{kv, k}] = off;
+                else {
+                    const uint32_t ty = blur_band_rows(blur_channels(w));
+                    if (blur_tile_supported(h->max_taps) && blur_tile_supported(hv->max_taps) && !c->blur_plans.count(std::make_tuple(kv, k, ty))) {
+                        std::vector<uint32_t> blk;
+                        build_blur_plan(*hv, *h, blur_tile_count(w.plan.out_w, h->max_taps), ty, blk);
+                        const uint32_t off = arena_append(c, blk.data(), blk.size());
+                        if (!off) full = true; else c->blur_plans[std::make_tuple(kv, k, ty)] = off;
+                    }
                 }
             }
         }
@@ -572,14 +587,12 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         const Work &w = work[i];
         if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         if (w.p->blur_sigma > 0.0f) {
-            // channels that really need filtering: a letterboxed picture of an opaque source has alpha == 255
-            // everywhere, and a grey one on a grey fill has R == G == B (see blur_tile_kernel)
-            uint32_t ce = w.plan.out_c;
-            if (w.plan.letterboxed && (w.cs == 1 || w.cs == 3)) {
-                const bool grey = mid_channels(w.cs, w.pre) == 1 && w.p->fill_r == w.p->fill_g && w.p->fill_g == w.p->fill_b;
-                ce = grey ? 1u : 3u;
-            }
-            blur_groups[{0, w.plan.out_c, ce, 0}].push_back(i);
+            const uint32_t ce = blur_channels(w);
+            // pictures of one launch share the workgroup width the kernel is instantiated for
+            AxisKey hk2; const HostAxis *hh2 = nullptr;
+            const uint32_t lanes = (get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &hk2, &hh2) && hh2 &&
+                                    blur_tile_supported(hh2->max_taps)) ? blur_lanes(w.plan.out_w, hh2->max_taps) : 256u;
+            blur_groups[{lanes, w.plan.out_c, ce, 0}].push_back(i);
         }
         if (w.p->front_end != FLGPU_FE_NONE) fe_groups[{w.p->front_end, 0, 0, 0}].push_back(i);
     }
@@ -659,7 +672,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             j.vtab = get_axis(c, pl.out_h, pl.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &vkey, nullptr);
             j.htab = get_axis(c, pl.out_w, pl.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &hkey, nullptr);
             {
-                auto bt = c->blur_plans.find({vkey, hkey});
+                auto bt = c->blur_plans.find(std::make_tuple(vkey, hkey, blur_band_rows(k.pre ? k.pre : pl.out_c)));
                 j.pad0 = bt != c->blur_plans.end() ? bt->second : 0u; // table block of the blur kernel
             }
             const size_t mid = (size_t)pl.out_w * pl.out_h * pl.out_c;
@@ -671,7 +684,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 const size_t lds = blur_lds_bytes(pl.out_w, k.pre ? k.pre : pl.out_c, vh->max_taps, hh->max_taps); // k.pre = channels filtered
                 if (!blur_tile_supported(hh->max_taps) || !blur_tile_supported(vh->max_taps) || lds > 150 * 1024 || !j.pad0) L.blur_tiled = false;
                 L.lds = std::max(L.lds, lds);
-                L.blur_grid_x = std::max(L.blur_grid_x, blur_grid_x(pl.out_w, pl.out_h, hh->max_taps));
+                L.blur_grid_x = std::max(L.blur_grid_x, blur_grid_x(pl.out_w, pl.out_h, hh->max_taps, k.pre ? k.pre : pl.out_c));
             }
             j.mid_off = (uint32_t)L.mid_floats;
             L.mid_floats += mid;
@@ -795,6 +808,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         ProfileScope ps(c, st, 1);
         if (L.blur_tiled && !force_generic) {
             L.g.pre = L.k.pre; // channels to filter (group key), see blur_tile_kernel
+            L.g.blur_lanes = L.k.kind;
             FL_HIP(c, launch_blur_tile(L.g, L.blur_grid_x, L.lds, st), "blur kernel");
         } else {
             L.g.pre = PRE_NONE;

@@ -50,6 +50,7 @@ struct LaunchGeneric {
     uint32_t max_cw, max_ch;  // horizontal pass grid
     uint32_t max_dw, max_dh;  // placement grid
     uint32_t nearest;         // place kernel: FilterType::Nearest gather (jobs carry the f32 ratios in vtab/htab)
+    uint32_t blur_lanes;      // blur kernel: lanes per workgroup of this group (blur_lanes() of its pictures)
 };
 
 struct LaunchStream {
@@ -70,9 +71,10 @@ hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st
 // fused LDS-tiled Gaussian blur (g.cs = channels of the blurred image; g.jobs[i].vtab/htab = Gaussian tables)
 bool blur_tile_supported(uint32_t htaps);
 size_t blur_lds_bytes(uint32_t w, uint32_t channels, uint32_t vtaps, uint32_t htaps);
-uint32_t blur_grid_x(uint32_t w, uint32_t h, uint32_t htaps);
+uint32_t blur_grid_x(uint32_t w, uint32_t h, uint32_t htaps, uint32_t channels_filtered);
 uint32_t blur_tile_count(uint32_t w, uint32_t htaps);
-uint32_t blur_band_rows(); // output rows per workgroup of the blur kernel // column tiles per image; tile width = ceil(w / count)
+uint32_t blur_lanes(uint32_t w, uint32_t htaps); // lanes per workgroup the blur kernel uses for pictures of this width
+uint32_t blur_band_rows(uint32_t channels_filtered); // output rows per workgroup of the blur kernel (see BLUR_TY / BLUR_TY_MONO)
 hipError_t launch_blur_tile(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st);
 
 bool stream_supported(uint32_t cs, uint32_t pre);

@@ -675,23 +675,36 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
 //                   LDS reads are conflict free; one weight read feeds BLUR_TY rows x C channels of FMAs.
 // ---------------------------------------------------------------------------
 
-constexpr int BLUR_TY = 8;
-constexpr uint32_t BLUR_T = 256;
+constexpr int BLUR_TY = 8;        // output rows per workgroup (colour)
+constexpr int BLUR_TY_MONO = 8;   // ... when one channel is filtered (16 measured slower: 0.80 vs 0.61 ms, more zero-weight FMAs per band)
+__host__ __device__ inline int blur_ty(uint32_t channels_filtered) { return channels_filtered == 1 ? BLUR_TY_MONO : BLUR_TY; }
 constexpr uint32_t BLUR_MAXTAPS = 128;            // sigma <= 20 gives 81 taps
-constexpr uint32_t BLUR_MIDW = BLUR_T + BLUR_MAXTAPS; // columns of the f32 hand-off rows in LDS
+__host__ __device__ constexpr uint32_t blur_midw(uint32_t threads) { return threads + BLUR_MAXTAPS; } // columns of the f32 hand-off rows in LDS
 
-__host__ __device__ inline uint32_t blur_tiles(uint32_t w, uint32_t taps) { const uint32_t cap = BLUR_T - (taps - 1); return (w + cap - 1) / cap; }
+__host__ __device__ inline uint32_t blur_tiles_t(uint32_t w, uint32_t taps, uint32_t threads) { const uint32_t cap = threads - (taps - 1); return (w + cap - 1) / cap; }
+// Lanes per workgroup: a tile of tw output columns needs tw + taps - 1 lanes in the vertical pass, so the width that
+// wastes the fewest lane slots wins (300 columns, 41 taps: 1 tile of 384 lanes instead of 2 of 256)
+__host__ __device__ inline uint32_t blur_threads(uint32_t w, uint32_t taps)
+{
+    uint32_t best = 256, cost = 0xffffffffu;
+    for (uint32_t t = 256; t <= 512; t += 128) {
+        const uint32_t c = blur_tiles_t(w, taps, t) * t;
+        if (c < cost) { cost = c; best = t; }
+    }
+    return best;
+}
+__host__ __device__ inline uint32_t blur_tiles(uint32_t w, uint32_t taps) { return blur_tiles_t(w, taps, blur_threads(w, taps)); }
 
 // CS = channels stored per pixel, C = channels filtered.  C < CS only for opaque Rgba8 pictures (every
 // letterboxed output of an opaque source): the alpha plane is the constant 255 (any normalised filter
 // maps it to 255 again, far from a rounding boundary) and, for a grey picture on a grey fill, R = G = B, so
 // one channel is filtered and replicated -- identical arithmetic on identical inputs, bit-identical output.
-template <int CS, int C>
-__global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ arena,
+template <int CS, int C, int TY, int THREADS>
+__global__ __launch_bounds__(THREADS) void blur_tile_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ arena,
                                                         uint32_t job_base)
 {
     constexpr int MS = C == 3 ? 4 : C; // floats per pixel in LDS
-    constexpr uint32_t T = BLUR_T;
+    constexpr uint32_t T = THREADS;
     const Job jb = jobs[job_base + blockIdx.y];
     const uint32_t w = jb.sw, h = jb.sh;
     // one table block per (w, h, sigma): header -> this workgroup's tile and band records -> bulk copies
@@ -701,26 +714,26 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
     if (blockIdx.x >= nt * hd.nb) return;
     const uint32_t band = blockIdx.x / nt, tile = blockIdx.x % nt;
     const uint32_t x0 = tile * tw_full, tw = min(tw_full, w - x0);
-    const uint32_t y0 = band * BLUR_TY, ty = min((uint32_t)BLUR_TY, h - y0);
+    const uint32_t y0 = band * TY, ty = min((uint32_t)TY, h - y0);
     const uint32_t tid = threadIdx.x;
     const uint32_t cl = blk[hd.tiles_off + 2 * tile], ncols = blk[hd.tiles_off + 2 * tile + 1]; // ncols <= T by construction
     const uint32_t top = blk[hd.bands_off + 2 * band], nrows = blk[hd.bands_off + 2 * band + 1];
 
-    // LDS: [ wv: rv x BLUR_TY | mid: BLUR_TY x (T + htaps) x MS | wh: htaps x nrows_h (distinct weight vectors) ]
+    // LDS: [ wv: rv x TY | mid: TY x (T + htaps) x MS | wh: htaps x nrows_h (distinct weight vectors) ]
     float *wv = fl_lds;
-    const uint32_t wv_floats = (hd.rv * BLUR_TY + 3u) & ~3u;
-    constexpr uint32_t midw = BLUR_MIDW; // compile-time row pitch: row offsets fold into the ds_read immediates
+    const uint32_t wv_floats = (hd.rv * TY + 3u) & ~3u;
+    constexpr uint32_t midw = blur_midw(THREADS); // compile-time row pitch: row offsets fold into the ds_read immediates
     float *mid = fl_lds + wv_floats;
-    float *wh = mid + BLUR_TY * midw * MS;
+    float *wh = mid + TY * midw * MS;
 
     {
-        const float *vsrc = reinterpret_cast<const float *>(blk + hd.vdense_off) + (size_t)band * hd.rv * BLUR_TY;
-        for (uint32_t i = tid; i < hd.rv * BLUR_TY; i += T) wv[i] = vsrc[i];
+        const float *vsrc = reinterpret_cast<const float *>(blk + hd.vdense_off) + (size_t)band * hd.rv * TY;
+        for (uint32_t i = tid; i < hd.rv * TY; i += T) wv[i] = vsrc[i];
     }
     // columns past the tile's source window are only ever read with zero weights, but must hold finite values
     // (loops are written without integer division: it costs ~40 instructions per element on this ISA)
 #pragma unroll
-    for (int o = 0; o < BLUR_TY; ++o)
+    for (int o = 0; o < TY; ++o)
         for (uint32_t cidx = ncols + tid; cidx < midw; cidx += T) {
 #pragma unroll
             for (int c = 0; c < MS; ++c) mid[(o * midw + cidx) * MS + c] = 0.0f;
@@ -737,9 +750,9 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
     __syncthreads();
 
     // ---- vertical pass ----
-    float acc[BLUR_TY][C];
+    float acc[TY][C];
 #pragma unroll
-    for (int o = 0; o < BLUR_TY; ++o)
+    for (int o = 0; o < TY; ++o)
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[o][c] = 0.0f;
     if (tid < ncols) {
@@ -775,11 +788,13 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
                 }
                 fetch(r + PF, ring[k]);
                 if (r < nrows) {
-                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(wv + r * BLUR_TY);
-                    const f32x4 wb = *reinterpret_cast<const f32x4 *>(wv + r * BLUR_TY + 4);
+                    f32x4 wq[TY / 4];
 #pragma unroll
-                    for (int o = 0; o < BLUR_TY; ++o) {
-                        const float wo = o == 0 ? wa.x : o == 1 ? wa.y : o == 2 ? wa.z : o == 3 ? wa.w : o == 4 ? wb.x : o == 5 ? wb.y : o == 6 ? wb.z : wb.w;
+                    for (int g = 0; g < TY / 4; ++g) wq[g] = *reinterpret_cast<const f32x4 *>(wv + r * TY + 4 * g);
+#pragma unroll
+                    for (int o = 0; o < TY; ++o) {
+                        const f32x4 q4 = wq[o / 4];
+                        const float wo = (o & 3) == 0 ? q4.x : (o & 3) == 1 ? q4.y : (o & 3) == 2 ? q4.z : q4.w;
 #pragma unroll
                         for (int c = 0; c < C; ++c) acc[o][c] = __builtin_fmaf(v[c], wo, acc[o][c]);
                     }
@@ -787,7 +802,7 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
             }
         }
 #pragma unroll
-        for (int o = 0; o < BLUR_TY; ++o) {
+        for (int o = 0; o < TY; ++o) {
             float *m = mid + (o * midw + tid) * MS;
 #pragma unroll
             for (int c = 0; c < C; ++c) m[c] = acc[o][c];
@@ -798,7 +813,7 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
     // ---- horizontal pass (tap order: one fused multiply-add per tap) ----
     if (tid < tw) {
 #pragma unroll
-        for (int o = 0; o < BLUR_TY; ++o)
+        for (int o = 0; o < TY; ++o)
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[o][c] = 0.0f;
         const float *m0 = mid + hleft * MS;
@@ -806,7 +821,7 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
         for (uint32_t i = 0; i < htaps; ++i) {
             const float wi = wh[i * nrh + hrow];
 #pragma unroll
-            for (int o = 0; o < BLUR_TY; ++o) {
+            for (int o = 0; o < TY; ++o) {
                 const float *px = m0 + (o * midw + i) * MS;
                 if constexpr (MS == 4) {
                     const f32x4 q = *reinterpret_cast<const f32x4 *>(px);
@@ -821,7 +836,7 @@ __global__ __launch_bounds__(256) void blur_tile_kernel(const Job *__restrict__ 
             }
         }
 #pragma unroll
-        for (int o = 0; o < BLUR_TY; ++o) {
+        for (int o = 0; o < TY; ++o) {
             if ((uint32_t)o < ty) {
                 uint32_t c8[CS];
 #pragma unroll
@@ -1168,32 +1183,50 @@ hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st
 
 size_t blur_lds_bytes(uint32_t w, uint32_t channels, uint32_t vtaps, uint32_t htaps)
 {
+    const size_t BLUR_TY = (size_t)blur_ty(channels);
     const uint32_t ms = channels == 3 ? 4 : channels;
     const uint32_t nt = blur_tiles(w, htaps), tw = (w + nt - 1) / nt;
     const size_t wv = (((size_t)(BLUR_TY + vtaps) * BLUR_TY + 3) & ~(size_t)3); // rv <= BLUR_TY + vtaps - 1
     (void)tw;
     const size_t rows_h = std::min<size_t>(w, 2 * (size_t)htaps); // distinct horizontal weight vectors: <= htaps (borders) + 1 (interior)
-    return (wv + (size_t)BLUR_TY * BLUR_MIDW * ms + (size_t)htaps * rows_h) * sizeof(float);
+    return (wv + (size_t)BLUR_TY * blur_midw(blur_threads(w, htaps)) * ms + (size_t)htaps * rows_h) * sizeof(float);
 }
 
 uint32_t blur_tile_count(uint32_t w, uint32_t htaps) { return blur_tiles(w, htaps); }
-uint32_t blur_band_rows() { return BLUR_TY; }
+uint32_t blur_lanes(uint32_t w, uint32_t htaps) { return blur_threads(w, htaps); }
+uint32_t blur_band_rows(uint32_t channels_filtered) { return (uint32_t)blur_ty(channels_filtered); }
 
-uint32_t blur_grid_x(uint32_t w, uint32_t h, uint32_t htaps) { return blur_tiles(w, htaps) * ((h + BLUR_TY - 1) / BLUR_TY); }
+uint32_t blur_grid_x(uint32_t w, uint32_t h, uint32_t htaps, uint32_t channels_filtered)
+{
+    const uint32_t ty = (uint32_t)blur_ty(channels_filtered);
+    return blur_tiles(w, htaps) * ((h + ty - 1) / ty);
+}
 
 bool blur_tile_supported(uint32_t htaps) { return htaps >= 1 && htaps <= BLUR_MAXTAPS; }
 
-template <int CS, int C>
-static hipError_t launch_blur_t(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st)
+template <int CS, int C, int THREADS>
+static hipError_t launch_blur_tt(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st)
 {
-    auto k = blur_tile_kernel<CS, C>;
+    auto k = blur_tile_kernel<CS, C, (C == 1 ? BLUR_TY_MONO : BLUR_TY), THREADS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(grid_x, g.njobs), dim3(BLUR_T), lds, st, g.jobs, g.arena, g.job_base);
+    hipLaunchKernelGGL(k, dim3(grid_x, g.njobs), dim3(THREADS), lds, st, g.jobs, g.arena, g.job_base);
     FL_LAUNCH_CHECK();
     return hipSuccess;
+}
+
+// g.blur_lanes = lanes per workgroup chosen for the group (blur_threads of its pictures)
+template <int CS, int C>
+static hipError_t launch_blur_t(const LaunchGeneric &g, uint32_t grid_x, size_t lds, hipStream_t st)
+{
+    switch (g.blur_lanes) {
+    case 256: return launch_blur_tt<CS, C, 256>(g, grid_x, lds, st);
+    case 384: return launch_blur_tt<CS, C, 384>(g, grid_x, lds, st);
+    case 512: return launch_blur_tt<CS, C, 512>(g, grid_x, lds, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 // g.cs = channels stored, g.pre = channels filtered (see blur_tile_kernel)
