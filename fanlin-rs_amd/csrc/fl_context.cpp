@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -171,6 +172,7 @@ struct flgpu_ctx {
     std::vector<std::thread> workers;
     std::vector<flgpu_ctx *> lanes;
     bool collecting = false; // a worker is gathering a batch (one collector at a time keeps batches large)
+    std::atomic<int> staging{0}; // callers currently copying their source into pinned memory, i.e. about to enqueue
     std::mutex qmu;
     std::condition_variable qcv, qdone;
     std::deque<Request *> queue;
@@ -1008,9 +1010,10 @@ void worker_main(flgpu_ctx *c, flgpu_ctx *lane)
             if (c->queue.empty()) { if (c->stop) return; continue; }
             if (c->collecting) continue;
             c->collecting = true;
-            // a first request arrived: wait for company until the batch is full or the flush timer fires
+            // a first request arrived: wait for company -- but only while somebody is actually on the way (a caller
+            // staging its source), and never beyond the flush timer or a full batch.  A lone caller is served at once.
             const auto deadline = std::chrono::steady_clock::now() + flush;
-            while (c->queue.size() < max_batch && !c->stop) {
+            while (c->queue.size() < max_batch && !c->stop && c->staging.load(std::memory_order_acquire) > 0) {
                 if (c->qcv.wait_until(lk, deadline) == std::cv_status::timeout) break;
             }
             while (!c->queue.empty() && batch.size() < max_batch) { batch.push_back(c->queue.front()); c->queue.pop_front(); }
@@ -1126,12 +1129,14 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
         const uint64_t worst = 1024ull + 2ull * kJpegMaxUnitBytes * 3ull * (plan.plane_w / 8u) * (plan.plane_h / 8u);
         r.out_bytes = std::max<uint64_t>(plan.out_bytes, std::min<uint64_t>(dst->capacity, worst));
     }
+    c->staging.fetch_add(1, std::memory_order_acq_rel);
     r.in = pin_acquire(c, r.src_bytes);
     r.out = pin_acquire(c, r.out_bytes);
-    if (!r.in.p || !r.out.p) { pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_OOM; }
+    if (!r.in.p || !r.out.p) { c->staging.fetch_sub(1, std::memory_order_acq_rel); pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_OOM; }
     memcpy(r.in.p, src->data, r.src_bytes); // on the caller's thread: concurrent callers stage in parallel
     {
         std::unique_lock<std::mutex> lk(c->qmu);
+        c->staging.fetch_sub(1, std::memory_order_acq_rel);
         if (c->stop) { lk.unlock(); pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_SHUTDOWN; }
         if (!c->worker_started) {
             // lanes: child contexts on the same device (cfg.queue_lanes, default 3)
