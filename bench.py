@@ -89,6 +89,45 @@ def measured_traffic(workload: str):
     return rec.get(workload, {}).get("hbm_bytes_per_launch")
 
 
+def broadcast_icc_lut(fl, st, rank, dev, cdev):
+    """the read-only CMYK -> sRGB device-link table (17^4 x 3 u16 = 501 KB) is baked once, on rank 0, and
+    reaches the other GPUs by one broadcast (RCCL over xGMI with --backend nccl); every rank then converts the same
+    CMYK pixels and the results are compared.  Untimed; any failure is reported in the JSON line, never raised."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    try:
+        lut = torch.zeros(17 ** 4 * 3 * 2, dtype=torch.uint8, device=cdev)   # u16 table as bytes (every backend moves uint8)
+        baked = 0
+        if rank == 0:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import synth_icc
+                st.set_cmyk_profile(synth_icc.cmyk_profile())          # needs liblcms2 on the host
+                lut = torch.from_numpy(st.get_cmyk_clut().view(np.uint8).reshape(-1).copy()).to(cdev)
+                baked = 1
+            except Exception:
+                baked = 0
+        flag = torch.tensor([baked], dtype=torch.int64, device=cdev)
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) == 0:
+            return {"ok": False, "reason": "rank 0 could not bake a table (liblcms2 missing?)"}
+        dist.broadcast(lut, src=0)
+        st.set_cmyk_clut(lut.cpu().numpy().view(np.uint16))
+        rng = np.random.default_rng(7)
+        px = rng.integers(0, 256, (1 << 16, 4), dtype=np.uint8)
+        rgb = st.cmyk_to_rgb(px)
+        digest = torch.tensor([int(rgb.astype(np.uint64).sum()), int((rgb.astype(np.uint64) * np.arange(1, rgb.size + 1, dtype=np.uint64).reshape(rgb.shape) % 65521).sum())],
+                              dtype=torch.int64, device=cdev)
+        ref = digest.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([int(bool((ref == digest).all()))], dtype=torch.int64, device=cdev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        return {"ok": bool(same.item()), "bytes": int(lut.numel()), "pixels_checked_per_rank": int(px.shape[0])}
+    except Exception as e:  # the bench line must survive
+        return {"ok": False, "reason": repr(e)[:200]}
+
+
 def latency_probe_c(args, query: str, front_end: int):
     """The same probe from a plain C program (tools/latency/latency_probe.c, built by __graft_entry__.build()):
     pthread callers instead of Python threads, so the interpreter lock is not part of the measurement."""
@@ -224,6 +263,9 @@ def main():
         torch.cuda.synchronize()
         st.import_tables(blob.data_ptr(), nbytes)
         del blob, payload
+        icc_note = broadcast_icc_lut(fl, st, rank, dev, cdev)
+    else:
+        icc_note = None
 
     for _ in range(args.warmup):
         run(stream)
@@ -274,6 +316,8 @@ def main():
                                   "frontend": stats["frontend_ms"] / args.steps},
         }
         line["roofline"]["traffic"] = measured_traffic(line["config"]["workload"])
+        if icc_note is not None:
+            line["icc_lut_broadcast"] = icc_note
         if args.latency_requests > 0 and world == 1:
             query = f"w={REQ_W}&h={REQ_H}" + ("&crop=true" if args.crop else "") + (f"&blur={int(args.blur)}" if args.blur else "") \
                 + ("&grayscale=true" if args.grayscale else "")
