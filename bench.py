@@ -108,22 +108,28 @@ def broadcast_icc_lut(fl, st, rank, dev, cdev):
                 baked = 1
             except Exception:
                 baked = 0
+        # from here on every rank issues the same collectives whatever happens locally (a rank that raised between
+        # two collectives would leave the others waiting)
         flag = torch.tensor([baked], dtype=torch.int64, device=cdev)
         dist.broadcast(flag, src=0)
         if int(flag.item()) == 0:
             return {"ok": False, "reason": "rank 0 could not bake a table (liblcms2 missing?)"}
         dist.broadcast(lut, src=0)
-        st.set_cmyk_clut(lut.cpu().numpy().view(np.uint16))
-        rng = np.random.default_rng(7)
-        px = rng.integers(0, 256, (1 << 16, 4), dtype=np.uint8)
-        rgb = st.cmyk_to_rgb(px)
-        digest = torch.tensor([int(rgb.astype(np.uint64).sum()), int((rgb.astype(np.uint64) * np.arange(1, rgb.size + 1, dtype=np.uint64).reshape(rgb.shape) % 65521).sum())],
-                              dtype=torch.int64, device=cdev)
+        digest = torch.zeros(2, dtype=torch.int64, device=cdev)
+        local_ok, n_px = 1, 1 << 16
+        try:
+            st.set_cmyk_clut(lut.cpu().numpy().view(np.uint16))
+            px = np.random.default_rng(7).integers(0, 256, (n_px, 4), dtype=np.uint8)
+            rgb = st.cmyk_to_rgb(px).astype(np.uint64)
+            digest = torch.tensor([int(rgb.sum()), int((rgb * (np.arange(rgb.size, dtype=np.uint64).reshape(rgb.shape) % 251 + 1)).sum() % (1 << 62))],
+                                  dtype=torch.int64, device=cdev)
+        except Exception:
+            local_ok = 0
         ref = digest.clone()
         dist.broadcast(ref, src=0)
-        same = torch.tensor([int(bool((ref == digest).all()))], dtype=torch.int64, device=cdev)
+        same = torch.tensor([int(local_ok and bool((ref == digest).all()))], dtype=torch.int64, device=cdev)
         dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        return {"ok": bool(same.item()), "bytes": int(lut.numel()), "pixels_checked_per_rank": int(px.shape[0])}
+        return {"ok": bool(same.item()), "bytes": int(lut.numel()), "pixels_checked_per_rank": n_px}
     except Exception as e:  # the bench line must survive
         return {"ok": False, "reason": repr(e)[:200]}
 
