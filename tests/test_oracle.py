@@ -254,9 +254,9 @@ def test_ycck_loop_known_answers(oracle):
 # ---- frozen outputs ----------------------------------------------------------------------------------
 
 def test_frozen_oracle_outputs(oracle):
-    # tools/gen_oracle_golden.py; freezes the restatement itself (not reference output)
+    # tests/tools/gen_oracle_golden.py; freezes the restatement itself (not reference output)
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import gen_oracle_golden as gen
     g = np.load(os.path.join(GOLDEN, "oracle_ref.npz"))
     for name, (h, w, c, dist, kw) in gen.CASES.items():

@@ -1,6 +1,6 @@
 """One-off: the extremes of the request space (size gate 20..2000 x 20..1000, 8K sources) against the oracle."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/tools/ -> repository root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib, synth

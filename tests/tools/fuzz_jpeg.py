@@ -1,7 +1,7 @@
 """One-off fuzzing of the device JPEG encoder against the oracle encoder (byte equality):
-    python tools/experiments/fuzz_jpeg.py <cases> <seed>"""
+    python tests/tools/fuzz_jpeg.py <cases> <seed>"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/tools/ -> repository root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib, synth

@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/tools/ -> repository root
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib  # noqa: E402
 import synth  # noqa: E402
