@@ -79,9 +79,10 @@ typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t> AxisKey; // in, out, 
 struct StreamPlanKey {
     AxisKey v, h;
     uint32_t cx, cy, cw, ch, nbands;
+    uint32_t mono; // single-channel rows keep 4-byte partial sums in LDS: a different LDS footprint for the same geometry
     bool operator<(const StreamPlanKey &o) const
     {
-        return std::tie(v, h, cx, cy, cw, ch, nbands) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.nbands);
+        return std::tie(v, h, cx, cy, cw, ch, nbands, mono) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.nbands, o.mono);
     }
 };
 
@@ -265,7 +266,7 @@ uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma
 const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
                                   uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs, uint32_t pre)
 {
-    StreamPlanKey key{vk, hk, cx, cy, cw, ch, nbands};
+    StreamPlanKey key{vk, hk, cx, cy, cw, ch, nbands, mid_channels(cs, pre) == 1 ? 1u : 0u};
     auto it = c->stream_plans.find(key);
     if (it != c->stream_plans.end()) return &it->second;
     StreamPlan plan;
@@ -311,7 +312,7 @@ const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxi
             const uint32_t wt_off = arena_append(c, s.wt.data(), s.wt.size());
             const uint32_t po_off = arena_append(c, s.po.data(), s.po.size());
             if (!wt_off || !po_off) { ok = false; break; }
-            plan.lds_bytes = std::max(plan.lds_bytes, stream_lds_bytes(s.jmax, s.x1 - s.x0, s.ks));
+            plan.lds_bytes = std::max(plan.lds_bytes, stream_lds_bytes(s.jmax, s.x1 - s.x0, s.ks, mid_channels(cs, pre)));
             for (size_t bi = 0; bi < bands.size(); ++bi) {
                 const Band &b = bands[bi];
                 StreamItem it2{};

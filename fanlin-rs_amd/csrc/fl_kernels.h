@@ -79,7 +79,7 @@ hipError_t launch_blur_tile(const LaunchGeneric &g, uint32_t grid_x, size_t lds,
 
 bool stream_supported(uint32_t cs, uint32_t pre);
 uint32_t stream_block_rows(); // source rows per block of the streaming kernel (emits are deferred to block ends)
-size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks);
+size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks, uint32_t mid_channels);
 uint32_t stream_lanes(); // lanes (threads) per workgroup of the streaming kernel
 hipError_t launch_stream(const LaunchStream &s, hipStream_t st);
 

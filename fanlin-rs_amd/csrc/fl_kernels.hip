@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "fl_kernels.h"
 #include "fl_pixel.h"
 
@@ -393,21 +395,22 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
     const uint32_t tid = threadIdx.x;
     const uint32_t nxs = it.x1 - it.x0;
 
-    // LDS: [ sch: 2 x SCHED_CHUNK RowSched | WT: jmax x T float4 | PO: jmax x T u32 | pbuf: (nxs * ks + 1) float4 ]
+    // LDS: [ sch: 2 x SCHED_CHUNK RowSched | WT: jmax x T float4 | PO: jmax x T u32 | pbuf: (nxs * ks + 1) x (float4, or float
+    // for single-channel rows: the smaller buffer lets a third workgroup fit a CU) ]
     constexpr uint32_t SCH_WORDS = SCHED_CHUNK * (sizeof(RowSched) / 4);
     uint32_t *sch = reinterpret_cast<uint32_t *>(lds);
     const uint32_t jmax = it.jmax, kmax = it.kmax, ks = it.ks;
     f32x4 *wt = reinterpret_cast<f32x4 *>(lds + 2 * SCH_WORDS);
     uint32_t *po = reinterpret_cast<uint32_t *>(lds + 2 * SCH_WORDS + jmax * T * 4);
     const uint32_t pbuf_off = 2 * SCH_WORDS + jmax * T * 5; // float offset, a multiple of 4
-    f32x4 *pbuf = reinterpret_cast<f32x4 *>(lds + pbuf_off);
+    using PT = typename std::conditional<MC == 1, float, f32x4>::type; // one partial sum (all channels of one output column)
+    PT *pbuf = reinterpret_cast<PT *>(lds + pbuf_off);
 
     // stage the strip's horizontal tables and zero the partial-sum buffer (slots no lane writes stay 0 forever)
     {
         const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(arena + it.wt_off);
         for (uint32_t i = tid; i < jmax * T; i += T) { wt[i] = wsrc[i]; po[i] = arena[it.po_off + i]; }
-        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (uint32_t i = tid; i < nxs * ks + 1; i += T) pbuf[i] = zero;
+        for (uint32_t i = tid; i < nxs * ks + 1; i += T) pbuf[i] = PT{};
         for (uint32_t i = tid; i < SCH_WORDS; i += T) sch[i] = arena[it.sched_off + i]; // first schedule chunk
     }
 
@@ -603,9 +606,13 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
 #pragma unroll
                         for (int c = 0; c < MC; ++c) part[c] = __builtin_fmaf(e[p * MC + c], wp, part[c]);
                     }
-                    f32x4 q;
-                    q.x = part[0]; q.y = part[1]; q.z = part[2]; q.w = part[3];
-                    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(pbuf) + slot) = q;
+                    if constexpr (MC == 1) {
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(pbuf) + (slot >> 2)) = part[0]; // table offsets are in 16-byte slots
+                    } else {
+                        f32x4 q;
+                        q.x = part[0]; q.y = part[1]; q.z = part[2]; q.w = part[3];
+                        *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(pbuf) + slot) = q;
+                    }
                 }
             }
             // LDS-only hand-off (no vmcnt drain: the prefetched rows and the pixel stores stay in flight)
@@ -614,42 +621,35 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
             // sums are fetched into registers first and the second barrier sits right behind the fetch, so
             // the other waves go back to the vertical pass while the additions, rounding and store run.
             constexpr uint32_t KREG = 12; // partial sums held in registers across the barrier
-            f32x4 q[KREG];
-            const f32x4 *pp = pbuf + tid * ks;
+            PT q[KREG];
+            const PT *pp = pbuf + tid * ks;
             const bool reducer = !(ablate & 1u) && !(ablate & 32u) && tid < nxs;
             if (reducer) {
 #pragma unroll
-                for (uint32_t k = 0; k < KREG; ++k) q[k] = k < kmax ? pp[k] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                for (uint32_t k = 0; k < KREG; ++k) q[k] = k < kmax ? pp[k] : PT{};
             }
             float sum[MC];
 #pragma unroll
             for (int c = 0; c < MC; ++c) sum[c] = 0.0f;
-            if (reducer && kmax > KREG) { // long windows (ratio > ~7): finish the fetch before releasing the buffer
-#pragma unroll
-                for (uint32_t k = 0; k < KREG; ++k) {
-                    sum[0] = sum[0] + q[k].x;
-                    if constexpr (MC > 1) sum[1] = sum[1] + q[k].y;
-                    if constexpr (MC > 2) sum[2] = sum[2] + q[k].z;
-                    if constexpr (MC > 3) sum[3] = sum[3] + q[k].w;
-                }
-                for (uint32_t k = KREG; k < kmax; ++k) {
-                    const f32x4 r = pp[k];
+            auto add_partial = [&](const PT &r) {
+                if constexpr (MC == 1) sum[0] = sum[0] + r;
+                else {
                     sum[0] = sum[0] + r.x;
                     if constexpr (MC > 1) sum[1] = sum[1] + r.y;
                     if constexpr (MC > 2) sum[2] = sum[2] + r.z;
                     if constexpr (MC > 3) sum[3] = sum[3] + r.w;
                 }
+            };
+            if (reducer && kmax > KREG) { // long windows (ratio > ~7): finish the fetch before releasing the buffer
+#pragma unroll
+                for (uint32_t k = 0; k < KREG; ++k) add_partial(q[k]);
+                for (uint32_t k = KREG; k < kmax; ++k) add_partial(pp[k]);
             }
             if (!(ablate & 8u)) lds_barrier();
             if (reducer) {
                 if (kmax <= KREG) {
 #pragma unroll
-                    for (uint32_t k = 0; k < KREG; ++k) { // slots past kmax hold +0: adding them changes nothing
-                        sum[0] = sum[0] + q[k].x;
-                        if constexpr (MC > 1) sum[1] = sum[1] + q[k].y;
-                        if constexpr (MC > 2) sum[2] = sum[2] + q[k].z;
-                        if constexpr (MC > 3) sum[3] = sum[3] + q[k].w;
-                    }
+                    for (uint32_t k = 0; k < KREG; ++k) add_partial(q[k]); // slots past kmax hold +0: adding them changes nothing
                 }
                 uint32_t c8[MC];
 #pragma unroll
@@ -1243,9 +1243,10 @@ hipError_t launch_blur_tile(const LaunchGeneric &g, uint32_t grid_x, size_t lds,
     return hipErrorInvalidValue;
 }
 
-size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks)
+size_t stream_lds_bytes(uint32_t jmax, uint32_t nxs, uint32_t ks, uint32_t mid_channels)
 {
-    return 2 * SCHED_CHUNK * sizeof(RowSched) + (size_t)jmax * 256 * 20 + ((size_t)nxs * ks + 1) * 16;
+    const size_t pbuf = (((size_t)nxs * ks + 1) * (mid_channels == 1 ? 4 : 16) + 15) & ~(size_t)15;
+    return 2 * SCHED_CHUNK * sizeof(RowSched) + (size_t)jmax * 256 * 20 + pbuf;
 }
 
 uint32_t stream_lanes() { return 256; }
