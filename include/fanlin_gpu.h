@@ -25,7 +25,14 @@
  *                                       src/handler.rs:274-278
  *   front_end = FLGPU_FE_WEBP420        WebPPictureImportRGBA + ARGB->YUV420 inside
  *                                       webp::Encoder::encode, src/handler.rs:295-297
+ *   front_end = FLGPU_FE_JPEG           the whole jpeg::JpegEncoder::new_with_quality(q).encode_image(&img),
+ *                                       src/handler.rs:274-278 (FDCT, quantiser, Huffman coder, framing)
+ *   params.filter = NEAREST             the per-frame pipeline of process_gif, src/handler.rs:327-353
+ *   flgpu_process_image                 State::process_image after the decoder as one call, src/handler.rs:198-308
  *   flgpu_ycck_to_cmyk                  the YCCK loop of convert_jpeg_color_if_needed, src/handler.rs:423-438
+ *   flgpu_set_cmyk_profile / _clut      create_cmyk_to_rgb_converter + CMYK2RGB::with_icc_profile,
+ *                                       src/main.rs:74-76, src/handler.rs:469-488
+ *   flgpu_cmyk_to_rgb[_device]          CMYK2RGB::convert = lcms2 transform_pixels, src/handler.rs:446-462,490-492
  *   flgpu_create / flgpu_destroy        lifetime of handler::State, src/handler.rs:14-21,36-52
  */
 #ifndef FANLIN_GPU_H
@@ -38,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FLGPU_ABI_VERSION 1
+#define FLGPU_ABI_VERSION 2
 
 typedef enum flgpu_status {
     FLGPU_OK = 0,

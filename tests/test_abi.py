@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(fl):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(fl.EXPORTED_SYMBOLS) == names, "python binding list is out of date with the header"
-    assert lib.flgpu_abi_version() == 1
+    assert lib.flgpu_abi_version() == 2   # bumped with flgpu_image::bytes, flgpu_params::orientation / filter, flgpu_plan::src_w / src_h
 
 
 def test_struct_layouts_match_the_header(fl):

@@ -12,10 +12,10 @@ SRC = os.path.join(ROOT, "tests", "c_client.c")
 LIBDIR = os.path.join(ROOT, "fanlin-rs_amd")
 
 
-def build(tmp_path):
-    exe = str(tmp_path / "c_client")
-    subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-std=c11", SRC, "-I", os.path.join(ROOT, "include"), "-L", LIBDIR,
-                    "-lfanlin_gpu", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+def build(tmp_path, src=SRC, name="c_client"):
+    exe = str(tmp_path / name)
+    subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-std=c11", src, "-I", os.path.join(ROOT, "include"), "-L", LIBDIR,
+                    "-lfanlin_gpu", "-lpthread", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     return exe
 
 
@@ -58,3 +58,19 @@ def test_c_client_matches_oracle(fl, oracle, tmp_path, query, shape):
     img = lcg_image(h, w, c)
     assert np.array_equal(got, oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **kw))
     assert np.abs(got.astype(int) - oracle.process_pixels(img, arith=oracle_lib.ARITH_REF, **kw).astype(int)).max() <= 1
+
+
+def test_c_stress_compiles(fl, tmp_path):
+    build(tmp_path, os.path.join(ROOT, "tests", "c_stress.c"), "c_stress")
+
+
+@pytest.mark.gpu
+def test_mixed_concurrent_requests_equal_sequential_ones(fl, tmp_path):
+    # 24 threads x 12 mixed requests through the multi-lane queue, then the same 288 requests one at a time
+    import json
+    exe = build(tmp_path, os.path.join(ROOT, "tests", "c_stress.c"), "c_stress")
+    r = subprocess.run([exe, "24", "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["requests"] == 288 and out["mismatches"] == 0
+    assert out["queue_flushes"] < 2 * 288          # the concurrent half really was batched
