@@ -77,3 +77,12 @@ def test_plan_known_geometry(fl):
         fl.plan_output(fl.make_params(0, 5), 10, 10, 3)
     with pytest.raises(fl.FanlinError):
         fl.plan_output(fl.make_params(), 10, 10, 5)
+
+
+def test_degenerate_cover_size_is_refused_not_guessed(fl):
+    # resize_to_fill of a 1-pixel-wide source to 658x240 first builds a 658 x 1,074,514 covering image in the reference
+    # (gigabytes of Rgba32F): the device path answers FLGPU_ERR_UNSUPPORTED and the handler's error arm takes over
+    with pytest.raises(fl.FanlinError) as e:
+        fl.plan_output(fl.make_params(658, 240, crop=True), 1, 1633, 4)
+    assert e.value.status == fl.ERR_UNSUPPORTED
+    assert fl.plan_output(fl.make_params(658, 240), 1, 1633, 4).out_w == 658        # without crop: 1 x 240 letterboxed, fine
