@@ -174,6 +174,11 @@ struct flgpu_ctx {
     std::vector<flgpu_ctx *> lanes;
     bool collecting = false; // a worker is gathering a batch (one collector at a time keeps batches large)
     std::atomic<int> staging{0}; // callers currently copying their source into pinned memory, i.e. about to enqueue
+    // admission: callers beyond a few batches' worth wait BEFORE staging (a thousand threads each copying megabytes
+    // into pinned memory only evict each other's buffers and starve the lane threads of CPU time)
+    std::mutex adm_mu;
+    std::condition_variable adm_cv;
+    uint32_t admitted = 0;
     std::mutex qmu;
     std::condition_variable qcv, qdone;
     std::deque<Request *> queue;
@@ -1130,6 +1135,17 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
         const uint64_t worst = 1024ull + 2ull * kJpegMaxUnitBytes * 3ull * (plan.plane_w / 8u) * (plan.plane_h / 8u);
         r.out_bytes = std::max<uint64_t>(plan.out_bytes, std::min<uint64_t>(dst->capacity, worst));
     }
+    {
+        const uint32_t lanes = std::min<uint32_t>(std::max<uint32_t>(c->cfg.queue_lanes ? c->cfg.queue_lanes : 3u, 1u), 8u);
+        const uint32_t limit = 4u * lanes * (c->cfg.max_batch ? c->cfg.max_batch : 32u);
+        std::unique_lock<std::mutex> lk(c->adm_mu);
+        c->adm_cv.wait(lk, [&] { return c->admitted < limit; });
+        c->admitted++;
+    }
+    struct Admission {
+        flgpu_ctx *c;
+        ~Admission() { { std::lock_guard<std::mutex> lk(c->adm_mu); c->admitted--; } c->adm_cv.notify_one(); }
+    } admission{c};
     c->staging.fetch_add(1, std::memory_order_acq_rel);
     r.in = pin_acquire(c, r.src_bytes);
     r.out = pin_acquire(c, r.out_bytes);
