@@ -146,10 +146,11 @@ __global__ __launch_bounds__(256) void vpass_generic_kernel(const Job *__restric
                                                             float *__restrict__ mid, uint32_t job_base)
 {
     constexpr int MC = mid_channels(CS, PRE);
-    const Job jb = jobs[job_base + blockIdx.z];
-    const uint32_t oy = blockIdx.y;
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
-    if (oy >= jb.rh || x >= jb.sw) return;
+    const Job jb = jobs[job_base + blockIdx.y];
+    // flat over rows x columns of THIS job: narrow pictures (thumbnails) still fill their waves
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= jb.rh * jb.sw) return;
+    const uint32_t oy = idx / jb.sw, x = idx - oy * jb.sw;
     const AxisTable *tab = reinterpret_cast<const AxisTable *>(arena + jb.vtab);
     const uint32_t left = arena[tab->left_off + oy];
     const uint32_t n = arena[tab->count_off + oy];
@@ -179,10 +180,10 @@ template <int MC, bool LB, bool GROUPED>
 __global__ __launch_bounds__(256) void hpass_generic_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ arena,
                                                             const float *__restrict__ mid, uint32_t job_base)
 {
-    const Job jb = jobs[job_base + blockIdx.z];
-    const uint32_t yy = blockIdx.y;                        // row inside the kept (cropped) window
-    const uint32_t xx = blockIdx.x * 256u + threadIdx.x;   // column inside the kept window
-    if (yy >= jb.ch || xx >= jb.cw) return;
+    const Job jb = jobs[job_base + blockIdx.y];
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;  // flat over the kept (cropped) window of this job
+    if (idx >= jb.ch * jb.cw) return;
+    const uint32_t yy = idx / jb.cw, xx = idx - yy * jb.cw; // row / column inside the kept window
     const uint32_t x = jb.cx + xx, y = jb.cy + yy;
     const AxisTable *tab = reinterpret_cast<const AxisTable *>(arena + jb.htab);
     const uint32_t left = arena[tab->left_off + x];
@@ -235,10 +236,10 @@ template <int CS, int PRE, bool LB, bool BORDER_ONLY, bool NEAREST = false>
 __global__ __launch_bounds__(256) void place_kernel(const Job *__restrict__ jobs, uint32_t job_base)
 {
     constexpr int MC = mid_channels(CS, PRE);
-    const Job jb = jobs[job_base + blockIdx.z];
-    const uint32_t y = blockIdx.y;
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
-    if (y >= jb.dh || x >= jb.dw) return;
+    const Job jb = jobs[job_base + blockIdx.y];
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;  // flat over the destination of this job
+    if (idx >= jb.dh * jb.dw) return;
+    const uint32_t y = idx / jb.dw, x = idx - y * jb.dw;
     const bool inside = x >= jb.ox && x < jb.ox + jb.cw && y >= jb.oy && y < jb.oy + jb.ch;
     if (!inside) {
         if (LB) reinterpret_cast<uint32_t *>(jb.dst)[y * jb.dw + x] = jb.fill;
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(256) void cmyk_clut_kernel(const uint4 *__restrict_
 template <int CS, int PRE>
 static hipError_t launch_vpass_t(const LaunchGeneric &g, hipStream_t st)
 {
-    dim3 grid((g.max_sw + 255u) / 256u, g.max_rh, g.njobs);
+    dim3 grid((g.max_sw * g.max_rh + 255u) / 256u, g.njobs);
     hipLaunchKernelGGL((vpass_generic_kernel<CS, PRE>), grid, dim3(256), 0, st, g.jobs, g.arena, g.mid, g.job_base);
     FL_LAUNCH_CHECK();
     return hipSuccess;
@@ -1136,7 +1137,7 @@ hipError_t launch_vpass_generic(const LaunchGeneric &g, hipStream_t st)
 template <int MC, bool LB>
 static hipError_t launch_hpass_t(const LaunchGeneric &g, hipStream_t st)
 {
-    dim3 grid((g.max_cw + 255u) / 256u, g.max_ch, g.njobs);
+    dim3 grid((g.max_cw * g.max_ch + 255u) / 256u, g.njobs);
     if (g.grouped) hipLaunchKernelGGL((hpass_generic_kernel<MC, LB, true>), grid, dim3(256), 0, st, g.jobs, g.arena, g.mid, g.job_base);
     else hipLaunchKernelGGL((hpass_generic_kernel<MC, LB, false>), grid, dim3(256), 0, st, g.jobs, g.arena, g.mid, g.job_base);
     FL_LAUNCH_CHECK();
@@ -1155,7 +1156,7 @@ hipError_t launch_hpass_generic(const LaunchGeneric &g, hipStream_t st)
 template <int CS, int PRE>
 static hipError_t launch_place_t(const LaunchGeneric &g, bool border_only, hipStream_t st)
 {
-    dim3 grid((g.max_dw + 255u) / 256u, g.max_dh, g.njobs);
+    dim3 grid((g.max_dw * g.max_dh + 255u) / 256u, g.njobs);
     if (g.nearest) {
         if (g.letterbox) hipLaunchKernelGGL((place_kernel<CS, PRE, true, false, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
         else hipLaunchKernelGGL((place_kernel<CS, PRE, false, false, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
