@@ -664,6 +664,12 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             jobs.push_back(j);
             L.njobs++;
         }
+        if ((k.kind & 255u) == S1_STREAM && L.nitems > 1) {
+            // longest workgroups first: in a mixed batch a 4K band walks four times the rows of a 1080p one, and the
+            // hardware hands out workgroups in index order -- started last, the long ones would be the launch's tail
+            auto first = items.begin() + L.item_base;
+            std::stable_sort(first, first + L.nitems, [](const StreamItem &a, const StreamItem &b) { return a.r1 - a.r0 > b.r1 - b.r0; });
+        }
         s1_launches.push_back(L);
     }
     for (auto &kv : blur_groups) {
