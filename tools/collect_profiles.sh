@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --cpu-images 0 --latency-requests 0"
 run() { echo "== $*" >&2; timeout -k 10 300 "$@"; }
 # kernel time summaries (the same commands bench.py is judged on, fewer steps)
-run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config1 -o c1 -- $B --steps 5 --warmup 2 > $O/config1.log 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config1 -o c1 -- $B --steps 20 --warmup 3 > $O/config1.log 2>&1   # bench.py defaults
 run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config2 -o c2 -- $B --steps 5 --warmup 2 --blur 10 --grayscale > $O/config2.log 2>&1
 run rocprofv3 --kernel-trace --stats --output-format csv -d $O/jpeg -o jp -- $B --steps 5 --warmup 2 --frontend jpeg > $O/jpeg.log 2>&1
 # HBM traffic and instruction counters of config 1, one pass per counter group

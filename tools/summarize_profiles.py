@@ -75,6 +75,19 @@ def main():
         line = open(p).read().strip().splitlines()[-1]
         json.loads(line)
         open(os.path.join(OUT, f"{tag}_" + os.path.basename(p)), "w").write(line + "\n")
+    with open(os.path.join(OUT, f"{tag}_commands.txt"), "w") as f:
+        f.write("""How the files of this round were produced (tools/collect_profiles.sh on a 1 x MI355X box, then tools/summarize_profiles.py):
+
+{tag}_config1_kernel_stats.csv       rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --cpu-images 0 --latency-requests 0 --steps 20 --warmup 3
+                                     (bench.py's defaults; 24 launches of the kernel: 1 planning run + 3 warm-up + 20 timed, so the average includes the cold first launch)
+{tag}_config2_kernel_stats.csv       ... -- python3 bench.py --cpu-images 0 --latency-requests 0 --steps 5 --warmup 2 --blur 10 --grayscale
+{tag}_config1_jpeg_kernel_stats.csv  ... -- python3 bench.py --cpu-images 0 --latency-requests 0 --steps 5 --warmup 2 --frontend jpeg
+{tag}_config1_pmc.txt, traffic.json  rocprofv3 --kernel-trace --pmc <one counter group per pass> --output-format csv -- python3 bench.py --cpu-images 0 --latency-requests 0 --steps 2 --warmup 1
+{tag}_bench_*.json                   python3 bench.py [--crop | --blur 10 --grayscale | --frontend jfif444|webp420|jpeg] (config1: plain defaults, with the latency probe and the CPU baseline)
+{tag}_latency_sweep.txt              tools/experiments/latency_sweep.sh + tools/latency/latency_probe <threads> 4096 1920 1080 "w=300&h=200"
+{tag}_microbench_valu_rate.txt       tools/microbench/valu_rate.hip
+(only rows of this repository's kernels, fl::*, are kept in the kernel statistics)
+""".replace("{tag}", tag))
     print("profiles/ updated:", sorted(os.listdir(OUT)))
 
 
