@@ -621,7 +621,8 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(const Job *__restr
             // step 2 (one lane per output column): add the partial sums in ascending pixel order.  The partial
             // sums are fetched into registers first and the second barrier sits right behind the fetch, so
             // the other waves go back to the vertical pass while the additions, rounding and store run.
-            constexpr uint32_t KREG = 12; // partial sums held in registers across the barrier
+            // partial sums held in registers across the barrier; Rgba8 rows (16 accumulators per slot) cannot afford 12 x 4
+            constexpr uint32_t KREG = (MC == 4) ? 2 : 12;
             PT q[KREG];
             const PT *pp = pbuf + tid * ks;
             const bool reducer = !(ablate & 1u) && !(ablate & 32u) && tid < nxs;
