@@ -74,3 +74,22 @@ def test_mixed_concurrent_requests_equal_sequential_ones(fl, tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["requests"] == 288 and out["mismatches"] == 0
     assert out["queue_flushes"] < 2 * 288          # the concurrent half really was batched
+
+
+def build_cpp(tmp_path):
+    exe = str(tmp_path / "cpp_host")
+    subprocess.run(["g++", "-O1", "-Wall", "-Wextra", "-Werror", "-std=c++17", os.path.join(ROOT, "tests", "cpp_host.cpp"), "-I", os.path.join(ROOT, "include"),
+                    "-L", LIBDIR, "-lfanlin_gpu", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_cpp_mirror_of_query_and_format(fl, tmp_path):
+    # include/fanlin_gpu.hpp: query::Query / content::Format / handler::State with the reference's names
+    r = subprocess.run([build_cpp(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "host ok" in r.stdout, r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_state_process_image(fl, tmp_path):
+    r = subprocess.run([build_cpp(tmp_path), "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "gpu ok" in r.stdout, r.stderr
