@@ -71,7 +71,9 @@ typedef struct flgpu_image {
 
 #define FLGPU_IMG_FRONTEND_PLANES 1u  /* dst->data holds encoder planes, not interleaved pixels */
 #define FLGPU_IMG_ENCODED         4u  /* JPEG: data holds an encoded stream of `bytes` bytes */
-#define FLGPU_IMG_HAS_ALPHA       2u  /* WEBP420: picture has non-opaque alpha; planes were NOT produced */
+#define FLGPU_IMG_HAS_ALPHA       2u  /* WEBP420: some pixel is not opaque.  libwebp then weights chroma by alpha and adds an
+                                         alpha plane (WebPPictureImportRGBA path): the planes returned here are NOT what it
+                                         would encode -- hand such pictures to the encoder as RGBA pixels instead */
 
 /* Encoder colour front end to run after the pixel pipeline. */
 typedef enum flgpu_front_end {
