@@ -330,6 +330,7 @@ class Planes:
     u: np.ndarray
     v: np.ndarray
     has_alpha: bool = False
+    a: Optional[np.ndarray] = None   # WebP: the alpha plane (all 255 unless has_alpha)
 
 
 def _as_image_array(a: np.ndarray) -> np.ndarray:
@@ -351,7 +352,8 @@ def _split_output(buf: np.ndarray, plan: flgpu_plan, front_end: int, flags: int,
     return Planes(y=buf[:ny].reshape(plan.plane_h, plan.plane_w),
                   u=buf[ny:ny + nc].reshape(plan.chroma_h, plan.chroma_w),
                   v=buf[ny + nc:ny + 2 * nc].reshape(plan.chroma_h, plan.chroma_w),
-                  has_alpha=bool(flags & IMG_HAS_ALPHA))
+                  has_alpha=bool(flags & IMG_HAS_ALPHA),
+                  a=buf[ny + 2 * nc:2 * ny + 2 * nc].reshape(plan.plane_h, plan.plane_w) if front_end == FE_WEBP420 else None)
 
 
 class State:

@@ -893,6 +893,38 @@ __device__ __forceinline__ int webp_linear_to_gamma(const int32_t *lin2gam, uint
     return (y + 64) >> 7;                    // kGammaTabRounder, GAMMA_TAB_FIX
 }
 
+// One 2x2 block of libwebp's chroma down-sampling (picture_csp_enc.c AccumulateRGB / AccumulateRGBA): the four pixels
+// (edge blocks repeat the last column / row: libwebp's SUM2 with shift 1, or step = 0 / rgb_stride = 0, are the same
+// numbers) are averaged in linear light; a block that is neither fully opaque nor fully transparent weights them by
+// alpha: LinearToGammaWeighted = LinearToGamma((sum a_i * GammaToLinear(c_i) * kInvAlpha[a]) >> 17), kInvAlpha[a] = 2^19 / a.
+struct WebpBlock {
+    uint32_t sr = 0, sg = 0, sb = 0;     // plain sums of GammaToLinear
+    uint32_t wr = 0, wg = 0, wb = 0;     // alpha-weighted sums
+    uint32_t a = 0;
+    bool translucent = false;
+    __device__ __forceinline__ void add(const int32_t *gam2lin, uint32_t r, uint32_t g, uint32_t b, uint32_t alpha)
+    {
+        const uint32_t lr = (uint32_t)gam2lin[r], lg = (uint32_t)gam2lin[g], lb = (uint32_t)gam2lin[b];
+        sr += lr; sg += lg; sb += lb;
+        wr += alpha * lr; wg += alpha * lg; wb += alpha * lb;
+        a += alpha;
+        translucent |= alpha != 255u;
+    }
+    __device__ __forceinline__ void finish(const int32_t *lin2gam, int &r, int &g, int &b) const
+    {
+        if (a == 4u * 255u || a == 0u) {
+            r = webp_linear_to_gamma(lin2gam, sr, 0);
+            g = webp_linear_to_gamma(lin2gam, sg, 0);
+            b = webp_linear_to_gamma(lin2gam, sb, 0);
+        } else {
+            const uint32_t inv = (1u << 19) / a; // rare path: a real division is fine
+            r = webp_linear_to_gamma(lin2gam, (wr * inv) >> 17, 0);
+            g = webp_linear_to_gamma(lin2gam, (wg * inv) >> 17, 0);
+            b = webp_linear_to_gamma(lin2gam, (wb * inv) >> 17, 0);
+        }
+    }
+};
+
 __global__ __launch_bounds__(256) void webp420_kernel(const FrontendJob *__restrict__ fjobs, const uint32_t *__restrict__ arena,
                                                       uint32_t gamma_off, uint32_t job_base)
 {
@@ -906,27 +938,24 @@ __global__ __launch_bounds__(256) void webp420_kernel(const FrontendJob *__restr
     const uint32_t x0 = 2u * bx, y0 = 2u * by;
     const uint32_t x1 = x0 + 1u < w ? x0 + 1u : x0;     // odd width: SUM2 path
     const uint32_t y1 = y0 + 1u < h ? y0 + 1u : y0;     // odd height: rgb_stride = 0
-    uint8_t *Y = fj.dst, *U = fj.dst + (size_t)w * h, *V = U + (size_t)fj.chroma_w * fj.chroma_h;
-    uint32_t sr = 0, sg = 0, sb = 0, any_alpha = 0;
+    uint8_t *Y = fj.dst, *U = fj.dst + (size_t)w * h, *V = U + (size_t)fj.chroma_w * fj.chroma_h, *A = V + (size_t)fj.chroma_w * fj.chroma_h;
+    WebpBlock blk;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t px = (k & 1) ? x1 : x0, py = (k & 2) ? y1 : y0;
         uint32_t r, g, b, a;
         load_rgba(fj.src + ((size_t)py * w + px) * c, c, r, g, b, a);
-        any_alpha |= (a != 255u);
-        // luma of each real pixel (duplicates of the edge replicate are rewritten with the same value)
+        // luma and alpha of each real pixel (duplicates of the edge replicate are rewritten with the same value)
         const int luma = 16839 * (int)r + 33059 * (int)g + 6420 * (int)b;
         Y[(size_t)py * w + px] = (uint8_t)((luma + (1 << 15) + (16 << 16)) >> 16);
-        if (x1 != x0 || !(k & 1)) { sr += (uint32_t)gam2lin[r]; sg += (uint32_t)gam2lin[g]; sb += (uint32_t)gam2lin[b]; }
+        A[(size_t)py * w + px] = (uint8_t)a;
+        blk.add(gam2lin, r, g, b, a);
     }
-    // SUM4 -> shift 0; SUM2 (odd width, last column: two rows of one pixel) -> shift 1
-    const int shift = (x1 == x0) ? 1 : 0;
-    const int r = webp_linear_to_gamma(lin2gam, sr, shift);
-    const int g = webp_linear_to_gamma(lin2gam, sg, shift);
-    const int b = webp_linear_to_gamma(lin2gam, sb, shift);
+    int r, g, b;
+    blk.finish(lin2gam, r, g, b);
     U[(size_t)by * fj.chroma_w + bx] = (uint8_t)webp_clip_uv(-9719 * r - 19081 * g + 28800 * b, 1 << 17);
     V[(size_t)by * fj.chroma_w + bx] = (uint8_t)webp_clip_uv(+28800 * r - 24116 * g - 4684 * b, 1 << 17);
-    if (any_alpha && fj.status) atomicOr(fj.status, 1u);
+    if (blk.translucent && fj.status) atomicOr(fj.status, 1u);
 }
 
 // Rgba8 fast paths of the front ends (every letterboxed output is Rgba8): 4 pixels per thread, dword loads,
@@ -970,25 +999,23 @@ __global__ __launch_bounds__(256) void webp420_rgba_kernel(const FrontendJob *__
     const uint32_t x1 = x0 + 1u < w ? x0 + 1u : x0;
     const uint32_t y1 = y0 + 1u < h ? y0 + 1u : y0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(fj.src), 0, (int)(w * h * 4u), 0x00020000);
-    uint8_t *Y = fj.dst, *U = fj.dst + (size_t)w * h, *V = U + (size_t)fj.chroma_w * fj.chroma_h;
-    uint32_t sr = 0, sg = 0, sb = 0, any_alpha = 0;
+    uint8_t *Y = fj.dst, *U = fj.dst + (size_t)w * h, *V = U + (size_t)fj.chroma_w * fj.chroma_h, *A = V + (size_t)fj.chroma_w * fj.chroma_h;
+    WebpBlock blk;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t px = (k & 1) ? x1 : x0, py = (k & 2) ? y1 : y0;
         const uint32_t d = __builtin_amdgcn_raw_buffer_load_b32(rs, (py * w + px) * 4u, 0, 0);
-        const uint32_t r = d & 255u, g = (d >> 8) & 255u, b = (d >> 16) & 255u;
-        any_alpha |= ((d >> 24) != 255u);
+        const uint32_t r = d & 255u, g = (d >> 8) & 255u, b = (d >> 16) & 255u, a = d >> 24;
         const int luma = 16839 * (int)r + 33059 * (int)g + 6420 * (int)b;
         Y[(size_t)py * w + px] = (uint8_t)((luma + (1 << 15) + (16 << 16)) >> 16);
-        if (x1 != x0 || !(k & 1)) { sr += (uint32_t)gam2lin[r]; sg += (uint32_t)gam2lin[g]; sb += (uint32_t)gam2lin[b]; }
+        A[(size_t)py * w + px] = (uint8_t)a;
+        blk.add(gam2lin, r, g, b, a);
     }
-    const int shift = (x1 == x0) ? 1 : 0;
-    const int r = webp_linear_to_gamma(lin2gam, sr, shift);
-    const int g = webp_linear_to_gamma(lin2gam, sg, shift);
-    const int b = webp_linear_to_gamma(lin2gam, sb, shift);
+    int r, g, b;
+    blk.finish(lin2gam, r, g, b);
     U[(size_t)by * fj.chroma_w + bx] = (uint8_t)webp_clip_uv(-9719 * r - 19081 * g + 28800 * b, 1 << 17);
     V[(size_t)by * fj.chroma_w + bx] = (uint8_t)webp_clip_uv(+28800 * r - 24116 * g - 4684 * b, 1 << 17);
-    if (any_alpha && fj.status) atomicOr(fj.status, 1u);
+    if (blk.translucent && fj.status) atomicOr(fj.status, 1u);
 }
 
 // reference src/handler.rs:423-438: per pixel (Y, Cb, Cr, K) -> (clamp(R), clamp(G), clamp(B), 255 - K), f32 with

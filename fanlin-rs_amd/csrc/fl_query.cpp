@@ -321,7 +321,8 @@ int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t 
         plan->plane_h = plan->out_h;
         plan->chroma_w = (plan->out_w + 1u) >> 1;
         plan->chroma_h = (plan->out_h + 1u) >> 1;
-        plan->out_bytes = (uint64_t)plan->plane_w * plan->plane_h + 2ull * plan->chroma_w * plan->chroma_h;
+        /* Y | U | V | A: the alpha plane (w x h) is always written; it matters when FLGPU_IMG_HAS_ALPHA comes back */
+        plan->out_bytes = 2ull * plan->plane_w * plan->plane_h + 2ull * plan->chroma_w * plan->chroma_h;
         break;
     default:
         plan->out_bytes = plan->pixel_bytes;

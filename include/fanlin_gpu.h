@@ -71,15 +71,15 @@ typedef struct flgpu_image {
 
 #define FLGPU_IMG_FRONTEND_PLANES 1u  /* dst->data holds encoder planes, not interleaved pixels */
 #define FLGPU_IMG_ENCODED         4u  /* JPEG: data holds an encoded stream of `bytes` bytes */
-#define FLGPU_IMG_HAS_ALPHA       2u  /* WEBP420: some pixel is not opaque.  libwebp then weights chroma by alpha and adds an
-                                         alpha plane (WebPPictureImportRGBA path): the planes returned here are NOT what it
-                                         would encode -- hand such pictures to the encoder as RGBA pixels instead */
+#define FLGPU_IMG_HAS_ALPHA       2u  /* WEBP420: some pixel is not opaque: the picture is WEBP_YUV420A for libwebp, i.e. the A
+                                         plane behind V must be handed to WebPEncode too (for opaque pictures it is all 255) */
 
 /* Encoder colour front end to run after the pixel pipeline. */
 typedef enum flgpu_front_end {
     FLGPU_FE_NONE = 0,     /* dst = interleaved pixels, out_c channels */
     FLGPU_FE_JFIF444 = 1,  /* dst = Y | Cb | Cr, each plane_w x plane_h (multiples of 8, edge replicated) */
-    FLGPU_FE_WEBP420 = 2,  /* dst = Y (w x h) | U | V (each ceil(w/2) x ceil(h/2)), BT.601 limited range */
+    FLGPU_FE_WEBP420 = 2,  /* dst = Y (w x h) | U | V (each ceil(w/2) x ceil(h/2)) | A (w x h), BT.601 limited range: what
+                              libwebp's WebPPictureARGBToYUVA makes of the RGBA picture, alpha-weighted chroma included */
     FLGPU_FE_JPEG = 3      /* dst = the finished JFIF stream of JpegEncoder::new_with_quality(q).encode_image(&img)
                               (src/handler.rs:274-278): baseline, 3 components, 4:4:4; dst->bytes long */
 } flgpu_front_end;

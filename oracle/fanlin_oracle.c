@@ -623,25 +623,28 @@ int fo_webp_yuv420(const fo_image *src, uint8_t *out)
             Y[(size_t)y * w + x] = (uint8_t)rgb_to_y(p[0], p[1], p[2], YUV_HALF);
             if (has_alpha) A[(size_t)y * w + x] = p[3];
         }
-    /* AccumulateRGB (opaque rows) + WebPConvertRGBA32ToUV.  The alpha-weighted
-     * AccumulateRGBA variant is not restated: the product reports has_alpha and
-     * leaves translucent pictures to the host encoder. */
+    /* AccumulateRGB / AccumulateRGBA + WebPConvertRGBA32ToUV.  Every chroma sample averages a 2x2 block in linear light;
+     * a block that is neither fully opaque nor fully transparent weights its pixels by alpha (LinearToGammaWeighted:
+     * sum of a_i * GammaToLinear(c_i), times the reciprocal table kInvAlpha[a] = (1 << 19) / a, >> 17).  Odd width /
+     * height repeat the last column / row (step = 0 / rgb_stride = 0 in libwebp). */
     for (uint32_t by = 0; by < uvh; ++by) {
-        uint32_t y0 = 2 * by, y1 = (2 * by + 1 < h) ? 2 * by + 1 : y0; /* last odd row: rgb_stride = 0 */
+        uint32_t y0 = 2 * by, y1 = (2 * by + 1 < h) ? 2 * by + 1 : y0;
         for (uint32_t bx = 0; bx < uvw; ++bx) {
-            uint32_t x0 = 2 * bx;
+            uint32_t x0 = 2 * bx, x1 = (x0 + 1 < w) ? x0 + 1 : x0;
+            const uint8_t *t[4] = {src->px + ((size_t)y0 * w + x0) * 4, src->px + ((size_t)y0 * w + x1) * 4,
+                                   src->px + ((size_t)y1 * w + x0) * 4, src->px + ((size_t)y1 * w + x1) * 4};
+            const uint32_t a = (uint32_t)t[0][3] + t[1][3] + t[2][3] + t[3][3];
             int rgb[3];
             for (int k = 0; k < 3; ++k) {
-                const uint8_t *p0 = src->px + ((size_t)y0 * w + x0) * 4 + k;
-                const uint8_t *p1 = src->px + ((size_t)y1 * w + x0) * 4 + k;
-                if (x0 + 1 < w) {
-                    /* SUM4 */
-                    uint32_t s = (uint32_t)g_gam2lin[p0[0]] + g_gam2lin[p0[4]] + g_gam2lin[p1[0]] + g_gam2lin[p1[4]];
-                    rgb[k] = linear_to_gamma(s, 0);
+                if (a == 4 * 0xff || a == 0) {
+                    /* SUM4 (or SUM2 with shift 1 at an odd edge: the same number) */
+                    uint32_t s4 = (uint32_t)g_gam2lin[t[0][k]] + g_gam2lin[t[1][k]] + g_gam2lin[t[2][k]] + g_gam2lin[t[3][k]];
+                    rgb[k] = linear_to_gamma(s4, 0);
                 } else {
-                    /* SUM2 (odd width, last column) */
-                    uint32_t s = (uint32_t)g_gam2lin[p0[0]] + g_gam2lin[p1[0]];
-                    rgb[k] = linear_to_gamma(s, 1);
+                    const uint32_t sum = t[0][3] * (uint32_t)g_gam2lin[t[0][k]] + t[1][3] * (uint32_t)g_gam2lin[t[1][k]] +
+                                         t[2][3] * (uint32_t)g_gam2lin[t[2][k]] + t[3][3] * (uint32_t)g_gam2lin[t[3][k]];
+                    const uint32_t inv = (1u << 19) / a;               /* kInvAlpha[a], kAlphaFix = 19 */
+                    rgb[k] = linear_to_gamma((sum * inv) >> (19 - 2), 0); /* DIVIDE_BY_ALPHA */
                 }
             }
             U[(size_t)by * uvw + bx] = (uint8_t)rgb_to_u(rgb[0], rgb[1], rgb[2], YUV_HALF << 2);

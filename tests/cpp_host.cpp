@@ -39,7 +39,7 @@ int main(int argc, char **argv)
     EXPECT(r.kind == FLGPU_RESULT_JPEG_STREAM && r.data.size() > 700 && r.data[0] == 0xFF && r.data[1] == 0xD8 &&
            r.data[r.data.size() - 2] == 0xFF && r.data[r.data.size() - 1] == 0xD9);
     r = state.process_image(img, query::Query::parse("w=300&h=200&webp=true"), f);
-    EXPECT(r.kind == FLGPU_RESULT_WEBP_PLANES && r.negotiated == FLGPU_OUT_WEBP && r.data.size() == 300 * 200 + 2 * 150 * 100);
+    EXPECT(r.kind == FLGPU_RESULT_WEBP_PLANES && r.negotiated == FLGPU_OUT_WEBP && r.data.size() == 2 * 300 * 200 + 2 * 150 * 100);
     r = state.process_image(img, query::Query::parse("w=300&h=200&avif=true"), f);
     EXPECT(r.kind == FLGPU_RESULT_PIXELS && r.negotiated == FLGPU_OUT_AVIF && r.data.size() == 300 * 200 * 4);
     threw = false;

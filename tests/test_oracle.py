@@ -234,8 +234,11 @@ def test_webp_front_end_matches_libwebp_fixture(oracle):
     assert len(names) >= 5
     for n in names:
         y, u, v, has_alpha = oracle.webp_yuv420(g[n + "_rgba"])
-        assert not has_alpha
+        assert has_alpha == (n + "_a" in g.files)             # translucent cases carry libwebp's alpha plane
         assert np.array_equal(y, g[n + "_y"]) and np.array_equal(u, g[n + "_u"]) and np.array_equal(v, g[n + "_v"]), n
+        if has_alpha:
+            assert np.array_equal(g[n + "_a"], g[n + "_rgba"][:, :, 3])
+    assert sum(1 for n in names if n + "_a" in g.files) >= 5
 
 
 def test_ycck_loop_known_answers(oracle):

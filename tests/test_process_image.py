@@ -48,7 +48,7 @@ def test_request_table_host_side(fl, src, query, status, mime, kind):
     elif kind == "JPEG_STREAM":
         assert (plan.out_w, plan.out_h, plan.out_c) == (300, 200, 4) and plan.out_bytes >= 623 + 3 * 304 * 200
     elif kind == "WEBP_PLANES":
-        assert plan.out_bytes == 300 * 200 + 2 * 150 * 100
+        assert plan.out_bytes == 2 * 300 * 200 + 2 * 150 * 100
     else:
         assert plan.out_bytes == 300 * 200 * 4
 

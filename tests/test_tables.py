@@ -72,7 +72,7 @@ def test_plan_known_geometry(fl):
     p = fl.plan_output(fl.make_params(300, 200, front_end=fl.FE_JFIF444), 1920, 1080, 3)
     assert (p.plane_w, p.plane_h, p.out_bytes) == (304, 200, 3 * 304 * 200)
     p = fl.plan_output(fl.make_params(301, 201, front_end=fl.FE_WEBP420), 301, 201, 3)
-    assert (p.chroma_w, p.chroma_h, p.out_bytes) == (151, 101, 301 * 201 + 2 * 151 * 101)
+    assert (p.chroma_w, p.chroma_h, p.out_bytes) == (151, 101, 2 * 301 * 201 + 2 * 151 * 101)   # Y | U | V | A
     with pytest.raises(fl.FanlinError):
         fl.plan_output(fl.make_params(0, 5), 10, 10, 3)
     with pytest.raises(fl.FanlinError):

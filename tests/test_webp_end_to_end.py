@@ -24,6 +24,41 @@ def test_oracle_planes_give_libwebps_own_file(oracle, shape, q):
     assert webp_lib.encode_planes(y, u, v, q) == webp_lib.encode_rgba(rgba, q)
 
 
+def translucent(shape, seed):
+    rng = np.random.default_rng(seed)
+    rgb = synth.photo(shape[0], shape[1], 3, index=seed)
+    alpha = rng.integers(0, 256, (shape[0], shape[1], 1), dtype=np.uint8)
+    alpha[rng.random(alpha.shape) < 0.4] = 255
+    alpha[rng.random(alpha.shape) < 0.2] = 0
+    return np.concatenate([rgb, alpha], axis=2)
+
+
+@pytest.mark.parametrize("shape,q", [((200, 300), 75), ((61, 83), 40), ((33, 17), 90)])
+def test_translucent_pictures_oracle(oracle, shape, q):
+    # PNG-with-alpha -> WebP: libwebp weights the chroma of partly transparent blocks by alpha and codes an alpha plane
+    rgba = translucent(shape, q)
+    y, u, v, has_alpha = oracle.webp_yuv420(rgba)
+    assert has_alpha
+    assert webp_lib.encode_planes(y, u, v, q, a=rgba[:, :, 3]) == webp_lib.encode_rgba(rgba, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,q", [((200, 300), 75), ((61, 83), 40), ((33, 17), 90), ((1, 1), 50)])
+def test_translucent_pictures_gpu(fl, gpu_state, oracle, shape, q):
+    rgba = translucent(shape, q)
+    pl = gpu_state.process_pixels(rgba, fl.make_params(quality=q, front_end=fl.FE_WEBP420))
+    assert pl.has_alpha and np.array_equal(pl.a, rgba[:, :, 3])
+    y, u, v, _ = oracle.webp_yuv420(rgba)
+    assert np.array_equal(pl.y, y) and np.array_equal(pl.u, u) and np.array_equal(pl.v, v)
+    assert webp_lib.encode_planes(pl.y, pl.u, pl.v, q, a=pl.a) == webp_lib.encode_rgba(rgba, q)
+    # LumaA sources go the same way (DynamicImage::into_rgba8 first, handler.rs:287)
+    la = np.ascontiguousarray(rgba[:, :, [0, 3]])
+    pl2 = gpu_state.process_pixels(la, fl.make_params(quality=q, front_end=fl.FE_WEBP420))
+    as_rgba = np.concatenate([la[:, :, :1]] * 3 + [la[:, :, 1:]], axis=2)
+    y2, u2, v2, _ = oracle.webp_yuv420(as_rgba)
+    assert pl2.has_alpha and np.array_equal(pl2.y, y2) and np.array_equal(pl2.u, u2) and np.array_equal(pl2.v, v2)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,q", [((200, 300), 75), ((61, 83), 90), ((33, 17), 10)])
 def test_gpu_planes_give_libwebps_own_file(fl, gpu_state, shape, q):

@@ -89,14 +89,20 @@ def encode_rgba(rgba, q):
     return _encode(pic, q)
 
 
-def encode_planes(y, u, v, q):
+def encode_planes(y, u, v, q, a=None):
+    """a: the alpha plane of a translucent picture (WEBP_YUV420A), None for opaque ones."""
     assert load() is not None
     h, w = y.shape
     pic = WebPPicture()
     assert _lib.WebPPictureInitInternal(C.byref(pic), _abi) == 1
     pic.use_argb, pic.width, pic.height = 0, w, h
+    if a is not None:
+        pic.colorspace = 4            # WEBP_YUV420A = WEBP_YUV420 | WEBP_CSP_ALPHA_BIT
     assert _lib.WebPPictureAlloc(C.byref(pic)) == 1
-    for plane, ptr, stride in ((y, pic.y, pic.y_stride), (u, pic.u, pic.uv_stride), (v, pic.v, pic.uv_stride)):
+    planes = [(y, pic.y, pic.y_stride), (u, pic.u, pic.uv_stride), (v, pic.v, pic.uv_stride)]
+    if a is not None:
+        planes.append((a, pic.a, pic.a_stride))
+    for plane, ptr, stride in planes:
         dst = np.ctypeslib.as_array(ptr, shape=(plane.shape[0] * stride,))
         for r in range(plane.shape[0]):
             dst[r * stride: r * stride + plane.shape[1]] = plane[r]

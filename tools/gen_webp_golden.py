@@ -47,8 +47,11 @@ def libwebp_yuv420(lib, abi, rgba):
     y = np.array([[pic.y[r * pic.y_stride + c] for c in range(w)] for r in range(h)], np.uint8)
     u = np.array([[pic.u[r * pic.uv_stride + c] for c in range(cw)] for r in range(ch)], np.uint8)
     v = np.array([[pic.v[r * pic.uv_stride + c] for c in range(cw)] for r in range(ch)], np.uint8)
+    a = None
+    if pic.a:  # WEBP_YUV420A: some pixel is not opaque
+        a = np.array([[pic.a[r * pic.a_stride + c] for c in range(w)] for r in range(h)], np.uint8)
     lib.WebPPictureFree(C.byref(pic))
-    return y, u, v
+    return y, u, v, a
 
 
 def main():
@@ -69,8 +72,20 @@ def main():
              "u_2x5": synth.uniform(5, 2, 3, index=904), "edges": synth.edges(8, 8, 3)["checker"]}
     for name, rgb in cases.items():
         rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
-        y, u, v = libwebp_yuv420(lib, abi, rgba)
+        y, u, v, a = libwebp_yuv420(lib, abi, rgba)
+        assert a is None
         out[name + "_rgba"], out[name + "_y"], out[name + "_u"], out[name + "_v"] = rgba, y, u, v
+    # translucent pictures: libwebp weights the chroma of partly transparent 2x2 blocks by alpha and keeps an alpha plane
+    rng = np.random.default_rng(0xA1FA)
+    for name, (h, w) in {"a_16x12": (12, 16), "a_17x13": (13, 17), "a_1x1": (1, 1), "a_2x5": (5, 2), "a_40x30": (30, 40)}.items():
+        rgb = synth.uniform(h, w, 3, index=950 + h)
+        alpha = rng.integers(0, 256, (h, w, 1), dtype=np.uint8)
+        alpha[rng.random(alpha.shape) < 0.3] = 255
+        alpha[rng.random(alpha.shape) < 0.2] = 0
+        rgba = np.concatenate([rgb, alpha], axis=2)
+        y, u, v, a = libwebp_yuv420(lib, abi, rgba)
+        assert a is not None
+        out[name + "_rgba"], out[name + "_y"], out[name + "_u"], out[name + "_v"], out[name + "_a"] = rgba, y, u, v, a
     dst = os.path.join(ROOT, "tests", "golden", "webp_yuv420_libwebp.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, "libwebp", ".".join(str(int(x)) for x in out["libwebp_version"]), "abi", hex(abi))
