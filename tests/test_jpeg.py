@@ -211,3 +211,19 @@ def test_webp_alpha_flag_reaches_the_caller(fl, gpu_state):
     assert not gpu_state.process_pixels(img, fl.make_params(front_end=fl.FE_WEBP420)).has_alpha
     img[5, 7, 3] = 254
     assert gpu_state.process_pixels(img, fl.make_params(front_end=fl.FE_WEBP420)).has_alpha
+
+
+def test_integer_quantiser_equals_the_f32_formula_exhaustively():
+    # jpeg_dct_quant_kernel replaces `((d / 8) as f32 / q as f32).round()` by sign(n) * ((2|n| + q) * ceil(2^32 / 2q) >> 32);
+    # the claim in its comment -- identical for every |n| <= 2048 and 1 <= q <= 255 -- checked value by value
+    n = np.arange(-2048, 2049, dtype=np.int64)[:, None]
+    q = np.arange(1, 256, dtype=np.int64)[None, :]
+    f = (n.astype(np.float32) / q.astype(np.float32)).astype(np.float32)
+    t = np.trunc(f)
+    want = (t + np.sign(f) * (np.abs(f - t) >= np.float32(0.5))).astype(np.int64)   # f32::round: half away from zero (f - t is exact)
+    magic = ((1 << 32) + 2 * q - 1) // (2 * q)
+    got = np.sign(n) * (((2 * np.abs(n) + q) * magic) >> 32)
+    assert np.array_equal(got, want)
+    # and the truncating `d / 8` written with shifts
+    d = np.arange(-20000, 20001, dtype=np.int64)
+    assert np.array_equal((d + ((d >> 63) & 7)) >> 3, np.trunc(d / 8).astype(np.int64))
