@@ -707,14 +707,26 @@ __global__ __launch_bounds__(THREADS) void blur_tile_kernel(const Job *__restric
 {
     constexpr int MS = C == 3 ? 4 : C; // floats per pixel in LDS
     constexpr uint32_t T = THREADS;
-    const Job jb = jobs[job_base + blockIdx.y];
+    // XCD-aware numbering: workgroups are handed to the 8 XCDs round-robin in launch order, and each XCD has its own
+    // L2.  The bands of one picture re-read each other's halo rows (41-81 taps against 8 output rows), so all
+    // workgroups of a picture are given launch indices that are congruent modulo 8: picture p of every group of 8
+    // lives on XCD p % 8 and its halo re-reads hit that L2.
+    uint32_t job_i, bid;
+    {
+        const uint32_t gx = gridDim.x, l = blockIdx.y * gx + blockIdx.x;
+        const uint32_t set = l / (8u * gx), m = l - set * 8u * gx;
+        const uint32_t inset = min(8u, gridDim.y - set * 8u);
+        bid = m / inset;
+        job_i = set * 8u + (m - bid * inset);
+    }
+    const Job jb = jobs[job_base + job_i];
     const uint32_t w = jb.sw, h = jb.sh;
     // one table block per (w, h, sigma): header -> this workgroup's tile and band records -> bulk copies
     const uint32_t *blk = arena + jb.pad0;
     const BlurPlanHeader hd = *reinterpret_cast<const BlurPlanHeader *>(blk);
     const uint32_t nt = hd.nt, htaps = hd.htaps, tw_full = hd.tw_full;
-    if (blockIdx.x >= nt * hd.nb) return;
-    const uint32_t band = blockIdx.x / nt, tile = blockIdx.x % nt;
+    if (bid >= nt * hd.nb) return;
+    const uint32_t band = bid / nt, tile = bid % nt;
     const uint32_t x0 = tile * tw_full, tw = min(tw_full, w - x0);
     const uint32_t y0 = band * TY, ty = min((uint32_t)TY, h - y0);
     const uint32_t tid = threadIdx.x;
