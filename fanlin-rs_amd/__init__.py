@@ -33,7 +33,7 @@ OUT_KEEP, OUT_WEBP, OUT_AVIF = 0, 1, 2
 IN_OTHER, IN_JPEG, IN_PNG, IN_WEBP, IN_GIF_FRAME = 0, 1, 2, 3, 4
 RESULT_AS_IS, RESULT_JPEG_STREAM, RESULT_WEBP_PLANES, RESULT_PIXELS = 0, 1, 2, 3
 MIME = {IN_JPEG: "image/jpeg", IN_PNG: "image/png", IN_WEBP: "image/webp", IN_GIF_FRAME: "image/gif"}
-IMG_FRONTEND_PLANES, IMG_HAS_ALPHA, IMG_ENCODED = 1, 2, 4
+IMG_FRONTEND_PLANES, IMG_HAS_ALPHA, IMG_ENCODED, IMG_PINNED = 1, 2, 4, 8
 BATCH_SAME_PARAMS = 1
 (OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_OOM, ERR_DEVICE, ERR_PARSE, ERR_BUFFER_TOO_SMALL,
  ERR_SHUTDOWN) = range(9)
@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_cropping", "flgpu_query_blur", "flgpu_query_grayscale", "flgpu_query_inverse",
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
     "flgpu_params_from_query", "flgpu_plan_output", "flgpu_process_image", "flgpu_process_image_plan", "flgpu_create", "flgpu_destroy", "flgpu_transform",
-    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_batch_results", "flgpu_ycck_to_cmyk",
+    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_batch_results", "flgpu_host_alloc", "flgpu_host_free", "flgpu_ycck_to_cmyk",
     "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
@@ -146,6 +146,10 @@ def load_library() -> C.CDLL:
     lib.flgpu_transform_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params), C.POINTER(flgpu_image)]
     lib.flgpu_transform_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params),
                                                  C.POINTER(flgpu_image), C.c_void_p, C.c_uint32]
+    lib.flgpu_host_alloc.argtypes = [C.c_void_p, C.c_uint64]
+    lib.flgpu_host_alloc.restype = C.c_void_p
+    lib.flgpu_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.flgpu_host_free.restype = None
     lib.flgpu_batch_results.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image)]
     lib.flgpu_ycck_to_cmyk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.flgpu_set_cmyk_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]

@@ -1153,14 +1153,21 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
         ~Admission() { { std::lock_guard<std::mutex> lk(c->adm_mu); c->admitted--; } c->adm_cv.notify_one(); }
     } admission{c};
     c->staging.fetch_add(1, std::memory_order_acq_rel);
-    r.in = pin_acquire(c, r.src_bytes);
-    r.out = pin_acquire(c, r.out_bytes);
-    if (!r.in.p || !r.out.p) { c->staging.fetch_sub(1, std::memory_order_acq_rel); pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_OOM; }
-    memcpy(r.in.p, src->data, r.src_bytes); // on the caller's thread: concurrent callers stage in parallel
+    // buffers from flgpu_host_alloc are page-locked already: the DMA engine reads / writes them directly, no staging copy
+    const bool src_pinned = (src->flags & FLGPU_IMG_PINNED) != 0, dst_pinned = (dst->flags & FLGPU_IMG_PINNED) != 0 && dst->capacity >= r.out_bytes;
+    if (src_pinned) r.in = PinBlock{src->data, 0}; else r.in = pin_acquire(c, r.src_bytes);
+    if (dst_pinned) r.out = PinBlock{dst->data, 0}; else r.out = pin_acquire(c, r.out_bytes);
+    if (!r.in.p || !r.out.p) {
+        c->staging.fetch_sub(1, std::memory_order_acq_rel);
+        if (!src_pinned) pin_release(c, r.in);
+        if (!dst_pinned) pin_release(c, r.out);
+        return FLGPU_ERR_OOM;
+    }
+    if (!src_pinned) memcpy(r.in.p, src->data, r.src_bytes); // on the caller's thread: concurrent callers stage in parallel
     {
         std::unique_lock<std::mutex> lk(c->qmu);
         c->staging.fetch_sub(1, std::memory_order_acq_rel);
-        if (c->stop) { lk.unlock(); pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_SHUTDOWN; }
+        if (c->stop) { lk.unlock(); if (!src_pinned) pin_release(c, r.in); if (!dst_pinned) pin_release(c, r.out); return FLGPU_ERR_SHUTDOWN; }
         if (!c->worker_started) {
             // lanes: child contexts on the same device (cfg.queue_lanes, default 3)
             const uint32_t nl = std::min<uint32_t>(std::max<uint32_t>(c->cfg.queue_lanes ? c->cfg.queue_lanes : 3u, 1u), 8u);
@@ -1173,7 +1180,7 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
                 if (!l) break;
                 c->lanes.push_back(l);
             }
-            if (c->lanes.empty()) { lk.unlock(); pin_release(c, r.in); pin_release(c, r.out); return FLGPU_ERR_OOM; }
+            if (c->lanes.empty()) { lk.unlock(); if (!src_pinned) pin_release(c, r.in); if (!dst_pinned) pin_release(c, r.out); return FLGPU_ERR_OOM; }
             for (flgpu_ctx *l : c->lanes) c->workers.emplace_back(worker_main, c, l);
             c->worker_started = true;
         }
@@ -1184,10 +1191,26 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
         std::unique_lock<std::mutex> lk(c->qmu);
         c->qdone.wait(lk, [&] { return r.done; });
     }
-    if (r.status == FLGPU_OK) memcpy(dst->data, r.out.p, std::min<uint64_t>(dst->bytes, r.out_bytes));
-    pin_release(c, r.in);
-    pin_release(c, r.out);
+    if (r.status == FLGPU_OK && !dst_pinned) memcpy(dst->data, r.out.p, std::min<uint64_t>(dst->bytes, r.out_bytes));
+    if (!src_pinned) pin_release(c, r.in);
+    if (!dst_pinned) pin_release(c, r.out);
+    if (dst_pinned) dst->flags |= FLGPU_IMG_PINNED;
     return r.status;
+}
+
+void *flgpu_host_alloc(flgpu_ctx *c, uint64_t bytes)
+{
+    if (!c || !bytes) return nullptr;
+    (void)hipSetDevice(c->device);
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void flgpu_host_free(flgpu_ctx *c, void *p)
+{
+    if (!c || !p) return;
+    (void)hipSetDevice(c->device);
+    (void)hipHostFree(p);
 }
 
 int flgpu_batch_results(flgpu_ctx *c, size_t n, flgpu_image *dsts)

@@ -70,6 +70,8 @@ typedef struct flgpu_image {
 } flgpu_image;
 
 #define FLGPU_IMG_FRONTEND_PLANES 1u  /* dst->data holds encoder planes, not interleaved pixels */
+#define FLGPU_IMG_PINNED          8u  /* in (src and dst of flgpu_transform): data comes from flgpu_host_alloc, i.e. is page-locked:
+                                         the copy through the library's own pinned staging blocks is skipped */
 #define FLGPU_IMG_ENCODED         4u  /* JPEG: data holds an encoded stream of `bytes` bytes */
 #define FLGPU_IMG_HAS_ALPHA       2u  /* WEBP420: some pixel is not opaque: the picture is WEBP_YUV420A for libwebp, i.e. the A
                                          plane behind V must be handed to WebPEncode too (for opaque pictures it is all 255) */
@@ -249,6 +251,11 @@ int flgpu_process_image(flgpu_ctx *ctx, const flgpu_image *decoded, uint8_t exif
 /* Room dst needs for that request (0 for AS_IS); same parsing and errors, no device work. */
 int flgpu_process_image_plan(const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string,
                              uint32_t accept_flags, int input_format, flgpu_plan *plan, int *result_kind);
+
+/* Page-locked host memory for sources / results of flgpu_transform (flag them FLGPU_IMG_PINNED): a decoder that
+ * writes straight into such a buffer (zune-jpeg's decode_into) saves the 6 MB staging copy of a 1080p request. */
+void *flgpu_host_alloc(flgpu_ctx *ctx, uint64_t bytes);
+void flgpu_host_free(flgpu_ctx *ctx, void *p);
 
 /* n images, host memory, blocking: staged through pinned buffers, one set of launches. */
 int flgpu_transform_batch(flgpu_ctx *ctx, size_t n, const flgpu_image *srcs, const flgpu_params *ps,

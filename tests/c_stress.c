@@ -35,9 +35,12 @@ static uint64_t run_request(int id)
     flgpu_plan plan;
     if (flgpu_plan_output(&p, sw, sh, c, &plan) != FLGPU_OK) return 1;
     const size_t n = (size_t)sw * sh * c, cap = plan.out_bytes + (size_t)plan.plane_w * plan.plane_h * 8 + 4096;
-    uint8_t *src = (uint8_t *)malloc(n), *dst = (uint8_t *)malloc(cap);
+    /* every third request uses page-locked buffers (FLGPU_IMG_PINNED: no staging copy inside the library) */
+    const int pinned = id % 3 == 0;
+    uint8_t *src = (uint8_t *)(pinned ? flgpu_host_alloc(g_ctx, n) : malloc(n)), *dst = (uint8_t *)(pinned ? flgpu_host_alloc(g_ctx, cap) : malloc(cap));
     for (size_t i = 0; i < n; ++i) src[i] = (uint8_t)(lcg(&s) >> 3);
-    flgpu_image in = {src, n, sw, sh, c, 0, 0}, out = {dst, cap, 0, 0, 0, 0, 0};
+    const uint32_t fl = pinned ? FLGPU_IMG_PINNED : 0u;
+    flgpu_image in = {src, n, sw, sh, c, fl, 0}, out = {dst, cap, 0, 0, 0, fl, 0};
     uint64_t h = 0xcbf29ce484222325ull;
     const int st = flgpu_transform(g_ctx, &in, &p, &out);
     if (st != FLGPU_OK) { __sync_fetch_and_add(&g_failed, 1); h = 0xDEAD0000u + (uint64_t)st; }
@@ -45,7 +48,7 @@ static uint64_t run_request(int id)
         for (uint64_t i = 0; i < out.bytes; ++i) h = (h ^ dst[i]) * 0x100000001b3ull;
         h ^= ((uint64_t)out.width << 40) ^ ((uint64_t)out.height << 20) ^ out.channels ^ (out.bytes << 3);
     }
-    free(src); free(dst);
+    if (pinned) { flgpu_host_free(g_ctx, src); flgpu_host_free(g_ctx, dst); } else { free(src); free(dst); }
     return h;
 }
 

@@ -1,7 +1,7 @@
 /* Per-image latency of the drop-in entry point, measured without Python in the way: T caller threads (the
  * reference's tokio workers, src/main.rs:33) call flgpu_transform concurrently with HOST buffers; the library's
  * request queue packs them into shared launches.  Prints one JSON object.
- *   latency_probe <threads> <requests> <src_w> <src_h> <query> [front_end] [queue_lanes] [max_batch]            */
+ *   latency_probe <threads> <requests> <src_w> <src_h> <query> [front_end] [queue_lanes] [max_batch] [pinned]   */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
 #include <stdint.h>
@@ -17,7 +17,7 @@ static flgpu_params g_params;
 static flgpu_plan g_plan;
 static uint32_t g_w, g_h;
 static uint8_t *g_src[8];
-static int g_requests, g_next, g_failed;
+static int g_requests, g_next, g_failed, g_pinned;
 static double *g_lat;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 
@@ -31,18 +31,19 @@ static double now_ms(void)
 static void *caller(void *arg)
 {
     (void)arg;
-    uint8_t *dst = (uint8_t *)malloc(g_plan.out_bytes);
+    uint8_t *dst = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, g_plan.out_bytes) : malloc(g_plan.out_bytes));
+    const uint32_t fl = g_pinned ? FLGPU_IMG_PINNED : 0u;
     for (;;) {
         pthread_mutex_lock(&g_mu);
         const int i = g_next++;
         pthread_mutex_unlock(&g_mu);
         if (i >= g_requests) break;
-        flgpu_image in = {g_src[i % 8], (uint64_t)g_w * g_h * 3, g_w, g_h, 3, 0, 0}, out = {dst, g_plan.out_bytes, 0, 0, 0, 0, 0};
+        flgpu_image in = {g_src[i % 8], (uint64_t)g_w * g_h * 3, g_w, g_h, 3, fl, 0}, out = {dst, g_plan.out_bytes, 0, 0, 0, fl, 0};
         const double t0 = now_ms();
         if (flgpu_transform(g_ctx, &in, &g_params, &out) != FLGPU_OK) { pthread_mutex_lock(&g_mu); g_failed++; pthread_mutex_unlock(&g_mu); }
         g_lat[i] = now_ms() - t0;
     }
-    free(dst);
+    if (g_pinned) flgpu_host_free(g_ctx, dst); else free(dst);
     return NULL;
 }
 
@@ -64,13 +65,14 @@ int main(int argc, char **argv)
     cfg.device = -1;
     cfg.queue_lanes = argc > 7 ? (uint32_t)atoi(argv[7]) : 0;
     cfg.max_batch = argc > 8 ? (uint32_t)atoi(argv[8]) : 0;
+    g_pinned = argc > 9 ? atoi(argv[9]) : 0;
     int st = 0;
     g_ctx = flgpu_create(&cfg, &st);
     if (!g_ctx) { fprintf(stderr, "flgpu_create: %s\n", flgpu_strerror(st)); return 5; }
     const size_t n = (size_t)g_w * g_h * 3;
     uint32_t s = 0xFA171200u;
     for (int k = 0; k < 8; ++k) {
-        g_src[k] = (uint8_t *)malloc(n);
+        g_src[k] = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, n) : malloc(n));
         for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; g_src[k][i] = (uint8_t)(s >> 24); }
     }
     g_lat = (double *)calloc((size_t)(g_requests > threads * 2 ? g_requests : threads * 2), sizeof(double));
@@ -90,9 +92,9 @@ int main(int argc, char **argv)
     flgpu_get_stats(g_ctx, &stats);
     qsort(g_lat, (size_t)g_requests, sizeof(double), cmp);
     printf("{\"p50_ms\": %.3f, \"p99_ms\": %.3f, \"requests\": %d, \"caller_threads\": %d, \"images_per_s\": %.1f, \"queue_flushes\": %llu, "
-           "\"failed\": %d, \"path\": \"flgpu_transform from C threads, host buffers (H2D + kernels + D2H), request-batching queue\"}\n",
+           "\"failed\": %d, \"pinned\": %d, \"path\": \"flgpu_transform from C threads, host buffers (H2D + kernels + D2H), request-batching queue\"}\n",
            g_lat[g_requests / 2], g_lat[(int)(g_requests * 0.99) < g_requests ? (int)(g_requests * 0.99) : g_requests - 1], g_requests, threads,
-           g_requests / wall * 1e3, (unsigned long long)stats.queue_flushes, g_failed);
+           g_requests / wall * 1e3, (unsigned long long)stats.queue_flushes, g_failed, g_pinned);
     flgpu_destroy(g_ctx);
     return g_failed ? 6 : 0;
 }
