@@ -79,6 +79,28 @@ constexpr Mat8 make_fdct_matrix()
 
 __constant__ Mat8 kFdct = make_fdct_matrix();
 
+constexpr bool fdct_matrix_fits_i16()
+{
+    const Mat8 m = make_fdct_matrix();
+    for (int k = 0; k < 8; ++k)
+        for (int j = 0; j < 8; ++j)
+            if (m.a[k][j] > 32767 || m.a[k][j] < -32768) return false;
+    return true;
+}
+static_assert(fdct_matrix_fits_i16(), "the passes use v_dot2_i32_i16: matrix entries must be 16-bit");
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i16x2 as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ uint32_t pack_i16(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+// 8-term dot product of packed 16-bit operands, exact in 32 bits (v_dot2_i32_i16: two multiply-adds per instruction)
+__device__ __forceinline__ int32_t dot8_i16(const uint32_t m[4], const uint4 v)
+{
+    int32_t p = __builtin_amdgcn_sdot2(as_i16x2(m[0]), as_i16x2(v.x), 0, false);
+    p = __builtin_amdgcn_sdot2(as_i16x2(m[1]), as_i16x2(v.y), p, false);
+    p = __builtin_amdgcn_sdot2(as_i16x2(m[2]), as_i16x2(v.z), p, false);
+    return __builtin_amdgcn_sdot2(as_i16x2(m[3]), as_i16x2(v.w), p, false);
+}
+
 // natural index -> zig-zag position (inverse of encoder.rs UNZIGZAG)
 __constant__ uint8_t kZigzagPos[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
                                        41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
@@ -248,7 +270,8 @@ __device__ __forceinline__ uint32_t block_pixel(const JpegJob &jb, uint32_t blk,
 __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__restrict__ jobs, const uint32_t *__restrict__ arena,
                                                              uint32_t job_base)
 {
-    __shared__ int32_t s_a[4][64], s_b[4][64];
+    __shared__ int32_t s_a[4][64];                       // zig-zag exchange
+    __shared__ __attribute__((aligned(16))) int16_t s_a16[4][64], s_b16[4][64]; // samples / pass-1 results (both fit 16 bits)
     __shared__ uint32_t s_ac[512], s_u[4][64];
     const JpegJob jb = jobs[job_base + blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, r = lane >> 3, c = lane & 7u;
@@ -259,16 +282,20 @@ __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__re
     const uint32_t first = blockIdx.x * kBlocksPerWg + wave * kBlocksPerWave;
     if (first >= nblocks) return;                      // wave-uniform; from here on waves never synchronise with each other
     const uint32_t last = min(first + (uint32_t)kBlocksPerWave, nblocks);
-    int32_t m1[8], m2[8];
+    uint32_t m1[4], m2[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { m1[j] = kFdct.a[c][j]; m2[j] = kFdct.a[r][j]; }
+    for (int j = 0; j < 4; ++j) {
+        m1[j] = pack_i16(kFdct.a[c][2 * j], kFdct.a[c][2 * j + 1]);
+        m2[j] = pack_i16(kFdct.a[r][2 * j], kFdct.a[r][2 * j + 1]);
+    }
     const uint8_t *qt = reinterpret_cast<const uint8_t *>(arena + jb.tab_off) + 624;
     const uint32_t ql = qt[lane], qc = qt[64 + lane];
     const uint32_t *magic = reinterpret_cast<const uint32_t *>(qt + 128);
     const uint32_t ml = magic[lane], mc = magic[64 + lane];
     const uint32_t lt_lo = lane >= 32u ? 0xffffffffu : (1u << lane) - 1u, lt_hi = lane >= 32u ? (1u << (lane - 32u)) - 1u : 0u;
     const uint32_t zz = kZigzagPos[lane];
-    int32_t *ta = s_a[wave], *tb = s_b[wave];
+    int32_t *ta = s_a[wave];
+    int16_t *ta16 = s_a16[wave], *tb16 = s_b16[wave];
     uint32_t *tu = s_u[wave];
     uint32_t rgb = block_pixel(jb, first, r, c);
     for (uint32_t blk = first; blk < last; ++blk) {
@@ -277,22 +304,18 @@ __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__re
         if (blk + 1u < last) rgb = block_pixel(jb, blk + 1u, r, c); // in flight while this block is transformed
 #pragma unroll
         for (int comp = 0; comp < 3; ++comp) {
-            ta[lane] = (int32_t)smp[comp];
+            ta16[lane] = (int16_t)smp[comp];
             wave_lds_sync();
             // Pass 1 (rows): lane (r, c) produces horizontal frequency c of row r
-            int32_t p = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p += __mul24(m1[j], ta[r * 8 + j]);   // |matrix| < 2^16, samples < 2^8: 24-bit multiplies are exact and full rate
+            const int32_t p = dot8_i16(m1, *reinterpret_cast<const uint4 *>(ta16 + r * 8)); // one 16-byte read: the row's 8 samples
             int32_t v1;
             if (c == 0) v1 = (p - 8 * 128) << 2;          // level shift folded in, scaled by 2^PASS1_BITS
             else if (c == 4) v1 = p << 2;
             else v1 = (p + (1 << 10)) >> 11;              // CONST_BITS - PASS1_BITS
-            tb[c * 8 + r] = v1;                              // transposed: the column pass reads 8 consecutive words
+            tb16[c * 8 + r] = (int16_t)v1;                   // |v1| <= 255 * 8 * 4; transposed: the column pass reads 8 consecutive values
             wave_lds_sync();
             // Pass 2 (columns): lane (r, c) produces vertical frequency r of column c
-            int32_t p2 = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p2 += __mul24(m2[j], tb[c * 8 + j]);  // |pass-1 output| <= 255 * 8 * 4 < 2^14
+            const int32_t p2 = dot8_i16(m2, *reinterpret_cast<const uint4 *>(tb16 + c * 8));
             int32_t d;
             if (r == 0 || r == 4) d = (p2 + 2) >> 2;
             else d = (p2 + (1 << 14)) >> 15;              // CONST_BITS + PASS1_BITS
