@@ -86,3 +86,16 @@ def test_error_strings(fl):
         assert s and s != "unknown status"
         seen.add(s)
     assert len(seen) == 9 and lib.flgpu_strerror(99).decode() == "unknown status"
+
+
+def test_rust_shim_in_integration_md_mirrors_the_structs(fl):
+    # INTEGRATION.md carries the reference-side binding as Rust source; its #[repr(C)] structs must list the header's
+    # fields in the header's order (the ctypes mirrors are already checked against the header above)
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for rust, cls in (("FlImage", fl.flgpu_image), ("FlParams", fl.flgpu_params), ("FlPlan", fl.flgpu_plan), ("FlConfig", fl.flgpu_config)):
+        m = re.search(r"pub struct %s \{(.*?)\}" % rust, text, re.S)
+        assert m, rust
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+        names = [f.split(":")[0].strip() for f in body.split(",") if ":" in f]
+        assert names == [n for n, _ in cls._fields_], (rust, names)
