@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the fanlin-rs image hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): a batch of 1024 synthetic 1920x1080 RGB8 images,
-HBM-resident, each resized to w=300&h=200 with Lanczos3 (300x169) and letterboxed onto
-the fill colour (300x200 RGBA8) -- one call of flgpu_transform_batch_device per step.
+Workload (BASELINE.json configs[1], the metric's "1080p -> 300x200 resize+encode"): a batch of 1024 synthetic
+1920x1080 RGB8 images, HBM-resident, each resized to w=300&h=200 with Lanczos3 (300x169), letterboxed onto the fill
+colour (300x200 RGBA8) and encoded to a baseline JPEG stream on the device (quality 75, the reference's default,
+src/query.rs:18) -- one call of flgpu_transform_batch_device per step.  After the timed region a sample of the results
+is copied back and compared with the CPU oracle; a mismatch fails the run.  The resize-only figure (--frontend none)
+and BASELINE config 2 (grayscale + blur) are measured next to it as extra keys.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -59,8 +62,9 @@ def cpu_baseline(n_images: int, workload: dict, max_threads: int = 16):
     imgs = [synth.uniform(SRC_H, SRC_W, SRC_C, index=1000 + i) for i in range(min(n_images, 8))]
 
     def one(i):
-        return oracle.process_pixels(imgs[i % len(imgs)], REQ_W, REQ_H, blur_sigma=workload["blur_sigma"],
-                                     grayscale=workload["grayscale"], crop=workload["crop"], arith=oracle_lib.ARITH_REF)
+        px = oracle.process_pixels(imgs[i % len(imgs)], REQ_W, REQ_H, blur_sigma=workload["blur_sigma"],
+                                   grayscale=workload["grayscale"], crop=workload["crop"], arith=oracle_lib.ARITH_REF)
+        return oracle.jpeg_encode(px, workload.get("quality", 75)) if workload.get("jpeg") else px
 
     one(0)  # page in
     t0 = time.perf_counter()
@@ -73,7 +77,8 @@ def cpu_baseline(n_images: int, workload: dict, max_threads: int = 16):
     return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "single_thread_ms_per_image": t1 * 1e3,
             "sample": f"{n_images} synthetic 1920x1080 RGB8 images (uniform bytes), oracle/libfanlin_oracle.so "
-                      f"(C restatement of image 0.25.6, reference arithmetic), one image per thread on {cores} threads"}
+                      f"(C restatement of image 0.25.6, reference arithmetic), resize + letterbox"
+                      + (" + JPEG encode (q 75)" if workload.get("jpeg") else "") + f", one image per thread on {cores} threads"}
 
 
 def measured_traffic(workload: str):
@@ -143,7 +148,39 @@ def broadcast_icc_lut(fl, st, rank, dev, cdev):
         return {"ok": False, "reason": repr(e)[:200]}
 
 
-def latency_probe_c(args, query: str, front_end: int):
+def verify_sample(fl, src, dst, out_stride, results, params, plan, fe_name, count=16):
+    """Copies `count` images of the batch just processed back to the host and compares them with the CPU oracle on the
+    same pixels: resize + letterbox bit-exact against the oracle's fused-arithmetic mode and within 1 LSB of its reference
+    arithmetic; with the JPEG front end the device stream must equal the oracle encoder's stream on those pixels byte
+    for byte.  Returns (n_verified, error string or None).  The oracle is the checker here, never the thing measured."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle = oracle_lib.load()
+    n = src.shape[0]
+    picks = sorted(set(int(i) for i in np.linspace(0, n - 1, count)))
+    for i in picks:
+        img = src[i].cpu().numpy()
+        kw = dict(blur_sigma=float(params.blur_sigma), grayscale=bool(params.grayscale), crop=bool(params.crop))
+        want_fma = oracle.process_pixels(img, REQ_W, REQ_H, arith=oracle_lib.ARITH_FMA, **kw)
+        want_ref = oracle.process_pixels(img, REQ_W, REQ_H, arith=oracle_lib.ARITH_REF, **kw)
+        if int(np.abs(want_fma.astype(np.int16) - want_ref.astype(np.int16)).max()) > 1:
+            return 0, f"oracle modes disagree by more than 1 LSB on image {i}"
+        raw = dst[i].cpu().numpy()
+        if fe_name == "jpeg":
+            nb = results[i][1]
+            if raw[:nb].tobytes() != oracle.jpeg_encode(want_fma, int(params.quality)):
+                return 0, f"JPEG stream of image {i} ({nb} bytes) differs from the oracle encoder"
+        elif fe_name == "none":
+            got = raw[: plan.pixel_bytes].reshape(want_fma.shape)
+            if not np.array_equal(got, want_fma):
+                return 0, f"pixels of image {i} differ from the oracle (max diff {int(np.abs(got.astype(np.int16) - want_fma.astype(np.int16)).max())})"
+        else:
+            return 0, None  # plane front ends are checked by the test-suite only
+    return len(picks), None
+
+
+def latency_probe_c(args, query: str, front_end: int, pinned: int = 0):
     """The same probe from a plain C program (tools/latency/latency_probe.c, built by __graft_entry__.build()):
     pthread callers instead of Python threads, so the interpreter lock is not part of the measurement."""
     exe = os.path.join(ROOT, "tools", "latency", "latency_probe")
@@ -152,7 +189,7 @@ def latency_probe_c(args, query: str, front_end: int):
     import subprocess
     try:
         r = subprocess.run([exe, str(args.latency_threads), str(args.latency_requests), str(SRC_W), str(SRC_H), query, str(front_end),
-                            str(args.queue_lanes), str(args.queue_max_batch)], capture_output=True, text=True, timeout=300)
+                            str(args.queue_lanes), str(args.queue_max_batch), str(pinned)], capture_output=True, text=True, timeout=300)
         return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
     except Exception:
         return None
@@ -196,17 +233,46 @@ def latency_probe(fl, st, params, n_requests: int, n_threads: int):
             "path": "flgpu_transform, host buffers (H2D + kernels + D2H), request-batching queue"}
 
 
+def timed_loop(run, stream, steps, warmup, st, world, dist, cdev):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    import torch
+    for _ in range(warmup):
+        run(stream)
+    torch.cuda.synchronize()
+    st.reset_stats()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, st.stats()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (the default keeps the timed region above one second)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--blur", type=float, default=0.0, help="blur sigma (config 2 uses 10)")
     ap.add_argument("--grayscale", action="store_true")
     ap.add_argument("--crop", action="store_true")
-    ap.add_argument("--frontend", choices=["none", "jfif444", "webp420", "jpeg"], default="none")
-    ap.add_argument("--cpu-images", type=int, default=1024, help="CPU-baseline sample size (0 = skip); ~14 ms of CPU work per image")
+    ap.add_argument("--quality", type=int, default=75, help="JPEG quality (reference default, src/query.rs:18)")
+    ap.add_argument("--frontend", choices=["none", "jfif444", "webp420", "jpeg"], default="jpeg",
+                    help="what follows the pixel pipeline; jpeg = the complete baseline JPEG encode on the device (the metric's resize+encode)")
+    ap.add_argument("--extra-steps", type=int, default=40, help="steps of the secondary measurements (resize only, config 2); 0 = skip")
+    ap.add_argument("--verify-images", type=int, default=16, help="images compared with the CPU oracle after the timed region (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=1024, help="CPU-baseline sample size (0 = skip); ~16 ms of CPU work per image")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (one image per thread)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal: several ranks may share one GPU)")
@@ -243,8 +309,9 @@ def main():
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collectives run
 
     fl = load_package()
-    fe = {"none": fl.FE_NONE, "jfif444": fl.FE_JFIF444, "webp420": fl.FE_WEBP420, "jpeg": fl.FE_JPEG}[args.frontend]
-    params = fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fe)
+    FE = {"none": fl.FE_NONE, "jfif444": fl.FE_JFIF444, "webp420": fl.FE_WEBP420, "jpeg": fl.FE_JPEG}
+    fe = FE[args.frontend]
+    params = fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fe, quality=args.quality)
     plan = fl.plan_output(params, SRC_W, SRC_H, SRC_C)
     n = args.batch
     src_bytes = SRC_W * SRC_H * SRC_C
@@ -255,12 +322,15 @@ def main():
     src = torch.empty((n, SRC_H, SRC_W, SRC_C), dtype=torch.uint8, device=dev)
     for i in range(0, n, 64):
         src[i:i + 64] = torch.randint(0, 256, (min(64, n - i), SRC_H, SRC_W, SRC_C), dtype=torch.uint8, device=dev, generator=gen)
-    out_stride = (int(plan.out_bytes) + 255) // 256 * 256
+    # uniform noise is the least compressible input there is: give every stream the format's worst case so none can overflow
+    out_stride = (int(plan.max_out_bytes) + 255) // 256 * 256
     dst = torch.zeros((n, out_stride), dtype=torch.uint8, device=dev)
 
     st = fl.State(device=local_dev, profile=True, queue_lanes=args.queue_lanes, max_batch=args.queue_max_batch)
-    run = st.prepared_batch([src.data_ptr() + i * src_bytes for i in range(n)], [(SRC_H, SRC_W, SRC_C)] * n, params,
-                            [dst.data_ptr() + i * out_stride for i in range(n)], [out_stride] * n)
+    srcp = [src.data_ptr() + i * src_bytes for i in range(n)]
+    dstp = [dst.data_ptr() + i * out_stride for i in range(n)]
+    shapes = [(SRC_H, SRC_W, SRC_C)] * n
+    run = st.prepared_batch(srcp, shapes, params, dstp, [out_stride] * n)
     stream = torch.cuda.current_stream().cuda_stream
 
     # plan + build tables (untimed), then make every rank use rank 0's table blob (RCCL broadcast over xGMI)
@@ -271,7 +341,15 @@ def main():
         nbytes = st.copy_tables(blob.data_ptr(), blob.numel())
         size_t = torch.tensor([nbytes], dtype=torch.int64, device=cdev)
         dist.broadcast(size_t, src=0)
-        assert int(size_t.item()) == nbytes, "ranks planned different tables"
+        # every rank learns whether ALL ranks planned the same tables before anybody moves on: a rank that raised between
+        # two collectives would leave the others waiting for the RCCL timeout
+        same = torch.tensor([int(int(size_t.item()) == nbytes)], dtype=torch.int64, device=cdev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        if int(same.item()) == 0:
+            if rank == 0:
+                print(json.dumps({"error": "ranks planned different tables"}), flush=True)
+            dist.destroy_process_group()
+            raise SystemExit(1)
         payload = blob[:nbytes].to(cdev)           # nccl: stays on the device (xGMI); gloo rehearsal: staged through the host
         dist.broadcast(payload, src=0)
         blob[:nbytes] = payload.to(dev)
@@ -282,26 +360,44 @@ def main():
     else:
         icc_note = None
 
-    for _ in range(args.warmup):
-        run(stream)
-    torch.cuda.synchronize()
-    st.reset_stats()
+    elapsed, stats = timed_loop(run, stream, args.steps, args.warmup, st, world, dist, cdev)
+
+    # ---- check what the timed region produced ----
+    verified, verr = 0, None
+    results = None
+    if fe == fl.FE_JPEG:
+        srcs_c, dsts_c, _ = run._keep
+        fl._check(st._lib.flgpu_batch_results(st._ctx, n, dsts_c), st._ctx)
+        results = [(d.flags, d.bytes) for d in dsts_c]
+        if any(b == 0 for _, b in results):
+            verr = "an encoded stream did not fit its destination"
+    if args.verify_images > 0 and verr is None:
+        verified, verr = verify_sample(fl, src, dst, out_stride, results, params, plan, args.frontend, args.verify_images)
+    ok_flag = 0 if verr else 1
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stats = st.stats()
+        okt = torch.tensor([ok_flag], dtype=torch.int64, device=cdev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok_flag = int(okt.item())
+
+    # ---- secondary measurements on the same batch (single-GPU runs only; untimed for `value`) ----
+    extra = {}
+    if world == 1 and args.extra_steps > 0 and ok_flag:
+        def measure(p):
+            r = st.prepared_batch(srcp, shapes, p, dstp, [out_stride] * n)
+            r(stream)
+            torch.cuda.synchronize()
+            el, s2 = timed_loop(r, stream, args.extra_steps, 2, st, 1, dist, cdev)
+            return {"images_per_s": n * args.extra_steps / el, "ms_per_step": el / args.extra_steps * 1e3,
+                    "stage_ms_per_step": {"resample": s2["resample_ms"] / args.extra_steps, "blur": s2["blur_ms"] / args.extra_steps,
+                                          "frontend": s2["frontend_ms"] / args.extra_steps}}
+        if fe != fl.FE_NONE:
+            extra["resize_only (config 1 without the encode)"] = measure(
+                fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fl.FE_NONE))
+        if not (args.grayscale and args.blur):
+            extra["config2 (grayscale + blur sigma 10, pixels out)"] = measure(
+                fl.make_params(REQ_W, REQ_H, blur_sigma=10.0, grayscale=True, front_end=fl.FE_NONE))
+            extra["config2 + JPEG encode"] = measure(
+                fl.make_params(REQ_W, REQ_H, blur_sigma=10.0, grayscale=True, front_end=fl.FE_JPEG, quality=args.quality))
 
     if rank == 0:
         total_images = n * world * args.steps
@@ -312,7 +408,7 @@ def main():
         k_ms = stats["resample_ms"] / launches
         alg_bytes = (stats["resample_src_bytes"] + stats["resample_dst_bytes"]) / launches
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        workload = {"blur_sigma": args.blur, "grayscale": args.grayscale, "crop": args.crop}
+        workload = {"blur_sigma": args.blur, "grayscale": args.grayscale, "crop": args.crop, "jpeg": fe == fl.FE_JPEG, "quality": args.quality}
         line = {
             "metric": baseline_metric(),
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -321,7 +417,8 @@ def main():
             "config": {"workload": f"{n} x {SRC_W}x{SRC_H} RGB8 (uniform bytes, HBM-resident) -> w={REQ_W}&h={REQ_H} Lanczos3"
                                    + (" crop" if args.crop else " + letterbox RGBA8")
                                    + (" + grayscale" if args.grayscale else "") + (f" + blur sigma {args.blur:g}" if args.blur else "")
-                                   + (f" + {args.frontend} front end" if fe else ""),
+                                   + (f" + baseline JPEG encode (q {args.quality}) on the device" if fe == fl.FE_JPEG else (f" + {args.frontend} front end" if fe else "")),
+                       "stages_in_value": ["resize", "letterbox"] + (["blur"] if args.blur else []) + ([args.frontend] if fe else []),
                        "images_per_gpu_per_step": n, "sharding": "one independent batch per rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -329,15 +426,26 @@ def main():
             "per_image_us_kernel": k_ms * 1e3 / n if n else None,
             "stage_ms_per_step": {"resample": stats["resample_ms"] / args.steps, "blur": stats["blur_ms"] / args.steps,
                                   "frontend": stats["frontend_ms"] / args.steps},
+            "verified_images": verified if ok_flag else 0,
+            "verified_against": "oracle: pixels bit-exact vs ARITH_FMA (itself <= 1 LSB from ARITH_REF)" + ("; JPEG streams byte-identical to the oracle encoder" if fe == fl.FE_JPEG else ""),
         }
+        if verr:
+            line["error"] = verr
+        if results is not None:
+            line["mean_stream_bytes"] = sum(b for _, b in results) / max(len(results), 1)
         line["roofline"]["traffic"] = measured_traffic(line["config"]["workload"])
+        if extra:
+            line["extra"] = extra
         if icc_note is not None:
             line["icc_lut_broadcast"] = icc_note
-        if args.latency_requests > 0 and world == 1:
+        if args.latency_requests > 0 and world == 1 and ok_flag:
             query = f"w={REQ_W}&h={REQ_H}" + ("&crop=true" if args.crop else "") + (f"&blur={int(args.blur)}" if args.blur else "") \
-                + ("&grayscale=true" if args.grayscale else "")
-            line["latency"] = latency_probe_c(args, query, fe) or latency_probe(fl, st, params, args.latency_requests, args.latency_threads)
-        if args.cpu_images > 0 and world == 1:
+                + ("&grayscale=true" if args.grayscale else "") + f"&quality={args.quality}"
+            line["latency"] = latency_probe_c(args, query, fe, 0) or latency_probe(fl, st, params, args.latency_requests, args.latency_threads)
+            pinned = latency_probe_c(args, query, fe, 1)
+            if pinned:
+                line["latency_pinned"] = pinned
+        if args.cpu_images > 0 and world == 1 and ok_flag:
             line["cpu_baseline"] = cpu_baseline(args.cpu_images, workload, args.cpu_threads)
         else:
             line["cpu_baseline"] = None
@@ -345,6 +453,8 @@ def main():
     st.close()
     if world > 1:
         dist.destroy_process_group()
+    if not ok_flag:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

@@ -69,12 +69,16 @@ class flgpu_plan(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("src_w", "src_h", "mid_c", "resampled", "resized_w", "resized_h", "crop_x", "crop_y",
                                            "letterboxed", "place_x", "place_y", "out_w", "out_h", "out_c",
                                            "plane_w", "plane_h", "chroma_w", "chroma_h")] + \
-               [("pixel_bytes", C.c_uint64), ("out_bytes", C.c_uint64)]
+               [("pixel_bytes", C.c_uint64), ("out_bytes", C.c_uint64), ("max_out_bytes", C.c_uint64)]
+
+
+MAX_DEVICES = 8
 
 
 class flgpu_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_batch", C.c_uint32), ("flush_timeout_us", C.c_uint32),
-                ("profile", C.c_uint32), ("queue_lanes", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("profile", C.c_uint32), ("queue_lanes", C.c_uint32), ("n_devices", C.c_uint32), ("reserved", C.c_uint32 * 2),
+                ("devices", C.c_int32 * MAX_DEVICES)]
 
 
 class flgpu_stats(C.Structure):
@@ -92,7 +96,8 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_cropping", "flgpu_query_blur", "flgpu_query_grayscale", "flgpu_query_inverse",
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
     "flgpu_params_from_query", "flgpu_plan_output", "flgpu_process_image", "flgpu_process_image_plan", "flgpu_create", "flgpu_destroy", "flgpu_transform",
-    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_batch_results", "flgpu_host_alloc", "flgpu_host_free", "flgpu_ycck_to_cmyk",
+    "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_batch_results", "flgpu_plan_shards", "flgpu_devices",
+    "flgpu_cmyk_distribution", "flgpu_host_alloc", "flgpu_host_free", "flgpu_ycck_to_cmyk",
     "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
@@ -151,6 +156,11 @@ def load_library() -> C.CDLL:
     lib.flgpu_host_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.flgpu_host_free.restype = None
     lib.flgpu_batch_results.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image)]
+    lib.flgpu_plan_shards.argtypes = [C.c_uint32, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params), C.c_uint32,
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.flgpu_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32]
+    lib.flgpu_devices.restype = C.c_uint32
+    lib.flgpu_cmyk_distribution.argtypes = [C.c_void_p]
     lib.flgpu_ycck_to_cmyk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.flgpu_set_cmyk_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     lib.flgpu_set_cmyk_clut.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
@@ -308,6 +318,22 @@ def plan_output(params: flgpu_params, sw: int, sh: int, sc: int) -> flgpu_plan:
     return plan
 
 
+def plan_shards(n_shards: int, shapes: Sequence[Tuple[int, int, int]], params) -> Tuple[np.ndarray, np.ndarray]:
+    """flgpu_plan_shards: (shard_of[n], shard_bytes[n_shards]) for images of shapes[i] = (height, width, channels);
+    ``params`` is one flgpu_params (shared) or a sequence of n.  Pure host function."""
+    n = len(shapes)
+    srcs = (flgpu_image * max(n, 1))(*[flgpu_image(None, shapes[i][0] * shapes[i][1] * shapes[i][2], shapes[i][1], shapes[i][0],
+                                                   shapes[i][2], 0) for i in range(n)])
+    if isinstance(params, flgpu_params):
+        ps, flags = (flgpu_params * 1)(params), BATCH_SAME_PARAMS
+    else:
+        ps, flags = (flgpu_params * max(n, 1))(*params), 0
+    shard_of = (C.c_uint32 * max(n, 1))()
+    shard_bytes = (C.c_uint64 * n_shards)()
+    _check(load_library().flgpu_plan_shards(n_shards, n, srcs, ps, flags, shard_of, shard_bytes))
+    return np.array(shard_of[:n], dtype=np.uint32), np.array(shard_bytes[:], dtype=np.uint64)
+
+
 def debug_axis_table(in_size: int, out_size: int, gaussian: bool = False, sigma: float = 0.0):
     """(left, count, weights) exactly as the runtime uploads them for one axis."""
     lib = load_library()
@@ -370,11 +396,19 @@ class State:
     """
 
     def __init__(self, device: int = -1, max_batch: int = 0, flush_timeout_us: int = 0, profile: bool = False,
-                 queue_lanes: int = 0):
+                 queue_lanes: int = 0, devices: Optional[Sequence[int]] = None):
+        """``devices``: two or more HIP ordinals make ONE context that shards every batch across those GPUs (an ordinal
+        may repeat: two shards on one GPU); None / one entry = a single-device context."""
         lib = load_library()
         cfg = flgpu_config()
         cfg.device, cfg.max_batch, cfg.flush_timeout_us, cfg.profile = device, max_batch, flush_timeout_us, int(profile)
         cfg.queue_lanes = queue_lanes
+        if devices:
+            if len(devices) > MAX_DEVICES:
+                raise ValueError("at most 8 devices")
+            cfg.n_devices = len(devices)
+            for k, d in enumerate(devices):
+                cfg.devices[k] = d
         st = C.c_int()
         self._ctx = lib.flgpu_create(C.byref(cfg), C.byref(st))
         if not self._ctx:
@@ -402,7 +436,9 @@ class State:
     def process_pixels(self, image: np.ndarray, params: flgpu_params, capacity: int = 0):
         img = _as_image_array(image)
         plan = plan_output(params, img.shape[1], img.shape[0], img.shape[2])
-        out = np.empty(max(int(plan.out_bytes), capacity, 1), dtype=np.uint8)
+        # capacity < 0: exactly -capacity bytes (tests of the too-small path); otherwise the format's worst case, so that the
+        # call fails as rarely as JpegEncoder::encode_image into a Vec does (never)
+        out = np.empty(-capacity if capacity < 0 else max(int(plan.max_out_bytes), capacity, 1), dtype=np.uint8)
         src = flgpu_image(img.ctypes.data, img.nbytes, img.shape[1], img.shape[0], img.shape[2], 0)
         dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
         _check(self._lib.flgpu_transform(self._ctx, C.byref(src), C.byref(params), C.byref(dst)), self._ctx)
@@ -420,7 +456,7 @@ class State:
         _check(self._lib.flgpu_process_image_plan(C.byref(src), orientation, qs, flags, input_format, C.byref(plan), C.byref(kind)))
         if kind.value == RESULT_AS_IS:
             return MIME.get(input_format, "application/octet-stream"), RESULT_AS_IS, None
-        out = np.empty(max(int(plan.out_bytes), 1), dtype=np.uint8)
+        out = np.empty(max(int(plan.max_out_bytes), 1), dtype=np.uint8)
         dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
         _check(self._lib.flgpu_process_image(self._ctx, C.byref(src), orientation, qs, flags, input_format, C.byref(dst), C.byref(plan),
                                              C.byref(kind), C.byref(fmt)), self._ctx)
@@ -432,7 +468,7 @@ class State:
         n = len(images)
         imgs = [_as_image_array(a) for a in images]
         plans = [plan_output(params[i], imgs[i].shape[1], imgs[i].shape[0], imgs[i].shape[2]) for i in range(n)]
-        outs = [np.empty(max(int(pl.out_bytes), 1), dtype=np.uint8) for pl in plans]
+        outs = [np.empty(max(int(pl.max_out_bytes), 1), dtype=np.uint8) for pl in plans]
         srcs = (flgpu_image * n)(*[flgpu_image(a.ctypes.data, a.nbytes, a.shape[1], a.shape[0], a.shape[2], 0) for a in imgs])
         dsts = (flgpu_image * n)(*[flgpu_image(o.ctypes.data, o.nbytes, 0, 0, 0, 0) for o in outs])
         ps = (flgpu_params * n)(*params)
@@ -517,6 +553,15 @@ class State:
     def cmyk_to_rgb_device(self, d_cmyk: int, d_rgb: int, n_pixels: int, ycck: bool = False, stream: int = 0) -> None:
         _check(self._lib.flgpu_cmyk_to_rgb_device(self._ctx, C.c_void_p(d_cmyk), C.c_void_p(d_rgb), n_pixels,
                                                   CMYK_INPUT_YCCK if ycck else 0, C.c_void_p(stream)), self._ctx)
+
+    def cmyk_distribution(self) -> int:
+        """How the configured CMYK table reached the devices of a multi-device context: 2 = RCCL broadcast, 1 = copies, 0 = n/a."""
+        return int(self._lib.flgpu_cmyk_distribution(self._ctx))
+
+    def devices(self) -> List[int]:
+        buf = (C.c_int32 * MAX_DEVICES)()
+        n = self._lib.flgpu_devices(self._ctx, buf, MAX_DEVICES)
+        return [int(buf[k]) for k in range(n)]
 
     def export_tables(self) -> Tuple[int, int]:
         ptr, nbytes = C.c_void_p(), C.c_uint64()

@@ -1,0 +1,590 @@
+// fl_batch.cpp -- the batch planner and launcher: geometry, buffer chain, table lookups, descriptor staging and kernel
+// launches of one batch on ONE device context (reference order of operations: src/handler.rs:221-278), the read-back of
+// per-image result words, and the host-memory batch built on top of it.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "fl_context.h"
+
+using namespace fl;
+
+namespace {
+
+// ---- batch execution -------------------------------------------------------
+
+enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3, S1_NEAREST = 4 };
+
+struct Work {
+    flgpu_plan plan;
+    const flgpu_params *p;
+    uint32_t cs, pre, sw, sh;
+    Stage1Kind s1;
+    const uint8_t *src;
+    uint8_t *s1_dst;   // output of stage 1 (== src when S1_NONE)
+    uint8_t *blur_dst; // output of the blur stage (or null)
+    uint8_t *final_dst;
+    AxisKey vk, hk;
+    const HostAxis *va = nullptr, *ha = nullptr;
+    uint32_t vtab = 0, htab = 0;
+    const StreamPlan *splan = nullptr;
+    bool unaligned = false;
+    size_t jpeg_coef_off = 0, jpeg_off_off = 0, jpeg_raw_off = 0; // FE_JPEG scratch (bytes)
+    uint32_t jpeg_tab = 0;
+    uint32_t orient = 0, raw_w = 0, raw_h = 0; // EXIF orientation pre-pass (2..8), source size before it
+    size_t orient_off = 0;
+    const uint8_t *raw_src = nullptr;
+};
+
+struct GroupKey {
+    uint32_t kind, cs, pre, lb;
+    bool operator<(const GroupKey &o) const { return std::tie(kind, cs, pre, lb) < std::tie(o.kind, o.cs, o.pre, o.lb); }
+};
+
+// Channels the blur really has to filter: a letterboxed picture of an opaque source has alpha == 255 everywhere,
+// and a grey one on a grey fill has R == G == B (see blur_tile_kernel).
+uint32_t blur_channels(const Work &w)
+{
+    uint32_t ce = w.plan.out_c;
+    if (w.plan.letterboxed && (w.cs == 1 || w.cs == 3)) {
+        const bool grey = mid_channels(w.cs, w.pre) == 1 && w.p->fill_r == w.p->fill_g && w.p->fill_g == w.p->fill_b;
+        ce = grey ? 1u : 3u;
+    }
+    return ce;
+}
+
+void fill_job(const Work &w, Job &j)
+{
+    memset(&j, 0, sizeof(j));
+    const flgpu_plan &pl = w.plan;
+    j.src = w.src;
+    j.dst = w.s1_dst;
+    j.src_bytes = w.sw * w.sh * w.cs;
+    j.sw = w.sw; j.sh = w.sh;
+    j.rw = pl.resized_w; j.rh = pl.resized_h;
+    j.cx = pl.crop_x; j.cy = pl.crop_y;
+    if (pl.letterboxed) {
+        j.cw = std::min(pl.resized_w - pl.crop_x, pl.out_w - pl.place_x);
+        j.ch = std::min(pl.resized_h - pl.crop_y, pl.out_h - pl.place_y);
+    } else {
+        j.cw = pl.out_w; j.ch = pl.out_h;
+    }
+    j.dw = pl.out_w; j.dh = pl.out_h;
+    j.ox = pl.place_x; j.oy = pl.place_y;
+    j.fill = (uint32_t)w.p->fill_r | ((uint32_t)w.p->fill_g << 8) | ((uint32_t)w.p->fill_b << 16) | (255u << 24);
+    j.vtab = w.vtab; j.htab = w.htab;
+    if (w.s1 == S1_NEAREST) {
+        // sample.rs: ratio = in as f32 / out as f32, carried as bits where the Lanczos3 jobs carry table offsets
+        const float ry = (float)w.sh / (float)pl.resized_h, rx = (float)w.sw / (float)pl.resized_w;
+        memcpy(&j.vtab, &ry, 4); memcpy(&j.htab, &rx, 4);
+    }
+}
+
+} // namespace
+
+namespace fl {
+
+uint64_t staged_out_bytes(const flgpu_params &p, const flgpu_plan &plan, uint64_t)
+{
+    return p.front_end == FLGPU_FE_JPEG ? plan.max_out_bytes : plan.out_bytes;
+}
+
+int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, bool same_params,
+                     flgpu_image *dsts, hipStream_t st)
+{
+    if (n == 0) return FLGPU_OK;
+    if (!srcs || !ps || !dsts) return FLGPU_ERR_INVALID_ARG;
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    if (!st) st = c->stream;
+    if (c->last_stream && c->last_stream != st && c->last_done) FL_HIP(c, hipStreamWaitEvent(st, c->last_done, 0), "stream handoff");
+
+    // ---- plan every image ------------------------------------------------
+    std::vector<Work> work(n);
+    size_t tmp_a_bytes = 0, tmp_b_bytes = 0, tmp_o_bytes = 0, jpeg_coef_bytes = 0, jpeg_off_bytes = 0, jpeg_raw_bytes = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Work &w = work[i];
+        const flgpu_image &s = srcs[i];
+        w.p = same_params ? &ps[0] : &ps[i];
+        if (!s.data || !dsts[i].data) return FLGPU_ERR_INVALID_ARG;
+        int rc = flgpu_plan_output(w.p, s.width, s.height, s.channels, &w.plan);
+        if (rc) return rc;
+        if (s.capacity < (uint64_t)s.width * s.height * s.channels) return FLGPU_ERR_INVALID_ARG;
+        if (dsts[i].capacity < w.plan.out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
+        w.cs = s.channels; w.sw = w.plan.src_w; w.sh = w.plan.src_h; // size after apply_orientation
+        w.raw_w = s.width; w.raw_h = s.height;
+        w.orient = w.p->orientation >= 2 ? w.p->orientation : 0;
+        if (w.orient) { w.orient_off = tmp_o_bytes; tmp_o_bytes += align_up((size_t)s.width * s.height * s.channels, 256); }
+        w.pre = w.p->grayscale ? PRE_GRAY : (w.p->inverse ? PRE_INVERT : PRE_NONE);
+        w.src = s.data;
+        w.final_dst = dsts[i].data;
+        const flgpu_plan &pl = w.plan;
+        const bool cropped = pl.crop_x || pl.crop_y || pl.out_w != pl.resized_w || pl.out_h != pl.resized_h;
+        // grayscale of Luma/LumaA and "no-op" pre-ops change nothing
+        const bool pre_changes = (w.pre == PRE_INVERT) || (w.pre == PRE_GRAY && w.cs >= 3);
+        if (!pre_changes) w.pre = PRE_NONE;
+        if (pl.resampled) w.s1 = w.p->filter == FLGPU_FILTER_NEAREST ? S1_NEAREST : S1_GENERIC;
+        else if (pre_changes || pl.letterboxed || cropped) w.s1 = S1_PLACE;
+        else w.s1 = S1_NONE;
+        const bool blur = w.p->blur_sigma > 0.0f;
+        const bool fe = w.p->front_end != FLGPU_FE_NONE;
+        // buffer chain
+        if (w.s1 == S1_NONE) w.s1_dst = const_cast<uint8_t *>(w.src);
+        else if (!blur && !fe) w.s1_dst = w.final_dst;
+        else { w.s1_dst = reinterpret_cast<uint8_t *>(tmp_a_bytes); tmp_a_bytes += align_up(pl.pixel_bytes, 256); }
+        if (blur) {
+            if (!fe) w.blur_dst = w.final_dst;
+            else { w.blur_dst = reinterpret_cast<uint8_t *>(tmp_b_bytes); tmp_b_bytes += align_up(pl.pixel_bytes, 256); }
+        } else w.blur_dst = nullptr;
+        if (w.p->front_end == FLGPU_FE_JPEG) {
+            if (pl.out_w > 65535u || pl.out_h > 65535u) return FLGPU_ERR_UNSUPPORTED; // SOF0 carries u16 dimensions
+            const size_t units = (size_t)(pl.plane_w / 8u) * (pl.plane_h / 8u) * 3u;
+            if (units * kJpegMaxUnitBytes * 8 >= ((size_t)1 << 32)) return FLGPU_ERR_UNSUPPORTED; // bit offsets are 32-bit
+            w.jpeg_coef_off = jpeg_coef_bytes; jpeg_coef_bytes += align_up(units * sizeof(uint32_t), 256);
+            w.jpeg_off_off = jpeg_off_bytes; jpeg_off_bytes += align_up((units + 1) * sizeof(uint32_t), 256);
+            w.jpeg_raw_off = jpeg_raw_bytes; jpeg_raw_bytes += align_up(units * kAcWordsPerUnit * sizeof(uint32_t), 256);
+        }
+    }
+    FL_HIP(c, c->d_jpeg_coef.reserve(jpeg_coef_bytes), "JPEG coefficient scratch");
+    FL_HIP(c, c->d_jpeg_off.reserve(jpeg_off_bytes), "JPEG offset scratch");
+    FL_HIP(c, c->d_jpeg_raw.reserve(jpeg_raw_bytes), "JPEG bit-stream scratch");
+    FL_HIP(c, c->d_tmp_o.reserve(tmp_o_bytes), "orientation scratch");
+    for (auto &w : work)
+        if (w.orient) { w.raw_src = w.src; w.src = static_cast<uint8_t *>(c->d_tmp_o.p) + w.orient_off; }
+    FL_HIP(c, c->d_tmp_a.reserve(tmp_a_bytes), "scratch A");
+    FL_HIP(c, c->d_tmp_b.reserve(tmp_b_bytes), "scratch B");
+    for (auto &w : work) {
+        const bool blur = w.p->blur_sigma > 0.0f, fe = w.p->front_end != FLGPU_FE_NONE;
+        if (w.s1 == S1_NONE) w.s1_dst = const_cast<uint8_t *>(w.src);
+        if (w.s1 != S1_NONE && (blur || fe)) w.s1_dst = static_cast<uint8_t *>(c->d_tmp_a.p) + reinterpret_cast<size_t>(w.s1_dst);
+        if (blur && fe) w.blur_dst = static_cast<uint8_t *>(c->d_tmp_b.p) + reinterpret_cast<size_t>(w.blur_dst);
+    }
+
+    // ---- tables ------------------------------------------------------------
+    // first pass may overflow the arena: reset once and retry
+    const char *env_generic = getenv("FLGPU_FORCE_GENERIC");
+    const char *env_bands = getenv("FLGPU_FORCE_BANDS");
+    const bool force_generic = env_generic && env_generic[0] == '1';
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool full = false;
+        size_t n_resample = 0;
+        for (auto &w : work) n_resample += (w.plan.resampled && w.s1 != S1_NEAREST) ? 1 : 0;
+        for (auto &w : work) {
+            if (!w.plan.resampled || w.s1 == S1_NEAREST) continue;
+            w.vtab = get_axis(c, w.sh, w.plan.resized_h, FILTER_LANCZOS3, 0.0f, &w.vk, &w.va);
+            w.htab = get_axis(c, w.sw, w.plan.resized_w, FILTER_LANCZOS3, 0.0f, &w.hk, &w.ha);
+            if (!w.vtab || !w.htab) { full = true; break; }
+            // fused streaming kernel if the geometry allows it
+            w.s1 = S1_GENERIC;
+            // rows that are not dword aligned: Rgb8 has a funnel-shift variant of the kernel, others use the generic path
+            w.unaligned = ((w.sw * w.cs) % 4u != 0) || ((uintptr_t)w.src % 4u != 0);
+            const bool aligned = (!w.unaligned || w.cs == 3) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
+            if (stream_supported(w.cs, w.pre) && aligned && !force_generic) {
+                Job jtmp; fill_job(w, jtmp);
+                uint32_t nbands = 1;
+                if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
+                else if (n_resample < 512) {
+                    // small batches: split images into row bands so that the chip still gets >= ~1024 workgroups
+                    const uint32_t want = (uint32_t)((1024 + n_resample * 2 - 1) / (n_resample * 2));
+                    nbands = std::max(1u, std::min(want, jtmp.ch / 24u));
+                }
+                nbands = std::min(nbands, std::max(1u, jtmp.ch));
+                const StreamPlan *sp = get_stream_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, nbands, w.cs, w.pre);
+                if (c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
+                if (sp->ok) { w.s1 = S1_STREAM; w.splan = sp; }
+            }
+        }
+        for (auto &w : work) {
+            if (full) break;
+            if (w.p->blur_sigma > 0.0f) {
+                AxisKey k; const HostAxis *h;
+                AxisKey kv; const HostAxis *hv;
+                if (!get_axis(c, w.plan.out_h, w.plan.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &kv, &hv) ||
+                    !get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h)) full = true;
+                else {
+                    const uint32_t ty = blur_band_rows(blur_channels(w));
+                    if (blur_tile_supported(h->max_taps) && blur_tile_supported(hv->max_taps) && !c->blur_plans.count(std::make_tuple(kv, k, ty))) {
+                        std::vector<uint32_t> blk;
+                        build_blur_plan(*hv, *h, blur_tile_count(w.plan.out_w, h->max_taps), ty, blk);
+                        const uint32_t off = arena_append(c, blk.data(), blk.size());
+                        if (!off) full = true; else c->blur_plans[std::make_tuple(kv, k, ty)] = off;
+                    }
+                }
+            }
+        }
+        for (auto &w : work) {
+            if (full) break;
+            if (w.p->front_end != FLGPU_FE_JPEG) continue;
+            const uint32_t q = std::min<uint32_t>(std::max<uint32_t>(w.p->quality, 1u), 100u); // handler.rs:275 quality().clamp(1, 100)
+            const auto key = std::make_tuple(w.plan.out_w, w.plan.out_h, q);
+            auto it = c->jpeg_tables.find(key);
+            if (it == c->jpeg_tables.end()) {
+                std::vector<uint32_t> blk;
+                build_jpeg_tables(w.plan.out_w, w.plan.out_h, q, blk);
+                const uint32_t off = arena_append(c, blk.data(), blk.size());
+                if (!off) { full = true; break; }
+                it = c->jpeg_tables.emplace(key, off).first;
+            }
+            w.jpeg_tab = it->second;
+        }
+        if (!full) break;
+        if (attempt == 1) return FLGPU_ERR_OOM;
+        FL_HIP(c, hipStreamSynchronize(st), "arena reset sync");
+        FL_HIP(c, hipDeviceSynchronize(), "arena reset sync");
+        arena_reset(c);
+    }
+    { int rc = arena_flush(c, st); if (rc) return rc; }
+
+    // ---- descriptors ---------------------------------------------------------
+    std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
+    for (size_t i = 0; i < n; ++i) {
+        const Work &w = work[i];
+        if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        if (w.p->blur_sigma > 0.0f) {
+            const uint32_t ce = blur_channels(w);
+            // pictures of one launch share the workgroup width the kernel is instantiated for
+            AxisKey hk2; const HostAxis *hh2 = nullptr;
+            const uint32_t lanes = (get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &hk2, &hh2) && hh2 &&
+                                    blur_tile_supported(hh2->max_taps)) ? blur_lanes(w.plan.out_w, hh2->max_taps) : 256u;
+            blur_groups[{lanes, w.plan.out_c, ce, 0}].push_back(i);
+        }
+        if (w.p->front_end != FLGPU_FE_NONE) fe_groups[{w.p->front_end, 0, 0, 0}].push_back(i);
+    }
+    std::vector<Job> jobs;
+    std::vector<StreamItem> items;
+    std::vector<FrontendJob> fjobs;
+    // EXIF orientation pre-pass jobs, grouped by channel count
+    struct OrientLaunch { uint32_t cs, base, n, mw, mh; };
+    std::vector<OrientLaunch> orient_launches;
+    for (uint32_t cs = 1; cs <= 4; ++cs) {
+        OrientLaunch O{cs, (uint32_t)jobs.size(), 0, 0, 0};
+        for (auto &w : work) {
+            if (!w.orient || w.cs != cs) continue;
+            Job j; memset(&j, 0, sizeof(j));
+            j.src = w.raw_src; j.dst = const_cast<uint8_t *>(w.src);
+            j.sw = w.raw_w; j.sh = w.raw_h; j.dw = w.sw; j.dh = w.sh; j.fill = w.orient;
+            O.mw = std::max(O.mw, j.dw); O.mh = std::max(O.mh, j.dh);
+            jobs.push_back(j);
+            O.n++;
+        }
+        if (O.n) orient_launches.push_back(O);
+    }
+    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc; LaunchGeneric g; size_t lds; size_t mid_floats; uint32_t blur_grid_x; bool blur_tiled; };
+    std::vector<S1Launch> s1_launches, blur_launches;
+    struct FeLaunch { uint32_t kind, base, n, mw, mh; bool rgba; };
+    std::vector<FeLaunch> fe_launches;
+    size_t mid_floats_max = 0;
+    const size_t kMidCapFloats = (size_t)256 << 20; // 1 GiB of f32 intermediate per launch group
+
+    auto new_launch = [&](const GroupKey &k) {
+        S1Launch L{};
+        L.k = k; L.job_base = (uint32_t)jobs.size(); L.item_base = (uint32_t)items.size();
+        L.g.cs = k.cs; L.g.pre = k.pre; L.g.letterbox = k.lb; L.g.grouped = 1;
+        return L;
+    };
+    for (auto &kv : s1_groups) {
+        const GroupKey &k = kv.first;
+        S1Launch L = new_launch(k);
+        for (size_t idx : kv.second) {
+            const Work &w = work[idx];
+            Job j; fill_job(w, j);
+            const size_t mid = ((k.kind & 255u) == S1_GENERIC) ? (size_t)w.sw * w.plan.resized_h * mid_channels(w.cs, w.pre) : 0;
+            if ((k.kind & 255u) == S1_GENERIC && L.njobs && L.mid_floats + mid > kMidCapFloats) {
+                s1_launches.push_back(L);
+                L = new_launch(k);
+            }
+            j.mid_off = (uint32_t)L.mid_floats;
+            L.mid_floats += mid;
+            mid_floats_max = std::max(mid_floats_max, L.mid_floats);
+            L.g.max_sw = std::max(L.g.max_sw, j.sw); L.g.max_rh = std::max(L.g.max_rh, j.rh);
+            L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
+            L.g.max_dw = std::max(L.g.max_dw, j.dw); L.g.max_dh = std::max(L.g.max_dh, j.dh);
+            if ((k.kind & 255u) == S1_STREAM) {
+                for (StreamItem it2 : w.splan->items) { it2.job = (uint32_t)jobs.size(); items.push_back(it2); }
+                L.nitems += (uint32_t)w.splan->items.size();
+                L.lds = std::max(L.lds, w.splan->lds_bytes);
+                L.nacc = w.splan->nacc;
+                c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
+                c->stats.resample_dst_bytes += w.plan.pixel_bytes;
+            }
+            jobs.push_back(j);
+            L.njobs++;
+        }
+        if ((k.kind & 255u) == S1_STREAM && L.nitems > 1) {
+            // longest workgroups first: in a mixed batch a 4K band walks four times the rows of a 1080p one, and the
+            // hardware hands out workgroups in index order -- started last, the long ones would be the launch's tail
+            auto first = items.begin() + L.item_base;
+            std::stable_sort(first, first + L.nitems, [](const StreamItem &a, const StreamItem &b) { return a.r1 - a.r0 > b.r1 - b.r0; });
+        }
+        s1_launches.push_back(L);
+    }
+    for (auto &kv : blur_groups) {
+        const GroupKey &k = kv.first; // cs = channel count of the blurred image
+        S1Launch L = new_launch(k);
+        for (size_t idx : kv.second) {
+            const Work &w = work[idx];
+            const flgpu_plan &pl = w.plan;
+            Job j; memset(&j, 0, sizeof(j));
+            j.src = w.s1_dst; j.dst = w.blur_dst; j.src_bytes = (uint32_t)pl.pixel_bytes;
+            j.sw = pl.out_w; j.sh = pl.out_h; j.rw = pl.out_w; j.rh = pl.out_h; j.cw = pl.out_w; j.ch = pl.out_h;
+            j.dw = pl.out_w; j.dh = pl.out_h;
+            AxisKey vkey, hkey;
+            j.vtab = get_axis(c, pl.out_h, pl.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &vkey, nullptr);
+            j.htab = get_axis(c, pl.out_w, pl.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &hkey, nullptr);
+            {
+                auto bt = c->blur_plans.find(std::make_tuple(vkey, hkey, blur_band_rows(k.pre ? k.pre : pl.out_c)));
+                j.pad0 = bt != c->blur_plans.end() ? bt->second : 0u; // table block of the blur kernel
+            }
+            const size_t mid = (size_t)pl.out_w * pl.out_h * pl.out_c;
+            if (L.njobs && L.mid_floats + mid > kMidCapFloats) { blur_launches.push_back(L); L = new_launch(k); }
+            {
+                const AxisTable *vh = reinterpret_cast<const AxisTable *>(c->h_arena.data() + j.vtab);
+                const AxisTable *hh = reinterpret_cast<const AxisTable *>(c->h_arena.data() + j.htab);
+                if (L.njobs == 0) L.blur_tiled = true;
+                const size_t lds = blur_lds_bytes(pl.out_w, k.pre ? k.pre : pl.out_c, vh->max_taps, hh->max_taps); // k.pre = channels filtered
+                if (!blur_tile_supported(hh->max_taps) || !blur_tile_supported(vh->max_taps) || lds > 150 * 1024 || !j.pad0) L.blur_tiled = false;
+                L.lds = std::max(L.lds, lds);
+                L.blur_grid_x = std::max(L.blur_grid_x, blur_grid_x(pl.out_w, pl.out_h, hh->max_taps, k.pre ? k.pre : pl.out_c));
+            }
+            j.mid_off = (uint32_t)L.mid_floats;
+            L.mid_floats += mid;
+            mid_floats_max = std::max(mid_floats_max, L.mid_floats);
+            L.g.max_sw = std::max(L.g.max_sw, j.sw); L.g.max_rh = std::max(L.g.max_rh, j.rh);
+            L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
+            jobs.push_back(j);
+            L.njobs++;
+        }
+        blur_launches.push_back(L);
+    }
+    // result words: two per image of the batch, see flgpu_ctx::last_fe
+    const bool has_results = !fe_groups.empty();
+    if (has_results) {
+        FL_HIP(c, c->d_status.reserve(n * 8), "result words");
+        FL_HIP(c, hipMemsetAsync(c->d_status.p, 0, n * 8, st), "result clear");
+    }
+    std::vector<JpegJob> jjobs;
+    uint32_t jpeg_max_blocks = 0;
+    for (auto &kv : fe_groups) {
+        if (kv.first.kind == FLGPU_FE_JPEG) {
+            for (size_t idx : kv.second) {
+                const Work &w = work[idx];
+                const flgpu_plan &pl = w.plan;
+                JpegJob j; memset(&j, 0, sizeof(j));
+                j.src = w.blur_dst ? w.blur_dst : w.s1_dst;
+                j.dst = w.final_dst;
+                j.meta = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_coef.p) + w.jpeg_coef_off);
+                j.unit_off = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_off.p) + w.jpeg_off_off);
+                j.acbits = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_raw.p) + w.jpeg_raw_off);
+                j.result = static_cast<uint32_t *>(c->d_status.p) + 2 * idx;
+                j.w = pl.out_w; j.h = pl.out_h; j.c = pl.out_c;
+                j.bx = pl.plane_w / 8u; j.by = pl.plane_h / 8u;
+                j.tab_off = w.jpeg_tab;
+                j.dst_cap = (uint32_t)std::min<uint64_t>(dsts[idx].capacity, 0xffffffffull);
+                jpeg_max_blocks = std::max(jpeg_max_blocks, j.bx * j.by);
+                jjobs.push_back(j);
+            }
+            continue;
+        }
+        FeLaunch F{kv.first.kind, (uint32_t)fjobs.size(), 0, 0, 0, true};
+        for (size_t idx : kv.second) {
+            const Work &w = work[idx];
+            const flgpu_plan &pl = w.plan;
+            FrontendJob f; memset(&f, 0, sizeof(f));
+            f.src = w.blur_dst ? w.blur_dst : w.s1_dst;
+            f.dst = w.final_dst;
+            f.status = static_cast<uint32_t *>(c->d_status.p) + 2 * idx;
+            f.w = pl.out_w; f.h = pl.out_h; f.c = pl.out_c;
+            f.plane_w = pl.plane_w; f.plane_h = pl.plane_h; f.chroma_w = pl.chroma_w; f.chroma_h = pl.chroma_h;
+            if (f.c != 4 || ((uintptr_t)f.src & 3u) || ((uintptr_t)f.dst & 3u)) F.rgba = false;
+            if (F.kind == FLGPU_FE_JFIF444) { F.mw = std::max(F.mw, f.plane_w); F.mh = std::max(F.mh, f.plane_h); }
+            else { F.mw = std::max(F.mw, f.chroma_w); F.mh = std::max(F.mh, f.chroma_h); }
+            fjobs.push_back(f);
+            F.n++;
+        }
+        fe_launches.push_back(F);
+    }
+    FL_HIP(c, c->d_mid.reserve(mid_floats_max * 4), "f32 intermediate");
+
+    // one staging slot: [jobs][items][fjobs][jjobs]
+    const size_t jobs_b = align_up(jobs.size() * sizeof(Job), 256), items_b = align_up(items.size() * sizeof(StreamItem), 256),
+                 fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256), jjobs_b = align_up(jjobs.size() * sizeof(JpegJob), 256);
+    const size_t desc_b = jobs_b + items_b + fjobs_b + jjobs_b;
+    const Job *d_jobs = nullptr; const StreamItem *d_items = nullptr; const FrontendJob *d_fjobs = nullptr; const JpegJob *d_jjobs = nullptr;
+    DescSlot *slot = nullptr;
+    if (desc_b) {
+        slot = &c->slots[c->next_slot];
+        c->next_slot = (c->next_slot + 1) % 4;
+        if (slot->busy) { FL_HIP(c, hipEventSynchronize(slot->done), "descriptor slot wait"); slot->busy = false; }
+        if (!slot->done) FL_HIP(c, hipEventCreateWithFlags(&slot->done, hipEventDisableTiming), "event");
+        FL_HIP(c, slot->host.reserve(desc_b), "pinned descriptors");
+        FL_HIP(c, slot->dev.reserve(desc_b), "device descriptors");
+        char *hp = static_cast<char *>(slot->host.p);
+        if (!jobs.empty()) memcpy(hp, jobs.data(), jobs.size() * sizeof(Job));
+        if (!items.empty()) memcpy(hp + jobs_b, items.data(), items.size() * sizeof(StreamItem));
+        if (!fjobs.empty()) memcpy(hp + jobs_b + items_b, fjobs.data(), fjobs.size() * sizeof(FrontendJob));
+        if (!jjobs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b, jjobs.data(), jjobs.size() * sizeof(JpegJob));
+        FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, st), "descriptor upload");
+        char *dp = static_cast<char *>(slot->dev.p);
+        d_jobs = reinterpret_cast<const Job *>(dp);
+        d_items = reinterpret_cast<const StreamItem *>(dp + jobs_b);
+        d_fjobs = reinterpret_cast<const FrontendJob *>(dp + jobs_b + items_b);
+        d_jjobs = reinterpret_cast<const JpegJob *>(dp + jobs_b + items_b + fjobs_b);
+    }
+
+    // ---- launches --------------------------------------------------------------
+    for (auto &O : orient_launches) {
+        LaunchGeneric g{};
+        g.jobs = d_jobs; g.job_base = O.base; g.njobs = O.n; g.cs = O.cs; g.max_dw = O.mw; g.max_dh = O.mh;
+        FL_HIP(c, launch_orient(g, st), "orientation kernel");
+    }
+    for (auto &L : s1_launches) {
+        L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
+        L.g.job_base = L.job_base; L.g.njobs = L.njobs;
+        if ((L.k.kind & 255u) == S1_NEAREST) {
+            L.g.nearest = 1;
+            FL_HIP(c, launch_place(L.g, false, st), "nearest kernel");
+        } else if ((L.k.kind & 255u) == S1_PLACE) {
+            FL_HIP(c, launch_place(L.g, false, st), "place kernel");
+        } else if ((L.k.kind & 255u) == S1_GENERIC) {
+            if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
+            FL_HIP(c, launch_vpass_generic(L.g, st), "generic vertical pass");
+            FL_HIP(c, launch_hpass_generic(L.g, st), "generic horizontal pass");
+            c->stats.generic_launches++;
+        } else {
+            LaunchStream s{}; // (the streaming kernel paints the letterbox frame itself)
+            s.jobs = d_jobs; s.items = d_items + L.item_base; s.arena = c->d_arena; s.nitems = L.nitems;
+            s.cs = L.k.cs; s.pre = L.k.pre; s.letterbox = L.k.lb; s.lds_bytes = L.lds; s.nacc = L.nacc; s.unaligned = (L.k.kind >> 16) & 1u;
+            {
+                ProfileScope ps(c, st, 0);
+                FL_HIP(c, launch_stream(s, st), "streaming resample kernel");
+            }
+            c->stats.resample_launches++;
+        }
+    }
+    for (auto &L : blur_launches) {
+        L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
+        L.g.job_base = L.job_base; L.g.njobs = L.njobs; L.g.letterbox = 0;
+        L.g.grouped = 0;
+        ProfileScope ps(c, st, 1);
+        if (L.blur_tiled && !force_generic) {
+            L.g.pre = L.k.pre; // channels to filter (group key), see blur_tile_kernel
+            L.g.blur_lanes = L.k.kind;
+            FL_HIP(c, launch_blur_tile(L.g, L.blur_grid_x, L.lds, st), "blur kernel");
+        } else {
+            L.g.pre = PRE_NONE;
+            FL_HIP(c, launch_vpass_generic(L.g, st), "blur vertical pass");
+            FL_HIP(c, launch_hpass_generic(L.g, st), "blur horizontal pass");
+        }
+        c->stats.blur_launches++;
+    }
+    for (auto &F : fe_launches) {
+        ProfileScope ps(c, st, 2);
+        if (F.kind == FLGPU_FE_JFIF444) FL_HIP(c, launch_jfif444(d_fjobs, F.base, F.n, F.mw, F.mh, F.rgba, st), "jfif front end");
+        else FL_HIP(c, launch_webp420(d_fjobs, c->d_arena, c->gamma_off, F.base, F.n, F.mw, F.mh, F.rgba, st), "webp front end");
+        c->stats.frontend_launches++;
+    }
+    if (!jjobs.empty()) {
+        ProfileScope ps(c, st, 2);
+        FL_HIP(c, launch_jpeg_encode(d_jjobs, c->d_arena, 0, (uint32_t)jjobs.size(), jpeg_max_blocks, st), "JPEG encode");
+        c->stats.frontend_launches++;
+    }
+    // plain copies for requests that change nothing
+    for (size_t i = 0; i < n; ++i) {
+        const Work &w = work[i];
+        if (w.s1 == S1_NONE && !(w.p->blur_sigma > 0.0f) && w.p->front_end == FLGPU_FE_NONE)
+            FL_HIP(c, hipMemcpyAsync(w.final_dst, w.src, w.plan.pixel_bytes, hipMemcpyDeviceToDevice, st), "copy");
+    }
+    if (slot) { FL_HIP(c, hipEventRecord(slot->done, st), "event record"); slot->busy = true; }
+    if (!c->last_done) FL_HIP(c, hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming), "event");
+    FL_HIP(c, hipEventRecord(c->last_done, st), "event record");
+    c->last_stream = st;
+
+    for (size_t i = 0; i < n; ++i) {
+        const flgpu_plan &pl = work[i].plan;
+        dsts[i].width = pl.out_w; dsts[i].height = pl.out_h; dsts[i].channels = pl.out_c;
+        const uint32_t fe = work[i].p->front_end;
+        dsts[i].flags = fe == FLGPU_FE_JPEG ? FLGPU_IMG_ENCODED : (fe != FLGPU_FE_NONE ? FLGPU_IMG_FRONTEND_PLANES : 0u);
+        dsts[i].bytes = fe == FLGPU_FE_JPEG ? 0 : pl.out_bytes; // an encoded stream's length is a result word: flgpu_batch_results
+    }
+    c->last_n = n;
+    c->last_has_results = has_results;
+    c->last_fe.resize(n);
+    for (size_t i = 0; i < n; ++i) c->last_fe[i] = work[i].p->front_end;
+    c->stats.images += n;
+    c->stats.batches++;
+    return FLGPU_OK;
+}
+
+// Reads the result words of the batch that was just enqueued on `st` (synchronises) and completes dsts[]:
+// the alpha flag of the WebP front end, the length of an encoded stream.
+int collect_results(flgpu_ctx *c, size_t n, flgpu_image *dsts, hipStream_t st)
+{
+    if (!c->last_has_results || n != c->last_n) { FL_HIP(c, hipStreamSynchronize(st), "batch sync"); return FLGPU_OK; }
+    FL_HIP(c, c->h_results.reserve(n * 8), "pinned result words");
+    FL_HIP(c, hipMemcpyAsync(c->h_results.p, c->d_status.p, n * 8, hipMemcpyDeviceToHost, st), "result words D2H");
+    FL_HIP(c, hipStreamSynchronize(st), "batch sync");
+    const uint32_t *r = static_cast<const uint32_t *>(c->h_results.p);
+    int rc = FLGPU_OK;
+    for (size_t i = 0; i < n; ++i) {
+        if (c->last_fe[i] == FLGPU_FE_WEBP420 && (r[2 * i] & 1u)) dsts[i].flags |= FLGPU_IMG_HAS_ALPHA;
+        if (c->last_fe[i] == FLGPU_FE_JPEG) {
+            dsts[i].bytes = r[2 * i + 1];
+            if (!r[2 * i + 1]) { c->set_error("encoded stream does not fit the destination"); rc = FLGPU_ERR_BUFFER_TOO_SMALL; }
+        }
+    }
+    return rc;
+}
+
+// Host-memory batch: stage in, run, stage out, wait.
+int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts)
+{
+    if (n == 0) return FLGPU_OK;
+    if (!srcs || !ps || !dsts) return FLGPU_ERR_INVALID_ARG;
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    std::vector<flgpu_image> dsrc(n), ddst(n);
+    std::vector<flgpu_plan> plans(n);
+    size_t in_b = 0, out_b = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!srcs[i].data || !dsts[i].data) return FLGPU_ERR_INVALID_ARG;
+        int rc = flgpu_plan_output(&ps[i], srcs[i].width, srcs[i].height, srcs[i].channels, &plans[i]);
+        if (rc) return rc;
+        const uint64_t sb = (uint64_t)srcs[i].width * srcs[i].height * srcs[i].channels;
+        if (srcs[i].capacity < sb) return FLGPU_ERR_INVALID_ARG;
+        if (dsts[i].capacity < plans[i].out_bytes && ps[i].front_end != FLGPU_FE_JPEG) return FLGPU_ERR_BUFFER_TOO_SMALL;
+        dsrc[i] = srcs[i]; ddst[i] = dsts[i];
+        dsrc[i].data = reinterpret_cast<uint8_t *>(in_b); dsrc[i].capacity = sb; in_b += align_up(sb, 256);
+        const uint64_t ob = plans[i].max_out_bytes; // JPEG: the format's worst case, so the device side never overflows
+        ddst[i].data = reinterpret_cast<uint8_t *>(out_b); ddst[i].capacity = ob; out_b += align_up(ob, 256);
+    }
+    FL_HIP(c, c->d_in.reserve(in_b), "device input staging");
+    FL_HIP(c, c->d_out.reserve(out_b), "device output staging");
+    FL_HIP(c, c->h_stage_in.reserve(in_b), "pinned input staging");
+    FL_HIP(c, c->h_stage_out.reserve(out_b), "pinned output staging");
+    hipStream_t st = c->stream;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t off = reinterpret_cast<size_t>(dsrc[i].data);
+        memcpy(static_cast<char *>(c->h_stage_in.p) + off, srcs[i].data, dsrc[i].capacity);
+        dsrc[i].data = static_cast<uint8_t *>(c->d_in.p) + off;
+        ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
+    }
+    FL_HIP(c, hipMemcpyAsync(c->d_in.p, c->h_stage_in.p, in_b, hipMemcpyHostToDevice, st), "H2D");
+    int rc = run_batch_device(c, n, dsrc.data(), ps, false, ddst.data(), st);
+    if (rc) return rc;
+    FL_HIP(c, hipMemcpyAsync(c->h_stage_out.p, c->d_out.p, out_b, hipMemcpyDeviceToHost, st), "D2H");
+    rc = collect_results(c, n, ddst.data(), st);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t off = static_cast<uint8_t *>(ddst[i].data) - static_cast<uint8_t *>(c->d_out.p);
+        if (ddst[i].bytes > dsts[i].capacity) { // only now is the length of an encoded stream known
+            c->set_error("encoded stream does not fit the destination");
+            if (rc == FLGPU_OK) rc = FLGPU_ERR_BUFFER_TOO_SMALL;
+            dsts[i].bytes = 0; dsts[i].flags = ddst[i].flags;
+            continue;
+        }
+        memcpy(dsts[i].data, static_cast<char *>(c->h_stage_out.p) + off, std::min<uint64_t>(ddst[i].bytes, ddst[i].capacity));
+        dsts[i].width = ddst[i].width; dsts[i].height = ddst[i].height; dsts[i].channels = ddst[i].channels; dsts[i].flags = ddst[i].flags;
+        dsts[i].bytes = ddst[i].bytes;
+    }
+    return rc;
+}
+
+} // namespace fl

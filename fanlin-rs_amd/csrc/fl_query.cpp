@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/fanlin_gpu.h"
+#include "fl_jpeg_tables.h"
 #include "fl_tables.h"
 
 namespace {
@@ -307,14 +308,16 @@ int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t 
         plan->out_bytes = 3ull * plan->plane_w * plan->plane_h;
         break;
     case FLGPU_FE_JPEG:
-        // capacity bound of the stream, not its length: header + one byte per sample (quantised photographs stay
-        // far below; if a stream does not fit, the call reports FLGPU_ERR_BUFFER_TOO_SMALL and may be retried
-        // with a larger dst->capacity, at most 623 + 2 + 2 * 208 bytes per 8x8 block and component)
+        // out_bytes: a planning bound of the stream, not its length: header + one byte per sample (quantised photographs
+        // stay far below).  max_out_bytes: the worst case of the format, 623 + 2 + 2 * 208 bytes per 8x8 block and
+        // component: the library's own staging uses it, so a request fails with FLGPU_ERR_BUFFER_TOO_SMALL only if the
+        // finished stream really exceeds the caller's dst->capacity.
         plan->plane_w = (plan->out_w + 7u) & ~7u;
         plan->plane_h = (plan->out_h + 7u) & ~7u;
         plan->chroma_w = plan->plane_w;
         plan->chroma_h = plan->plane_h;
         plan->out_bytes = 3ull * plan->plane_w * plan->plane_h + 1024ull;
+        plan->max_out_bytes = 1024ull + 2ull * fl::kJpegMaxUnitBytes * 3ull * (plan->plane_w / 8u) * (plan->plane_h / 8u);
         break;
     case FLGPU_FE_WEBP420:
         plan->plane_w = plan->out_w;
@@ -328,6 +331,7 @@ int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t 
         plan->out_bytes = plan->pixel_bytes;
         break;
     }
+    if (plan->max_out_bytes < plan->out_bytes) plan->max_out_bytes = plan->out_bytes;
     return FLGPU_OK;
 }
 

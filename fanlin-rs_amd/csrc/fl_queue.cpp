@@ -1,0 +1,449 @@
+// fl_queue.cpp -- the persistent request-batching queue behind flgpu_transform and the sharding of every batch across
+// the devices of a node.
+//
+// Reference analogue: one Arc<State> shared by every tokio worker (src/main.rs:108-112), each request processed on the
+// worker that received it (src/main.rs:179).  Here concurrent callers of flgpu_transform are packed into shared kernel
+// launches; a context that spans several GPUs splits every flushed batch -- and every batch entry point -- into one
+// contiguous shard per device, balanced by algorithmic bytes (W*H*C + output bytes), and returns results in
+// request order.  Images are independent, so no pixel ever crosses between devices.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <chrono>
+
+#include "fl_context.h"
+
+using namespace fl;
+
+namespace fl {
+
+void split_by_weight(const uint64_t *weight, size_t n, uint32_t n_shards, uint32_t *shard_of)
+{
+    if (n_shards == 0) n_shards = 1;
+    unsigned __int128 total = 0;
+    for (size_t i = 0; i < n; ++i) total += weight[i] ? weight[i] : 1;
+    // image i goes to the shard that the midpoint of its weight interval falls into: monotone, hence contiguous
+    unsigned __int128 before = 0;
+    uint32_t prev = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t w = weight[i] ? weight[i] : 1;
+        const unsigned __int128 mid2 = 2 * before + w; // twice the midpoint
+        uint32_t s = (uint32_t)((mid2 * n_shards) / (2 * total));
+        if (s >= n_shards) s = n_shards - 1;
+        if (s < prev) s = prev;
+        shard_of[i] = s;
+        prev = s;
+        before += w;
+    }
+}
+
+PinBlock pin_acquire(flgpu_ctx *c, size_t bytes)
+{
+    size_t cap = 64 * 1024;
+    while (cap < bytes) cap <<= 1;
+    {
+        std::lock_guard<std::mutex> g(c->pin_mu);
+        auto it = c->pin_free.find(cap);
+        if (it != c->pin_free.end()) { PinBlock b{it->second, cap}; c->pin_free.erase(it); return b; }
+    }
+    PinBlock b;
+    (void)hipSetDevice(c->device);
+    // portable: with several devices any of them may DMA from / into the block
+    if (hipHostMalloc(&b.p, cap, c->devices.size() > 1 ? hipHostMallocPortable : hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return b; }
+    b.cap = cap;
+    return b;
+}
+
+void pin_release(flgpu_ctx *c, PinBlock &b)
+{
+    if (!b.p) return;
+    std::lock_guard<std::mutex> g(c->pin_mu);
+    c->pin_free.emplace(b.cap, b.p);
+    b.p = nullptr;
+}
+
+} // namespace fl
+
+namespace {
+
+uint32_t lanes_per_device(const flgpu_ctx *c) { return std::min<uint32_t>(std::max<uint32_t>(c->cfg.queue_lanes ? c->cfg.queue_lanes : 3u, 1u), 8u); }
+uint32_t batch_per_device(const flgpu_ctx *c) { return c->cfg.max_batch ? c->cfg.max_batch : 32u; } // measured: 3 lanes x 32 keeps the PCIe link busiest
+
+// One shard of a flushed batch on one lane: sources already sit in pinned blocks (copied there by the calling
+// threads), results are left in pinned blocks for the callers to copy out.
+int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
+{
+    const size_t n = batch.size();
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    hipStream_t st = c->stream;
+    // Whatever happens below, nothing of this batch may still be in flight when the requests are marked done: their
+    // callers recycle (or free) the pinned blocks the DMA engine reads and writes.
+    struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{st};
+    std::vector<flgpu_image> dsrc(n), ddst(n);
+    std::vector<flgpu_params> ps(n);
+    std::vector<uint64_t> dev_out(n);
+    size_t in_b = 0, out_b = 0;
+    for (size_t i = 0; i < n; ++i) {
+        dsrc[i] = *batch[i]->src; ddst[i] = *batch[i]->dst; ps[i] = *batch[i]->p;
+        flgpu_plan plan;
+        int prc = flgpu_plan_output(&ps[i], dsrc[i].width, dsrc[i].height, dsrc[i].channels, &plan);
+        if (prc) return prc; // validated by the caller already
+        dev_out[i] = staged_out_bytes(ps[i], plan, 0); // an encoded stream gets the format's worst case on the device
+        dsrc[i].data = reinterpret_cast<uint8_t *>(in_b); dsrc[i].capacity = batch[i]->src_bytes; in_b += align_up(batch[i]->src_bytes, 256);
+        ddst[i].data = reinterpret_cast<uint8_t *>(out_b); ddst[i].capacity = dev_out[i]; out_b += align_up(dev_out[i], 256);
+    }
+    FL_HIP(c, c->d_in.reserve(in_b), "device input staging");
+    FL_HIP(c, c->d_out.reserve(out_b), "device output staging");
+    for (size_t i = 0; i < n; ++i) {
+        dsrc[i].data = static_cast<uint8_t *>(c->d_in.p) + reinterpret_cast<size_t>(dsrc[i].data);
+        ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
+        FL_HIP(c, hipMemcpyAsync(dsrc[i].data, batch[i]->in.p, batch[i]->src_bytes, hipMemcpyHostToDevice, st), "H2D");
+    }
+    int rc = run_batch_device(c, n, dsrc.data(), ps.data(), false, ddst.data(), st);
+    if (rc) return rc;
+    // encoded streams: learn their lengths first, then fetch exactly those bytes (a 300x200 JPEG is ~16 KB of a 183 KB bound)
+    bool encoded = false;
+    for (size_t i = 0; i < n; ++i) encoded |= ps[i].front_end == FLGPU_FE_JPEG;
+    int rrc = FLGPU_OK;
+    if (encoded) rrc = collect_results(c, n, ddst.data(), st);
+    for (size_t i = 0; i < n; ++i) {
+        const bool jpeg = ps[i].front_end == FLGPU_FE_JPEG;
+        const uint64_t nb = jpeg ? ddst[i].bytes : batch[i]->out_bytes;
+        if (jpeg && nb > batch[i]->out_bytes) { batch[i]->status = FLGPU_ERR_BUFFER_TOO_SMALL; ddst[i].bytes = 0; continue; } // the caller's dst really is too small
+        if (nb) FL_HIP(c, hipMemcpyAsync(batch[i]->out.p, ddst[i].data, nb, hipMemcpyDeviceToHost, st), "D2H");
+    }
+    if (!encoded) rrc = collect_results(c, n, ddst.data(), st);
+    else FL_HIP(c, hipStreamSynchronize(st), "batch sync");
+    for (size_t i = 0; i < n; ++i) {
+        batch[i]->dst->width = ddst[i].width; batch[i]->dst->height = ddst[i].height;
+        batch[i]->dst->channels = ddst[i].channels; batch[i]->dst->flags = ddst[i].flags;
+        batch[i]->dst->bytes = ddst[i].bytes;
+        if (ps[i].front_end == FLGPU_FE_JPEG && !ddst[i].bytes && batch[i]->status == FLGPU_OK) batch[i]->status = FLGPU_ERR_BUFFER_TOO_SMALL;
+    }
+    (void)rrc; // per-request status above: one oversized stream must not fail its batch mates
+    return FLGPU_OK;
+}
+
+// `slot` = index of this lane's device in the context's device list (0 for a single-device context)
+void worker_main(flgpu_ctx *c, flgpu_ctx *lane, uint32_t slot)
+{
+    const uint32_t ndev = c->n_dev();
+    const size_t max_batch = (size_t)batch_per_device(c) * ndev;
+    const auto flush = std::chrono::microseconds(c->cfg.flush_timeout_us ? c->cfg.flush_timeout_us : 200);
+    for (;;) {
+        std::vector<Request *> batch;
+        {
+            std::unique_lock<std::mutex> lk(c->qmu);
+            c->qcv.wait(lk, [&] { return c->stop || !c->inbox[slot].empty() || (!c->collecting && !c->queue.empty()); });
+            if (!c->inbox[slot].empty()) {
+                // a shard another worker cut for this device
+                batch.swap(c->inbox[slot].front());
+                c->inbox[slot].pop_front();
+            } else {
+                if (c->queue.empty()) { if (c->stop) return; continue; }
+                if (c->collecting) continue;
+                c->collecting = true;
+                // a first request arrived: wait for company -- but only while somebody is actually on the way (a caller
+                // staging its source), and never beyond the flush timer or a full batch.  A lone caller is served at once.
+                const auto deadline = std::chrono::steady_clock::now() + flush;
+                while (c->queue.size() < max_batch && !c->stop && c->staging.load(std::memory_order_acquire) > 0) {
+                    if (c->qcv.wait_until(lk, deadline) == std::cv_status::timeout) break;
+                }
+                std::vector<Request *> all;
+                while (!c->queue.empty() && all.size() < max_batch) { all.push_back(c->queue.front()); c->queue.pop_front(); }
+                c->collecting = false;
+                if (ndev <= 1 || all.size() <= 1) batch.swap(all);
+                else {
+                    // one contiguous shard per device, balanced by algorithmic bytes; this worker keeps its own device's
+                    // shard, the others go to the inboxes of the other devices' lanes.  Requests complete individually,
+                    // so "request order" is preserved by construction: each caller waits on its own slot.
+                    std::vector<uint64_t> w(all.size());
+                    std::vector<uint32_t> shard_of(all.size());
+                    for (size_t i = 0; i < all.size(); ++i) w[i] = all[i]->weight;
+                    split_by_weight(w.data(), all.size(), ndev, shard_of.data());
+                    std::vector<std::vector<Request *>> shards(ndev);
+                    for (size_t i = 0; i < all.size(); ++i) shards[shard_of[i]].push_back(all[i]);
+                    // a small flush may leave this device's shard empty: then take the first non-empty one
+                    uint32_t keep = slot;
+                    if (shards[keep].empty()) for (uint32_t k = 0; k < ndev; ++k) if (!shards[k].empty()) { keep = k; break; }
+                    for (uint32_t k = 0; k < ndev; ++k) {
+                        if (shards[k].empty()) continue;
+                        if (k == keep) batch.swap(shards[k]);
+                        else c->inbox[k].push_back(std::move(shards[k]));
+                    }
+                }
+            }
+        }
+        c->qcv.notify_all(); // the next batch may be collected (and the other devices' shards picked up) while this one is in flight
+        if (batch.empty()) continue;
+        int rc;
+        {
+            std::lock_guard<std::mutex> g(lane->mu);
+            rc = run_batch_queued(lane, batch);
+            lane->stats.queue_flushes++;
+            if (rc) c->set_error(lane->get_error());
+        }
+        {
+            std::lock_guard<std::mutex> lk(c->qmu);
+            for (Request *r : batch) { if (rc) r->status = rc; r->done = true; }
+        }
+        c->qdone.notify_all();
+    }
+}
+
+// Starts the lanes on first use (qmu held).  Lane i serves device slot i % n_dev.
+int start_workers(flgpu_ctx *c)
+{
+    if (c->worker_started) return FLGPU_OK;
+    const uint32_t ndev = c->n_dev(), per = lanes_per_device(c);
+    for (uint32_t i = 0; i < per * ndev; ++i) {
+        const uint32_t slot = i % ndev;
+        flgpu_ctx *l = create_child(c, c->devices.empty() ? c->device : c->devices[slot]);
+        if (!l) break;
+        c->lanes.push_back(l); // capacity reserved at creation: published entries never move
+        c->n_lanes.store(c->lanes.size(), std::memory_order_release);
+    }
+    if (c->lanes.size() < ndev) { // every device needs at least one lane, or its shards would never run
+        for (flgpu_ctx *l : c->lanes) flgpu_destroy(l);
+        c->n_lanes.store(0, std::memory_order_release);
+        c->lanes.clear();
+        return FLGPU_ERR_OOM;
+    }
+    for (size_t i = 0; i < c->lanes.size(); ++i) c->workers.emplace_back(worker_main, c, c->lanes[i], (uint32_t)(i % ndev));
+    c->worker_started = true;
+    return FLGPU_OK;
+}
+
+// Runs fn(k, first, last) for every non-empty shard on its own thread (shard 0 on the calling thread).
+template <typename F> int for_each_shard(flgpu_ctx *c, const std::vector<std::pair<size_t, size_t>> &ranges, F fn)
+{
+    std::vector<int> rcs(ranges.size(), FLGPU_OK);
+    std::vector<std::thread> ts;
+    for (size_t k = 1; k < ranges.size(); ++k)
+        if (ranges[k].second > ranges[k].first) ts.emplace_back([&, k] { rcs[k] = fn((uint32_t)k, ranges[k].first, ranges[k].second); });
+    if (!ranges.empty() && ranges[0].second > ranges[0].first) rcs[0] = fn(0u, ranges[0].first, ranges[0].second);
+    for (auto &t : ts) t.join();
+    for (size_t k = 0; k < rcs.size(); ++k)
+        if (rcs[k]) { c->set_error(c->shard_ctx[k]->get_error()); return rcs[k]; }
+    return FLGPU_OK;
+}
+
+int shard_ranges(uint32_t n_shards, size_t n, const flgpu_image *srcs, const flgpu_params *ps, bool same_params,
+                 std::vector<std::pair<size_t, size_t>> &ranges)
+{
+    std::vector<uint32_t> shard_of(n);
+    int rc = flgpu_plan_shards(n_shards, n, srcs, ps, same_params ? FLGPU_BATCH_SAME_PARAMS : 0u, shard_of.data(), nullptr);
+    if (rc) return rc;
+    ranges.assign(n_shards, {0, 0});
+    for (uint32_t k = 0; k < n_shards; ++k) ranges[k] = {n, n};
+    for (size_t i = 0; i < n; ++i) {
+        auto &r = ranges[shard_of[i]];
+        if (r.first == n) r.first = i;
+        r.second = i + 1;
+    }
+    for (auto &r : ranges) if (r.first == n) r = {0, 0};
+    return FLGPU_OK;
+}
+
+} // namespace
+
+namespace fl {
+
+void stop_queue(flgpu_ctx *c)
+{
+    {
+        std::lock_guard<std::mutex> lk(c->qmu);
+        c->stop = true;
+    }
+    c->qcv.notify_all();
+    for (auto &t : c->workers) t.join();
+    c->workers.clear();
+    const size_t nl = c->n_lanes.load(std::memory_order_acquire);
+    for (size_t i = 0; i < nl; ++i) flgpu_destroy(c->lanes[i]);
+    c->n_lanes.store(0, std::memory_order_release);
+    c->lanes.clear();
+}
+
+} // namespace fl
+
+extern "C" {
+
+int flgpu_plan_shards(uint32_t n_shards, size_t n, const flgpu_image *srcs, const flgpu_params *ps, uint32_t flags,
+                      uint32_t *shard_of, uint64_t *shard_bytes)
+{
+    if (n_shards == 0 || n_shards > FLGPU_MAX_DEVICES || (n && (!srcs || !ps || !shard_of))) return FLGPU_ERR_INVALID_ARG;
+    std::vector<uint64_t> w(n);
+    for (size_t i = 0; i < n; ++i) {
+        flgpu_plan plan;
+        const flgpu_params *p = (flags & FLGPU_BATCH_SAME_PARAMS) ? &ps[0] : &ps[i];
+        int rc = flgpu_plan_output(p, srcs[i].width, srcs[i].height, srcs[i].channels, &plan);
+        if (rc) return rc;
+        w[i] = (uint64_t)srcs[i].width * srcs[i].height * srcs[i].channels + plan.out_bytes;
+    }
+    split_by_weight(w.data(), n, n_shards, shard_of);
+    if (shard_bytes) {
+        for (uint32_t k = 0; k < n_shards; ++k) shard_bytes[k] = 0;
+        for (size_t i = 0; i < n; ++i) shard_bytes[shard_of[i]] += w[i];
+    }
+    return FLGPU_OK;
+}
+
+int flgpu_transform_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts,
+                                 void *hip_stream, uint32_t flags)
+{
+    if (!c) return FLGPU_ERR_INVALID_ARG;
+    const bool same = (flags & FLGPU_BATCH_SAME_PARAMS) != 0;
+    if (c->shard_ctx.empty()) {
+        std::lock_guard<std::mutex> g(c->mu);
+        return run_batch_device(c, n, srcs, ps, same, dsts, static_cast<hipStream_t>(hip_stream));
+    }
+    // several devices: shard k of the batch runs on devices[k], on that shard context's own stream; the call returns
+    // when every shard has finished (a caller's stream belongs to one device and cannot order the others)
+    if (n == 0) return FLGPU_OK;
+    if (!srcs || !ps || !dsts) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    std::vector<std::pair<size_t, size_t>> ranges;
+    int rc = shard_ranges((uint32_t)c->shard_ctx.size(), n, srcs, ps, same, ranges);
+    if (rc) return rc;
+    for (size_t k = 0; k < ranges.size(); ++k) {
+        if (ranges[k].second == ranges[k].first) continue;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, srcs[ranges[k].first].data) == hipSuccess && attr.type == hipMemoryTypeDevice &&
+            attr.device != c->shard_ctx[k]->device) {
+            int peer = 0;
+            (void)hipDeviceCanAccessPeer(&peer, c->shard_ctx[k]->device, attr.device);
+            if (!peer) { c->set_error("flgpu_transform_batch_device: an image is not resident on the device of its shard (see flgpu_plan_shards)"); return FLGPU_ERR_INVALID_ARG; }
+        }
+    }
+    rc = for_each_shard(c, ranges, [&](uint32_t k, size_t a, size_t b) {
+        flgpu_ctx *s = c->shard_ctx[k];
+        std::lock_guard<std::mutex> gs(s->mu);
+        int r = run_batch_device(s, b - a, srcs + a, same ? ps : ps + a, same, dsts + a, nullptr);
+        if (r) return r;
+        hipError_t e = hipStreamSynchronize(s->stream);
+        return e == hipSuccess ? FLGPU_OK : s->fail(e, "shard sync");
+    });
+    c->last_shards = ranges;
+    c->last_n = n;
+    return rc;
+}
+
+int flgpu_transform_batch(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts)
+{
+    if (!c) return FLGPU_ERR_INVALID_ARG;
+    if (c->shard_ctx.empty()) {
+        std::lock_guard<std::mutex> g(c->mu);
+        return run_batch_host(c, n, srcs, ps, dsts);
+    }
+    if (n == 0) return FLGPU_OK;
+    if (!srcs || !ps || !dsts) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    std::vector<std::pair<size_t, size_t>> ranges;
+    int rc = shard_ranges((uint32_t)c->shard_ctx.size(), n, srcs, ps, false, ranges);
+    if (rc) return rc;
+    return for_each_shard(c, ranges, [&](uint32_t k, size_t a, size_t b) {
+        flgpu_ctx *s = c->shard_ctx[k];
+        std::lock_guard<std::mutex> gs(s->mu);
+        return run_batch_host(s, b - a, srcs + a, ps + a, dsts + a);
+    });
+}
+
+int flgpu_batch_results(flgpu_ctx *c, size_t n, flgpu_image *dsts)
+{
+    if (!c || (!dsts && n)) return FLGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n != c->last_n) { c->set_error("flgpu_batch_results: n differs from the last device batch"); return FLGPU_ERR_INVALID_ARG; }
+    if (c->shard_ctx.empty()) {
+        FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+        return collect_results(c, n, dsts, c->last_stream ? c->last_stream : c->stream);
+    }
+    int rc = FLGPU_OK;
+    for (size_t k = 0; k < c->last_shards.size(); ++k) {
+        const auto r = c->last_shards[k];
+        if (r.second == r.first) continue;
+        flgpu_ctx *s = c->shard_ctx[k];
+        std::lock_guard<std::mutex> gs(s->mu);
+        if (hipSetDevice(s->device) != hipSuccess) return FLGPU_ERR_DEVICE;
+        int r2 = collect_results(s, r.second - r.first, dsts + r.first, s->last_stream ? s->last_stream : s->stream);
+        if (r2 && !rc) { rc = r2; c->set_error(s->get_error()); }
+    }
+    return rc;
+}
+
+int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p, flgpu_image *dst)
+{
+    if (!c || !src || !p || !dst || !src->data || !dst->data) return FLGPU_ERR_INVALID_ARG;
+    // validate on the caller's thread so that one bad request cannot fail a shared batch
+    flgpu_plan plan;
+    int rc = flgpu_plan_output(p, src->width, src->height, src->channels, &plan);
+    if (rc) return rc;
+    if (src->capacity < (uint64_t)src->width * src->height * src->channels) return FLGPU_ERR_INVALID_ARG;
+    const bool jpeg = p->front_end == FLGPU_FE_JPEG;
+    if (!jpeg && dst->capacity < plan.out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
+    Request r{};
+    r.src = src; r.p = p; r.dst = dst;
+    r.src_bytes = (uint64_t)src->width * src->height * src->channels;
+    r.weight = r.src_bytes + plan.out_bytes;
+    // an encoded stream is staged with the format's worst case on the device, so only the caller's own capacity can be
+    // too small, and that is known once the stream's length is (JpegEncoder into a Vec never fails, handler.rs:274-278)
+    r.out_bytes = jpeg ? std::min<uint64_t>(dst->capacity, plan.max_out_bytes) : plan.out_bytes;
+    if (r.out_bytes == 0) return FLGPU_ERR_BUFFER_TOO_SMALL;
+    {
+        const uint32_t limit = 4u * lanes_per_device(c) * batch_per_device(c) * c->n_dev();
+        std::unique_lock<std::mutex> lk(c->adm_mu);
+        c->adm_cv.wait(lk, [&] { return c->admitted < limit; });
+        c->admitted++;
+    }
+    struct Admission {
+        flgpu_ctx *c;
+        ~Admission() { { std::lock_guard<std::mutex> lk(c->adm_mu); c->admitted--; } c->adm_cv.notify_one(); }
+    } admission{c};
+    c->staging.fetch_add(1, std::memory_order_acq_rel);
+    // buffers from flgpu_host_alloc are page-locked already: the DMA engine reads / writes them directly, no staging copy
+    const bool src_pinned = (src->flags & FLGPU_IMG_PINNED) != 0, dst_pinned = (dst->flags & FLGPU_IMG_PINNED) != 0 && dst->capacity >= r.out_bytes;
+    if (src_pinned) r.in = PinBlock{src->data, 0}; else r.in = pin_acquire(c, r.src_bytes);
+    if (dst_pinned) r.out = PinBlock{dst->data, 0}; else r.out = pin_acquire(c, r.out_bytes);
+    auto give_back = [&] { if (!src_pinned) pin_release(c, r.in); if (!dst_pinned) pin_release(c, r.out); };
+    if (!r.in.p || !r.out.p) {
+        c->staging.fetch_sub(1, std::memory_order_acq_rel);
+        give_back();
+        return FLGPU_ERR_OOM;
+    }
+    if (!src_pinned) memcpy(r.in.p, src->data, r.src_bytes); // on the caller's thread: concurrent callers stage in parallel
+    {
+        std::unique_lock<std::mutex> lk(c->qmu);
+        c->staging.fetch_sub(1, std::memory_order_acq_rel);
+        if (c->stop) { lk.unlock(); give_back(); return FLGPU_ERR_SHUTDOWN; }
+        const int wrc = start_workers(c);
+        if (wrc) { lk.unlock(); give_back(); return wrc; }
+        c->queue.push_back(&r);
+    }
+    c->qcv.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(c->qmu);
+        c->qdone.wait(lk, [&] { return r.done; });
+    }
+    if (r.status == FLGPU_OK && !dst_pinned) memcpy(dst->data, r.out.p, std::min<uint64_t>(dst->bytes, r.out_bytes));
+    give_back();
+    if (dst_pinned) dst->flags |= FLGPU_IMG_PINNED;
+    return r.status;
+}
+
+int flgpu_ycck_to_cmyk(flgpu_ctx *c, uint8_t *raw, uint64_t n_pixels)
+{
+    if (!c || (!raw && n_pixels)) return FLGPU_ERR_INVALID_ARG;
+    if (n_pixels == 0) return FLGPU_OK;
+    if (n_pixels >= (1ull << 30)) return FLGPU_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> g(c->mu);
+    FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
+    const size_t bytes = (size_t)n_pixels * 4;
+    FL_HIP(c, c->d_in.reserve(bytes), "device staging");
+    FL_HIP(c, hipMemcpyAsync(c->d_in.p, raw, bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    FL_HIP(c, launch_ycck_to_cmyk(static_cast<uint32_t *>(c->d_in.p), n_pixels, c->stream), "ycck kernel");
+    FL_HIP(c, hipMemcpyAsync(raw, c->d_in.p, bytes, hipMemcpyDeviceToHost, c->stream), "D2H");
+    FL_HIP(c, hipStreamSynchronize(c->stream), "sync");
+    return FLGPU_OK;
+}
+
+} // extern "C"

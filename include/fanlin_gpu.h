@@ -34,6 +34,7 @@
  *                                       src/main.rs:74-76, src/handler.rs:469-488
  *   flgpu_cmyk_to_rgb[_device]          CMYK2RGB::convert = lcms2 transform_pixels, src/handler.rs:446-462,490-492
  *   flgpu_create / flgpu_destroy        lifetime of handler::State, src/handler.rs:14-21,36-52
+ *   flgpu_config.devices / flgpu_plan_shards   the one shared Arc<State> behind all tokio workers, src/main.rs:108-112
  */
 #ifndef FANLIN_GPU_H
 #define FANLIN_GPU_H
@@ -45,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FLGPU_ABI_VERSION 2
+#define FLGPU_ABI_VERSION 3
 
 typedef enum flgpu_status {
     FLGPU_OK = 0,
@@ -132,17 +133,29 @@ typedef struct flgpu_plan {
     uint32_t plane_w, plane_h;         /* front end luma plane size */
     uint32_t chroma_w, chroma_h;       /* front end chroma plane size */
     uint64_t pixel_bytes;              /* out_w * out_h * out_c */
-    uint64_t out_bytes;                /* bytes the call writes to dst (pixels or planes) */
+    uint64_t out_bytes;                /* bytes the call writes to dst (pixels or planes); for FLGPU_FE_JPEG a planning bound
+                                          (about 1 byte per sample) that ordinary pictures stay far below */
+    uint64_t max_out_bytes;            /* FLGPU_FE_JPEG: the worst case of the format (every 8x8 block of every component at its
+                                          longest code, every byte stuffed): a dst of this capacity can never be too small, as
+                                          JpegEncoder::encode_image into a Vec never fails (src/handler.rs:274-278).  Otherwise
+                                          equal to out_bytes. */
 } flgpu_plan;
 
+#define FLGPU_MAX_DEVICES 8
 typedef struct flgpu_config {
-    int32_t device;            /* HIP device ordinal; -1 = current device */
-    uint32_t max_batch;        /* request-queue flush size (0 = default 32) */
+    int32_t device;            /* HIP device ordinal; -1 = current device (used when n_devices <= 1) */
+    uint32_t max_batch;        /* request-queue flush size PER DEVICE (0 = default 32) */
     uint32_t flush_timeout_us; /* request-queue flush timer (0 = default 200) */
     uint32_t profile;          /* 1 = bracket kernels with HIP events and report them in flgpu_stats */
-    uint32_t queue_lanes;      /* flgpu_transform: batches kept in flight at once (each lane has its own stream and
-                                  scratch, so one batch's PCIe transfers overlap another's kernels); 0 = default 3 */
-    uint32_t reserved[3];
+    uint32_t queue_lanes;      /* flgpu_transform: batches kept in flight at once PER DEVICE (each lane has its own stream
+                                  and scratch, so one batch's PCIe transfers overlap another's kernels); 0 = default 3 */
+    uint32_t n_devices;        /* 0 or 1: one GPU (`device`).  2..FLGPU_MAX_DEVICES: ONE context for the GPUs of a node, as
+                                  the reference shares one Arc<State> between all its workers (src/main.rs:108-112): every
+                                  flushed batch of the request queue and every batch call is split into n_devices contiguous
+                                  shards balanced by algorithmic bytes (W*H*C + output bytes), shard k runs on devices[k],
+                                  results come back in request order.  An ordinal may repeat (two shards on one GPU). */
+    uint32_t reserved[2];
+    int32_t devices[FLGPU_MAX_DEVICES];
 } flgpu_config;
 
 typedef struct flgpu_stats {
@@ -211,6 +224,10 @@ int flgpu_cmyk_bake_available(void); /* 1 if liblcms2 could be loaded */
  * for hosts that bake it themselves and for copying rank 0's table to the other GPUs. */
 int flgpu_set_cmyk_clut(flgpu_ctx *ctx, uint32_t grid, const uint16_t *rgb_nodes);
 int flgpu_get_cmyk_clut(flgpu_ctx *ctx, uint16_t *rgb_nodes, uint64_t capacity_entries, uint32_t *grid);
+/* A context that spans several devices bakes the table once and hands it from devices[0] to the others: 2 = by one
+ * ncclBroadcast (RCCL over xGMI; one rank per distinct GPU, librccl loaded on demand), 1 = by plain copies (shards sharing
+ * a GPU, or no RCCL on the host), 0 = single-device context or no table yet. */
+int flgpu_cmyk_distribution(flgpu_ctx *ctx);
 /* Replaces CMYK2RGB::convert = lcms2 transform_pixels (src/handler.rs:490-492) and, with
  * FLGPU_CMYK_INPUT_YCCK, the YCCK loop in front of it (423-438).  n_pixels x 4 bytes in, n_pixels x 3 bytes out.
  * `embedded_icc` (may be NULL) is the JPEG's own profile when use_embedded_profile is set: it is baked once and
@@ -274,6 +291,17 @@ int flgpu_transform_batch_device(flgpu_ctx *ctx, size_t n, const flgpu_image *sr
  * FLGPU_IMG_HAS_ALPHA of the WebP front end: waits for the most recent device batch of this context and completes
  * the same dsts[] array.  The host-memory entry points do this themselves. */
 int flgpu_batch_results(flgpu_ctx *ctx, size_t n, flgpu_image *dsts);
+
+/* How a context of n_shards devices splits a batch (pure function, no device needed): shard_of[i] = the shard, hence the
+ * device devices[shard_of[i]], that image i runs on -- contiguous runs of images, balanced by algorithmic bytes
+ * (W*H*C + flgpu_plan.out_bytes per image).  With a multi-device context the images handed to
+ * flgpu_transform_batch_device must be resident on (or peer-accessible from) exactly these devices, and the call then
+ * returns only when every shard has finished (`hip_stream` is not used).  shard_bytes (optional, n_shards entries)
+ * receives the weight of each shard.  ps has n entries, or one with FLGPU_BATCH_SAME_PARAMS. */
+int flgpu_plan_shards(uint32_t n_shards, size_t n, const flgpu_image *srcs, const flgpu_params *ps, uint32_t flags,
+                      uint32_t *shard_of, uint64_t *shard_bytes);
+/* Devices of a context: returns n_devices (1 for a single-device context) and writes up to `cap` ordinals. */
+uint32_t flgpu_devices(flgpu_ctx *ctx, int32_t *devices, uint32_t cap);
 
 /* In-place YCCK -> "CMYK with inverted K" on n_pixels x 4 host bytes: the pointwise loop of
  * convert_jpeg_color_if_needed (src/handler.rs:423-438) that precedes the lcms2 transform.  Blocking. */

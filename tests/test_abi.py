@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(fl):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(fl.EXPORTED_SYMBOLS) == names, "python binding list is out of date with the header"
-    assert lib.flgpu_abi_version() == 2   # bumped with flgpu_image::bytes, flgpu_params::orientation / filter, flgpu_plan::src_w / src_h
+    assert lib.flgpu_abi_version() == 3   # 3: flgpu_plan::max_out_bytes, flgpu_config::n_devices / devices
 
 
 def test_struct_layouts_match_the_header(fl):
@@ -39,8 +39,8 @@ int main(void) {
   printf("flgpu_image %zu %zu %zu\n", sizeof(flgpu_image), offsetof(flgpu_image, width), offsetof(flgpu_image, flags));
   printf("flgpu_query %zu %zu %zu\n", sizeof(flgpu_query), offsetof(flgpu_query, w), offsetof(flgpu_query, rgb));
   printf("flgpu_params %zu %zu %zu\n", sizeof(flgpu_params), offsetof(flgpu_params, blur_sigma), offsetof(flgpu_params, front_end));
-  printf("flgpu_plan %zu %zu %zu\n", sizeof(flgpu_plan), offsetof(flgpu_plan, out_w), offsetof(flgpu_plan, out_bytes));
-  printf("flgpu_config %zu %zu %zu\n", sizeof(flgpu_config), offsetof(flgpu_config, profile), offsetof(flgpu_config, reserved));
+  printf("flgpu_plan %zu %zu %zu\n", sizeof(flgpu_plan), offsetof(flgpu_plan, out_w), offsetof(flgpu_plan, max_out_bytes));
+  printf("flgpu_config %zu %zu %zu\n", sizeof(flgpu_config), offsetof(flgpu_config, profile), offsetof(flgpu_config, devices));
   printf("flgpu_stats %zu %zu %zu\n", sizeof(flgpu_stats), offsetof(flgpu_stats, resample_ms), offsetof(flgpu_stats, frontend_ms));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
@@ -55,8 +55,8 @@ int main(void) {
         "flgpu_image": (C.sizeof(S.flgpu_image), S.flgpu_image.width.offset, S.flgpu_image.flags.offset),
         "flgpu_query": (C.sizeof(S.flgpu_query), S.flgpu_query.w.offset, S.flgpu_query.rgb.offset),
         "flgpu_params": (C.sizeof(S.flgpu_params), S.flgpu_params.blur_sigma.offset, S.flgpu_params.front_end.offset),
-        "flgpu_plan": (C.sizeof(S.flgpu_plan), S.flgpu_plan.out_w.offset, S.flgpu_plan.out_bytes.offset),
-        "flgpu_config": (C.sizeof(S.flgpu_config), S.flgpu_config.profile.offset, S.flgpu_config.reserved.offset),
+        "flgpu_plan": (C.sizeof(S.flgpu_plan), S.flgpu_plan.out_w.offset, S.flgpu_plan.max_out_bytes.offset),
+        "flgpu_config": (C.sizeof(S.flgpu_config), S.flgpu_config.profile.offset, S.flgpu_config.devices.offset),
         "flgpu_stats": (C.sizeof(S.flgpu_stats), S.flgpu_stats.resample_ms.offset, S.flgpu_stats.frontend_ms.offset),
     }
     assert got == want
@@ -88,11 +88,12 @@ def test_error_strings(fl):
     assert len(seen) == 9 and lib.flgpu_strerror(99).decode() == "unknown status"
 
 
-def test_rust_shim_in_integration_md_mirrors_the_structs(fl):
-    # INTEGRATION.md carries the reference-side binding as Rust source; its #[repr(C)] structs must list the header's
+def test_rust_shim_mirrors_the_structs(fl):
+    # shim/handler_gpu.rs is the reference-side binding as Rust source; its #[repr(C)] structs must list the header's
     # fields in the header's order (the ctypes mirrors are already checked against the header above)
     import re
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    text = open(os.path.join(ROOT, "shim", "handler_gpu.rs")).read()
+    assert "flgpu_abi_version() }, 3" in text
     for rust, cls in (("FlImage", fl.flgpu_image), ("FlParams", fl.flgpu_params), ("FlPlan", fl.flgpu_plan), ("FlConfig", fl.flgpu_config)):
         m = re.search(r"pub struct %s \{(.*?)\}" % rust, text, re.S)
         assert m, rust

@@ -171,11 +171,19 @@ def test_gpu_stream_that_does_not_fit(fl, gpu_state, oracle):
     noise = synth.uniform(64, 64, 3)
     want = oracle.jpeg_encode(noise, 100)
     plan = fl.plan_output(fl.make_params(quality=100, front_end=fl.FE_JPEG), 64, 64, 3)
-    assert len(want) > plan.out_bytes                               # incompressible input beats the default bound
+    assert plan.out_bytes < len(want) <= plan.max_out_bytes         # incompressible input beats the planning bound, never the worst case
+    # a caller that offers only the planning bound learns it once the stream's length is known ...
     with pytest.raises(fl.FanlinError) as e:
-        gpu_state.process_pixels(noise, fl.make_params(quality=100, front_end=fl.FE_JPEG))
+        gpu_state.process_pixels(noise, fl.make_params(quality=100, front_end=fl.FE_JPEG), capacity=-int(plan.out_bytes))
     assert e.value.status == fl.ERR_BUFFER_TOO_SMALL
-    assert gpu_jpeg(fl, gpu_state, noise, 100) == want              # same request with room
+    # ... with exactly enough room it fits, and with plan.max_out_bytes (what the bindings allocate) it cannot fail
+    exact = gpu_state.process_pixels(noise, fl.make_params(quality=100, front_end=fl.FE_JPEG), capacity=-len(want))
+    assert exact == want
+    assert gpu_state.process_pixels(noise, fl.make_params(quality=100, front_end=fl.FE_JPEG)) == want
+    # the same through the host batch entry point and the one-call entry point (State::process_image never fails here)
+    assert gpu_state.process_batch([noise, noise], [fl.make_params(quality=100, front_end=fl.FE_JPEG)] * 2) == [want, want]
+    mime, kind, body = gpu_state.process_image(noise, "quality=100&blur=10", None, fl.IN_JPEG)
+    assert mime == "image/jpeg" and kind == fl.RESULT_JPEG_STREAM and len(body) > 0
 
 
 @pytest.mark.gpu
