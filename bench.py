@@ -180,7 +180,23 @@ def verify_sample(fl, src, dst, out_stride, results, params, plan, fe_name, coun
     return len(picks), None
 
 
-def latency_probe_c(args, query: str, front_end: int, pinned: int = 0):
+def synthetic_jpeg_files(count=4):
+    """Photo-like 1920x1080 baseline JPEGs (quality 85, 4:2:0 -- what a web origin typically serves) for the JPEG-source
+    latency probe; written to a temporary directory."""
+    import tempfile
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    d = tempfile.mkdtemp(prefix="flgpu_jpeg_")
+    paths = []
+    for i in range(count):
+        p = os.path.join(d, f"src{i}.jpg")
+        Image.fromarray(synth.photo(SRC_H, SRC_W, 3, index=3000 + i)).save(p, "JPEG", quality=85, subsampling=2)
+        paths.append(p)
+    return paths
+
+
+def latency_probe_c(args, query: str, front_end: int, pinned: int = 0, jpeg_files=()):
     """The same probe from a plain C program (tools/latency/latency_probe.c, built by __graft_entry__.build()):
     pthread callers instead of Python threads, so the interpreter lock is not part of the measurement."""
     exe = os.path.join(ROOT, "tools", "latency", "latency_probe")
@@ -189,7 +205,7 @@ def latency_probe_c(args, query: str, front_end: int, pinned: int = 0):
     import subprocess
     try:
         r = subprocess.run([exe, str(args.latency_threads), str(args.latency_requests), str(SRC_W), str(SRC_H), query, str(front_end),
-                            str(args.queue_lanes), str(args.queue_max_batch), str(pinned)], capture_output=True, text=True, timeout=300)
+                            str(args.queue_lanes), str(args.queue_max_batch), str(pinned)] + list(jpeg_files), capture_output=True, text=True, timeout=300)
         return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
     except Exception:
         return None
@@ -445,6 +461,14 @@ def main():
             pinned = latency_probe_c(args, query, fe, 1)
             if pinned:
                 line["latency_pinned"] = pinned
+            # the same requests with JPEG FILES as sources: Huffman decoding on the caller threads, IDCT + colour on the device
+            try:
+                jp = latency_probe_c(args, query, fe, 0, synthetic_jpeg_files())
+                if jp:
+                    jp["path"] = "flgpu_transform with FLGPU_IMG_JPEG_SOURCE (1920x1080 q85 4:2:0 files): host Huffman decode + device IDCT/colour + pipeline"
+                    line["latency_jpeg_sources"] = jp
+            except Exception as e:  # Pillow missing: the probe is optional
+                line["latency_jpeg_sources"] = {"skipped": repr(e)[:120]}
         if args.cpu_images > 0 and world == 1 and ok_flag:
             line["cpu_baseline"] = cpu_baseline(args.cpu_images, workload, args.cpu_threads)
         else:

@@ -33,7 +33,7 @@ OUT_KEEP, OUT_WEBP, OUT_AVIF = 0, 1, 2
 IN_OTHER, IN_JPEG, IN_PNG, IN_WEBP, IN_GIF_FRAME = 0, 1, 2, 3, 4
 RESULT_AS_IS, RESULT_JPEG_STREAM, RESULT_WEBP_PLANES, RESULT_PIXELS = 0, 1, 2, 3
 MIME = {IN_JPEG: "image/jpeg", IN_PNG: "image/png", IN_WEBP: "image/webp", IN_GIF_FRAME: "image/gif"}
-IMG_FRONTEND_PLANES, IMG_HAS_ALPHA, IMG_ENCODED, IMG_PINNED = 1, 2, 4, 8
+IMG_FRONTEND_PLANES, IMG_HAS_ALPHA, IMG_ENCODED, IMG_PINNED, IMG_JPEG_SOURCE = 1, 2, 4, 8, 16
 BATCH_SAME_PARAMS = 1
 (OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_OOM, ERR_DEVICE, ERR_PARSE, ERR_BUFFER_TOO_SMALL,
  ERR_SHUTDOWN) = range(9)
@@ -87,7 +87,13 @@ class flgpu_stats(C.Structure):
                 ("resample_src_bytes", C.c_uint64), ("resample_dst_bytes", C.c_uint64),
                 ("generic_launches", C.c_uint64), ("blur_launches", C.c_uint64), ("blur_ms", C.c_double),
                 ("frontend_launches", C.c_uint64), ("frontend_ms", C.c_double),
-                ("cmyk_pixels", C.c_uint64), ("cmyk_tables_baked", C.c_uint64)]
+                ("cmyk_pixels", C.c_uint64), ("cmyk_tables_baked", C.c_uint64),
+                ("jpeg_sources", C.c_uint64), ("jpeg_file_bytes", C.c_uint64), ("jpeg_upload_bytes", C.c_uint64)]
+
+
+class flgpu_jpeg_info(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "components", "channels", "progressive", "restart_interval",
+                                           "h_max", "v_max", "exif_orientation", "supported")] + [("reserved", C.c_uint32 * 2)]
 
 
 # every symbol include/fanlin_gpu.h declares
@@ -97,12 +103,12 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
     "flgpu_params_from_query", "flgpu_plan_output", "flgpu_process_image", "flgpu_process_image_plan", "flgpu_create", "flgpu_destroy", "flgpu_transform",
     "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_batch_results", "flgpu_plan_shards", "flgpu_devices",
-    "flgpu_cmyk_distribution", "flgpu_host_alloc", "flgpu_host_free", "flgpu_ycck_to_cmyk",
+    "flgpu_cmyk_distribution", "flgpu_jpeg_info_of", "flgpu_decode_jpeg", "flgpu_process_jpeg", "flgpu_process_jpeg_plan", "flgpu_host_alloc", "flgpu_host_free", "flgpu_ycck_to_cmyk",
     "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
     "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version",
-    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable",
+    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob",
 )
 
 _lib = None
@@ -158,6 +164,11 @@ def load_library() -> C.CDLL:
     lib.flgpu_batch_results.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(flgpu_image)]
     lib.flgpu_plan_shards.argtypes = [C.c_uint32, C.c_size_t, C.POINTER(flgpu_image), C.POINTER(flgpu_params), C.c_uint32,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.flgpu_jpeg_info_of.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(flgpu_jpeg_info)]
+    lib.flgpu_decode_jpeg.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(flgpu_image)]
+    lib.flgpu_process_jpeg.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(flgpu_image), C.POINTER(flgpu_plan),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.flgpu_process_jpeg_plan.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint32, C.POINTER(flgpu_plan), C.POINTER(C.c_int)]
     lib.flgpu_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32]
     lib.flgpu_devices.restype = C.c_uint32
     lib.flgpu_cmyk_distribution.argtypes = [C.c_void_p]
@@ -318,6 +329,37 @@ def plan_output(params: flgpu_params, sw: int, sh: int, sc: int) -> flgpu_plan:
     return plan
 
 
+def jpeg_info(data: bytes) -> dict:
+    """flgpu_jpeg_info_of: header fields of a JPEG file (pure host function); raises FanlinError(ERR_PARSE) if it is none."""
+    info = flgpu_jpeg_info()
+    _check(load_library().flgpu_jpeg_info_of(data, len(data), C.byref(info)))
+    return {n: getattr(info, n) for n, _ in flgpu_jpeg_info._fields_ if n != "reserved"}
+
+
+def debug_jpeg_blob(data: bytes):
+    """Host half of the JPEG decode front end: returns (header dict, quantised coefficients [block][64] zig-zag, raw blob)."""
+    lib = load_library()
+    lib.flgpu_debug_jpeg_blob.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    used = C.c_uint64()
+    _check(lib.flgpu_debug_jpeg_blob(data, len(data), None, 0, C.byref(used)))
+    blob = np.zeros(used.value, np.uint8)
+    _check(lib.flgpu_debug_jpeg_blob(data, len(data), blob.ctypes.data, blob.size, C.byref(used)))
+    blob = blob[: used.value]
+    u32 = blob[: (blob.size // 4) * 4].view(np.uint32)
+    hdr = dict(zip(("magic", "width", "height", "nc", "hmax", "vmax", "is_rgb", "nblocks", "blocks_off", "coef_off", "plane_bytes", "total_bytes"), u32[:12].tolist()))
+    words = blob[hdr["blocks_off"]: hdr["blocks_off"] + 4 * hdr["nblocks"]].view(np.uint32)
+    data = blob[hdr["coef_off"]:]
+    out = np.zeros((hdr["nblocks"], 64), np.int16)
+    HEAD = 4  # kJpegWideHead
+    for b, w in enumerate(words.tolist()):
+        cnt, wide, first = ((w >> 1) & 63) + 1, w & 1, (w >> 7) * 2
+        head = cnt if wide else min(cnt, HEAD)
+        out[b, :head] = data[first: first + 2 * head].view(np.int16)
+        if cnt > head:
+            out[b, head:cnt] = data[first + 2 * head: first + 2 * head + cnt - head].view(np.int8)
+    return hdr, out, blob
+
+
 def plan_shards(n_shards: int, shapes: Sequence[Tuple[int, int, int]], params) -> Tuple[np.ndarray, np.ndarray]:
     """flgpu_plan_shards: (shard_of[n], shard_bytes[n_shards]) for images of shapes[i] = (height, width, channels);
     ``params`` is one flgpu_params (shared) or a sequence of n.  Pure host function."""
@@ -464,12 +506,52 @@ class State:
         fe = {RESULT_JPEG_STREAM: FE_JPEG, RESULT_WEBP_PLANES: FE_WEBP420, RESULT_PIXELS: FE_NONE}[kind.value]
         return mime, kind.value, _split_output(out, plan, fe, dst.flags, dst.bytes)
 
-    def process_batch(self, images: Sequence[np.ndarray], params: Sequence[flgpu_params]) -> List:
+    # -- JPEG sources: the decode front end (handler.rs:205-220) --------------------------------------------------
+    def decode_jpeg(self, data: bytes) -> np.ndarray:
+        """DynamicImage::from_decoder(JpegDecoder::new(..)) on the device: (h, w, 1 or 3) uint8."""
+        info = jpeg_info(data)
+        out = np.empty((info["height"], info["width"], max(info["channels"], 1)), np.uint8)
+        dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
+        _check(self._lib.flgpu_decode_jpeg(self._ctx, data, len(data), C.byref(dst)), self._ctx)
+        return out
+
+    def process_jpeg_pixels(self, data: bytes, params: flgpu_params):
+        """process_pixels with a JPEG FILE as the source (FLGPU_IMG_JPEG_SOURCE): decode + pipeline in one device pass."""
+        info = jpeg_info(data)
+        plan = plan_output(params, info["width"], info["height"], max(info["channels"], 1))
+        out = np.empty(max(int(plan.max_out_bytes), 1), dtype=np.uint8)
+        buf = C.create_string_buffer(data, len(data))
+        src = flgpu_image(C.cast(buf, C.c_void_p).value, len(data), info["width"], info["height"], max(info["channels"], 1), IMG_JPEG_SOURCE)
+        dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
+        _check(self._lib.flgpu_transform(self._ctx, C.byref(src), C.byref(params), C.byref(dst)), self._ctx)
+        return _split_output(out, plan, params.front_end, dst.flags, dst.bytes)
+
+    def process_jpeg(self, data: bytes, query_string: str, content: "Format" = None):
+        """State::process_image for a JPEG input from the file bytes on: (mime, kind, payload) as process_image."""
+        plan, kind, fmt = flgpu_plan(), C.c_int(), C.c_int()
+        flags = content.flags if content else 0
+        qs = query_string.encode()
+        _check(self._lib.flgpu_process_jpeg_plan(data, len(data), qs, flags, C.byref(plan), C.byref(kind)))
+        if kind.value == RESULT_AS_IS:
+            return "image/jpeg", RESULT_AS_IS, None
+        out = np.empty(max(int(plan.max_out_bytes), 1), dtype=np.uint8)
+        dst = flgpu_image(out.ctypes.data, out.nbytes, 0, 0, 0, 0)
+        _check(self._lib.flgpu_process_jpeg(self._ctx, data, len(data), qs, flags, C.byref(dst), C.byref(plan), C.byref(kind), C.byref(fmt)), self._ctx)
+        mime = "image/webp" if fmt.value == OUT_WEBP else "image/avif" if fmt.value == OUT_AVIF else "image/jpeg"
+        fe = {RESULT_JPEG_STREAM: FE_JPEG, RESULT_WEBP_PLANES: FE_WEBP420, RESULT_PIXELS: FE_NONE}[kind.value]
+        return mime, kind.value, _split_output(out, plan, fe, dst.flags, dst.bytes)
+
+    def process_batch(self, images: Sequence, params: Sequence[flgpu_params]) -> List:
+        """images[i]: an ndarray of pixels, or `bytes` holding a JPEG file (decoded by the library)."""
         n = len(images)
-        imgs = [_as_image_array(a) for a in images]
-        plans = [plan_output(params[i], imgs[i].shape[1], imgs[i].shape[0], imgs[i].shape[2]) for i in range(n)]
+        infos = [jpeg_info(a) if isinstance(a, (bytes, bytearray)) else None for a in images]
+        keep = [C.create_string_buffer(bytes(a), len(a)) if infos[i] else None for i, a in enumerate(images)]
+        imgs = [None if infos[i] else _as_image_array(a) for i, a in enumerate(images)]
+        shapes = [(infos[i]["height"], infos[i]["width"], max(infos[i]["channels"], 1)) if infos[i] else imgs[i].shape for i in range(n)]
+        plans = [plan_output(params[i], shapes[i][1], shapes[i][0], shapes[i][2]) for i in range(n)]
         outs = [np.empty(max(int(pl.max_out_bytes), 1), dtype=np.uint8) for pl in plans]
-        srcs = (flgpu_image * n)(*[flgpu_image(a.ctypes.data, a.nbytes, a.shape[1], a.shape[0], a.shape[2], 0) for a in imgs])
+        srcs = (flgpu_image * n)(*[flgpu_image(C.cast(keep[i], C.c_void_p).value, len(images[i]), shapes[i][1], shapes[i][0], shapes[i][2], IMG_JPEG_SOURCE)
+                                   if infos[i] else flgpu_image(imgs[i].ctypes.data, imgs[i].nbytes, shapes[i][1], shapes[i][0], shapes[i][2], 0) for i in range(n)])
         dsts = (flgpu_image * n)(*[flgpu_image(o.ctypes.data, o.nbytes, 0, 0, 0, 0) for o in outs])
         ps = (flgpu_params * n)(*params)
         _check(self._lib.flgpu_transform_batch(self._ctx, n, srcs, ps, dsts), self._ctx)

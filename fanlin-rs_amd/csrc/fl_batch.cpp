@@ -85,6 +85,52 @@ void fill_job(const Work &w, Job &j)
 
 namespace fl {
 
+int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used)
+{
+    const int rc = jpeg_entropy_decode(src->data, (size_t)src->capacity, blob, cap, used);
+    if (rc == -2) { c->set_error("JPEG stream not covered by the device decoder (progressive, arithmetic, 12-bit, CMYK or several scans)"); return FLGPU_ERR_UNSUPPORTED; }
+    if (rc) { c->set_error("malformed JPEG stream"); return FLGPU_ERR_INVALID_ARG; }
+    memcpy(hdr, blob, sizeof(*hdr));
+    if (hdr->width != src->width || hdr->height != src->height || hdr->nc != src->channels) {
+        c->set_error("FLGPU_IMG_JPEG_SOURCE: width / height / channels do not match the file (see flgpu_jpeg_info_of)");
+        return FLGPU_ERR_INVALID_ARG;
+    }
+    return FLGPU_OK;
+}
+
+int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegBlobHeader *const *hdrs, hipStream_t st)
+{
+    size_t nj = 0, scratch = 0;
+    for (size_t i = 0; i < n; ++i) if (hdrs[i]) { ++nj; scratch += align_up(hdrs[i]->plane_bytes, 256) + align_up((size_t)hdrs[i]->width * hdrs[i]->height * hdrs[i]->nc, 256); }
+    if (!nj) return FLGPU_OK;
+    FL_HIP(c, c->d_dec.reserve(scratch), "JPEG decode scratch");
+    FL_HIP(c, c->h_decjobs.reserve(nj * sizeof(JpegDecJob)), "JPEG decode descriptors");
+    FL_HIP(c, c->d_decjobs.reserve(nj * sizeof(JpegDecJob)), "JPEG decode descriptors");
+    JpegDecJob *jobs = static_cast<JpegDecJob *>(c->h_decjobs.p);
+    size_t off = 0, k = 0;
+    uint32_t max_blocks = 0, max_w = 0, max_h = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!hdrs[i]) continue;
+        const JpegBlobHeader &H = *hdrs[i];
+        JpegDecJob &j = jobs[k++];
+        j.blob = dsrc[i].data;
+        j.planes = static_cast<uint8_t *>(c->d_dec.p) + off; off += align_up(H.plane_bytes, 256);
+        j.dst = static_cast<uint8_t *>(c->d_dec.p) + off; off += align_up((size_t)H.width * H.height * H.nc, 256);
+        max_blocks = std::max(max_blocks, H.nblocks); max_w = std::max(max_w, H.width); max_h = std::max(max_h, H.height);
+        c->stats.jpeg_sources++;
+        c->stats.jpeg_upload_bytes += H.total_bytes;
+        dsrc[i].data = j.dst;
+        dsrc[i].capacity = (uint64_t)H.width * H.height * H.nc;
+        dsrc[i].flags &= ~FLGPU_IMG_JPEG_SOURCE;
+    }
+    FL_HIP(c, hipMemcpyAsync(c->d_decjobs.p, jobs, nj * sizeof(JpegDecJob), hipMemcpyHostToDevice, st), "JPEG decode descriptors");
+    for (size_t base = 0; base < nj; base += 32768) { // grid.y / .z limits
+        const uint32_t cnt = (uint32_t)std::min<size_t>(32768, nj - base);
+        FL_HIP(c, launch_jpeg_decode(static_cast<const JpegDecJob *>(c->d_decjobs.p) + base, cnt, max_blocks, max_w, max_h, st), "JPEG decode kernels");
+    }
+    return FLGPU_OK;
+}
+
 uint64_t staged_out_bytes(const flgpu_params &p, const flgpu_plan &plan, uint64_t)
 {
     return p.front_end == FLGPU_FE_JPEG ? plan.max_out_bytes : plan.out_bytes;
@@ -543,12 +589,29 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
     FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
     std::vector<flgpu_image> dsrc(n), ddst(n);
     std::vector<flgpu_plan> plans(n);
+    // JPEG sources: the serial half (parsing + Huffman decoding) runs here, on the host; what is staged is the blob
+    std::vector<std::vector<uint8_t>> blobs(n);
+    std::vector<JpegBlobHeader> jh(n);
+    std::vector<const JpegBlobHeader *> jhp(n, nullptr);
     size_t in_b = 0, out_b = 0;
     for (size_t i = 0; i < n; ++i) {
         if (!srcs[i].data || !dsts[i].data) return FLGPU_ERR_INVALID_ARG;
         int rc = flgpu_plan_output(&ps[i], srcs[i].width, srcs[i].height, srcs[i].channels, &plans[i]);
         if (rc) return rc;
-        const uint64_t sb = (uint64_t)srcs[i].width * srcs[i].height * srcs[i].channels;
+        uint64_t sb = (uint64_t)srcs[i].width * srcs[i].height * srcs[i].channels;
+        if (srcs[i].flags & FLGPU_IMG_JPEG_SOURCE) {
+            JpegInfo info;
+            if (jpeg_parse_info(srcs[i].data, (size_t)srcs[i].capacity, info) != 0) return FLGPU_ERR_INVALID_ARG;
+            if (!info.supported) return FLGPU_ERR_UNSUPPORTED;
+            blobs[i].resize(jpeg_blob_bound(info));
+            size_t used = 0;
+            rc = jpeg_source_to_blob(c, &srcs[i], blobs[i].data(), blobs[i].size(), &jh[i], &used);
+            if (rc) return rc;
+            blobs[i].resize(used);
+            jhp[i] = &jh[i];
+            c->stats.jpeg_file_bytes += srcs[i].capacity;
+            sb = used;
+        } else
         if (srcs[i].capacity < sb) return FLGPU_ERR_INVALID_ARG;
         if (dsts[i].capacity < plans[i].out_bytes && ps[i].front_end != FLGPU_FE_JPEG) return FLGPU_ERR_BUFFER_TOO_SMALL;
         dsrc[i] = srcs[i]; ddst[i] = dsts[i];
@@ -563,11 +626,12 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
     hipStream_t st = c->stream;
     for (size_t i = 0; i < n; ++i) {
         const size_t off = reinterpret_cast<size_t>(dsrc[i].data);
-        memcpy(static_cast<char *>(c->h_stage_in.p) + off, srcs[i].data, dsrc[i].capacity);
+        memcpy(static_cast<char *>(c->h_stage_in.p) + off, jhp[i] ? blobs[i].data() : srcs[i].data, dsrc[i].capacity);
         dsrc[i].data = static_cast<uint8_t *>(c->d_in.p) + off;
         ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
     }
     FL_HIP(c, hipMemcpyAsync(c->d_in.p, c->h_stage_in.p, in_b, hipMemcpyHostToDevice, st), "H2D");
+    { int drc = decode_jpeg_sources(c, n, dsrc.data(), jhp.data(), st); if (drc) return drc; }
     int rc = run_batch_device(c, n, dsrc.data(), ps, false, ddst.data(), st);
     if (rc) return rc;
     FL_HIP(c, hipMemcpyAsync(c->h_stage_out.p, c->d_out.p, out_b, hipMemcpyDeviceToHost, st), "D2H");

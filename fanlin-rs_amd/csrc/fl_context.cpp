@@ -296,6 +296,7 @@ void flgpu_destroy(flgpu_ctx *c)
     if (c->last_done) (void)hipEventDestroy(c->last_done);
     c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_tmp_o.release(); c->d_status.release(); c->d_in.release(); c->d_out.release();
     c->d_jpeg_coef.release(); c->d_jpeg_off.release(); c->d_jpeg_raw.release();
+    c->d_dec.release(); c->d_decjobs.release(); c->h_decjobs.release();
     release_cmyk(c);
     c->h_results.release();
     c->h_stage_in.release(); c->h_stage_out.release();
@@ -377,6 +378,7 @@ static void add_stats(flgpu_stats *out, const flgpu_stats &ls)
     out->generic_launches += ls.generic_launches; out->blur_launches += ls.blur_launches; out->blur_ms += ls.blur_ms;
     out->frontend_launches += ls.frontend_launches; out->frontend_ms += ls.frontend_ms;
     out->cmyk_pixels += ls.cmyk_pixels; out->cmyk_tables_baked += ls.cmyk_tables_baked;
+    out->jpeg_sources += ls.jpeg_sources; out->jpeg_file_bytes += ls.jpeg_file_bytes; out->jpeg_upload_bytes += ls.jpeg_upload_bytes;
 }
 
 int flgpu_get_stats(flgpu_ctx *c, flgpu_stats *out)

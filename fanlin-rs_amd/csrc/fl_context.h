@@ -25,6 +25,7 @@
 #include "../../include/fanlin_gpu.h"
 #include "fl_cmyk.h"
 #include "fl_jpeg_tables.h"
+#include "fl_jpegdec.h"
 #include "fl_kernels.h"
 #include "fl_tables.h"
 
@@ -84,6 +85,9 @@ struct Request {
     PinBlock in, out;      // pinned staging filled / drained by the CALLER thread (parallel memcpy)
     uint64_t src_bytes = 0, out_bytes = 0;
     uint64_t weight = 0;   // algorithmic bytes: W*H*C + out_bytes (shard balancing)
+    bool jpeg = false;     // FLGPU_IMG_JPEG_SOURCE: `in` holds the coefficient blob the caller's thread decoded, jhdr its header
+    JpegBlobHeader jhdr;
+    uint64_t file_bytes = 0;
     int status = 0;
     bool done = false;
 };
@@ -120,6 +124,8 @@ struct flgpu_ctx {
     int next_slot = 0;
     fl::DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_tmp_o, d_status;
     fl::DeviceBuf d_in, d_out;
+    fl::DeviceBuf d_dec, d_decjobs;                    // JPEG decode: planes + decoded pixels of a batch, job descriptors
+    fl::PinnedBuf h_decjobs;
     fl::DeviceBuf d_jpeg_coef, d_jpeg_off, d_jpeg_raw; // JPEG encode scratch (fl_jpeg.hip): block meta words, bit offsets, AC bits
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> jpeg_tables; // (w, h, quality) -> arena offset of header + q tables
     // per-image result words of the most recent device batch: [2i] flags (bit 0: non-opaque alpha seen by the WebP front
@@ -228,6 +234,11 @@ int collect_results(flgpu_ctx *c, size_t n, flgpu_image *dsts, hipStream_t st);
 int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts);
 // room to give an encoded result on the device: the planning bound, or the format's worst case if the caller offers it
 uint64_t staged_out_bytes(const flgpu_params &p, const flgpu_plan &plan, uint64_t dst_capacity);
+// JPEG sources of a batch: dsrc[i].data = DEVICE copy of the coefficient blob whose header (host copy) is hdrs[i], or
+// hdrs[i] == nullptr for ordinary pixel sources.  Runs the decode kernels into scratch and points dsrc[i] at the pixels.
+int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegBlobHeader *const *hdrs, hipStream_t st);
+// Host half for one source: parses + Huffman-decodes `src` (a JPEG file) into `blob`; validates the declared size.
+int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used);
 
 // ---- fl_queue.cpp ----------------------------------------------------------------------------------------------------
 // contiguous split of n weighted items into n_shards shards of about equal weight: shard_of[i] is non-decreasing

@@ -1,0 +1,184 @@
+// fl_jpegdec.hip -- device half of the JPEG decode front end (gfx950): dequantisation + integer IDCT per 8x8 block, then
+// chroma up-sampling + YCbCr -> RGB per pixel, with the arithmetic of zune-jpeg 0.4.14 as restated in
+// oracle/fanlin_oracle_jpegdec.c (reference src/handler.rs:205-220).  Integer work throughout: results are required to be
+// bit-identical to that oracle.
+//
+// jpeg_idct_kernel   one 8-lane group per block, 32 blocks per workgroup.  The block's coefficients arrive in zig-zag order,
+//                    only up to the last non-zero one (the host decoder's compact blob); they are dequantised while being
+//                    scattered into an LDS tile (9-word row pitch, 73-word block pitch: column and row passes are both
+//                    conflict free), lane t then runs the butterfly on column t, then on row t, and stores 8 samples.
+// jpeg_color_kernel  one thread per 4 output pixels of a row: fetch Y, interpolate Cb / Cr (separable (3a + b + 2) >> 2
+//                    steps, vertical first), convert, store 12 bytes (or copy 4 luma bytes for grayscale files).
+// Both are memory-light (a few MB per picture) and sit in front of the resample kernel, whose input they produce in HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fl_jpegdec.h"
+
+namespace fl {
+
+namespace {
+
+__constant__ uint8_t kUnzig[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                   41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                   30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+constexpr int BLK_PITCH = 73; // 8 rows x 9 words + 1
+constexpr int BLOCKS_PER_WG = 32;
+
+__device__ __forceinline__ uint32_t clamp8(int v) { return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+// clamp8(v >> 17), written as clamp-then-shift.  The natural form lets hipcc (ROCm 7.2) fuse pairs of them into gfx950's
+// v_ashr_pk_u8_i32, whose destination keeps stale bits above bit 15 while the compiler treats them as zero: OR-ing the other
+// two samples of a dword onto it corrupted bytes 2 and 3 of every stored dword (found by the bit-exact decode test).
+__device__ __forceinline__ uint32_t sat17(int v)
+{
+    v = v < 0 ? 0 : (v > 0x1FFFFFF ? 0x1FFFFFF : v);
+    return (uint32_t)v >> 17;
+}
+
+// the 1-D butterfly shared by both passes (stb_image / zune-jpeg idct_int): d[0..7] -> o[0..7] before the final shift
+__device__ __forceinline__ void butterfly(const int *d, int bias, int *o)
+{
+    int p2 = d[2], p3 = d[6];
+    int p1 = (p2 + p3) * 2217;
+    int t2 = p1 + p3 * -7567;
+    int t3 = p1 + p2 * 3135;
+    p2 = d[0]; p3 = d[4];
+    int t0 = (p2 + p3) * 4096, t1 = (p2 - p3) * 4096;
+    const int x0 = t0 + t3 + bias, x3 = t0 - t3 + bias, x1 = t1 + t2 + bias, x2 = t1 - t2 + bias;
+    t0 = d[7]; t1 = d[5]; t2 = d[3]; t3 = d[1];
+    p3 = t0 + t2;
+    int p4 = t1 + t3;
+    p1 = t0 + t3; p2 = t1 + t2;
+    const int p5 = (p3 + p4) * 4816;
+    t0 *= 1223; t1 *= 8410; t2 *= 12586; t3 *= 6149;
+    p1 = p5 + p1 * -3685; p2 = p5 + p2 * -10497; p3 = p3 * -8034; p4 = p4 * -1597;
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+    o[0] = x0 + t3; o[7] = x0 - t3;
+    o[1] = x1 + t2; o[6] = x1 - t2;
+    o[2] = x2 + t1; o[5] = x2 - t1;
+    o[3] = x3 + t0; o[4] = x3 - t0;
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegDecJob *__restrict__ jobs)
+{
+    __shared__ int tile[BLOCKS_PER_WG * BLK_PITCH];
+    const JpegDecJob jb = jobs[blockIdx.y];
+    const JpegBlobHeader *H = reinterpret_cast<const JpegBlobHeader *>(jb.blob);
+    const uint32_t tid = threadIdx.x, t = tid & 7u, lb = tid >> 3;
+    const uint32_t b = blockIdx.x * BLOCKS_PER_WG + lb;
+    const uint32_t nblocks = H->nblocks;
+    const bool live = b < nblocks;
+    int *my = tile + lb * BLK_PITCH;
+    // component of this block (block words are grouped by component)
+    uint32_t ci = 0;
+    if (live) { if (H->nc == 3) ci = b >= H->comp[2].block_base ? 2u : (b >= H->comp[1].block_base ? 1u : 0u); }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) my[t * 9 + k] = 0;
+    __syncthreads();
+    if (live) {
+        const uint32_t word = reinterpret_cast<const uint32_t *>(jb.blob + H->blocks_off)[b];
+        const uint32_t cnt = ((word >> 1) & 63u) + 1u, wide = word & 1u, first = word >> 7;
+        const uint8_t *data = jb.blob + H->coef_off + (size_t)first * 2u;
+        const int16_t *c16 = reinterpret_cast<const int16_t *>(data);
+        const int8_t *c8 = reinterpret_cast<const int8_t *>(data) + 2u * kJpegWideHead;
+        for (uint32_t k = t; k < cnt; k += 8u) {
+            const int q = (wide || k < kJpegWideHead) ? (int)c16[k] : (int)c8[k - kJpegWideHead];
+            const int v = q * (int)H->qt[ci][k]; // dequantised in i32, as zune-jpeg does while decoding
+            const uint32_t nat = kUnzig[k];
+            my[(nat >> 3) * 9 + (nat & 7u)] = v;
+        }
+    }
+    __syncthreads();
+    int d[8], o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = my[r * 9 + t]; // column t
+    butterfly(d, 512, o);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) my[r * 9 + t] = o[r] >> 10;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) d[c] = my[t * 9 + c]; // row t
+    butterfly(d, 65536 + (128 << 17), o);
+    if (live) {
+        const JpegComponent &C = H->comp[ci];
+        const uint32_t bi = b - C.block_base, by = bi / C.bw, bx = bi - by * C.bw;
+        uint8_t *p = jb.planes + C.plane_off + (size_t)(by * 8u + t) * (C.bw * 8u) + bx * 8u;
+        const uint32_t lo = sat17(o[0]) | (sat17(o[1]) << 8) | (sat17(o[2]) << 16) | (sat17(o[3]) << 24);
+        const uint32_t hi = sat17(o[4]) | (sat17(o[5]) << 8) | (sat17(o[6]) << 16) | (sat17(o[7]) << 24);
+        reinterpret_cast<uint2 *>(p)[0] = make_uint2(lo, hi);
+    }
+}
+
+// zune-jpeg's separable chroma interpolation at full-resolution position (x, y); sh / sv = 1 or 2
+__device__ __forceinline__ int chroma_at(const uint8_t *plane, uint32_t pw, uint32_t cw, uint32_t chh, uint32_t sh, uint32_t sv, uint32_t x, uint32_t y)
+{
+    if (sv == 1u) {
+        const uint8_t *row = plane + (size_t)y * pw;
+        if (sh == 1u) return row[x];
+        const uint32_t i = x >> 1;
+        if (cw == 1u || x == 0u || x == 2u * cw - 1u) return row[i];
+        return (x & 1u) ? (3 * row[i] + row[i + 1] + 2) >> 2 : (3 * row[i] + row[i - 1] + 2) >> 2;
+    }
+    const uint32_t r = y >> 1;
+    int fr = (y & 1u) ? (int)r + 1 : (int)r - 1;
+    fr = fr < 0 ? 0 : (fr > (int)chh - 1 ? (int)chh - 1 : fr);
+    const uint8_t *nr = plane + (size_t)r * pw, *fa = plane + (size_t)fr * pw;
+    if (sh == 1u) return (3 * nr[x] + fa[x] + 2) >> 2;
+    const uint32_t ix = x >> 1;
+    const int a = (3 * nr[ix] + fa[ix] + 2) >> 2;
+    if (cw == 1u || x == 0u || x == 2u * cw - 1u) return a;
+    const uint32_t k = (x & 1u) ? ix + 1u : ix - 1u;
+    const int b = (3 * nr[k] + fa[k] + 2) >> 2;
+    return (3 * a + b + 2) >> 2;
+}
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegDecJob *__restrict__ jobs)
+{
+    const JpegDecJob jb = jobs[blockIdx.z];
+    const JpegBlobHeader *H = reinterpret_cast<const JpegBlobHeader *>(jb.blob);
+    const uint32_t W = H->width, Hh = H->height;
+    const uint32_t y = blockIdx.y, x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (y >= Hh || x0 >= W) return;
+    const JpegComponent &Y = H->comp[0];
+    const uint8_t *yrow = jb.planes + Y.plane_off + (size_t)y * (Y.bw * 8u);
+    if (H->nc == 1u) {
+        uint8_t *o = jb.dst + (size_t)y * W + x0;
+        for (uint32_t k = 0; k < 4u && x0 + k < W; ++k) o[k] = yrow[x0 + k];
+        return;
+    }
+    const JpegComponent &CB = H->comp[1], &CR = H->comp[2];
+    const uint32_t sh = H->hmax / CB.h, sv = H->vmax / CB.v;
+    const uint8_t *pb = jb.planes + CB.plane_off, *pr = jb.planes + CR.plane_off;
+    const uint32_t cpw = CB.bw * 8u;
+    uint8_t *o = jb.dst + ((size_t)y * W + x0) * 3u;
+    for (uint32_t k = 0; k < 4u && x0 + k < W; ++k) {
+        const uint32_t x = x0 + k;
+        const int s0 = yrow[x];
+        const int s1 = chroma_at(pb, cpw, CB.w, CB.hpx, sh, sv, x, y);
+        const int s2 = chroma_at(pr, cpw, CR.w, CR.hpx, sh, sv, x, y);
+        if (H->is_rgb) { o[3 * k] = (uint8_t)s0; o[3 * k + 1] = (uint8_t)s1; o[3 * k + 2] = (uint8_t)s2; continue; }
+        // zune-jpeg color_convert/scalar.rs: i16 arithmetic with 5/6-bit constants, arithmetic shifts
+        const int cb = s1 - 128, cr = s2 - 128;
+        o[3 * k] = (uint8_t)clamp8(s0 + ((45 * cr) >> 5));
+        o[3 * k + 1] = (uint8_t)clamp8(s0 - ((11 * cb + 23 * cr) >> 5));
+        o[3 * k + 2] = (uint8_t)clamp8(s0 + ((113 * cb) >> 6));
+    }
+}
+
+} // namespace
+
+hipError_t launch_jpeg_decode(const JpegDecJob *jobs, uint32_t njobs, uint32_t max_blocks, uint32_t max_w, uint32_t max_h, hipStream_t st)
+{
+    if (!njobs) return hipSuccess;
+    // grid.y / grid.z are limited to 65535: callers split larger batches
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG, njobs), dim3(256), 0, st, jobs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_w + 1023u) / 1024u, max_h, njobs), dim3(256), 0, st, jobs);
+    return hipGetLastError();
+}
+
+} // namespace fl

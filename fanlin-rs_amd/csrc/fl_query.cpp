@@ -11,6 +11,7 @@
 
 #include "../../include/fanlin_gpu.h"
 #include "fl_jpeg_tables.h"
+#include "fl_jpegdec.h"
 #include "fl_tables.h"
 
 namespace {
@@ -241,6 +242,92 @@ int flgpu_process_image(flgpu_ctx *ctx, const flgpu_image *decoded, uint8_t exif
     if (result_kind) *result_kind = kind;
     if (rc || kind == FLGPU_RESULT_AS_IS) return rc;
     return flgpu_transform(ctx, decoded, &p, dst);
+}
+
+int flgpu_jpeg_info_of(const uint8_t *jpeg, uint64_t n, flgpu_jpeg_info *info)
+{
+    if (!jpeg || !info) return FLGPU_ERR_INVALID_ARG;
+    fl::JpegInfo I;
+    if (fl::jpeg_parse_info(jpeg, (size_t)n, I) != 0) return FLGPU_ERR_PARSE;
+    memset(info, 0, sizeof(*info));
+    info->width = I.width; info->height = I.height; info->components = I.components;
+    info->channels = I.supported ? (I.components == 1 ? 1u : 3u) : 0u;
+    info->progressive = I.progressive; info->restart_interval = I.restart_interval;
+    info->h_max = I.hmax; info->v_max = I.vmax;
+    info->exif_orientation = I.exif_orientation; info->supported = I.supported;
+    return FLGPU_OK;
+}
+
+static int plan_jpeg(const uint8_t *jpeg, uint64_t n, const char *query_string, uint32_t accept_flags, flgpu_image *src, uint8_t *orientation,
+                     flgpu_params *p, flgpu_plan *plan, int *kind, int *out_format)
+{
+    flgpu_jpeg_info info;
+    int rc = flgpu_jpeg_info_of(jpeg, n, &info);
+    if (rc) return rc;
+    memset(src, 0, sizeof(*src));
+    src->data = const_cast<uint8_t *>(jpeg);
+    src->capacity = n;
+    src->width = info.width; src->height = info.height; src->channels = info.components == 1 ? 1u : 3u;
+    src->flags = FLGPU_IMG_JPEG_SOURCE;
+    *orientation = (uint8_t)(info.exif_orientation ? info.exif_orientation : 1u);
+    rc = plan_request(src, *orientation, query_string, accept_flags, FLGPU_IN_JPEG, p, plan, kind, out_format);
+    if (rc) return rc;
+    if (*kind != FLGPU_RESULT_AS_IS && !info.supported) return FLGPU_ERR_UNSUPPORTED; /* as_is never decodes (handler.rs:202-204) */
+    return FLGPU_OK;
+}
+
+int flgpu_process_jpeg_plan(const uint8_t *jpeg, uint64_t n, const char *query_string, uint32_t accept_flags, flgpu_plan *plan, int *result_kind)
+{
+    flgpu_image src;
+    flgpu_params p;
+    uint8_t o = 1;
+    return plan_jpeg(jpeg, n, query_string, accept_flags, &src, &o, &p, plan, result_kind, nullptr);
+}
+
+int flgpu_process_jpeg(flgpu_ctx *ctx, const uint8_t *jpeg, uint64_t n, const char *query_string, uint32_t accept_flags,
+                       flgpu_image *dst, flgpu_plan *plan, int *result_kind, int *out_format)
+{
+    if (!ctx || !dst) return FLGPU_ERR_INVALID_ARG;
+    flgpu_image src;
+    flgpu_params p;
+    flgpu_plan local;
+    uint8_t o = 1;
+    int kind = 0;
+    int rc = plan_jpeg(jpeg, n, query_string, accept_flags, &src, &o, &p, plan ? plan : &local, &kind, out_format);
+    if (result_kind) *result_kind = kind;
+    if (rc || kind == FLGPU_RESULT_AS_IS) return rc;
+    return flgpu_transform(ctx, &src, &p, dst);
+}
+
+int flgpu_debug_jpeg_blob(const uint8_t *jpeg, uint64_t n, uint8_t *blob, uint64_t capacity, uint64_t *used)
+{
+    if (!jpeg || !used) return FLGPU_ERR_INVALID_ARG;
+    fl::JpegInfo I;
+    if (fl::jpeg_parse_info(jpeg, (size_t)n, I) != 0) return FLGPU_ERR_PARSE;
+    if (!I.supported) return FLGPU_ERR_UNSUPPORTED;
+    *used = fl::jpeg_blob_bound(I);
+    if (!blob) return FLGPU_OK;
+    if (capacity < *used) return FLGPU_ERR_BUFFER_TOO_SMALL;
+    size_t u = 0;
+    const int rc = fl::jpeg_entropy_decode(jpeg, (size_t)n, blob, (size_t)capacity, &u);
+    *used = u;
+    return rc == 0 ? FLGPU_OK : rc == -2 ? FLGPU_ERR_UNSUPPORTED : FLGPU_ERR_INVALID_ARG;
+}
+
+int flgpu_decode_jpeg(flgpu_ctx *ctx, const uint8_t *jpeg, uint64_t n, flgpu_image *dst)
+{
+    if (!ctx || !dst || !dst->data) return FLGPU_ERR_INVALID_ARG;
+    flgpu_jpeg_info info;
+    int rc = flgpu_jpeg_info_of(jpeg, n, &info);
+    if (rc) return rc;
+    if (!info.supported) return FLGPU_ERR_UNSUPPORTED;
+    flgpu_image src;
+    memset(&src, 0, sizeof(src));
+    src.data = const_cast<uint8_t *>(jpeg); src.capacity = n;
+    src.width = info.width; src.height = info.height; src.channels = info.channels; src.flags = FLGPU_IMG_JPEG_SOURCE;
+    flgpu_params p;
+    memset(&p, 0, sizeof(p)); /* no dimensions, no operation: the pipeline is the identity, the result the decoded picture */
+    return flgpu_transform(ctx, &src, &p, dst);
 }
 
 int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t sc, flgpu_plan *plan)

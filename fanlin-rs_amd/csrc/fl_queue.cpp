@@ -83,6 +83,7 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
     std::vector<flgpu_image> dsrc(n), ddst(n);
     std::vector<flgpu_params> ps(n);
     std::vector<uint64_t> dev_out(n);
+    std::vector<const JpegBlobHeader *> jhp(n, nullptr);
     size_t in_b = 0, out_b = 0;
     for (size_t i = 0; i < n; ++i) {
         dsrc[i] = *batch[i]->src; ddst[i] = *batch[i]->dst; ps[i] = *batch[i]->p;
@@ -99,7 +100,9 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
         dsrc[i].data = static_cast<uint8_t *>(c->d_in.p) + reinterpret_cast<size_t>(dsrc[i].data);
         ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
         FL_HIP(c, hipMemcpyAsync(dsrc[i].data, batch[i]->in.p, batch[i]->src_bytes, hipMemcpyHostToDevice, st), "H2D");
+        if (batch[i]->jpeg) { jhp[i] = &batch[i]->jhdr; c->stats.jpeg_file_bytes += batch[i]->file_bytes; }
     }
+    { int drc = decode_jpeg_sources(c, n, dsrc.data(), jhp.data(), st); if (drc) return drc; }
     int rc = run_batch_device(c, n, dsrc.data(), ps.data(), false, ddst.data(), st);
     if (rc) return rc;
     // encoded streams: learn their lengths first, then fetch exactly those bytes (a 300x200 JPEG is ~16 KB of a 183 KB bound)
@@ -378,7 +381,12 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
     flgpu_plan plan;
     int rc = flgpu_plan_output(p, src->width, src->height, src->channels, &plan);
     if (rc) return rc;
-    if (src->capacity < (uint64_t)src->width * src->height * src->channels) return FLGPU_ERR_INVALID_ARG;
+    const bool jsrc = (src->flags & FLGPU_IMG_JPEG_SOURCE) != 0;
+    JpegInfo jinfo;
+    if (jsrc) {
+        if (jpeg_parse_info(src->data, (size_t)src->capacity, jinfo) != 0) return FLGPU_ERR_INVALID_ARG;
+        if (!jinfo.supported) { c->set_error("JPEG stream not covered by the device decoder"); return FLGPU_ERR_UNSUPPORTED; }
+    } else if (src->capacity < (uint64_t)src->width * src->height * src->channels) return FLGPU_ERR_INVALID_ARG;
     const bool jpeg = p->front_end == FLGPU_FE_JPEG;
     if (!jpeg && dst->capacity < plan.out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
     Request r{};
@@ -401,8 +409,8 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
     } admission{c};
     c->staging.fetch_add(1, std::memory_order_acq_rel);
     // buffers from flgpu_host_alloc are page-locked already: the DMA engine reads / writes them directly, no staging copy
-    const bool src_pinned = (src->flags & FLGPU_IMG_PINNED) != 0, dst_pinned = (dst->flags & FLGPU_IMG_PINNED) != 0 && dst->capacity >= r.out_bytes;
-    if (src_pinned) r.in = PinBlock{src->data, 0}; else r.in = pin_acquire(c, r.src_bytes);
+    const bool src_pinned = (src->flags & FLGPU_IMG_PINNED) != 0 && !jsrc, dst_pinned = (dst->flags & FLGPU_IMG_PINNED) != 0 && dst->capacity >= r.out_bytes;
+    if (src_pinned) r.in = PinBlock{src->data, 0}; else r.in = pin_acquire(c, jsrc ? jpeg_blob_bound(jinfo) : r.src_bytes);
     if (dst_pinned) r.out = PinBlock{dst->data, 0}; else r.out = pin_acquire(c, r.out_bytes);
     auto give_back = [&] { if (!src_pinned) pin_release(c, r.in); if (!dst_pinned) pin_release(c, r.out); };
     if (!r.in.p || !r.out.p) {
@@ -410,6 +418,16 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
         give_back();
         return FLGPU_ERR_OOM;
     }
+    if (jsrc) {
+        // the serial half of the decoder (parsing + Huffman) on the caller's thread, straight into pinned memory:
+        // concurrent requests decode in parallel and only the coefficient blob crosses PCIe
+        size_t used = 0;
+        const int jrc = jpeg_source_to_blob(c, src, static_cast<uint8_t *>(r.in.p), r.in.cap, &r.jhdr, &used);
+        if (jrc) { c->staging.fetch_sub(1, std::memory_order_acq_rel); give_back(); return jrc; }
+        r.jpeg = true;
+        r.file_bytes = src->capacity;
+        r.src_bytes = used;
+    } else
     if (!src_pinned) memcpy(r.in.p, src->data, r.src_bytes); // on the caller's thread: concurrent callers stage in parallel
     {
         std::unique_lock<std::mutex> lk(c->qmu);

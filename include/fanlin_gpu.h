@@ -33,6 +33,7 @@
  *   flgpu_set_cmyk_profile / _clut      create_cmyk_to_rgb_converter + CMYK2RGB::with_icc_profile,
  *                                       src/main.rs:74-76, src/handler.rs:469-488
  *   flgpu_cmyk_to_rgb[_device]          CMYK2RGB::convert = lcms2 transform_pixels, src/handler.rs:446-462,490-492
+ *   FLGPU_IMG_JPEG_SOURCE / flgpu_process_jpeg   JpegDecoder::new + DynamicImage::from_decoder, src/handler.rs:205-220
  *   flgpu_create / flgpu_destroy        lifetime of handler::State, src/handler.rs:14-21,36-52
  *   flgpu_config.devices / flgpu_plan_shards   the one shared Arc<State> behind all tokio workers, src/main.rs:108-112
  */
@@ -74,6 +75,12 @@ typedef struct flgpu_image {
 #define FLGPU_IMG_PINNED          8u  /* in (src and dst of flgpu_transform): data comes from flgpu_host_alloc, i.e. is page-locked:
                                          the copy through the library's own pinned staging blocks is skipped */
 #define FLGPU_IMG_ENCODED         4u  /* JPEG: data holds an encoded stream of `bytes` bytes */
+#define FLGPU_IMG_JPEG_SOURCE     16u /* in (src of flgpu_transform / flgpu_transform_batch): data holds a baseline JPEG FILE of `capacity`
+                                         bytes instead of pixels, width / height / channels say what it decodes to (flgpu_jpeg_info):
+                                         the library decodes it itself -- Huffman decoding on the calling thread, dequantisation, IDCT,
+                                         chroma up-sampling and YCbCr -> RGB on the device -- replacing JpegDecoder::new +
+                                         DynamicImage::from_decoder (src/handler.rs:205-220).  ~1 MB crosses PCIe instead of 6.2 MB
+                                         for a 1080p picture.  Streams it does not cover: FLGPU_ERR_UNSUPPORTED (decode on the host). */
 #define FLGPU_IMG_HAS_ALPHA       2u  /* WEBP420: some pixel is not opaque: the picture is WEBP_YUV420A for libwebp, i.e. the A
                                          plane behind V must be handed to WebPEncode too (for opaque pictures it is all 255) */
 
@@ -174,6 +181,9 @@ typedef struct flgpu_stats {
     double frontend_ms;
     uint64_t cmyk_pixels;         /* pixels converted CMYK -> RGB */
     uint64_t cmyk_tables_baked;   /* device-link tables baked from ICC profiles */
+    uint64_t jpeg_sources;        /* FLGPU_IMG_JPEG_SOURCE pictures decoded on the device */
+    uint64_t jpeg_file_bytes;     /* their file bytes ... */
+    uint64_t jpeg_upload_bytes;   /* ... and what crossed PCIe for them (coefficient blobs) */
 } flgpu_stats;
 
 typedef struct flgpu_ctx flgpu_ctx;
@@ -269,6 +279,32 @@ int flgpu_process_image(flgpu_ctx *ctx, const flgpu_image *decoded, uint8_t exif
 int flgpu_process_image_plan(const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string,
                              uint32_t accept_flags, int input_format, flgpu_plan *plan, int *result_kind);
 
+/* ---- JPEG sources (src/handler.rs:205-220: zune-jpeg through the image crate) ----------------------------------------- */
+typedef struct flgpu_jpeg_info {
+    uint32_t width, height;
+    uint32_t components;        /* as stored: 1 (decodes to Luma8), 3 (Rgb8), 4 (CMYK / YCCK: not decoded here) */
+    uint32_t channels;          /* of the decoded picture: 1 or 3 (0 if unsupported) */
+    uint32_t progressive;       /* SOF2, or any process other than baseline / extended sequential Huffman */
+    uint32_t restart_interval;  /* DRI, in MCUs (0 = none) */
+    uint32_t h_max, v_max;      /* largest sampling factors: 1x1 = 4:4:4, 2x1 = 4:2:2, 2x2 = 4:2:0 */
+    uint32_t exif_orientation;  /* 1..8 from the APP1 Exif segment (decoder.orientation(), src/handler.rs:206); 0 = no tag */
+    uint32_t supported;         /* 1 = FLGPU_IMG_JPEG_SOURCE decodes it: 8-bit baseline, one interleaved scan, 1 or 3
+                                   components, chroma planes at full or half resolution per direction */
+    uint32_t reserved[2];
+} flgpu_jpeg_info;
+/* Header inspection only (no device needed).  FLGPU_ERR_PARSE if the bytes are not a JPEG. */
+int flgpu_jpeg_info_of(const uint8_t *jpeg, uint64_t n, flgpu_jpeg_info *info);
+/* Decodes a supported JPEG to interleaved pixels in HOST memory at dst->data (capacity >= width*height*channels). */
+int flgpu_decode_jpeg(flgpu_ctx *ctx, const uint8_t *jpeg, uint64_t n, flgpu_image *dst);
+/* State::process_image for a JPEG input from the file bytes on (src/handler.rs:198-308): header + EXIF orientation,
+ * query parsing, size gate, as_is, container negotiation, then decode + pixel pipeline + encode in one device pass.
+ * Same outcomes as flgpu_process_image; additionally FLGPU_ERR_UNSUPPORTED for streams the device decoder does not cover
+ * (the host then decodes with its own decoder and calls flgpu_process_image). */
+int flgpu_process_jpeg(flgpu_ctx *ctx, const uint8_t *jpeg, uint64_t n, const char *query_string, uint32_t accept_flags,
+                       flgpu_image *dst, flgpu_plan *plan, int *result_kind, int *out_format);
+int flgpu_process_jpeg_plan(const uint8_t *jpeg, uint64_t n, const char *query_string, uint32_t accept_flags, flgpu_plan *plan,
+                            int *result_kind);
+
 /* Page-locked host memory for sources / results of flgpu_transform (flag them FLGPU_IMG_PINNED): a decoder that
  * writes straight into such a buffer (zune-jpeg's decode_into) saves the 6 MB staging copy of a 1080p request. */
 void *flgpu_host_alloc(flgpu_ctx *ctx, uint64_t bytes);
@@ -335,6 +371,11 @@ int flgpu_debug_axis_table(uint32_t in_size, uint32_t out_size, int filter, floa
 /* Row schedule of the streaming kernel for output rows [y0,y1) of a Lanczos3 axis:
  * returns 1 if the fused kernel can run it (<= 8 rows alive per source row), 0 if the
  * generic two-pass kernels are used instead; *max_live receives the peak. */
+/* The host half of the JPEG decode front end alone: the coefficient blob flgpu_transform uploads for a
+ * FLGPU_IMG_JPEG_SOURCE (csrc/fl_jpegdec.h: header, one u32 word per block = first coefficient << 7 | count, i16
+ * coefficients in zig-zag order up to the last non-zero one).  blob == NULL: *used = capacity to provide. */
+int flgpu_debug_jpeg_blob(const uint8_t *jpeg, uint64_t n, uint8_t *blob, uint64_t capacity, uint64_t *used);
+
 int flgpu_debug_stream_schedulable(uint32_t in_size, uint32_t out_size, uint32_t y0, uint32_t y1, uint32_t *max_live);
 
 const char *flgpu_strerror(int status);

@@ -121,6 +121,32 @@ class Oracle:
         assert 0 < n <= cap
         return buf[:n].tobytes()
 
+    def jpeg_info(self, data: bytes):
+        """(rc, w, h, components, exif orientation); rc 0 ok, -1 malformed, -2 not covered"""
+        w, h, c, o = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.lib.fo_jpeg_info.argtypes = [C.c_char_p, C.c_size_t] + [C.POINTER(C.c_uint32)] * 4
+        rc = self.lib.fo_jpeg_info(data, len(data), C.byref(w), C.byref(h), C.byref(c), C.byref(o))
+        return rc, w.value, h.value, c.value, o.value
+
+    def jpeg_decode(self, data: bytes):
+        """Baseline JPEG -> Luma8 / Rgb8 pixels with zune-jpeg's IDCT / upsampling / colour arithmetic (restated)."""
+        rc, w, h, c, _ = self.jpeg_info(data)
+        assert rc == 0, rc
+        out = np.zeros((h, w, 1 if c == 1 else 3), np.uint8)
+        self.lib.fo_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        rc = self.lib.fo_jpeg_decode(data, len(data), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0, rc
+        return out
+
+    def jpeg_file_coefficients(self, data: bytes):
+        """Quantised coefficients of every block of a JPEG file, [block][64] zig-zag (entropy decoding only)."""
+        nb = C.c_uint32()
+        self.lib.fo_jpeg_coefficients_of.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+        assert self.lib.fo_jpeg_coefficients_of(data, len(data), None, 0, C.byref(nb)) == 0
+        out = np.zeros((nb.value, 64), np.int16)
+        assert self.lib.fo_jpeg_coefficients_of(data, len(data), out.ctypes.data_as(C.c_void_p), nb.value, C.byref(nb)) == 0
+        return out
+
     def cmyk_to_rgb(self, cmyk, clut):
         a = np.ascontiguousarray(cmyk, dtype=np.uint8)
         t = np.ascontiguousarray(clut, dtype=np.uint16)

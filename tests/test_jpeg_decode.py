@@ -1,0 +1,220 @@
+"""JPEG decode front end (reference src/handler.rs:205-220: image 0.25.6 -> zune-jpeg 0.4.14).
+
+Three layers, three bars:
+  * host half (marker parsing + Huffman decoding, product code that runs on the CPU): its coefficient blob must hold
+    exactly the quantised coefficients an independent bit-by-bit decoder (the oracle, T.81 F.2.2.3) reads from the same
+    file -- checked without a GPU;
+  * oracle restatement of zune-jpeg's IDCT / up-sampling / colour arithmetic vs libjpeg-turbo (Pillow): PARITY UNPINNED for
+    zune-jpeg itself (no Rust here); what is pinned is the distance to the other production decoder on the reference's own
+    images/lenna.jpg and on synthetic streams: <= 4 LSB per channel, mean < 1 (two integer IDCTs differ by <= 1, zune's
+    5/6-bit colour constants by <= 2-3 from libjpeg's 16-bit ones, its two-step chroma interpolation by <= 1);
+  * device half (-m gpu): bit-identical to the oracle decoder, for every sampling layout, odd sizes and restart intervals,
+    alone and inside the whole request (decode + resize + letterbox + encode in one pass)."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle_lib
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LENNA = os.path.join(ROOT, "tests", "golden", "lenna_reference.jpg")
+
+
+def make_jpeg(h, w, c=3, q=85, subsampling=0, restart_blocks=0, dist="photo", index=0, exif_orientation=None):
+    img = getattr(synth, dist)(h, w, c, index=index)
+    pil = Image.fromarray(img[:, :, 0] if c == 1 else img)
+    kw = dict(quality=q)
+    if c == 3:
+        kw["subsampling"] = subsampling
+    if restart_blocks:
+        kw["restart_marker_blocks"] = restart_blocks
+    if exif_orientation:
+        ex = Image.Exif()
+        ex[0x0112] = exif_orientation
+        kw["exif"] = ex
+    b = io.BytesIO()
+    pil.save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+CASES = [
+    # h, w, c, quality, subsampling (0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0), restart interval in blocks
+    (64, 96, 3, 85, 0, 0), (64, 96, 3, 85, 1, 0), (64, 96, 3, 85, 2, 0),
+    (37, 53, 3, 70, 0, 0), (37, 53, 3, 70, 1, 0), (37, 53, 3, 70, 2, 0),
+    (1, 1, 3, 90, 2, 0), (8, 8, 3, 90, 0, 0), (17, 16, 3, 50, 2, 0), (16, 17, 3, 50, 1, 0), (9, 300, 3, 95, 2, 0),
+    (120, 160, 3, 90, 2, 3), (120, 160, 3, 30, 0, 1), (50, 70, 3, 75, 1, 7),
+    (50, 70, 1, 75, 0, 0), (33, 9, 1, 60, 0, 2), (200, 301, 3, 100, 2, 0), (200, 301, 3, 5, 0, 0),
+]
+
+
+def lenna_bytes():
+    # the reference's own picture (images/lenna.jpg, 512x512 baseline 4:4:4 with a restart interval): a committed copy,
+    # because /root/reference does not exist on the GPU box -- a test fixture (data the reference's tests hold), not source
+    return open(LENNA, "rb").read()
+
+
+# ------------------------------------------------------------------------------------------------- host half, CPU --
+
+@pytest.mark.parametrize("case", CASES)
+def test_host_huffman_decoder_reads_the_same_coefficients_as_the_oracle(fl, oracle, case):
+    h, w, c, q, sub, rst = case
+    data = make_jpeg(h, w, c, q, sub, rst, index=h + w)
+    hdr, got, _ = fl.debug_jpeg_blob(data)
+    want = oracle.jpeg_file_coefficients(data)
+    assert (hdr["width"], hdr["height"], hdr["nc"]) == (w, h, c)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_host_decoder_on_the_reference_picture(fl, oracle):
+    data = lenna_bytes()
+    info = fl.jpeg_info(data)
+    assert (info["width"], info["height"], info["components"], info["supported"], info["exif_orientation"]) == (512, 512, 3, 1, 1)
+    assert info["restart_interval"] > 0 and (info["h_max"], info["v_max"]) == (1, 1)
+    hdr, got, blob = fl.debug_jpeg_blob(data)
+    assert np.array_equal(got, oracle.jpeg_file_coefficients(data))
+    assert hdr["is_rgb"] == 0                                  # APP14 Adobe transform 1 = YCbCr
+    # this file is near-lossless (10.5 bits per pixel): its blob is no smaller than the decoded picture; typical web
+    # JPEGs (the synthetic q <= 90 cases) shrink 3-6x -- see test_blob_is_much_smaller_than_the_pixels_for_typical_files
+    assert blob.size < 1.2 * 512 * 512 * 3
+
+
+def test_blob_is_much_smaller_than_the_pixels_for_typical_files(fl):
+    for q, sub, factor in ((75, 2, 5.0), (85, 2, 4.0), (85, 0, 2.5)):
+        data = make_jpeg(1080, 1920, 3, q, sub, index=q)
+        _, _, blob = fl.debug_jpeg_blob(data)
+        assert blob.size * factor < 1080 * 1920 * 3, (q, sub, blob.size, len(data))
+
+
+def test_exif_orientation_and_unsupported_streams(fl):
+    for o in (1, 3, 6, 8):
+        assert fl.jpeg_info(make_jpeg(40, 30, exif_orientation=o))["exif_orientation"] == o
+    assert fl.jpeg_info(make_jpeg(40, 30))["exif_orientation"] == 0
+    b = io.BytesIO()
+    Image.fromarray(synth.photo(40, 50, 3)).save(b, "JPEG", progressive=True)
+    info = fl.jpeg_info(b.getvalue())
+    assert info["progressive"] == 1 and info["supported"] == 0 and info["channels"] == 0
+    with pytest.raises(fl.FanlinError) as e:
+        fl.debug_jpeg_blob(b.getvalue())
+    assert e.value.status == fl.ERR_UNSUPPORTED
+    b = io.BytesIO()
+    Image.fromarray(synth.uniform(24, 24, 4)).convert("CMYK").save(b, "JPEG")
+    assert fl.jpeg_info(b.getvalue())["supported"] == 0          # 4 components: the CMYK path of handler.rs:398-493, not this one
+    for junk in (b"", b"\xff\xd8", b"GIF89a" + bytes(64), make_jpeg(16, 16)[:40]):
+        with pytest.raises(fl.FanlinError):
+            fl.jpeg_info(junk)
+    # truncated entropy-coded data must come back as an error or a picture, never a crash
+    data = make_jpeg(64, 64, q=90)
+    for cut in (len(data) - 2, len(data) // 2, 700):
+        try:
+            fl.debug_jpeg_blob(data[:cut])
+        except fl.FanlinError:
+            pass
+
+
+# ------------------------------------------------------------------------- oracle vs libjpeg-turbo (the pinned bound) --
+
+def _vs_pillow(oracle, data):
+    got = oracle.jpeg_decode(data)
+    ref = np.array(Image.open(io.BytesIO(data)))
+    if ref.ndim == 2:
+        ref = ref[:, :, None]
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    return int(d.max()), float(d.mean())
+
+
+def test_oracle_decoder_vs_libjpeg_on_the_reference_picture(oracle):
+    mx, mean = _vs_pillow(oracle, lenna_bytes())
+    assert mx <= 4 and mean < 1.0, (mx, mean)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_decoder_vs_libjpeg_on_synthetic_streams(oracle, case):
+    h, w, c, q, sub, rst = case
+    mx, mean = _vs_pillow(oracle, make_jpeg(h, w, c, q, sub, rst, index=h + w))
+    assert mx <= (2 if c == 1 else 4) and mean < 1.0, (case, mx, mean)   # grayscale: only the two integer IDCTs differ
+
+
+def test_committed_lenna_is_the_reference_file():
+    ref = "/root/reference/images/lenna.jpg"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    assert open(ref, "rb").read() == lenna_bytes()
+
+
+# ----------------------------------------------------------------------------------------------- device half (GPU) --
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_device_decode_is_bit_identical_to_the_oracle(fl, gpu_state, oracle, case):
+    h, w, c, q, sub, rst = case
+    data = make_jpeg(h, w, c, q, sub, rst, index=h + w)
+    assert np.array_equal(gpu_state.decode_jpeg(data), oracle.jpeg_decode(data))
+
+
+@pytest.mark.gpu
+def test_device_decode_of_the_reference_picture_and_config0(fl, gpu_state, oracle):
+    data = lenna_bytes()
+    want = oracle.jpeg_decode(data)
+    assert np.array_equal(gpu_state.decode_jpeg(data), want)
+    # BASELINE config 0: lenna.jpg -> w=300&h=200, the whole request from the file bytes on, in one call
+    mime, kind, body = gpu_state.process_jpeg(data, "w=300&h=200")
+    px = oracle.process_pixels(want, 300, 200, arith=oracle_lib.ARITH_FMA)
+    assert mime == "image/jpeg" and kind == fl.RESULT_JPEG_STREAM and body == oracle.jpeg_encode(px, 75)
+    assert px.shape == (200, 300, 4) and tuple(px[0, 0]) == (32, 32, 32, 255) and tuple(px[0, 49]) == (32, 32, 32, 255)   # 200x200 at x offset 50
+    mime, kind, planes = gpu_state.process_jpeg(data, "w=300&h=200&webp=true&quality=20", fl.Format.from_accept_header("image/webp"))
+    assert mime == "image/webp" and kind == fl.RESULT_WEBP_PLANES and planes.y.shape == (200, 300)
+    assert gpu_state.process_jpeg(data, "quality=80")[1] == fl.RESULT_AS_IS            # as_is never decodes (handler.rs:202-204)
+    st = gpu_state.stats()
+    assert st["jpeg_sources"] >= 3 and 0 < st["jpeg_upload_bytes"] < st["jpeg_sources"] * 512 * 512 * 3
+
+
+@pytest.mark.gpu
+def test_jpeg_sources_through_the_queue_and_batches(fl, gpu_state, oracle):
+    import threading
+    files = [make_jpeg(120 + 16 * i, 200 + 8 * i, 3 if i % 4 else 1, 60 + 5 * i, i % 3, (i % 2) * 4, index=300 + i) for i in range(8)]
+    decoded = [oracle.jpeg_decode(f) for f in files]
+    ps = [fl.make_params(64 + i, 48, crop=bool(i % 2), grayscale=bool(i == 3), front_end=fl.FE_JPEG if i % 3 == 0 else fl.FE_NONE, quality=70) for i in range(8)]
+    want = [gpu_state.process_pixels(decoded[i], ps[i]) for i in range(8)]             # the pixel-source path, already checked against the oracle elsewhere
+    got = gpu_state.process_batch(files, ps)
+    for a, b in zip(got, want):
+        assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b)
+    mixed = gpu_state.process_batch([files[0], decoded[1], files[2]], ps[:3])          # JPEG and pixel sources in one batch
+    for a, b in zip(mixed, want[:3]):
+        assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b)
+    out = [None] * 64
+    def worker(t):
+        for i in range(t, 64, 8):
+            out[i] = gpu_state.process_jpeg_pixels(files[i % 8], ps[i % 8])
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(64):
+        b = want[i % 8]
+        assert (out[i] == b) if isinstance(b, bytes) else np.array_equal(out[i], b)
+
+
+@pytest.mark.gpu
+def test_exif_orientation_is_applied_by_process_jpeg(fl, gpu_state, oracle):
+    data = make_jpeg(90, 60, q=92, exif_orientation=6, index=77)
+    px = oracle.jpeg_decode(data)
+    mime, kind, got = gpu_state.process_jpeg(data, "w=40&h=40&webp=true&quality=100", fl.Format.from_accept_header("image/webp"))
+    assert kind == fl.RESULT_PIXELS                               # lossless WebP: pixels for the host encoder
+    want = oracle.process_pixels(px, 40, 40, orientation=6, arith=oracle_lib.ARITH_FMA)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_unsupported_jpeg_sources_are_refused_not_mangled(fl, gpu_state):
+    b = io.BytesIO()
+    Image.fromarray(synth.photo(40, 50, 3)).save(b, "JPEG", progressive=True)
+    with pytest.raises(fl.FanlinError) as e:
+        gpu_state.decode_jpeg(b.getvalue())
+    assert e.value.status == fl.ERR_UNSUPPORTED
+    with pytest.raises(fl.FanlinError) as e:
+        gpu_state.process_jpeg(b.getvalue(), "w=30&h=30")
+    assert e.value.status == fl.ERR_UNSUPPORTED
+    assert gpu_state.process_jpeg(b.getvalue(), "rgb=1,2,3")[1] == fl.RESULT_AS_IS

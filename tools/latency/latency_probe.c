@@ -1,7 +1,8 @@
 /* Per-image latency of the drop-in entry point, measured without Python in the way: T caller threads (the
  * reference's tokio workers, src/main.rs:33) call flgpu_transform concurrently with HOST buffers; the library's
  * request queue packs them into shared launches.  Prints one JSON object.
- *   latency_probe <threads> <requests> <src_w> <src_h> <query> [front_end] [queue_lanes] [max_batch] [pinned]   */
+ *   latency_probe <threads> <requests> <src_w> <src_h> <query> [front_end] [queue_lanes] [max_batch] [pinned] [jpeg files...]
+ * With JPEG files (each src_w x src_h) the requests carry the FILE bytes (FLGPU_IMG_JPEG_SOURCE): the library decodes them. */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
 #include <stdint.h>
@@ -17,6 +18,9 @@ static flgpu_params g_params;
 static flgpu_plan g_plan;
 static uint32_t g_w, g_h;
 static uint8_t *g_src[8];
+static size_t g_src_len[8];
+static int g_jpeg, g_nsrc = 8;
+static uint32_t g_c = 3;
 static int g_requests, g_next, g_failed, g_pinned;
 static double *g_lat;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -31,14 +35,14 @@ static double now_ms(void)
 static void *caller(void *arg)
 {
     (void)arg;
-    uint8_t *dst = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, g_plan.out_bytes) : malloc(g_plan.out_bytes));
+    uint8_t *dst = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, g_plan.max_out_bytes) : malloc(g_plan.max_out_bytes));
     const uint32_t fl = g_pinned ? FLGPU_IMG_PINNED : 0u;
     for (;;) {
         pthread_mutex_lock(&g_mu);
         const int i = g_next++;
         pthread_mutex_unlock(&g_mu);
         if (i >= g_requests) break;
-        flgpu_image in = {g_src[i % 8], (uint64_t)g_w * g_h * 3, g_w, g_h, 3, fl, 0}, out = {dst, g_plan.out_bytes, 0, 0, 0, fl, 0};
+        flgpu_image in = {g_src[i % g_nsrc], g_jpeg ? (uint64_t)g_src_len[i % g_nsrc] : (uint64_t)g_w * g_h * 3, g_w, g_h, g_c, g_jpeg ? FLGPU_IMG_JPEG_SOURCE : fl, 0}, out = {dst, g_plan.max_out_bytes, 0, 0, 0, fl, 0};
         const double t0 = now_ms();
         if (flgpu_transform(g_ctx, &in, &g_params, &out) != FLGPU_OK) { pthread_mutex_lock(&g_mu); g_failed++; pthread_mutex_unlock(&g_mu); }
         g_lat[i] = now_ms() - t0;
@@ -71,7 +75,28 @@ int main(int argc, char **argv)
     if (!g_ctx) { fprintf(stderr, "flgpu_create: %s\n", flgpu_strerror(st)); return 5; }
     const size_t n = (size_t)g_w * g_h * 3;
     uint32_t s = 0xFA171200u;
-    for (int k = 0; k < 8; ++k) {
+    if (argc > 10) {
+        g_jpeg = 1;
+        g_nsrc = argc - 10 > 8 ? 8 : argc - 10;
+        for (int k = 0; k < g_nsrc; ++k) {
+            FILE *f = fopen(argv[10 + k], "rb");
+            if (!f) { fprintf(stderr, "cannot open %s\n", argv[10 + k]); return 7; }
+            fseek(f, 0, SEEK_END);
+            g_src_len[k] = (size_t)ftell(f);
+            fseek(f, 0, SEEK_SET);
+            g_src[k] = (uint8_t *)malloc(g_src_len[k]);
+            if (fread(g_src[k], 1, g_src_len[k], f) != g_src_len[k]) return 7;
+            fclose(f);
+            flgpu_jpeg_info info;
+            if (flgpu_jpeg_info_of(g_src[k], g_src_len[k], &info) != FLGPU_OK || !info.supported || info.width != g_w || info.height != g_h) {
+                fprintf(stderr, "%s is not a supported %ux%u JPEG\n", argv[10 + k], g_w, g_h);
+                return 7;
+            }
+            g_c = info.channels;
+        }
+        if (flgpu_plan_output(&g_params, g_w, g_h, g_c, &g_plan) != FLGPU_OK) return 4;
+    }
+    for (int k = 0; k < 8 && !g_jpeg; ++k) {
         g_src[k] = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, n) : malloc(n));
         for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; g_src[k][i] = (uint8_t)(s >> 24); }
     }
@@ -92,9 +117,11 @@ int main(int argc, char **argv)
     flgpu_get_stats(g_ctx, &stats);
     qsort(g_lat, (size_t)g_requests, sizeof(double), cmp);
     printf("{\"p50_ms\": %.3f, \"p99_ms\": %.3f, \"requests\": %d, \"caller_threads\": %d, \"images_per_s\": %.1f, \"queue_flushes\": %llu, "
-           "\"failed\": %d, \"pinned\": %d, \"path\": \"flgpu_transform from C threads, host buffers (H2D + kernels + D2H), request-batching queue\"}\n",
+           "\"failed\": %d, \"pinned\": %d, \"jpeg_sources\": %llu, \"mean_file_bytes\": %.0f, \"mean_upload_bytes\": %.0f, "
+           "\"path\": \"flgpu_transform from C threads, host buffers (H2D + kernels + D2H), request-batching queue\"}\n",
            g_lat[g_requests / 2], g_lat[(int)(g_requests * 0.99) < g_requests ? (int)(g_requests * 0.99) : g_requests - 1], g_requests, threads,
-           g_requests / wall * 1e3, (unsigned long long)stats.queue_flushes, g_failed, g_pinned);
+           g_requests / wall * 1e3, (unsigned long long)stats.queue_flushes, g_failed, g_pinned, (unsigned long long)stats.jpeg_sources,
+           stats.jpeg_sources ? (double)stats.jpeg_file_bytes / (double)stats.jpeg_sources : 0.0, stats.jpeg_sources ? (double)stats.jpeg_upload_bytes / (double)stats.jpeg_sources : 0.0);
     flgpu_destroy(g_ctx);
     return g_failed ? 6 : 0;
 }
