@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <memory>
 
 #include "fl_context.h"
 
@@ -145,7 +146,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     if (!st) st = c->stream;
     if (c->last_stream && c->last_stream != st && c->last_done) FL_HIP(c, hipStreamWaitEvent(st, c->last_done, 0), "stream handoff");
 
+    RoctxRange range_batch("flgpu batch");
     // ---- plan every image ------------------------------------------------
+    std::unique_ptr<RoctxRange> range_plan(new RoctxRange("flgpu plan + tables"));
     std::vector<Work> work(n);
     size_t tmp_a_bytes = 0, tmp_b_bytes = 0, tmp_o_bytes = 0, jpeg_coef_bytes = 0, jpeg_off_bytes = 0, jpeg_raw_bytes = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -477,7 +480,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         d_jjobs = reinterpret_cast<const JpegJob *>(dp + jobs_b + items_b + fjobs_b);
     }
 
+    range_plan.reset();
     // ---- launches --------------------------------------------------------------
+    RoctxRange range_launch("flgpu launches");
     for (auto &O : orient_launches) {
         LaunchGeneric g{};
         g.jobs = d_jobs; g.job_base = O.base; g.njobs = O.n; g.cs = O.cs; g.max_dw = O.mw; g.max_dh = O.mh;

@@ -1,6 +1,7 @@
 // fl_context.cpp -- context lifetime, the read-only table arena and its caches, statistics and table export / import.
 // The batch planner / launcher is fl_batch.cpp, the request queue and the sharding across devices fl_queue.cpp,
 // the CMYK tables fl_cmyk_ctx.cpp (see fl_context.h).
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -195,6 +196,28 @@ void resolve_pending(flgpu_ctx *c)
     }
     c->pending.clear();
 }
+
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = getenv("FLGPU_ROCTX");
+        if (!e || e[0] != '1') return;
+        void *lib = nullptr;
+        for (const char *n : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so"}) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+Roctx &roctx() { static Roctx r; return r; }
+} // namespace
+
+RoctxRange::RoctxRange(const char *name) { if (roctx().push) { roctx().push(name); on = true; } }
+RoctxRange::~RoctxRange() { if (on) roctx().pop(); }
 
 ProfileScope::ProfileScope(flgpu_ctx *c_, hipStream_t st_, int kind_) : c(c_), st(st_), kind(kind_)
 {

@@ -221,6 +221,14 @@ hipEvent_t get_event(flgpu_ctx *c);
 void resolve_pending(flgpu_ctx *c);
 flgpu_ctx *create_child(flgpu_ctx *parent, int device); // a lane / device shard: same config, one device, no queue of its own
 
+// roctx ranges around the phases of a batch (tracing): visible to `rocprofv3 --marker-trace`; libroctx64 is
+// loaded on demand and only when FLGPU_ROCTX=1, so production runs pay nothing.
+struct RoctxRange {
+    explicit RoctxRange(const char *name);
+    ~RoctxRange();
+    bool on = false;
+};
+
 struct ProfileScope {
     flgpu_ctx *c; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr;
     ProfileScope(flgpu_ctx *c_, hipStream_t st_, int kind_);

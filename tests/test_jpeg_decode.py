@@ -169,7 +169,7 @@ def test_device_decode_of_the_reference_picture_and_config0(fl, gpu_state, oracl
     assert mime == "image/webp" and kind == fl.RESULT_WEBP_PLANES and planes.y.shape == (200, 300)
     assert gpu_state.process_jpeg(data, "quality=80")[1] == fl.RESULT_AS_IS            # as_is never decodes (handler.rs:202-204)
     st = gpu_state.stats()
-    assert st["jpeg_sources"] >= 3 and 0 < st["jpeg_upload_bytes"] < st["jpeg_sources"] * 512 * 512 * 3
+    assert st["jpeg_sources"] >= 3 and 0 < st["jpeg_upload_bytes"] < st["jpeg_sources"] * 1.2 * 512 * 512 * 3   # near-lossless file: see the CPU test
 
 
 @pytest.mark.gpu

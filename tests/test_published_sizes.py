@@ -31,11 +31,24 @@ def test_webp_q20_response_size(oracle, thumbnail):
     assert abs(n - 2684) / 2684 < 0.02, n                    # 2,692 B with libwebp 1.2.2 (the reference vendors a newer one)
 
 
-def test_jpeg_response_size(oracle, thumbnail):
-    # 16,021 B is published for the request WITHOUT a quality parameter.  The restated encoder gives 16,011 B at
-    # quality 85 and 12,141 B at today's default of 75 (src/query.rs:18): a 10-byte agreement on a content-dependent
-    # 16 KB stream is not a coincidence, so the README run evidently used 85 (its own example value, README.md:59).
-    # What this pins: the encoder restatement (tables, DCT, quantiser, Huffman coder, framing) to ~0.1 % in size.
-    n85, n75 = len(oracle.jpeg_encode(thumbnail, 85)), len(oracle.jpeg_encode(thumbnail, 75))
-    assert abs(n85 - 16021) / 16021 < 0.005, n85
-    assert 11500 < n75 < 12800, n75
+def test_jpeg_response_size_is_no_anchor_but_the_encoder_tracks_libjpeg(oracle, thumbnail):
+    """README.md:115 publishes a mean of 16,021 B for `?w=300&h=200` (no quality parameter).  At the documented default
+    (src/query.rs:18, quality 75) the restated chain gives ~12.1 KB -- and so does libjpeg at the same tables, sampling
+    and Huffman codes (12.3 KB), so no faithful quality-75 encoder produces 16 KB from this picture: the README figure does
+    not come from today's default.  It equals what the chain gives at quality 85 (16,011 B with libjpeg-turbo's decode of
+    lenna.jpg, 16,026 B with the restated zune-jpeg decode), but that choice is made after the fact, so it ANCHORS NOTHING
+    and DESIGN.md says so.  What IS checked here: the restated encoder stays within 2.5 % of libjpeg's size at identical
+    quantisation tables, 4:4:4 sampling and the standard Huffman tables, at four qualities -- an independent bound on the
+    whole encoder (tables, DCT, quantiser, entropy coder, framing)."""
+    import io
+    rgb = PIL.fromarray(thumbnail[:, :, :3])
+    sizes = {}
+    for q in (75, 80, 85, 90):
+        ours = len(oracle.jpeg_encode(thumbnail, q))
+        b = io.BytesIO()
+        rgb.save(b, "JPEG", quality=q, subsampling=0, optimize=False)
+        theirs = len(b.getvalue())
+        sizes[q] = (ours, theirs)
+        assert abs(ours - theirs) / theirs < 0.025, (q, ours, theirs)
+    assert 11500 < sizes[75][0] < 12800 and 11500 < sizes[75][1] < 12800      # quality 75: ~12 KB either way, not 16 KB
+    assert abs(sizes[85][0] - 16021) < 100                                      # (recorded, not relied upon)
