@@ -206,7 +206,7 @@ struct Roctx {
         const char *e = getenv("FLGPU_ROCTX");
         if (!e || e[0] != '1') return;
         void *lib = nullptr;
-        for (const char *n : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so"}) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
         if (!lib) return;
         push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
         pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));

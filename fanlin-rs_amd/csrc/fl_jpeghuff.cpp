@@ -18,6 +18,8 @@ struct Huff {
     int32_t maxcode[18];  // per length, -1 = none; [17] = sentinel
     int32_t valoff[17];   // symbol index of the first code of a length minus that code
     uint8_t vals[256];
+    // AC tables only: code AND magnitude bits inside the 9-bit lookahead -> (value << 8) | (run << 4) | total bits, 0 = slow path
+    int16_t fastac[512];
     bool present = false;
 };
 
@@ -40,6 +42,17 @@ bool build_huff(Huff &h, const uint8_t *bits /*[16] counts of lengths 1..16*/, c
         code <<= 1;
     }
     h.maxcode[17] = 0x7fffffff;
+    // short code + short magnitude in one lookup (the common case of AC coefficients: small values after short runs)
+    for (int i = 0; i < 512; ++i) {
+        h.fastac[i] = 0;
+        const uint32_t f = h.fast[i];
+        if (!f) continue;
+        const int len = (int)(f >> 8), rs = (int)(f & 255u), run = rs >> 4, mag = rs & 15;
+        if (mag == 0 || len + mag > 9) continue;
+        int v = ((i << len) & 511) >> (9 - mag);           // the magnitude bits that follow the code
+        if (v < (1 << (mag - 1))) v += (int)(~0u << mag) + 1; // F.2.2.1 EXTEND
+        if (v >= -128 && v <= 127) h.fastac[i] = (int16_t)((v * 256) | (run << 4) | (len + mag));
+    }
     h.present = true;
     return true;
 }
@@ -53,6 +66,20 @@ struct BitReader {
 
     void fill()
     {
+        // fast path: the next 8 bytes hold no 0xFF (no stuffing, no marker): take as many whole bytes as fit in one go
+        if (!marker && pos + 8 <= n && cnt <= 56) {
+            uint64_t raw;
+            memcpy(&raw, d + pos, 8);
+            const uint64_t inv = ~raw;
+            if (!((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull)) {
+                const int k = (64 - cnt) >> 3; // 1..8 bytes
+                const uint64_t be = __builtin_bswap64(raw);
+                buf |= (k == 8 ? be : (be >> (64 - 8 * k)) << (64 - cnt - 8 * k));
+                pos += (size_t)k;
+                cnt += 8 * k;
+                return;
+            }
+        }
         while (cnt <= 56) {
             uint32_t b = 0;
             if (!marker && pos < n) {
@@ -323,6 +350,18 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                         int last = 0;
                         bool narrow = true;
                         for (int k = 1; k < 64;) {
+                            if (br.cnt < 16) br.fill();
+                            const int fa = ha.fastac[br.peek(9)];
+                            if (fa) { // code + magnitude in one step
+                                k += (fa >> 4) & 15;
+                                if (k > 63) return -1;
+                                br.drop(fa & 15);
+                                while (last + 1 < k) blk[++last] = 0;
+                                blk[k] = (int16_t)(fa >> 8);
+                                last = k;
+                                ++k;
+                                continue;
+                            }
                             const int rs = decode_sym(br, ha);
                             if (rs < 0) return -1;
                             const int r = rs >> 4, s = rs & 15;

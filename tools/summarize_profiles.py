@@ -40,7 +40,14 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     kernel_stats("config1", "c1", f"{tag}_config1_kernel_stats.csv")
     kernel_stats("config2", "c2", f"{tag}_config2_kernel_stats.csv")
-    kernel_stats("jpeg", "jp", f"{tag}_config1_jpeg_kernel_stats.csv")
+    kernel_stats("jpeg", "jp", f"{tag}_config1_resize_only_kernel_stats.csv")
+    try:  # roctx ranges of the runtime (FLGPU_ROCTX=1) as rocprofv3 --marker-trace reports them
+        import shutil
+        for f in glob.glob(os.path.join(RAW, "markers", "*marker*stats*.csv")) + glob.glob(os.path.join(RAW, "markers", "*/*marker*stats*.csv")):
+            shutil.copy(f, os.path.join(OUT, f"{tag}_roctx_marker_stats.csv"))
+            break
+    except Exception:
+        pass
     vals, nd = {}, 0
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         v, n = counters(sub, "resample_stream_kernel")
@@ -65,12 +72,21 @@ def main():
             clk = vals["GRBM_GUI_ACTIVE"] / 8.0 / (k_ms * 1e-3) / 1e9
             f.write(f"effective clock = GRBM_GUI_ACTIVE / 8 / kernel time = {clk:.2f} GHz; VALU issue = "
                     f"{vals['SQ_INSTS_VALU'] / (k_ms * 1e-3 * clk * 1e9 * 256):.2f} wave-instr/clk/CU\n")
+    try:
+        traffic_all = json.load(open(os.path.join(OUT, "traffic.json")))
+    except (OSError, ValueError):
+        traffic_all = {}
     traffic = {workload: {"kernel": "resample_stream_kernel", "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"],
                           "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE as is; separate --pmc passes",
                           "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
                           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-images 0 --latency-requests 0",
                           "round": int(tag[1:])}}
-    json.dump(traffic, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
+    # the resample kernel's traffic does not depend on what follows it: the resize-only workload string gets the same record
+    traffic_all.update(traffic)
+    base = workload.split(" + baseline JPEG encode")[0]
+    if base != workload:
+        traffic_all[base] = traffic[workload]
+    json.dump(traffic_all, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
     for p in glob.glob(os.path.join(RAW, "bench_*.json")):
         line = open(p).read().strip().splitlines()[-1]
         json.loads(line)
@@ -78,12 +94,15 @@ def main():
     with open(os.path.join(OUT, f"{tag}_commands.txt"), "w") as f:
         f.write("""How the files of this round were produced (tools/collect_profiles.sh on a 1 x MI355X box, then tools/summarize_profiles.py):
 
-{tag}_config1_kernel_stats.csv       rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --cpu-images 0 --latency-requests 0 --steps 20 --warmup 3
-                                     (bench.py's defaults; 24 launches of the kernel: 1 planning run + 3 warm-up + 20 timed, so the average includes the cold first launch)
-{tag}_config2_kernel_stats.csv       ... -- python3 bench.py --cpu-images 0 --latency-requests 0 --steps 5 --warmup 2 --blur 10 --grayscale
-{tag}_config1_jpeg_kernel_stats.csv  ... -- python3 bench.py --cpu-images 0 --latency-requests 0 --steps 5 --warmup 2 --frontend jpeg
-{tag}_config1_pmc.txt, traffic.json  rocprofv3 --kernel-trace --pmc <one counter group per pass> --output-format csv -- python3 bench.py --cpu-images 0 --latency-requests 0 --steps 2 --warmup 1
-{tag}_bench_*.json                   python3 bench.py [--crop | --blur 10 --grayscale | --frontend jfif444|webp420|jpeg] (config1: plain defaults, with the latency probe and the CPU baseline)
+(B = python3 bench.py --cpu-images 0 --latency-requests 0 --extra-steps 0 --verify-images 0; the default workload is resize + letterbox + JPEG encode)
+{tag}_config1_kernel_stats.csv              rocprofv3 --kernel-trace --stats --output-format csv -- B --steps 20 --warmup 3
+                                            (24 launches of each kernel: 1 planning run + 3 warm-up + 20 timed, so the average includes the cold first launch)
+{tag}_config2_kernel_stats.csv              ... -- B --steps 5 --warmup 2 --blur 10 --grayscale --frontend none
+{tag}_config1_resize_only_kernel_stats.csv  ... -- B --steps 5 --warmup 2 --frontend none
+{tag}_roctx_marker_stats.csv                FLGPU_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --stats -- B --steps 3 --warmup 1
+{tag}_config1_pmc.txt, traffic.json         rocprofv3 --kernel-trace --pmc <one counter group per pass> --output-format csv -- B --steps 2 --warmup 1
+{tag}_bench_*.json                          python3 bench.py [--frontend none | --crop | --blur 10 --grayscale | --frontend jfif444|webp420] (config1: plain defaults with
+                                            verification, extras, the three latency probes and the CPU baseline)
 {tag}_latency_sweep.txt              tools/experiments/latency_sweep.sh + tools/latency/latency_probe <threads> 4096 1920 1080 "w=300&h=200"
 {tag}_microbench_valu_rate.txt       tools/microbench/valu_rate.hip
 (only rows of this repository's kernels, fl::*, are kept in the kernel statistics)
