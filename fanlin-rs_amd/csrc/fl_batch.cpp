@@ -369,7 +369,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             // items of 8 pictures are interleaved: picture p's strips get launch indices congruent modulo 8 (same XCD, close
             // in time) and the halo is served by that XCD's L2 instead of HBM.  Speed only; any placement is correct.
             std::vector<StreamItem> tmp;
-            for (uint32_t a = 0; a < L.nitems;) {
+            static const bool no_xcd_order = [] { const char *e = getenv("FLGPU_NO_XCD_ORDER"); return e && e[0] == '1'; }(); // A/B experiments
+            for (uint32_t a = 0; a < L.nitems && !no_xcd_order;) {
                 uint32_t b = a;
                 const uint32_t len = first[a].r1 - first[a].r0;
                 while (b < L.nitems && first[b].r1 - first[b].r0 == len) ++b;

@@ -30,6 +30,9 @@
 #ifndef FL_RING_MULT
 #define FL_RING_MULT 2    // prefetch ring of the streaming kernel = FL_RING_MULT blocks of FL_STREAM_DEPTH rows
 #endif
+#ifndef FL_LOAD_AUX
+#define FL_LOAD_AUX 0     // cache policy bits of the streaming kernel's source-row loads (experiments: 2 = nt)
+#endif
 #ifndef FL_STREAM_DEPTH
 #define FL_STREAM_DEPTH 4 // source rows per block of the streaming kernel
 #endif
@@ -309,10 +312,10 @@ template <> struct RowRaw<4> { u32x4 v; __device__ uint32_t dw(int i) const { re
 template <int CS>
 __device__ __forceinline__ void load_row(RowRaw<CS> &r, __amdgpu_buffer_rsrc_t rs, uint32_t voff)
 {
-    if constexpr (CS == 1) r.v = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0);
-    if constexpr (CS == 2) r.v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
-    if constexpr (CS == 3) r.v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, 0, 0);
-    if constexpr (CS == 4) r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+    if constexpr (CS == 1) r.v = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, FL_LOAD_AUX);
+    if constexpr (CS == 2) r.v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, FL_LOAD_AUX);
+    if constexpr (CS == 3) r.v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, 0, FL_LOAD_AUX);
+    if constexpr (CS == 4) r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, FL_LOAD_AUX);
 }
 
 // PXL pixels of CS bytes, packed in CS dwords -> PXL*MC floats with the pre-op applied.

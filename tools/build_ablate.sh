@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../fanlin-rs_amd/csrc"
 mkdir -p /tmp/abl
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math"
-OTHERS="fl_context.cpp fl_tables.cpp fl_query.cpp fl_cmyk.cpp fl_jpeg.hip"
+OTHERS="fl_context.cpp fl_batch.cpp fl_queue.cpp fl_cmyk_ctx.cpp fl_tables.cpp fl_query.cpp fl_cmyk.cpp fl_jpeghuff.cpp fl_jpeg.hip fl_jpegdec.hip"
 for f in $OTHERS; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o /tmp/abl/$f.o & done
 for v in "$@"; do
   IFS=: read -r name mask extra <<< "$v"
