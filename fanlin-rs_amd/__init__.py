@@ -77,7 +77,8 @@ MAX_DEVICES = 8
 
 class flgpu_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_batch", C.c_uint32), ("flush_timeout_us", C.c_uint32),
-                ("profile", C.c_uint32), ("queue_lanes", C.c_uint32), ("n_devices", C.c_uint32), ("reserved", C.c_uint32 * 2),
+                ("profile", C.c_uint32), ("queue_lanes", C.c_uint32), ("n_devices", C.c_uint32), ("use_embedded_profile", C.c_uint32),
+                ("reserved", C.c_uint32 * 1),
                 ("devices", C.c_int32 * MAX_DEVICES)]
 
 
@@ -93,7 +94,7 @@ class flgpu_stats(C.Structure):
 
 class flgpu_jpeg_info(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "components", "channels", "progressive", "restart_interval",
-                                           "h_max", "v_max", "exif_orientation", "supported")] + [("reserved", C.c_uint32 * 2)]
+                                           "h_max", "v_max", "exif_orientation", "supported", "adobe_transform", "has_icc_profile")]
 
 
 # every symbol include/fanlin_gpu.h declares
@@ -333,7 +334,7 @@ def jpeg_info(data: bytes) -> dict:
     """flgpu_jpeg_info_of: header fields of a JPEG file (pure host function); raises FanlinError(ERR_PARSE) if it is none."""
     info = flgpu_jpeg_info()
     _check(load_library().flgpu_jpeg_info_of(data, len(data), C.byref(info)))
-    return {n: getattr(info, n) for n, _ in flgpu_jpeg_info._fields_ if n != "reserved"}
+    return {n: getattr(info, n) for n, _ in flgpu_jpeg_info._fields_}
 
 
 def debug_jpeg_blob(data: bytes):
@@ -438,13 +439,14 @@ class State:
     """
 
     def __init__(self, device: int = -1, max_batch: int = 0, flush_timeout_us: int = 0, profile: bool = False,
-                 queue_lanes: int = 0, devices: Optional[Sequence[int]] = None):
+                 queue_lanes: int = 0, devices: Optional[Sequence[int]] = None, use_embedded_profile: bool = False):
         """``devices``: two or more HIP ordinals make ONE context that shards every batch across those GPUs (an ordinal
         may repeat: two shards on one GPU); None / one entry = a single-device context."""
         lib = load_library()
         cfg = flgpu_config()
         cfg.device, cfg.max_batch, cfg.flush_timeout_us, cfg.profile = device, max_batch, flush_timeout_us, int(profile)
         cfg.queue_lanes = queue_lanes
+        cfg.use_embedded_profile = int(use_embedded_profile)
         if devices:
             if len(devices) > MAX_DEVICES:
                 raise ValueError("at most 8 devices")

@@ -92,17 +92,24 @@ int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, siz
     if (rc == -2) { c->set_error("JPEG stream not covered by the device decoder (progressive, arithmetic, 12-bit, CMYK or several scans)"); return FLGPU_ERR_UNSUPPORTED; }
     if (rc) { c->set_error("malformed JPEG stream"); return FLGPU_ERR_INVALID_ARG; }
     memcpy(hdr, blob, sizeof(*hdr));
-    if (hdr->width != src->width || hdr->height != src->height || hdr->nc != src->channels) {
+    if (hdr->width != src->width || hdr->height != src->height || (hdr->nc == 4 ? 3u : hdr->nc) != src->channels) {
         c->set_error("FLGPU_IMG_JPEG_SOURCE: width / height / channels do not match the file (see flgpu_jpeg_info_of)");
         return FLGPU_ERR_INVALID_ARG;
     }
     return FLGPU_OK;
 }
 
-int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegBlobHeader *const *hdrs, hipStream_t st)
+int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc *srcs, hipStream_t st)
 {
     size_t nj = 0, scratch = 0;
-    for (size_t i = 0; i < n; ++i) if (hdrs[i]) { ++nj; scratch += align_up(hdrs[i]->plane_bytes, 256) + align_up((size_t)hdrs[i]->width * hdrs[i]->height * hdrs[i]->nc, 256); }
+    for (size_t i = 0; i < n; ++i) {
+        const JpegBlobHeader *H = srcs[i].hdr;
+        if (!H) continue;
+        ++nj;
+        const size_t px = (size_t)H->width * H->height;
+        scratch += align_up(H->plane_bytes, 256) + align_up(px * H->nc + 64, 256);
+        if (H->nc == 4) scratch += align_up((px + 3) / 4 * 12, 256); // the Rgb8 picture after the CMYK table
+    }
     if (!nj) return FLGPU_OK;
     FL_HIP(c, c->d_dec.reserve(scratch), "JPEG decode scratch");
     FL_HIP(c, c->h_decjobs.reserve(nj * sizeof(JpegDecJob)), "JPEG decode descriptors");
@@ -110,18 +117,35 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegBlo
     JpegDecJob *jobs = static_cast<JpegDecJob *>(c->h_decjobs.p);
     size_t off = 0, k = 0;
     uint32_t max_blocks = 0, max_w = 0, max_h = 0;
+    struct Cmyk { const void *raw; void *rgb; const void *clut; uint64_t px; bool ycck; };
+    std::vector<Cmyk> cmyk;
     for (size_t i = 0; i < n; ++i) {
-        if (!hdrs[i]) continue;
-        const JpegBlobHeader &H = *hdrs[i];
+        if (!srcs[i].hdr) continue;
+        const JpegBlobHeader &H = *srcs[i].hdr;
+        const size_t px = (size_t)H.width * H.height;
         JpegDecJob &j = jobs[k++];
         j.blob = dsrc[i].data;
         j.planes = static_cast<uint8_t *>(c->d_dec.p) + off; off += align_up(H.plane_bytes, 256);
-        j.dst = static_cast<uint8_t *>(c->d_dec.p) + off; off += align_up((size_t)H.width * H.height * H.nc, 256);
+        j.dst = static_cast<uint8_t *>(c->d_dec.p) + off; off += align_up(px * H.nc + 64, 256);
         max_blocks = std::max(max_blocks, H.nblocks); max_w = std::max(max_w, H.width); max_h = std::max(max_h, H.height);
         c->stats.jpeg_sources++;
         c->stats.jpeg_upload_bytes += H.total_bytes;
-        dsrc[i].data = j.dst;
-        dsrc[i].capacity = (uint64_t)H.width * H.height * H.nc;
+        uint8_t *pixels = j.dst;
+        uint32_t channels = H.nc;
+        if (H.nc == 4) {
+            // convert_jpeg_color_if_needed (handler.rs:398-466): raw CMYK / YCCK samples -> (YCCK loop) -> the profile's table
+            const void *clut = nullptr;
+            const int rc = select_clut(c, srcs[i].icc, srcs[i].icc_len, &clut);
+            if (rc) return rc;
+            uint8_t *rgb = static_cast<uint8_t *>(c->d_dec.p) + off; off += align_up((px + 3) / 4 * 12, 256);
+            cmyk.push_back({j.dst, rgb, clut, px, H.adobe_transform == 3u});
+            pixels = rgb;
+            channels = 3;
+            c->stats.cmyk_pixels += px;
+        }
+        dsrc[i].data = pixels;
+        dsrc[i].channels = channels;
+        dsrc[i].capacity = (uint64_t)px * channels;
         dsrc[i].flags &= ~FLGPU_IMG_JPEG_SOURCE;
     }
     FL_HIP(c, hipMemcpyAsync(c->d_decjobs.p, jobs, nj * sizeof(JpegDecJob), hipMemcpyHostToDevice, st), "JPEG decode descriptors");
@@ -129,6 +153,7 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegBlo
         const uint32_t cnt = (uint32_t)std::min<size_t>(32768, nj - base);
         FL_HIP(c, launch_jpeg_decode(static_cast<const JpegDecJob *>(c->d_decjobs.p) + base, cnt, max_blocks, max_w, max_h, st), "JPEG decode kernels");
     }
+    for (const Cmyk &m : cmyk) FL_HIP(c, launch_cmyk_clut(m.raw, m.rgb, m.clut, kCmykGrid, m.px, m.ycck, st), "CMYK kernel");
     return FLGPU_OK;
 }
 
@@ -629,7 +654,8 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
     // JPEG sources: the serial half (parsing + Huffman decoding) runs here, on the host; what is staged is the blob
     std::vector<std::vector<uint8_t>> blobs(n);
     std::vector<JpegBlobHeader> jh(n);
-    std::vector<const JpegBlobHeader *> jhp(n, nullptr);
+    std::vector<JpegSrc> jhp(n);
+    std::vector<std::vector<uint8_t>> iccs(n);
     size_t in_b = 0, out_b = 0;
     for (size_t i = 0; i < n; ++i) {
         if (!srcs[i].data || !dsts[i].data) return FLGPU_ERR_INVALID_ARG;
@@ -645,7 +671,8 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
             rc = jpeg_source_to_blob(c, &srcs[i], blobs[i].data(), blobs[i].size(), &jh[i], &used);
             if (rc) return rc;
             blobs[i].resize(used);
-            jhp[i] = &jh[i];
+            jhp[i].hdr = &jh[i];
+            if (jh[i].nc == 4 && c->cfg.use_embedded_profile && !info.icc.empty()) { iccs[i].swap(info.icc); jhp[i].icc = iccs[i].data(); jhp[i].icc_len = iccs[i].size(); }
             c->stats.jpeg_file_bytes += srcs[i].capacity;
             sb = used;
         } else
@@ -663,7 +690,7 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
     hipStream_t st = c->stream;
     for (size_t i = 0; i < n; ++i) {
         const size_t off = reinterpret_cast<size_t>(dsrc[i].data);
-        memcpy(static_cast<char *>(c->h_stage_in.p) + off, jhp[i] ? blobs[i].data() : srcs[i].data, dsrc[i].capacity);
+        memcpy(static_cast<char *>(c->h_stage_in.p) + off, jhp[i].hdr ? blobs[i].data() : srcs[i].data, dsrc[i].capacity);
         dsrc[i].data = static_cast<uint8_t *>(c->d_in.p) + off;
         ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
     }

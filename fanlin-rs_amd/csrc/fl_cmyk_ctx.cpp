@@ -31,7 +31,7 @@ int upload_clut(flgpu_ctx *c, flgpu_ctx::Clut &t)
 
 
 // picks the table for one conversion: the embedded profile's if it can be baked (cached), else the default
-int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev)
+int select_clut_impl(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev)
 {
     if (icc && icc_len) {
         const uint64_t h = hash_bytes(icc, icc_len);
@@ -57,8 +57,9 @@ int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void *
         if (it != c->cmyk_embedded.end()) { it->second.stamp = ++c->cmyk_stamp; *dev = it->second.dev.p; return FLGPU_OK; }
         // handler.rs:449-455: an embedded profile that cannot be used falls back to the configured one
     }
-    if (!c->has_cmyk_default) { c->set_error("no CMYK profile configured"); return FLGPU_ERR_UNSUPPORTED; }
-    *dev = c->cmyk_default.dev.p;
+    flgpu_ctx *o = c->clut_owner ? c->clut_owner : c; // a queue lane borrows the table of the context that owns it on this device
+    if (!o->has_cmyk_default) { c->set_error("no CMYK profile configured"); return FLGPU_ERR_UNSUPPORTED; }
+    *dev = o->cmyk_default.dev.p;
     return FLGPU_OK;
 }
 
@@ -161,6 +162,8 @@ int install_default(flgpu_ctx *c)
 
 namespace fl {
 
+int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev) { return select_clut_impl(c, icc, icc_len, dev); }
+
 void release_cmyk(flgpu_ctx *c)
 {
     c->cmyk_default.dev.release();
@@ -232,7 +235,7 @@ int flgpu_cmyk_to_rgb_device(flgpu_ctx *c, const void *d_cmyk, void *d_rgb, uint
     std::lock_guard<std::mutex> g(c->mu);
     FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
     const void *clut = nullptr;
-    const int rc = select_clut(c, nullptr, 0, &clut);
+    const int rc = select_clut_impl(c, nullptr, 0, &clut);
     if (rc) return rc;
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     FL_HIP(c, launch_cmyk_clut(d_cmyk, d_rgb, clut, kCmykGrid, n_pixels, (flags & FLGPU_CMYK_INPUT_YCCK) != 0, st), "CMYK kernel");
@@ -285,7 +288,7 @@ int flgpu_cmyk_to_rgb(flgpu_ctx *c, const uint8_t *cmyk, uint64_t n_pixels, uint
     }
     FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
     const void *clut = nullptr;
-    const int rc = select_clut(c, embedded_icc, icc_len, &clut);
+    const int rc = select_clut_impl(c, embedded_icc, icc_len, &clut);
     if (rc) return rc;
     return cmyk_range(c, clut, cmyk, n_pixels, rgb, flags);
 }

@@ -87,6 +87,7 @@ struct Request {
     uint64_t weight = 0;   // algorithmic bytes: W*H*C + out_bytes (shard balancing)
     bool jpeg = false;     // FLGPU_IMG_JPEG_SOURCE: `in` holds the coefficient blob the caller's thread decoded, jhdr its header
     JpegBlobHeader jhdr;
+    std::vector<uint8_t> icc; // four-component source + use_embedded_profile: the file's own ICC profile
     uint64_t file_bytes = 0;
     int status = 0;
     bool done = false;
@@ -163,6 +164,7 @@ struct flgpu_ctx {
     // One context, several GPUs (reference analogue: one Arc<State> shared by all workers, src/main.rs:108-112): the
     // parent owns the request queue; `shard_ctx[k]` is a child context bound to devices[k] (own stream, arena, scratch)
     // that runs shard k of every batch entry point.  Empty for a single-device context (the parent is the device context).
+    flgpu_ctx *clut_owner = nullptr; // a queue lane: the context on ITS device that holds the configured CMYK table (the parent, or the parent's shard context of that device)
     std::vector<int> devices;
     std::vector<flgpu_ctx *> shard_ctx;
     std::vector<std::pair<size_t, size_t>> last_shards; // [first, last) image range of each shard in the last device batch
@@ -244,9 +246,13 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
 uint64_t staged_out_bytes(const flgpu_params &p, const flgpu_plan &plan, uint64_t dst_capacity);
 // JPEG sources of a batch: dsrc[i].data = DEVICE copy of the coefficient blob whose header (host copy) is hdrs[i], or
 // hdrs[i] == nullptr for ordinary pixel sources.  Runs the decode kernels into scratch and points dsrc[i] at the pixels.
-int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegBlobHeader *const *hdrs, hipStream_t st);
+struct JpegSrc { const JpegBlobHeader *hdr = nullptr; const uint8_t *icc = nullptr; size_t icc_len = 0; };
+int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc *srcs, hipStream_t st);
 // Host half for one source: parses + Huffman-decodes `src` (a JPEG file) into `blob`; validates the declared size.
 int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used);
+// fl_cmyk_ctx.cpp: the device-link table for one conversion on context c: the embedded profile's if given and usable
+// (baked once, cached on c), else the configured one (c's own, or its clut_owner's)
+int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev);
 
 // ---- fl_queue.cpp ----------------------------------------------------------------------------------------------------
 // contiguous split of n weighted items into n_shards shards of about equal weight: shard_of[i] is non-decreasing

@@ -26,9 +26,9 @@ struct JpegComponent {
 // Header of the coefficient blob (host -> device), followed by the block words and the coefficients.
 struct alignas(16) JpegBlobHeader {
     uint32_t magic;             // 'FJD1'
-    uint32_t width, height, nc; // decoded picture: nc = 1 (Luma8) or 3 (Rgb8)
+    uint32_t width, height, nc; // stored components: 1 (decodes to Luma8), 3 (Rgb8) or 4 (raw CMYK / YCCK samples, 4 bytes per pixel)
     uint32_t hmax, vmax;
-    uint32_t is_rgb;            // Adobe transform 0: the three components are R, G, B already
+    uint32_t is_rgb;            // three components with Adobe transform 0: they are R, G, B already
     uint32_t nblocks;           // over all components
     uint32_t blocks_off;        // byte offset of u32 block words [nblocks]: (data offset in halfwords << 7) | (count - 1) << 1 | wide
     uint32_t coef_off;          // byte offset of the block data: quantised coefficients in zig-zag order up to the last non-zero
@@ -36,8 +36,10 @@ struct alignas(16) JpegBlobHeader {
                                 // the rest as i8 (typical files: ~1.2 bytes per coded coefficient)
     uint32_t plane_bytes;       // scratch the planes need
     uint32_t total_bytes;       // size of the whole blob
-    JpegComponent comp[3];
-    uint16_t qt[3][64];         // per COMPONENT, zig-zag order
+    uint32_t adobe_transform;   // APP14 transform byte + 1 (0 = no Adobe segment): four components with 2 + 1 are YCCK
+    uint32_t pad[3];
+    JpegComponent comp[4];
+    uint16_t qt[4][64];         // per COMPONENT, zig-zag order
 };
 
 constexpr uint32_t kJpegWideHead = 4; // coefficients of a narrow block kept as i16 (DC and the largest ACs)
@@ -48,6 +50,7 @@ struct JpegInfo {
     uint32_t exif_orientation = 0; // 1..8, 0 = no tag
     int adobe_transform = -1;
     uint32_t supported = 0;        // 1 = the device path decodes it
+    std::vector<uint8_t> icc;      // embedded ICC profile (APP2 "ICC_PROFILE" chunks in order), empty if none / inconsistent
 };
 
 // 0 = ok, -1 = not a JPEG / malformed header

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegDecJob *__rest
     int *my = tile + lb * BLK_PITCH;
     // component of this block (block words are grouped by component)
     uint32_t ci = 0;
-    if (live) { if (H->nc == 3) ci = b >= H->comp[2].block_base ? 2u : (b >= H->comp[1].block_base ? 1u : 0u); }
+    if (live) { for (uint32_t k = 1; k < H->nc; ++k) if (b >= H->comp[k].block_base) ci = k; }
 #pragma unroll
     for (int k = 0; k < 9; ++k) my[t * 9 + k] = 0;
     __syncthreads();
@@ -139,32 +139,28 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegDecJob *__res
 {
     const JpegDecJob jb = jobs[blockIdx.z];
     const JpegBlobHeader *H = reinterpret_cast<const JpegBlobHeader *>(jb.blob);
-    const uint32_t W = H->width, Hh = H->height;
+    const uint32_t W = H->width, Hh = H->height, nc = H->nc;
     const uint32_t y = blockIdx.y, x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
     if (y >= Hh || x0 >= W) return;
-    const JpegComponent &Y = H->comp[0];
-    const uint8_t *yrow = jb.planes + Y.plane_off + (size_t)y * (Y.bw * 8u);
-    if (H->nc == 1u) {
-        uint8_t *o = jb.dst + (size_t)y * W + x0;
-        for (uint32_t k = 0; k < 4u && x0 + k < W; ++k) o[k] = yrow[x0 + k];
-        return;
-    }
-    const JpegComponent &CB = H->comp[1], &CR = H->comp[2];
-    const uint32_t sh = H->hmax / CB.h, sv = H->vmax / CB.v;
-    const uint8_t *pb = jb.planes + CB.plane_off, *pr = jb.planes + CR.plane_off;
-    const uint32_t cpw = CB.bw * 8u;
-    uint8_t *o = jb.dst + ((size_t)y * W + x0) * 3u;
+    uint8_t *o = jb.dst + ((size_t)y * W + x0) * nc;
     for (uint32_t k = 0; k < 4u && x0 + k < W; ++k) {
         const uint32_t x = x0 + k;
-        const int s0 = yrow[x];
-        const int s1 = chroma_at(pb, cpw, CB.w, CB.hpx, sh, sv, x, y);
-        const int s2 = chroma_at(pr, cpw, CR.w, CR.hpx, sh, sv, x, y);
-        if (H->is_rgb) { o[3 * k] = (uint8_t)s0; o[3 * k + 1] = (uint8_t)s1; o[3 * k + 2] = (uint8_t)s2; continue; }
+        int s[4];
+        for (uint32_t i = 0; i < nc; ++i) { // every plane through zune-jpeg's interpolation (a plain read at full resolution)
+            const JpegComponent &C = H->comp[i];
+            s[i] = chroma_at(jb.planes + C.plane_off, C.bw * 8u, C.w, C.hpx, H->hmax / C.h, H->vmax / C.v, x, y);
+        }
+        if (nc == 1u) { o[k] = (uint8_t)s[0]; continue; }
+        if (nc == 4u) { // CMYK / YCCK: the raw samples, as JpegDecoder with out_colorspace = the input colour space returns them (handler.rs:417-419)
+            o[4 * k] = (uint8_t)s[0]; o[4 * k + 1] = (uint8_t)s[1]; o[4 * k + 2] = (uint8_t)s[2]; o[4 * k + 3] = (uint8_t)s[3];
+            continue;
+        }
+        if (H->is_rgb) { o[3 * k] = (uint8_t)s[0]; o[3 * k + 1] = (uint8_t)s[1]; o[3 * k + 2] = (uint8_t)s[2]; continue; }
         // zune-jpeg color_convert/scalar.rs: i16 arithmetic with 5/6-bit constants, arithmetic shifts
-        const int cb = s1 - 128, cr = s2 - 128;
-        o[3 * k] = (uint8_t)clamp8(s0 + ((45 * cr) >> 5));
-        o[3 * k + 1] = (uint8_t)clamp8(s0 - ((11 * cb + 23 * cr) >> 5));
-        o[3 * k + 2] = (uint8_t)clamp8(s0 + ((113 * cb) >> 6));
+        const int cb = s[1] - 128, cr = s[2] - 128;
+        o[3 * k] = (uint8_t)clamp8(s[0] + ((45 * cr) >> 5));
+        o[3 * k + 1] = (uint8_t)clamp8(s[0] - ((11 * cb + 23 * cr) >> 5));
+        o[3 * k + 2] = (uint8_t)clamp8(s[0] + ((113 * cb) >> 6));
     }
 }
 

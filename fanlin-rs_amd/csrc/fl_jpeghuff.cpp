@@ -6,6 +6,8 @@
 
 #include <string.h>
 
+#include <map>
+
 namespace fl {
 
 namespace {
@@ -154,6 +156,8 @@ struct Parsed {
     Huff ht[2][4];
     size_t scan_pos = 0;
     bool one_scan = false; // SOS names every component in frame order
+    std::map<uint32_t, std::vector<uint8_t>> icc_chunks;
+    uint32_t icc_count = 0;
 };
 
 // -1 malformed; 0 ok (info.supported says whether the scan can be decoded here)
@@ -222,6 +226,9 @@ int parse(const uint8_t *d, size_t n, Parsed &P, bool want_tables)
             P.info.restart_interval = be16(p);
         } else if (m == 0xEE) {
             if (pl >= 12 && !memcmp(p, "Adobe", 5)) P.info.adobe_transform = p[11];
+        } else if (m == 0xE2) {
+            // ICC profile, possibly in several chunks: "ICC_PROFILE\0" seq count data (decoder.icc_profile(), handler.rs:447)
+            if (pl > 14 && !memcmp(p, "ICC_PROFILE\0", 12)) P.icc_chunks[p[12]] = std::vector<uint8_t>(p + 14, p + pl), P.icc_count = p[13];
         } else if (m == 0xE1) {
             if (!P.info.exif_orientation) P.info.exif_orientation = (uint32_t)exif_orientation(p, pl);
         } else if (m == 0xDA) {
@@ -235,13 +242,17 @@ int parse(const uint8_t *d, size_t n, Parsed &P, bool want_tables)
                 if (P.c[i].td > 3 || P.c[i].ta > 3) return -1;
             }
             P.scan_pos = pos + len;
-            bool ok = !P.info.progressive && P.info.precision == 8 && P.one_scan && (nc == 1 || nc == 3);
-            if (ok && nc == 3) {
-                // luma at full resolution, both chroma planes alike and full size or half size per direction
-                ok = P.c[0].h == P.info.hmax && P.c[0].v == P.info.vmax && P.c[1].h == P.c[2].h && P.c[1].v == P.c[2].v &&
-                     P.info.hmax % P.c[1].h == 0 && P.info.vmax % P.c[1].v == 0 && P.info.hmax / P.c[1].h <= 2 && P.info.vmax / P.c[1].v <= 2;
-            }
+            bool ok = !P.info.progressive && P.info.precision == 8 && P.one_scan && (nc == 1 || nc == 3 || nc == 4);
+            for (uint32_t i = 0; ok && nc > 1 && i < nc; ++i) // every plane at full or half resolution per direction
+                ok = P.info.hmax % P.c[i].h == 0 && P.info.vmax % P.c[i].v == 0 && P.info.hmax / P.c[i].h <= 2 && P.info.vmax / P.c[i].v <= 2;
             P.info.supported = ok ? 1u : 0u;
+            if (P.icc_count && P.icc_chunks.size() == P.icc_count) {
+                for (uint32_t k = 1; k <= P.icc_count; ++k) {
+                    auto it = P.icc_chunks.find(k);
+                    if (it == P.icc_chunks.end()) { P.info.icc.clear(); break; }
+                    P.info.icc.insert(P.info.icc.end(), it->second.begin(), it->second.end());
+                }
+            }
             return 0;
         }
         pos += len;
@@ -258,6 +269,7 @@ void layout(const Parsed &P, JpegBlobHeader &H)
     H.hmax = I.components == 1 ? 1u : I.hmax;
     H.vmax = I.components == 1 ? 1u : I.vmax;
     H.is_rgb = I.components == 3 && I.adobe_transform == 0;
+    H.adobe_transform = (uint32_t)(I.adobe_transform + 1);
     const uint32_t mcux = (I.width + 8 * H.hmax - 1) / (8 * H.hmax), mcuy = (I.height + 8 * H.vmax - 1) / (8 * H.vmax);
     uint32_t nb = 0, po = 0;
     for (uint32_t i = 0; i < I.components; ++i) {
@@ -295,8 +307,8 @@ size_t jpeg_blob_bound(const JpegInfo &I)
     if (!I.supported) return 0;
     const uint32_t hmax = I.components == 1 ? 1u : I.hmax, vmax = I.components == 1 ? 1u : I.vmax;
     const size_t mcux = (I.width + 8 * hmax - 1) / (8 * hmax), mcuy = (I.height + 8 * vmax - 1) / (8 * vmax);
-    // blocks per MCU <= hmax*vmax + 2 * (chroma) <= 3 * hmax * vmax
-    const size_t nb = mcux * mcuy * (I.components == 1 ? 1u : 3u * hmax * vmax);
+    // blocks per MCU <= components * hmax * vmax
+    const size_t nb = mcux * mcuy * (I.components == 1 ? 1u : (size_t)I.components * hmax * vmax);
     return sizeof(JpegBlobHeader) + nb * 4 + nb * 128 + 64;
 }
 
@@ -316,7 +328,7 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
     uint8_t *coef = blob + H.coef_off; // block data, 2-byte aligned, see fl_jpegdec.h
     size_t nhalf = 0;                  // halfwords written
     BitReader br{data, n, P.scan_pos};
-    int pred[3] = {0, 0, 0};
+    int pred[4] = {0, 0, 0, 0};
     const uint32_t mcux = H.comp[0].bw / H.comp[0].h, mcuy = H.comp[0].bh / H.comp[0].v;
     uint32_t rst_left = P.info.restart_interval;
     int16_t blk[64];
@@ -333,7 +345,7 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                     br.marker = 0;
                 } else return -1;
                 br.buf = 0; br.cnt = 0;
-                pred[0] = pred[1] = pred[2] = 0;
+                pred[0] = pred[1] = pred[2] = pred[3] = 0;
                 rst_left = P.info.restart_interval;
             }
             for (uint32_t i = 0; i < nc; ++i) {

@@ -252,6 +252,8 @@ int flgpu_jpeg_info_of(const uint8_t *jpeg, uint64_t n, flgpu_jpeg_info *info)
     memset(info, 0, sizeof(*info));
     info->width = I.width; info->height = I.height; info->components = I.components;
     info->channels = I.supported ? (I.components == 1 ? 1u : 3u) : 0u;
+    info->adobe_transform = (uint32_t)(I.adobe_transform + 1);
+    info->has_icc_profile = I.icc.empty() ? 0u : 1u;
     info->progressive = I.progressive; info->restart_interval = I.restart_interval;
     info->h_max = I.hmax; info->v_max = I.vmax;
     info->exif_orientation = I.exif_orientation; info->supported = I.supported;

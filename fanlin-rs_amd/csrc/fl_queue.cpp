@@ -83,7 +83,7 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
     std::vector<flgpu_image> dsrc(n), ddst(n);
     std::vector<flgpu_params> ps(n);
     std::vector<uint64_t> dev_out(n);
-    std::vector<const JpegBlobHeader *> jhp(n, nullptr);
+    std::vector<JpegSrc> jhp(n);
     size_t in_b = 0, out_b = 0;
     for (size_t i = 0; i < n; ++i) {
         dsrc[i] = *batch[i]->src; ddst[i] = *batch[i]->dst; ps[i] = *batch[i]->p;
@@ -100,7 +100,10 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
         dsrc[i].data = static_cast<uint8_t *>(c->d_in.p) + reinterpret_cast<size_t>(dsrc[i].data);
         ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
         FL_HIP(c, hipMemcpyAsync(dsrc[i].data, batch[i]->in.p, batch[i]->src_bytes, hipMemcpyHostToDevice, st), "H2D");
-        if (batch[i]->jpeg) { jhp[i] = &batch[i]->jhdr; c->stats.jpeg_file_bytes += batch[i]->file_bytes; }
+        if (batch[i]->jpeg) {
+            jhp[i].hdr = &batch[i]->jhdr; jhp[i].icc = batch[i]->icc.empty() ? nullptr : batch[i]->icc.data(); jhp[i].icc_len = batch[i]->icc.size();
+            c->stats.jpeg_file_bytes += batch[i]->file_bytes;
+        }
     }
     { int drc = decode_jpeg_sources(c, n, dsrc.data(), jhp.data(), st); if (drc) return drc; }
     int rc = run_batch_device(c, n, dsrc.data(), ps.data(), false, ddst.data(), st);
@@ -204,6 +207,7 @@ int start_workers(flgpu_ctx *c)
         const uint32_t slot = i % ndev;
         flgpu_ctx *l = create_child(c, c->devices.empty() ? c->device : c->devices[slot]);
         if (!l) break;
+        l->clut_owner = c->shard_ctx.empty() ? c : c->shard_ctx[slot]; // the configured CMYK table of this lane's device
         c->lanes.push_back(l); // capacity reserved at creation: published entries never move
         c->n_lanes.store(c->lanes.size(), std::memory_order_release);
     }
@@ -425,6 +429,7 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
         const int jrc = jpeg_source_to_blob(c, src, static_cast<uint8_t *>(r.in.p), r.in.cap, &r.jhdr, &used);
         if (jrc) { c->staging.fetch_sub(1, std::memory_order_acq_rel); give_back(); return jrc; }
         r.jpeg = true;
+        if (r.jhdr.nc == 4 && c->cfg.use_embedded_profile) r.icc.swap(jinfo.icc);
         r.file_bytes = src->capacity;
         r.src_bytes = used;
     } else

@@ -161,7 +161,9 @@ typedef struct flgpu_config {
                                   flushed batch of the request queue and every batch call is split into n_devices contiguous
                                   shards balanced by algorithmic bytes (W*H*C + output bytes), shard k runs on devices[k],
                                   results come back in request order.  An ordinal may repeat (two shards on one GPU). */
-    uint32_t reserved[2];
+    uint32_t use_embedded_profile; /* config `use_embedded_profile` (src/handler.rs:19,446-458): CMYK / YCCK JPEG SOURCES decoded by the
+                                      library are converted with their own embedded ICC profile when they carry a usable one */
+    uint32_t reserved[1];
     int32_t devices[FLGPU_MAX_DEVICES];
 } flgpu_config;
 
@@ -282,15 +284,18 @@ int flgpu_process_image_plan(const flgpu_image *decoded, uint8_t exif_orientatio
 /* ---- JPEG sources (src/handler.rs:205-220: zune-jpeg through the image crate) ----------------------------------------- */
 typedef struct flgpu_jpeg_info {
     uint32_t width, height;
-    uint32_t components;        /* as stored: 1 (decodes to Luma8), 3 (Rgb8), 4 (CMYK / YCCK: not decoded here) */
-    uint32_t channels;          /* of the decoded picture: 1 or 3 (0 if unsupported) */
+    uint32_t components;        /* as stored: 1 (decodes to Luma8), 3 (Rgb8), 4 (CMYK / YCCK) */
+    uint32_t channels;          /* of the picture the pipeline sees: 1 or 3 (0 if unsupported).  Four-component files are decoded to
+                                   their raw samples and converted to Rgb8 with the configured (or embedded) CMYK profile -- the whole
+                                   of convert_jpeg_color_if_needed, src/handler.rs:398-466; without any profile: FLGPU_ERR_UNSUPPORTED */
     uint32_t progressive;       /* SOF2, or any process other than baseline / extended sequential Huffman */
     uint32_t restart_interval;  /* DRI, in MCUs (0 = none) */
     uint32_t h_max, v_max;      /* largest sampling factors: 1x1 = 4:4:4, 2x1 = 4:2:2, 2x2 = 4:2:0 */
     uint32_t exif_orientation;  /* 1..8 from the APP1 Exif segment (decoder.orientation(), src/handler.rs:206); 0 = no tag */
-    uint32_t supported;         /* 1 = FLGPU_IMG_JPEG_SOURCE decodes it: 8-bit baseline, one interleaved scan, 1 or 3
-                                   components, chroma planes at full or half resolution per direction */
-    uint32_t reserved[2];
+    uint32_t supported;         /* 1 = FLGPU_IMG_JPEG_SOURCE decodes it: 8-bit baseline, one interleaved scan, 1, 3 or 4
+                                   components, every plane at full or half resolution per direction */
+    uint32_t adobe_transform;   /* APP14 transform byte + 1 (0 = no Adobe segment); 4 components: 1 = CMYK, 3 = YCCK */
+    uint32_t has_icc_profile;   /* an embedded ICC profile (APP2) is present */
 } flgpu_jpeg_info;
 /* Header inspection only (no device needed).  FLGPU_ERR_PARSE if the bytes are not a JPEG. */
 int flgpu_jpeg_info_of(const uint8_t *jpeg, uint64_t n, flgpu_jpeg_info *info);

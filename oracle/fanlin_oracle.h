@@ -124,7 +124,8 @@ void fo_cmyk_to_rgb(const uint8_t *cmyk, size_t n_pixels, const uint16_t *clut, 
 /* ---- baseline JPEG decoding (fanlin_oracle_jpegdec.c): reference src/handler.rs:205-220 via zune-jpeg 0.4.14 ---- */
 /* 0 = ok, -1 = malformed, -2 = valid JPEG this decoder does not cover (progressive, arithmetic, 12-bit, several scans) */
 int fo_jpeg_info(const uint8_t *data, size_t n, uint32_t *w, uint32_t *h, uint32_t *components, uint32_t *exif_orientation);
-/* out: w*h (one component: Luma8) or w*h*3 (Rgb8) bytes */
+/* out: w*h (one component: Luma8), w*h*3 (Rgb8) or w*h*4 (four components: raw CMYK / YCCK samples) bytes */
+int fo_jpeg_adobe_transform(const uint8_t *data, size_t n);
 int fo_jpeg_decode(const uint8_t *data, size_t n, uint8_t *out);
 /* entropy decoding only: quantised coefficients [block][64] in zig-zag order, component after component */
 int fo_jpeg_coefficients_of(const uint8_t *data, size_t n, int16_t *sink, size_t sink_blocks, uint32_t *nblocks);

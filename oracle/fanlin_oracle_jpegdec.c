@@ -342,6 +342,17 @@ static int up_h(const uint8_t *row, int n, int x)
     return (x & 1) ? (3 * row[i] + row[i + 1] + 2) >> 2 : (3 * row[i] + row[i - 1] + 2) >> 2;
 }
 
+int fo_jpeg_adobe_transform(const uint8_t *data, size_t n) /* -1 = no APP14 Adobe segment, else its transform byte */
+{
+    jd *j = (jd *)calloc(1, sizeof(jd));
+    if (!j) return -1;
+    j->d = data; j->n = n;
+    const int rc = parse(j);
+    const int t = (rc == 0 || rc == -2) ? j->adobe_transform : -1;
+    free(j);
+    return t;
+}
+
 int fo_jpeg_info(const uint8_t *data, size_t n, uint32_t *w, uint32_t *h, uint32_t *c, uint32_t *orientation)
 {
     jd *j = (jd *)calloc(1, sizeof(jd));
@@ -358,7 +369,7 @@ int fo_jpeg_info(const uint8_t *data, size_t n, uint32_t *w, uint32_t *h, uint32
     return rc;
 }
 
-/* out: W*H*1 (grayscale files) or W*H*3 (YCbCr / RGB files).  0 = ok, -1 malformed, -2 unsupported */
+/* out: W*H*1 (grayscale files), W*H*3 (YCbCr / RGB files) or W*H*4 (raw CMYK / YCCK samples).  0 = ok, -1 malformed, -2 unsupported */
 static int decode_impl(const uint8_t *data, size_t n, uint8_t *out, int16_t *sink, size_t sink_blocks, uint32_t *nblocks_out)
 {
     jd *j = (jd *)calloc(1, sizeof(jd));
@@ -366,15 +377,13 @@ static int decode_impl(const uint8_t *data, size_t n, uint8_t *out, int16_t *sin
     j->d = data; j->n = n;
     int rc = parse(j);
     if (rc) { free(j); return rc; }
-    if (j->nc != 1 && j->nc != 3) { free(j); return -2; }
+    if (j->nc != 1 && j->nc != 3 && j->nc != 4) { free(j); return -2; }
     if (j->nc == 1) { j->c[0].h = j->c[0].v = 1; j->hmax = j->vmax = 1; } /* a single component is never interleaved: its MCU is one block */
     /* chroma planes must be full size or exactly half in a direction (what the upsampler of zune-jpeg covers) */
     for (int i = 0; i < j->nc; ++i) {
         if (j->hmax % j->c[i].h || j->vmax % j->c[i].v || j->hmax / j->c[i].h > 2 || j->vmax / j->c[i].v > 2) { free(j); return -2; }
-        if (i > 0 && (j->c[i].h != j->c[1].h || j->c[i].v != j->c[1].v)) { free(j); return -2; }
         if (!j->have_qt[j->c[i].tq] || !j->have_ht[0][j->c[i].td] || !j->have_ht[1][j->c[i].ta]) { free(j); return -1; }
     }
-    if (j->nc == 3 && (j->c[0].h != j->hmax || j->c[0].v != j->vmax)) { free(j); return -2; }
     const int mcux = (j->W + 8 * j->hmax - 1) / (8 * j->hmax), mcuy = (j->H + 8 * j->vmax - 1) / (8 * j->vmax);
     for (int i = 0; i < j->nc; ++i) {
         jd_comp *c = &j->c[i];
@@ -419,18 +428,16 @@ static int decode_impl(const uint8_t *data, size_t n, uint8_t *out, int16_t *sin
             }
     }
     if (rc || !out) goto done;
-    if (j->nc == 1) {
-        for (int y = 0; y < j->H; ++y) memcpy(out + (size_t)y * j->W, j->c[0].plane + (size_t)y * j->c[0].pw, (size_t)j->W);
-    } else {
-        const int sh = j->hmax / j->c[1].h, sv = j->vmax / j->c[1].v; /* 1 or 2 */
-        /* Adobe transform 0 with three components = the samples ARE R, G, B */
-        const int is_rgb = j->adobe_transform == 0;
+    {
+        /* Adobe transform 0 with three components = the samples ARE R, G, B; four components (CMYK / YCCK) come out raw, as
+         * JpegDecoder with out_colorspace = the input colour space returns them (reference src/handler.rs:417-419) */
+        const int is_rgb = j->nc == 3 && j->adobe_transform == 0;
         for (int y = 0; y < j->H; ++y)
             for (int x = 0; x < j->W; ++x) {
-                int s[3];
-                s[0] = j->c[0].plane[(size_t)y * j->c[0].pw + x];
-                for (int i = 1; i < 3; ++i) {
+                int s[4] = {0, 0, 0, 0};
+                for (int i = 0; i < j->nc; ++i) {
                     const jd_comp *c = &j->c[i];
+                    const int sh = j->hmax / c->h, sv = j->vmax / c->v; /* 1 or 2 */
                     const int cw = c->w, chh = c->h_px;
                     if (sv == 1 && sh == 1) s[i] = c->plane[(size_t)y * c->pw + x];
                     else if (sv == 1) s[i] = up_h(c->plane + (size_t)y * c->pw, cw, x);
@@ -456,8 +463,10 @@ static int decode_impl(const uint8_t *data, size_t n, uint8_t *out, int16_t *sin
                         }
                     }
                 }
-                uint8_t *o = out + ((size_t)y * j->W + x) * 3;
-                if (is_rgb) { o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; }
+                uint8_t *o = out + ((size_t)y * j->W + x) * j->nc;
+                if (j->nc == 1) o[0] = (uint8_t)s[0];
+                else if (j->nc == 4) { o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; o[3] = (uint8_t)s[3]; }
+                else if (is_rgb) { o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; }
                 else {
                     const int16_t yy = (int16_t)s[0], cb = (int16_t)(s[1] - 128), cr = (int16_t)(s[2] - 128);
                     o[0] = clamp8(yy + ((45 * cr) >> 5));

@@ -18,7 +18,7 @@ pub struct FlPlan { src_w: u32, src_h: u32, mid_c: u32, resampled: u32, resized_
                     plane_w: u32, plane_h: u32, chroma_w: u32, chroma_h: u32, pixel_bytes: u64, out_bytes: u64, max_out_bytes: u64 }
 #[repr(C)] #[derive(Default)]
 pub struct FlConfig { device: i32, max_batch: u32, flush_timeout_us: u32, profile: u32, queue_lanes: u32, n_devices: u32,
-                      reserved: [u32; 2], devices: [i32; 8] }
+                      use_embedded_profile: u32 /* config `use_embedded_profile`, handler.rs:19 */, reserved: [u32; 1], devices: [i32; 8] }
 
 pub const FE_NONE: u8 = 0;
 pub const FE_JFIF444: u8 = 1;
@@ -59,10 +59,10 @@ pub enum Outcome {
 impl Gpu {
     /// `devices`: HIP ordinals of the node's GPUs (`&[0]` for one); all of them serve the one shared State,
     /// as all tokio workers share one `Arc<State>` (src/main.rs:108-112).
-    pub fn new(max_clients: u32, devices: &[i32]) -> Result<Self, String> {
+    pub fn new(max_clients: u32, devices: &[i32], use_embedded_profile: bool) -> Result<Self, String> {
         assert_eq!(unsafe { flgpu_abi_version() }, 3, "libfanlin_gpu.so / shim mismatch");
         let mut cfg = FlConfig { device: devices.first().copied().unwrap_or(-1), max_batch: max_clients.max(1),
-                                 flush_timeout_us: 200, ..Default::default() };
+                                 flush_timeout_us: 200, use_embedded_profile: use_embedded_profile as u32, ..Default::default() };
         if devices.len() > 1 {
             cfg.n_devices = devices.len().min(8) as u32;
             for (k, d) in devices.iter().take(8).enumerate() { cfg.devices[k] = *d; }

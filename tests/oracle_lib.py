@@ -132,11 +132,15 @@ class Oracle:
         """Baseline JPEG -> Luma8 / Rgb8 pixels with zune-jpeg's IDCT / upsampling / colour arithmetic (restated)."""
         rc, w, h, c, _ = self.jpeg_info(data)
         assert rc == 0, rc
-        out = np.zeros((h, w, 1 if c == 1 else 3), np.uint8)
+        out = np.zeros((h, w, c), np.uint8)
         self.lib.fo_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
         rc = self.lib.fo_jpeg_decode(data, len(data), out.ctypes.data_as(C.c_void_p))
         assert rc == 0, rc
         return out
+
+    def jpeg_adobe_transform(self, data: bytes) -> int:
+        self.lib.fo_jpeg_adobe_transform.argtypes = [C.c_char_p, C.c_size_t]
+        return int(self.lib.fo_jpeg_adobe_transform(data, len(data)))
 
     def jpeg_file_coefficients(self, data: bytes):
         """Quantised coefficients of every block of a JPEG file, [block][64] zig-zag (entropy decoding only)."""

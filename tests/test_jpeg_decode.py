@@ -101,8 +101,9 @@ def test_exif_orientation_and_unsupported_streams(fl):
         fl.debug_jpeg_blob(b.getvalue())
     assert e.value.status == fl.ERR_UNSUPPORTED
     b = io.BytesIO()
-    Image.fromarray(synth.uniform(24, 24, 4)).convert("CMYK").save(b, "JPEG")
-    assert fl.jpeg_info(b.getvalue())["supported"] == 0          # 4 components: the CMYK path of handler.rs:398-493, not this one
+    Image.fromarray(synth.uniform(24, 24, 4), "CMYK").save(b, "JPEG")
+    info = fl.jpeg_info(b.getvalue())                             # 4 components: raw samples + the CMYK table, see the tests below
+    assert info["supported"] == 1 and info["components"] == 4 and info["channels"] == 3 and info["adobe_transform"] == 1
     for junk in (b"", b"\xff\xd8", b"GIF89a" + bytes(64), make_jpeg(16, 16)[:40]):
         with pytest.raises(fl.FanlinError):
             fl.jpeg_info(junk)
@@ -145,7 +146,85 @@ def test_committed_lenna_is_the_reference_file():
     assert open(ref, "rb").read() == lenna_bytes()
 
 
+def make_cmyk_jpeg(h, w, q=90, subsampling=0, ycck=False, icc=None, index=0):
+    """A four-component Adobe JPEG (Pillow writes transform 0 = CMYK; the YCCK variant is the same stream with the APP14
+    transform byte set to 2, which is all that tells a decoder how to read the samples)."""
+    img = synth.photo(h, w, 4, index=index)
+    b = io.BytesIO()
+    kw = dict(quality=q, subsampling=subsampling)
+    if icc:
+        kw["icc_profile"] = icc
+    Image.fromarray(img, "CMYK").save(b, "JPEG", **kw)
+    data = bytearray(b.getvalue())
+    if ycck:
+        k = data.find(b"Adobe")
+        assert k > 0
+        data[k + 11] = 2
+    return bytes(data)
+
+
+@pytest.mark.parametrize("sub,ycck", [(0, False), (2, False), (0, True), (2, True)])
+def test_four_component_files_host_half_and_oracle(fl, oracle, sub, ycck):
+    data = make_cmyk_jpeg(40, 56, subsampling=sub, ycck=ycck, index=sub)
+    info = fl.jpeg_info(data)
+    assert info["adobe_transform"] == (3 if ycck else 1) and info["components"] == 4
+    hdr, got, _ = fl.debug_jpeg_blob(data)
+    assert hdr["nc"] == 4 and np.array_equal(got, oracle.jpeg_file_coefficients(data))
+    raw = oracle.jpeg_decode(data)
+    assert raw.shape == (40, 56, 4) and oracle.jpeg_adobe_transform(data) == (2 if ycck else 0)
+    if not ycck:  # Pillow un-inverts Adobe CMYK: its decode is 255 - the raw samples (within the IDCT / up-sampling difference)
+        ref = 255 - np.array(Image.open(io.BytesIO(data))).astype(np.int16)
+        assert int(np.abs(raw.astype(np.int16) - ref).max()) <= 2
+
+
 # ----------------------------------------------------------------------------------------------- device half (GPU) --
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub,ycck", [(0, False), (2, False), (0, True), (2, True)])
+def test_cmyk_and_ycck_files_through_the_profile_table(fl, oracle, sub, ycck):
+    """convert_jpeg_color_if_needed (handler.rs:398-466) from the file bytes on: decode to raw samples, the YCCK loop when the
+    Adobe marker says so, the profile's table, then the pipeline -- one device pass, against the oracle's chain."""
+    from conftest import require_device
+    require_device()
+    clut = np.random.default_rng(21).integers(0, 65536, (17, 17, 17, 17, 3), dtype=np.uint16)
+    data = make_cmyk_jpeg(72, 100, subsampling=sub, ycck=ycck, index=5 + sub)
+    raw = oracle.jpeg_decode(data)
+    cmyk = oracle.ycck_to_cmyk(raw).reshape(raw.shape) if ycck else raw
+    rgb = oracle.cmyk_to_rgb(cmyk, clut)
+    with fl.State(device=0) as st:
+        with pytest.raises(fl.FanlinError) as e:                  # no profile configured: the reference's `None` -> the host decodes
+            st.decode_jpeg(data)
+        assert e.value.status == fl.ERR_UNSUPPORTED
+        st.set_cmyk_clut(clut)
+        assert np.array_equal(st.decode_jpeg(data), rgb)
+        got = st.process_jpeg_pixels(data, fl.make_params(50, 30))
+        assert np.array_equal(got, oracle.process_pixels(rgb, 50, 30, arith=oracle_lib.ARITH_FMA))
+        mime, kind, body = st.process_jpeg(data, "w=64&h=64&quality=80")
+        assert kind == fl.RESULT_JPEG_STREAM and body == oracle.jpeg_encode(oracle.process_pixels(rgb, 64, 64, arith=oracle_lib.ARITH_FMA), 80)
+        assert st.process_batch([data, rgb], [fl.make_params(50, 30)] * 2)[0].tobytes() == got.tobytes()
+
+
+@pytest.mark.gpu
+def test_embedded_profile_of_a_cmyk_file(fl, oracle):
+    import lcms2_lib
+    import synth_icc
+    from conftest import require_device
+    require_device()
+    if lcms2_lib.load() is None:
+        pytest.skip("liblcms2 not installed")
+    icc = synth_icc.cmyk_profile()
+    other = np.random.default_rng(22).integers(0, 65536, (17, 17, 17, 17, 3), dtype=np.uint16)
+    data = make_cmyk_jpeg(48, 64, icc=icc, index=9)
+    assert fl.jpeg_info(data)["has_icc_profile"] == 1
+    raw = oracle.jpeg_decode(data)
+    with fl.State(device=0, use_embedded_profile=True) as st:
+        st.set_cmyk_clut(other)                                   # the configured profile is NOT what converts this file ...
+        want = lcms2_lib.Cmyk2Rgb(icc).convert(raw.reshape(-1, 4)).reshape(48, 64, 3)
+        assert np.array_equal(st.decode_jpeg(data), want)         # ... its own profile is (handler.rs:446-449), bit-exact vs liblcms2
+    with fl.State(device=0) as st:                                # use_embedded_profile = false: the configured one
+        st.set_cmyk_clut(other)
+        assert np.array_equal(st.decode_jpeg(data), oracle.cmyk_to_rgb(raw, other))
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)

@@ -22,7 +22,7 @@ constexpr int TPITCH = 193; // i32 per tile row (180 outputs of a strip, odd pit
 extern __shared__ __attribute__((aligned(16))) int lds_i[];
 
 // MODE bit 0: vertical-second emulation; bit 1: no MFMA (VALU stand-in); bit 2: no ds_add
-template <int WAVES, int MODE>
+template <int WAVES, int MODE, int DEPTH = 3>
 __global__ __launch_bounds__(WAVES * 64) void hfirst(const uint8_t *__restrict__ src, const i32x4 *__restrict__ wtab, float *__restrict__ out,
                                                      uint32_t pitch, uint32_t rows, uint32_t img_bytes, uint32_t nstrips, uint32_t strip_stride)
 {
@@ -43,7 +43,6 @@ __global__ __launch_bounds__(WAVES * 64) void hfirst(const uint8_t *__restrict__
         for (int d = 0; d < 3; ++d) wa[p][d] = wtab[((wave * NPAIR + p) * 3 + d) * 64 + lane];
     // which M-tile each pair feeds and which K-block it reads (static pattern: kb0 -> tiles 0,1,2; kb1 -> tiles 1,2,3)
     const uint32_t nsteps = (rows + 15u) / 16u;
-    constexpr int DEPTH = 3;
     u32x4 ring[DEPTH][2];
     auto issue = [&](int slot, uint32_t s) {
         const uint32_t soff = s * 16u * pitch;
@@ -104,16 +103,16 @@ __global__ __launch_bounds__(WAVES * 64) void hfirst(const uint8_t *__restrict__
         }
     };
     for (uint32_t s = 0; s < nsteps; s += DEPTH) {
-        step(0, s);
-        if (s + 1 < nsteps) step(1, s + 1);
-        if (s + 2 < nsteps) step(2, s + 2);
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k)
+            if (s + k < nsteps) step(k, s + k);
     }
     float keep = 0;
     for (int k = 0; k < 7; ++k) keep += vacc[k].x + vacc[k].y;
     if (keep == 123.456f) out[blockIdx.x] = keep;
 }
 
-template <int WAVES, int MODE>
+template <int WAVES, int MODE, int DEPTH = 3>
 static void run(const char *name, const uint8_t *src, const i32x4 *wtab, float *out, int nimg)
 {
     const uint32_t W = 1920, H = 1080, C = 3, pitch = W * C, img_bytes = pitch * H;
@@ -123,10 +122,10 @@ static void run(const char *name, const uint8_t *src, const i32x4 *wtab, float *
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    hfirst<WAVES, MODE><<<nimg * nstrips, WAVES * 64, ldsb>>>(src, wtab, out, pitch, H, img_bytes, nstrips, stride);
+    hfirst<WAVES, MODE, DEPTH><<<nimg * nstrips, WAVES * 64, ldsb>>>(src, wtab, out, pitch, H, img_bytes, nstrips, stride);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < 3; ++r) hfirst<WAVES, MODE><<<nimg * nstrips, WAVES * 64, ldsb>>>(src, wtab, out, pitch, H, img_bytes, nstrips, stride);
+    for (int r = 0; r < 3; ++r) hfirst<WAVES, MODE, DEPTH><<<nimg * nstrips, WAVES * 64, ldsb>>>(src, wtab, out, pitch, H, img_bytes, nstrips, stride);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -164,6 +163,10 @@ int main()
     run<8, 1>("8 waves: + vertical pass on the tile (2 waves)", src, wtab, out, nimg);
     run<10, 0>("10 waves: horizontal stage + ds_add", src, wtab, out, nimg);
     run<10, 1>("10 waves: + vertical pass on the tile (2 waves)", src, wtab, out, nimg);
-    run<12, 1>("12 waves: + vertical pass on the tile (2 waves)", src, wtab, out, nimg);
+    run<10, 0, 6>("10 waves, prefetch 6 steps: horizontal stage + ds_add", src, wtab, out, nimg);
+    run<10, 4, 6>("10 waves, prefetch 6 steps: horizontal stage, no LDS, no barrier", src, wtab, out, nimg);
+    run<10, 6, 6>("10 waves, prefetch 6 steps: loads + xor only", src, wtab, out, nimg);
+    run<10, 6, 3>("10 waves, prefetch 3 steps: loads + xor only", src, wtab, out, nimg);
+    run<10, 4, 3>("10 waves, prefetch 3 steps: horizontal stage, no LDS, no barrier", src, wtab, out, nimg);
     return 0;
 }
