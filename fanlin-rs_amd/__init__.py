@@ -108,7 +108,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
-    "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version",
+    "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version", "flgpu_build_info",
     "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob",
 )
 
@@ -189,11 +189,31 @@ def load_library() -> C.CDLL:
     lib.flgpu_last_error.argtypes = [C.c_void_p]
     lib.flgpu_last_error.restype = C.c_char_p
     lib.flgpu_abi_version.restype = C.c_uint32
+    lib.flgpu_build_info.restype = C.c_char_p
     lib.flgpu_debug_axis_table.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_uint64)]
     lib.flgpu_debug_stream_schedulable.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
     _lib = lib
     return lib
+
+
+def build_info() -> str:
+    """flgpu_build_info(): which sources (hash), compiler and flags the loaded library was built from."""
+    return load_library().flgpu_build_info().decode()
+
+
+def source_hash() -> str:
+    """The hash csrc/Makefile computes over the library's sources as they are on disk now (same file order)."""
+    import hashlib
+    import re
+    csrc = os.path.join(_HERE, "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = re.search(r"^SRCS\s*=\s*(.*)$", mk, re.M).group(1).split()
+    hdrs = re.search(r"^HDRS\s*=\s*(.*)$", mk, re.M).group(1).split()
+    h = hashlib.sha256()
+    for f in srcs + hdrs + ["Makefile"]:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _check(status: int, ctx: Optional[int] = None) -> None:

@@ -386,6 +386,9 @@ int flgpu_debug_stream_schedulable(uint32_t in_size, uint32_t out_size, uint32_t
 const char *flgpu_strerror(int status);
 const char *flgpu_last_error(flgpu_ctx *ctx); /* detail of the last FLGPU_ERR_DEVICE on this context */
 uint32_t flgpu_abi_version(void);
+/* Build provenance: "sources <first 16 hex digits of the SHA-256 over every source and header of the library>; <hipcc version>;
+ * arch ...; flags ..." -- compiled in by csrc/Makefile, which also writes fanlin-rs_amd/build_info.json. */
+const char *flgpu_build_info(void);
 
 #ifdef __cplusplus
 }

@@ -100,3 +100,14 @@ def test_rust_shim_mirrors_the_structs(fl):
         body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
         names = [f.split(":")[0].strip() for f in body.split(",") if ":" in f]
         assert names == [n for n, _ in cls._fields_], (rust, names)
+
+
+def test_loaded_library_was_built_from_the_sources_beside_it(fl):
+    # build provenance: the hash of the sources is compiled into the library (and written to build_info.json); a stale
+    # binary -- built from other sources than the ones in the tree -- is caught here, on the CPU box and on the GPU box
+    import json
+    info = fl.build_info()
+    assert info.startswith("sources ") and "gfx950" in info
+    assert info.split()[1].rstrip(";") == fl.source_hash(), "libfanlin_gpu.so is stale: rebuild with __graft_entry__.build()"
+    rec = json.load(open(os.path.join(ROOT, "fanlin-rs_amd", "build_info.json")))
+    assert rec["sources_sha256_16"] == fl.source_hash()
