@@ -116,6 +116,38 @@ def test_exif_orientation_and_unsupported_streams(fl):
             pass
 
 
+def test_host_decoder_survives_mutated_streams_under_address_sanitizer(tmp_path):
+    """The entropy decoder reads bytes fetched from an origin server (src/handler.rs:192-220): tests/tools/fuzz_jpeg_huff.cpp
+    is built here with g++ -fsanitize=address,undefined over csrc/fl_jpeghuff.cpp itself (host-only code, no GPU) and fed
+    the reference picture plus five synthetic layouts, each under 400 truncations / byte flips / stray markers / splices:
+    every stream must end in a blob or an error code; any out-of-bounds access or signed overflow aborts the harness."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs g++ and the HIP headers")
+    csrc = os.path.join(ROOT, "fanlin-rs_amd", "csrc")
+    exe = str(tmp_path / "fuzz_jpeg_huff")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + csrc,
+                    os.path.join(ROOT, "tests", "tools", "fuzz_jpeg_huff.cpp"), os.path.join(csrc, "fl_jpeghuff.cpp"), "-o", exe],
+                   check=True, capture_output=True, text=True)
+    seeds = [LENNA]
+    layouts = [(64, 96, 3, 85, 0, 0), (37, 53, 3, 70, 2, 3), (50, 70, 1, 75, 0, 0), (33, 47, 3, 60, 1, 2)]
+    for i, (h, w, c, q, sub, rst) in enumerate(layouts):
+        p = tmp_path / f"seed{i}.jpg"
+        p.write_bytes(make_jpeg(h, w, c, q, sub, rst, index=i))
+        seeds.append(str(p))
+    b = io.BytesIO()
+    Image.fromarray(synth.photo(40, 56, 4, index=9), "CMYK").save(b, "JPEG", quality=85, subsampling=2)
+    (tmp_path / "cmyk.jpg").write_bytes(b.getvalue())
+    seeds.append(str(tmp_path / "cmyk.jpg"))
+    r = subprocess.run([exe] + seeds, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    decoded, rejected = (int(x) for x in r.stdout.replace(",", "").split() if x.isdigit())
+    assert decoded > 300 and rejected > 300, r.stdout             # both outcomes are exercised
+
+
 # ------------------------------------------------------------------------- oracle vs libjpeg-turbo (the pinned bound) --
 
 def _vs_pillow(oracle, data):
