@@ -89,7 +89,8 @@ class flgpu_stats(C.Structure):
                 ("generic_launches", C.c_uint64), ("blur_launches", C.c_uint64), ("blur_ms", C.c_double),
                 ("frontend_launches", C.c_uint64), ("frontend_ms", C.c_double),
                 ("cmyk_pixels", C.c_uint64), ("cmyk_tables_baked", C.c_uint64),
-                ("jpeg_sources", C.c_uint64), ("jpeg_file_bytes", C.c_uint64), ("jpeg_upload_bytes", C.c_uint64)]
+                ("jpeg_sources", C.c_uint64), ("jpeg_file_bytes", C.c_uint64), ("jpeg_upload_bytes", C.c_uint64),
+                ("mfma_launches", C.c_uint64)]
 
 
 class flgpu_jpeg_info(C.Structure):

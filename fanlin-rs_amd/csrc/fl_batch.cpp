@@ -15,7 +15,7 @@ namespace {
 
 // ---- batch execution -------------------------------------------------------
 
-enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3, S1_NEAREST = 4 };
+enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3, S1_NEAREST = 4, S1_MFMA = 5 };
 
 struct Work {
     flgpu_plan plan;
@@ -30,6 +30,7 @@ struct Work {
     const HostAxis *va = nullptr, *ha = nullptr;
     uint32_t vtab = 0, htab = 0;
     const StreamPlan *splan = nullptr;
+    const MfmaPlan *mplan = nullptr;
     bool unaligned = false;
     size_t jpeg_coef_off = 0, jpeg_off_off = 0, jpeg_raw_off = 0; // FE_JPEG scratch (bytes)
     uint32_t jpeg_tab = 0;
@@ -239,6 +240,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     const char *env_generic = getenv("FLGPU_FORCE_GENERIC");
     const char *env_bands = getenv("FLGPU_FORCE_BANDS");
     const bool force_generic = env_generic && env_generic[0] == '1';
+    static const bool no_mfma = [] { const char *e = getenv("FLGPU_NO_MFMA"); return e && e[0] == '1'; }(); // tests / A-B runs: keep the streaming kernel
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool full = false;
         size_t n_resample = 0;
@@ -253,6 +255,18 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             // rows that are not dword aligned: Rgb8 has a funnel-shift variant of the kernel, others use the generic path
             w.unaligned = ((w.sw * w.cs) % 4u != 0) || ((uintptr_t)w.src % 4u != 0);
             const bool aligned = (!w.unaligned || w.cs == 3) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
+            // The matrix-pipe kernel takes Rgb8 down-scales whose rows are 16-byte aligned (it moves 16-byte pieces of a row
+            // straight into LDS).  The choice depends on the request's geometry only, never on the batch around it.
+            if (w.cs == 3 && w.pre == PRE_NONE && !force_generic && !no_mfma && (w.sw * 3u) % 16u == 0 && (uintptr_t)w.src % 16u == 0 &&
+                (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0) && w.sw * 3u >= 64u) {
+                Job jtmp; fill_job(w, jtmp);
+                uint32_t nbands = 1;
+                if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
+                else if (n_resample < 128) nbands = (uint32_t)std::min<size_t>(16, (256 + n_resample * 3 - 1) / (n_resample * 3));
+                const MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, nbands);
+                if (c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
+                if (mp->ok) { w.s1 = S1_MFMA; w.mplan = mp; continue; }
+            }
             if (stream_supported(w.cs, w.pre) && aligned && !force_generic) {
                 Job jtmp; fill_job(w, jtmp);
                 uint32_t nbands = 1;
@@ -313,7 +327,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
-        if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        else if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         if (w.p->blur_sigma > 0.0f) {
             const uint32_t ce = blur_channels(w);
             // pictures of one launch share the workgroup width the kernel is instantiated for
@@ -326,6 +341,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     }
     std::vector<Job> jobs;
     std::vector<StreamItem> items;
+    std::vector<MfmaItem> mitems;
     std::vector<FrontendJob> fjobs;
     // EXIF orientation pre-pass jobs, grouped by channel count
     struct OrientLaunch { uint32_t cs, base, n, mw, mh; };
@@ -343,7 +359,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         }
         if (O.n) orient_launches.push_back(O);
     }
-    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc; LaunchGeneric g; size_t lds; size_t mid_floats; uint32_t blur_grid_x; bool blur_tiled; };
+    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc, max_nout; LaunchGeneric g; size_t lds; size_t mid_floats; uint32_t blur_grid_x; bool blur_tiled; };
     std::vector<S1Launch> s1_launches, blur_launches;
     struct FeLaunch { uint32_t kind, base, n, mw, mh; bool rgba; };
     std::vector<FeLaunch> fe_launches;
@@ -352,7 +368,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
 
     auto new_launch = [&](const GroupKey &k) {
         S1Launch L{};
-        L.k = k; L.job_base = (uint32_t)jobs.size(); L.item_base = (uint32_t)items.size();
+        L.k = k; L.job_base = (uint32_t)jobs.size(); L.item_base = (uint32_t)((k.kind & 255u) == S1_MFMA ? mitems.size() : items.size());
         L.g.cs = k.cs; L.g.pre = k.pre; L.g.letterbox = k.lb; L.g.grouped = 1;
         return L;
     };
@@ -373,6 +389,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             L.g.max_sw = std::max(L.g.max_sw, j.sw); L.g.max_rh = std::max(L.g.max_rh, j.rh);
             L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
             L.g.max_dw = std::max(L.g.max_dw, j.dw); L.g.max_dh = std::max(L.g.max_dh, j.dh);
+            if ((k.kind & 255u) == S1_MFMA) {
+                for (MfmaItem it2 : w.mplan->items) { it2.job = (uint32_t)jobs.size(); mitems.push_back(it2); }
+                L.nitems += (uint32_t)w.mplan->items.size();
+                L.max_nout = std::max(L.max_nout, w.mplan->max_nout);
+                c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
+                c->stats.resample_dst_bytes += w.plan.pixel_bytes;
+            }
             if ((k.kind & 255u) == S1_STREAM) {
                 for (StreamItem it2 : w.splan->items) { it2.job = (uint32_t)jobs.size(); items.push_back(it2); }
                 L.nitems += (uint32_t)w.splan->items.size();
@@ -383,6 +406,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             }
             jobs.push_back(j);
             L.njobs++;
+        }
+        if ((k.kind & 255u) == S1_MFMA && L.nitems > 1) {
+            // longest workgroups first, as below; the strips of one picture share only a few halo bytes, so no XCD shuffle
+            auto first = mitems.begin() + L.item_base;
+            std::stable_sort(first, first + L.nitems, [](const MfmaItem &a, const MfmaItem &b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
         }
         if ((k.kind & 255u) == S1_STREAM && L.nitems > 1) {
             // longest workgroups first: in a mixed batch a 4K band walks four times the rows of a 1080p one, and the
@@ -511,11 +539,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     }
     FL_HIP(c, c->d_mid.reserve(mid_floats_max * 4), "f32 intermediate");
 
-    // one staging slot: [jobs][items][fjobs][jjobs]
+    // one staging slot: [jobs][items][fjobs][jjobs][mitems]
     const size_t jobs_b = align_up(jobs.size() * sizeof(Job), 256), items_b = align_up(items.size() * sizeof(StreamItem), 256),
-                 fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256), jjobs_b = align_up(jjobs.size() * sizeof(JpegJob), 256);
-    const size_t desc_b = jobs_b + items_b + fjobs_b + jjobs_b;
+                 fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256), jjobs_b = align_up(jjobs.size() * sizeof(JpegJob), 256),
+                 mitems_b = align_up(mitems.size() * sizeof(MfmaItem), 256);
+    const size_t desc_b = jobs_b + items_b + fjobs_b + jjobs_b + mitems_b;
     const Job *d_jobs = nullptr; const StreamItem *d_items = nullptr; const FrontendJob *d_fjobs = nullptr; const JpegJob *d_jjobs = nullptr;
+    const MfmaItem *d_mitems = nullptr;
     DescSlot *slot = nullptr;
     if (desc_b) {
         slot = &c->slots[c->next_slot];
@@ -529,12 +559,14 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (!items.empty()) memcpy(hp + jobs_b, items.data(), items.size() * sizeof(StreamItem));
         if (!fjobs.empty()) memcpy(hp + jobs_b + items_b, fjobs.data(), fjobs.size() * sizeof(FrontendJob));
         if (!jjobs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b, jjobs.data(), jjobs.size() * sizeof(JpegJob));
+        if (!mitems.empty()) memcpy(hp + jobs_b + items_b + fjobs_b + jjobs_b, mitems.data(), mitems.size() * sizeof(MfmaItem));
         FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, st), "descriptor upload");
         char *dp = static_cast<char *>(slot->dev.p);
         d_jobs = reinterpret_cast<const Job *>(dp);
         d_items = reinterpret_cast<const StreamItem *>(dp + jobs_b);
         d_fjobs = reinterpret_cast<const FrontendJob *>(dp + jobs_b + items_b);
         d_jjobs = reinterpret_cast<const JpegJob *>(dp + jobs_b + items_b + fjobs_b);
+        d_mitems = reinterpret_cast<const MfmaItem *>(dp + jobs_b + items_b + fjobs_b + jjobs_b);
     }
 
     range_plan.reset();
@@ -558,6 +590,16 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             FL_HIP(c, launch_vpass_generic(L.g, st), "generic vertical pass");
             FL_HIP(c, launch_hpass_generic(L.g, st), "generic horizontal pass");
             c->stats.generic_launches++;
+        } else if ((L.k.kind & 255u) == S1_MFMA) {
+            LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
+            m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
+            m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.max_nout = L.max_nout;
+            {
+                ProfileScope ps(c, st, 0);
+                FL_HIP(c, launch_mfma(m, st), "matrix-pipe resample kernel");
+            }
+            c->stats.resample_launches++;
+            c->stats.mfma_launches++;
         } else {
             LaunchStream s{}; // (the streaming kernel paints the letterbox frame itself)
             s.jobs = d_jobs; s.items = d_items + L.item_base; s.arena = c->d_arena; s.nitems = L.nitems;

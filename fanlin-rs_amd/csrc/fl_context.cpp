@@ -57,6 +57,7 @@ void arena_reset(flgpu_ctx *c)
     c->axis_off.clear();
     c->axis_host.clear();
     c->stream_plans.clear();
+    c->mfma_plans.clear();
     c->blur_plans.clear();
     c->jpeg_tables.clear();
     std::vector<uint32_t> g;
@@ -103,6 +104,56 @@ uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma
     c->axis_off[key] = hoff;
     if (host_out) *host_out = &ha;
     return hoff;
+}
+
+// Tables and workgroup list of the matrix-pipe kernel for one geometry; bands are runs of whole 16-row tiles.
+const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
+                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands)
+{
+    MfmaPlanKey key{vk, hk, cx, cy, cw, ch, nbands};
+    auto it = c->mfma_plans.find(key);
+    if (it != c->mfma_plans.end()) return &it->second;
+    MfmaPlan plan;
+    HostMfmaPlan hp;
+    build_mfma_plan(va, ha, cx, cy, cw, ch, hp);
+    bool ok = hp.ok;
+    uint32_t vplan_off = 0;
+    if (ok) {
+        MfmaVPlan vp{};
+        vp.ntiles = hp.ntiles; vp.nkb = hp.nkb; vp.y0 = hp.y0; vp.rows = hp.rows;
+        vplan_off = arena_append(c, nullptr, sizeof(MfmaVPlan) / 4);
+        vp.meta_off = arena_append(c, hp.vmeta.data(), hp.vmeta.size());
+        vp.w_off = arena_append(c, hp.vw.data(), hp.vw.size());
+        if (!vplan_off || !vp.meta_off || !vp.w_off) ok = false;
+        else memcpy(c->h_arena.data() + vplan_off, &vp, sizeof(vp));
+    }
+    if (ok) {
+        plan.ops_in_lds = true;
+        const uint32_t nb = std::max(1u, std::min(nbands, hp.ntiles));
+        for (auto &S : hp.strips) {
+            MfmaStrip sh = S.hdr;
+            const uint32_t soff = arena_append(c, nullptr, sizeof(MfmaStrip) / 4);
+            sh.ctab_off = arena_append(c, S.ctab.data(), S.ctab.size());
+            sh.ops_off = arena_append(c, S.ops.data(), S.ops.size());
+            if (!soff || !sh.ctab_off || !sh.ops_off) { ok = false; break; }
+            memcpy(c->h_arena.data() + soff, &sh, sizeof(sh));
+            plan.max_nout = std::max(plan.max_nout, sh.nout);
+            if (sh.n_ops > kMfmaLdsOperands) plan.ops_in_lds = false;
+            for (uint32_t b = 0; b < nb; ++b) {
+                const uint32_t t0 = (uint32_t)((uint64_t)hp.ntiles * b / nb), t1 = (uint32_t)((uint64_t)hp.ntiles * (b + 1) / nb);
+                if (t1 <= t0) continue;
+                MfmaItem mi{};
+                mi.vplan_off = vplan_off; mi.strip_off = soff; mi.tile0 = t0; mi.tile1 = t1;
+                mi.kb0 = hp.tiles[t0].kb_first; mi.kb1 = hp.tiles[t1 - 1].kb_last + 1u;
+                plan.items.push_back(mi);
+            }
+        }
+        if (ok && mfma_lds_bytes(plan.max_nout, plan.ops_in_lds) > 160 * 1024) ok = false;
+    }
+    plan.ok = ok;
+    if (!ok) plan.items.clear();
+    auto res = c->mfma_plans.emplace(key, std::move(plan));
+    return &res.first->second;
 }
 
 const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
@@ -402,6 +453,7 @@ static void add_stats(flgpu_stats *out, const flgpu_stats &ls)
     out->frontend_launches += ls.frontend_launches; out->frontend_ms += ls.frontend_ms;
     out->cmyk_pixels += ls.cmyk_pixels; out->cmyk_tables_baked += ls.cmyk_tables_baked;
     out->jpeg_sources += ls.jpeg_sources; out->jpeg_file_bytes += ls.jpeg_file_bytes; out->jpeg_upload_bytes += ls.jpeg_upload_bytes;
+    out->mfma_launches += ls.mfma_launches;
 }
 
 int flgpu_get_stats(flgpu_ctx *c, flgpu_stats *out)

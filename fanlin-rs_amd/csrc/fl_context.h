@@ -27,6 +27,7 @@
 #include "fl_jpeg_tables.h"
 #include "fl_jpegdec.h"
 #include "fl_kernels.h"
+#include "fl_mfma.h"
 #include "fl_tables.h"
 
 namespace fl {
@@ -70,6 +71,20 @@ struct StreamPlan {
     uint32_t nacc = NACC;
     std::vector<StreamItem> items; // job field unset
     size_t lds_bytes = 0;
+};
+
+struct MfmaPlanKey {
+    AxisKey v, h;
+    uint32_t cx, cy, cw, ch, nbands;
+    bool operator<(const MfmaPlanKey &o) const { return std::tie(v, h, cx, cy, cw, ch, nbands) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.nbands); }
+};
+
+// Workgroups of the matrix-pipe resample kernel for one geometry (fl_mfma.h); job field unset.
+struct MfmaPlan {
+    bool ok = false;
+    std::vector<MfmaItem> items;
+    uint32_t max_nout = 0;
+    bool ops_in_lds = false;
 };
 
 struct PinBlock {
@@ -118,6 +133,7 @@ struct flgpu_ctx {
     std::map<fl::AxisKey, uint32_t> axis_off;
     std::map<fl::AxisKey, fl::HostAxis> axis_host;
     std::map<fl::StreamPlanKey, fl::StreamPlan> stream_plans;
+    std::map<fl::MfmaPlanKey, fl::MfmaPlan> mfma_plans;
     std::map<std::tuple<fl::AxisKey, fl::AxisKey, uint32_t>, uint32_t> blur_plans; // blur kernel table blocks per (vertical, horizontal) Gaussian axis
     uint32_t gamma_off = 0;
 
@@ -217,6 +233,8 @@ uint32_t arena_append(flgpu_ctx *c, const void *data, size_t words, size_t align
 void arena_reset(flgpu_ctx *c);
 int arena_flush(flgpu_ctx *c, hipStream_t st);
 uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma, AxisKey *key_out, const HostAxis **host_out);
+const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
+                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands);
 const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
                                   uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs, uint32_t pre);
 hipEvent_t get_event(flgpu_ctx *c);

@@ -1,0 +1,103 @@
+// fl_mfma.h -- the matrix-pipe resample kernel (fl_mfma.hip): descriptors, table layout and the host-side builders.
+//
+// Same job as the streaming kernel (fused vertical + horizontal Lanczos3 down-scale of an Rgb8 picture,
+// reference image 0.25.6 imageops/sample.rs vertical_sample + horizontal_sample), arranged for gfx950's MFMA units:
+//
+//   one workgroup (8 waves) = one picture x one strip of <= 2048 source bytes per row x a band of 16-row output tiles.
+//   vertical pass    the source rows stream once, in K-blocks of 32 rows, from HBM straight into LDS
+//                    (global_load_lds_dwordx4, a wave-private 8 KB image per K-block, no VGPRs, no barrier);
+//                    ds_read_b64_tr_b8 hands every lane the 8 rows of one byte column, two v_perm_b32 turn them into
+//                    f16 (0x6400 | byte = 1024 + byte, exact) and v_mfma_f32_16x16x32_f16 multiplies 16 byte columns
+//                    x 32 rows by the 32 x 16 slice of the banded weight matrix (two f16 terms per weight = 22 bits).
+//                    At most two 16-row output tiles are alive per K-block; their sums stay in registers.
+//   horizontal pass  a finished tile goes f32 -> 16-bit fixed point (1/64 steps around 128) -> two byte planes, which
+//                    are already laid out as the A operand of v_mfma_i32_16x16x64_i8; the B operand holds the
+//                    horizontal weights as two signed byte digits, and the three digit products are summed exactly
+//                    in i32.  Waves add their partial sums into a shared [16][outputs] LDS tile (integer adds
+//                    commute, so the result does not depend on the order); rounding, clamping and the store follow.
+//
+// Arithmetic: vertical weights are the reference's f32 weights split into two f16 terms, summed in f32 by the matrix
+// unit (error < 2^-12 of a pixel step); horizontal weights are rounded to 2^-hs (hs = 15..17, sums forced to exactly
+// 1) and the intermediate to 1/64.  Worst case |error| < 0.1 before the final rounding, so every output byte is
+// within 1 of the reference's (tests/test_mfma_resample.py measures the rate of such off-by-one bytes).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "fl_tables.h"
+#include "fl_types.h"
+
+namespace fl {
+
+constexpr uint32_t kMfmaWaves = 8;          // waves per workgroup
+constexpr uint32_t kMfmaKRows = 32;         // source rows per K-block
+constexpr uint32_t kMfmaWaveCols = 256;     // byte columns per wave
+constexpr uint32_t kMfmaStripBytes = kMfmaWaves * kMfmaWaveCols;
+constexpr uint32_t kMfmaMaxStripPx = 128;   // output pixels per strip (bounds the LDS output tiles)
+constexpr uint32_t kMfmaVScaleLog2 = 8;     // vertical weights are stored times 2^8 (keeps the low f16 term normal)
+constexpr uint32_t kMfmaXFracBits = 6;      // intermediate rows: (value - 128) * 64 as i16
+constexpr uint32_t kMfmaLdsOperands = 40;   // horizontal operands (1 KB each) kept in LDS when a strip has no more distinct ones
+
+// One workgroup.
+struct alignas(16) MfmaItem {
+    uint32_t job;
+    uint32_t vplan_off;    // arena word offset of MfmaVPlan
+    uint32_t strip_off;    // arena word offset of MfmaStrip
+    uint32_t tile0, tile1; // output tiles [tile0, tile1) of this band
+    uint32_t kb0, kb1;     // K-blocks walked [kb0, kb1)
+    uint32_t flags;        // ITEM_* letterbox duties
+};
+
+// Vertical plan of one (axis, kept rows) pair.  All offsets are arena word offsets.
+//   kb_meta[nkb]   per K-block: bits 0-15 = tile that is complete after it (0xffff: none), bit 16/17 = set 0/1 has weights in it
+//   kb_w[nkb][2 sets][2 terms][64 lanes] x 16 bytes: B operand of v_mfma_f32_16x16x32_f16: lane 16g + n holds the
+//                  weights of source rows 32 s + 8 g .. + 7 towards output row 16 tile + n as 8 f16
+struct MfmaVPlan {
+    uint32_t ntiles, nkb;
+    uint32_t y0, rows;     // first kept output row (resized coordinates) and how many
+    uint32_t meta_off, w_off;
+    uint32_t pad0, pad1;
+};
+
+// Horizontal plan of one strip.
+//   ctab[8 waves][4 chunks][3]: { first output index of the tile (may be negative or past nout: lanes outside go to the
+//                  dummy column), operand index of the high weight digit, of the low digit }; operand index 0xffffffff = tile unused
+//   ops[n_ops][64 lanes] x 16 bytes: B operands of v_mfma_i32_16x16x64_i8, deduplicated
+struct MfmaStrip {
+    uint32_t x0, x1;       // output columns [x0, x1) in resized coordinates
+    uint32_t byte0;        // first source byte of the strip inside a row (multiple of 16)
+    uint32_t nout;         // (x1 - x0) * 3
+    uint32_t hs;           // horizontal weights are scaled by 2^hs
+    uint32_t n_ops;
+    uint32_t ctab_off, ops_off;
+};
+
+struct HostMfmaPlan {
+    bool ok = false;
+    std::vector<uint32_t> vmeta, vw;     // MfmaVPlan tables
+    uint32_t ntiles = 0, nkb = 0, y0 = 0, rows = 0;
+    struct Tile { uint32_t kb_first, kb_last; };
+    std::vector<Tile> tiles;
+    struct Strip { MfmaStrip hdr; std::vector<int32_t> ctab; std::vector<uint32_t> ops; };
+    std::vector<Strip> strips;
+};
+
+// Builds the tables for output rows [cy, cy+ch) x columns [cx, cx+cw) of an Rgb8 picture (3 bytes per pixel).
+// ok = false when the geometry does not fit the kernel (more than two tiles alive in a K-block, horizontal windows
+// that touch more than three 16-output tiles per 64-byte chunk, weights too large for the digit planes).
+void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out);
+
+struct LaunchMfma {
+    const Job *jobs;
+    const MfmaItem *items;
+    const uint32_t *arena;
+    uint32_t nitems;
+    uint32_t letterbox;
+    uint32_t ops_in_lds;   // every strip of the launch has <= kMfmaLdsOperands distinct operands
+    uint32_t max_nout;
+};
+size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds);
+hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st);
+
+} // namespace fl

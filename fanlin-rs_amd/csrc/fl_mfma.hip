@@ -1,0 +1,261 @@
+// fl_mfma.hip -- the matrix-pipe resample kernel for gfx950 (design and arithmetic: fl_mfma.h).
+// Reference: image 0.25.6 imageops/sample.rs vertical_sample + horizontal_sample behind DynamicImage::resize_exact
+// (src/handler.rs:229-247 of the reference calls resize / resize_to_fill).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "fl_mfma.h"
+
+namespace fl {
+
+namespace {
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t THREADS = kMfmaWaves * 64;
+constexpr uint32_t RING_BYTES = kMfmaKRows * kMfmaWaveCols; // one K-block of one wave
+constexpr uint32_t CNT_BYTES = 16;                          // add_cnt[2], conv_cnt[2]
+
+extern __shared__ __attribute__((aligned(16))) uint8_t mfma_lds[];
+
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0)
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); } // lgkmcnt(0)
+
+__device__ __forceinline__ uint32_t lds_counter(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// LB: the destination is Rgba8 with the picture placed on a fill frame.  HLDS: the strip's horizontal operands sit in LDS.
+template <bool LB, bool HLDS>
+__global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
+                                                                   const uint32_t *__restrict__ arena, uint32_t ot_words)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, g = lane >> 4, i = lane & 15u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const MfmaItem it = items[blockIdx.x];
+    const Job jb = jobs[it.job];
+    const MfmaVPlan vp = *reinterpret_cast<const MfmaVPlan *>(arena + it.vplan_off);
+    const MfmaStrip sp = *reinterpret_cast<const MfmaStrip *>(arena + it.strip_off);
+    const uint32_t np = sp.nout + 1u; // words per output-tile row: the outputs and one dummy column
+
+    uint32_t *otile = reinterpret_cast<uint32_t *>(mfma_lds);
+    uint32_t *add_cnt = reinterpret_cast<uint32_t *>(mfma_lds + 2u * ot_words * 4u);
+    uint32_t *conv_cnt = add_cnt + 2;
+    constexpr uint32_t OPS_BYTES = HLDS ? kMfmaLdsOperands * 1024u : 0u;
+    const u32x4 *ops_lds = reinterpret_cast<const u32x4 *>(mfma_lds + 2u * ot_words * 4u + CNT_BYTES);
+    uint8_t *ring = mfma_lds + 2u * ot_words * 4u + CNT_BYTES + OPS_BYTES + wave * RING_BYTES;
+    const u32x4 *ops_glb = reinterpret_cast<const u32x4 *>(arena + sp.ops_off);
+
+    for (uint32_t k = tid; k < 2u * ot_words + CNT_BYTES / 4u; k += THREADS) otile[k] = 0u;
+    if (HLDS)
+        for (uint32_t k = tid; k < sp.n_ops * 64u; k += THREADS) reinterpret_cast<u32x4 *>(mfma_lds + 2u * ot_words * 4u + CNT_BYTES)[k] = ops_glb[k];
+
+    // Letterbox frame: every workgroup paints the part next to its own band and strip (same split as the streaming kernel).
+    const uint32_t y_first = vp.y0 + 16u * it.tile0, y_end = min(vp.y0 + 16u * it.tile1, vp.y0 + vp.rows);
+    if (LB) {
+        const uint32_t dx0 = sp.x0 == jb.cx ? 0u : jb.ox + sp.x0 - jb.cx;
+        const uint32_t dx1 = sp.x1 == jb.cx + jb.cw ? jb.dw : jb.ox + sp.x1 - jb.cx;
+        const uint32_t dy0 = y_first == jb.cy ? 0u : jb.oy + y_first - jb.cy;
+        const uint32_t dy1 = y_end == jb.cy + jb.ch ? jb.dh : jb.oy + y_end - jb.cy;
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(jb.dst);
+        const uint32_t wcols = dx1 - dx0;
+        const uint32_t top_rows = dy0 < jb.oy ? min(dy1, jb.oy) - dy0 : 0u;
+        for (uint32_t k = tid; k < top_rows * wcols; k += THREADS) d32[(dy0 + k / wcols) * jb.dw + dx0 + k % wcols] = jb.fill;
+        const uint32_t by0 = max(dy0, jb.oy + jb.ch);
+        const uint32_t bot_rows = dy1 > by0 ? dy1 - by0 : 0u;
+        for (uint32_t k = tid; k < bot_rows * wcols; k += THREADS) d32[(by0 + k / wcols) * jb.dw + dx0 + k % wcols] = jb.fill;
+        const uint32_t my0 = max(dy0, jb.oy), my1 = min(dy1, jb.oy + jb.ch);
+        const uint32_t mrows = my1 > my0 ? my1 - my0 : 0u;
+        const uint32_t lcols = dx0 < jb.ox ? min(dx1, jb.ox) - dx0 : 0u;
+        for (uint32_t k = tid; k < mrows * lcols; k += THREADS) d32[(my0 + k / lcols) * jb.dw + dx0 + k % lcols] = jb.fill;
+        const uint32_t rx0 = max(dx0, jb.ox + jb.cw);
+        const uint32_t rcols = dx1 > rx0 ? dx1 - rx0 : 0u;
+        for (uint32_t k = tid; k < mrows * rcols; k += THREADS) d32[(my0 + k / rcols) * jb.dw + rx0 + k % rcols] = jb.fill;
+    }
+    __syncthreads();
+
+    // ---- source rows -> LDS ---------------------------------------------------------------------------------------
+    // Load instruction u of a K-block (u = 0..7): row octet u >> 1, column half u & 1.  Lane: row q = lane & 7 of the
+    // octet, 16-byte column tile t = lane >> 3 of the half; the data lands lane-linear, i.e. as eight [8 rows][16 bytes]
+    // tiles of 128 bytes, which is the block ds_read_b64_tr_b8 transposes.  Odd octets swap neighbouring tiles so that
+    // the two 16-lane groups of a transposed read hit different banks.
+    const uint32_t pitch = jb.sw * 3u;
+    const uint32_t lq = lane & 7u, lt = lane >> 3;
+    uint32_t coff[2][2]; // [column half][octet parity]: byte offset inside the row, clamped so that 16 bytes stay inside it
+#pragma unroll
+    for (uint32_t hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (uint32_t par = 0; par < 2; ++par)
+            coff[hh][par] = min(sp.byte0 + wave * kMfmaWaveCols + hh * 128u + ((lt ^ par) * 16u), pitch - 16u);
+    const uint32_t last_row = jb.sh - 1u;
+    auto issue = [&](uint32_t s) {
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t ro = u >> 1, hh = u & 1u;
+            const uint32_t row = min(s * kMfmaKRows + ro * 8u + lq, last_row);
+            const uint8_t *gp = jb.src + (size_t)row * pitch + coff[hh][ro & 1u];
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)gp, (void __attribute__((address_space(3))) *)(ring + u * 1024u), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) acc[s2][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const uint32_t traddr = (i >> 1) * 16u + (i & 1u) * 8u;
+    const u32x4 *vw = reinterpret_cast<const u32x4 *>(arena + vp.w_off);
+    const int32_t *ctab = reinterpret_cast<const int32_t *>(arena + sp.ctab_off) + wave * 36u;
+    const uint32_t hs = sp.hs;
+    const int32_t round_add = (int32_t)((128u << hs) + (1u << (hs + kMfmaXFracBits - 1u)));
+    const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
+    const uint32_t npx = sp.x1 - sp.x0;
+
+    // One wave's share (2 of the 16 rows) of a finished output tile: i32 sums -> bytes -> destination.
+    auto convert_rows = [&](uint32_t tile, uint32_t buf) {
+        uint32_t *ot = otile + buf * ot_words;
+#pragma unroll
+        for (uint32_t rr = 0; rr < 2; ++rr) {
+            const uint32_t row = 2u * wave + rr;
+            const uint32_t oy = vp.y0 + 16u * tile + row;
+            const bool live = 16u * tile + row < vp.rows;
+            for (uint32_t xo = lane; xo < npx; xo += 64u) {
+                uint32_t *o = ot + row * np + 3u * xo;
+                uint32_t c8[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int32_t q = ((int32_t)o[c] + round_add) >> (hs + kMfmaXFracBits);
+                    c8[c] = (uint32_t)min(max(q + 128, 0), 255);
+                    o[c] = 0u;
+                }
+                if (live) {
+                    if (LB) reinterpret_cast<uint32_t *>(jb.dst)[pix_base + oy * jb.dw + xo] = c8[0] | (c8[1] << 8) | (c8[2] << 16) | 0xff000000u;
+                    else {
+                        uint8_t *p = jb.dst + (size_t)(pix_base + oy * jb.dw + xo) * 3u;
+                        p[0] = (uint8_t)c8[0]; p[1] = (uint8_t)c8[1]; p[2] = (uint8_t)c8[2];
+                    }
+                }
+            }
+        }
+    };
+
+    issue(it.kb0);
+    for (uint32_t s = it.kb0; s < it.kb1; ++s) {
+        const uint32_t meta = __builtin_amdgcn_readfirstlane(arena[vp.meta_off + s]);
+        u32x4 wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wv[k] = vw[(s * 4u + k) * 64u + lane];
+        wait_vm0();
+        v2i raw[16];
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) {
+            const uint32_t off = (2u * g + (ct >> 3)) * 1024u + (((ct & 7) ^ (g & 1u)) * 128u) + traddr;
+            raw[ct] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + off));
+        }
+        wait_lgkm0();
+        if (s + 1u < it.kb1) issue(s + 1u);
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) {
+            u32x4 a;
+            a[0] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][0], 0x04010400u); // f16 pairs: 0x6400 | byte = 1024 + byte
+            a[1] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][0], 0x04030402u);
+            a[2] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][1], 0x04010400u);
+            a[3] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][1], 0x04030402u);
+            const f16x8 av = __builtin_bit_cast(f16x8, a);
+            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[0]), acc[0][ct], 0, 0, 0);
+            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[1]), acc[0][ct], 0, 0, 0);
+            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[2]), acc[1][ct], 0, 0, 0);
+            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[3]), acc[1][ct], 0, 0, 0);
+        }
+        const uint32_t ft = meta & 0xffffu;
+        if (ft != 0xffffu) { // output tile ft is complete
+            const uint32_t set = ft & 1u;
+            const bool mine = ft >= it.tile0 && ft < it.tile1;
+            if (mine) {
+                const uint32_t li = ft - it.tile0, buf = li & 1u;
+                uint32_t *ot = otile + buf * ot_words;
+                // the tile that used this buffer two tiles ago must have been converted by every wave
+                while (lds_counter(&conv_cnt[buf]) < kMfmaWaves * (li >> 1)) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    u32x4 ahi, alo;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const f32x4 v = set ? acc[1][4 * c + a] : acc[0][4 * c + a];
+                        // acc = 256 * (1024 + value); 1.5 * 2^23 - 64 * (1024 + 128) = 12509184: the sum's low 16 bits are
+                        // round((value - 128) * 64) in two's complement
+                        const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[0], 0.25f, 12509184.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[1], 0.25f, 12509184.0f)),
+                                       x2 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[2], 0.25f, 12509184.0f)), x3 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[3], 0.25f, 12509184.0f));
+                        const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x3, x2, 0x05010400u); // (x0.b0, x1.b0, x0.b1, x1.b1)
+                        alo[a] = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u; // low bytes, as signed value - 128
+                        ahi[a] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);               // high bytes (signed)
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int32_t *e = ctab + (c * 3 + t) * 3;
+                        const int32_t obase = __builtin_amdgcn_readfirstlane(e[0]);
+                        const uint32_t i1 = __builtin_amdgcn_readfirstlane((uint32_t)e[1]), i0 = __builtin_amdgcn_readfirstlane((uint32_t)e[2]);
+                        if (i1 == 0xffffffffu) continue;
+                        const u32x4 h1 = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
+                        const u32x4 h0 = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
+                        i32x4 t2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, ahi), __builtin_bit_cast(i32x4, h1), i32x4{0, 0, 0, 0}, 0, 0, 0);
+                        i32x4 t1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, ahi), __builtin_bit_cast(i32x4, h0), i32x4{0, 0, 0, 0}, 0, 0, 0);
+                        t1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, alo), __builtin_bit_cast(i32x4, h1), t1, 0, 0, 0);
+                        i32x4 t0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, alo), __builtin_bit_cast(i32x4, h0), i32x4{0, 0, 0, 0}, 0, 0, 0);
+                        const uint32_t o = (uint32_t)(obase + (int32_t)i);
+                        const uint32_t col = o < sp.nout ? o : sp.nout; // lanes outside the strip's outputs add into the dummy column
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t p = ((uint32_t)t2[r] << 16) + ((uint32_t)t1[r] << 8) + (uint32_t)t0[r];
+                            __hip_atomic_fetch_add(&ot[(4u * g + r) * np + col], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+                if (lane == 0) __hip_atomic_fetch_add(&add_cnt[buf], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (li >= 1u) { // this wave's two rows of the previous tile, once every wave has added its sums
+                    const uint32_t pb = buf ^ 1u;
+                    while (lds_counter(&add_cnt[pb]) < kMfmaWaves * (((li - 1u) >> 1) + 1u)) __builtin_amdgcn_s_sleep(1);
+                    convert_rows(ft - 1u, pb);
+                    if (lane == 0) __hip_atomic_fetch_add(&conv_cnt[pb], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct) { if (set) acc[1][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; else acc[0][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+        }
+    }
+    __syncthreads(); // every wave has added its sums of the last tile
+    convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
+}
+
+} // namespace
+
+size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds)
+{
+    return (size_t)2 * 16 * (max_nout + 1u) * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u) + kMfmaWaves * RING_BYTES;
+}
+
+template <bool LB, bool HLDS>
+static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
+{
+    const size_t lds = mfma_lds_bytes(m.max_nout, HLDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<LB, HLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    resample_mfma_kernel<LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (m.max_nout + 1u));
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st)
+{
+    if (m.nitems == 0) return hipSuccess;
+    if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<true, true>(m, st) : launch_mfma_t<true, false>(m, st);
+    return m.ops_in_lds ? launch_mfma_t<false, true>(m, st) : launch_mfma_t<false, false>(m, st);
+}
+
+} // namespace fl

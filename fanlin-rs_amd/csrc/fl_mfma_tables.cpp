@@ -1,0 +1,200 @@
+// fl_mfma_tables.cpp -- host-side tables of the matrix-pipe resample kernel (layout: fl_mfma.h).
+// The weights themselves come from build_axis (image 0.25.6 imageops/sample.rs, evaluated in f32 as the reference does);
+// this file only re-arranges them as MFMA operands.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+
+#include "fl_mfma.h"
+
+namespace fl {
+
+namespace {
+
+// IEEE binary16, round to nearest even (host side; the device consumes the bits)
+uint16_t f16_bits(double v)
+{
+    const float f = (float)v;
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 255u) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e; // 14..24
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r; // may carry into the exponent: still the right value
+    return (uint16_t)(sign | r);
+}
+
+double f16_value(uint16_t h)
+{
+    const int s = (h & 0x8000u) ? -1 : 1;
+    const int e = (h >> 10) & 31;
+    const int m = h & 0x3ff;
+    if (e == 0) return s * ldexp((double)m, -24);
+    return s * ldexp((double)(m | 0x400), e - 25);
+}
+
+} // namespace
+
+void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out)
+{
+    out = HostMfmaPlan();
+    if (cw == 0 || ch == 0 || cy + ch > v.out_size || cx + cw > h.out_size) return;
+    const uint32_t sh = v.in_size, sw = h.in_size;
+    // ---- vertical: tiles of 16 output rows, K-blocks of 32 source rows --------------------------------------------
+    const uint32_t NT = (ch + 15u) / 16u, NKB = (sh + kMfmaKRows - 1u) / kMfmaKRows;
+    if (NT >= 0xffffu) return;
+    std::vector<uint32_t> A(NT), B(NT);
+    for (uint32_t j = 0; j < NT; ++j) {
+        uint32_t a = 0xffffffffu, b = 0;
+        for (uint32_t n = 0; n < 16 && 16 * j + n < ch; ++n) {
+            const uint32_t oy = cy + 16 * j + n;
+            a = std::min(a, v.left[oy]);
+            b = std::max(b, v.left[oy] + v.count[oy]);
+        }
+        A[j] = a; B[j] = b;
+        if (j && (A[j] < A[j - 1] || B[j] < B[j - 1])) return; // windows must move down monotonically
+    }
+    out.tiles.resize(NT);
+    for (uint32_t j = 0; j < NT; ++j) out.tiles[j] = {A[j] / kMfmaKRows, (B[j] - 1u) / kMfmaKRows};
+    for (uint32_t j = 0; j + 2 < NT; ++j)
+        if (out.tiles[j + 2].kb_first <= out.tiles[j].kb_last) return; // the accumulator set of tile j is free again before tile j + 2 starts
+    for (uint32_t j = 0; j + 1 < NT; ++j)
+        if (out.tiles[j + 1].kb_last == out.tiles[j].kb_last) return;  // one tile finishes per K-block at most
+    out.vmeta.assign(NKB, 0xffffu);
+    out.vw.assign((size_t)NKB * 2 * 2 * 64 * 4, 0u);
+    for (uint32_t j = 0; j < NT; ++j) {
+        const uint32_t set = j & 1u;
+        for (uint32_t s = out.tiles[j].kb_first; s <= out.tiles[j].kb_last; ++s) {
+            out.vmeta[s] |= 1u << (16 + set);
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                const uint32_t g = lane >> 4, n = lane & 15u;
+                if (16 * j + n >= ch) continue;
+                const uint32_t oy = cy + 16 * j + n;
+                for (uint32_t jj = 0; jj < 8; ++jj) {
+                    const uint32_t r = kMfmaKRows * s + 8 * g + jj;
+                    if (r < v.left[oy] || r >= v.left[oy] + v.count[oy]) continue;
+                    const double w = ldexp((double)v.weights[v.woff[oy] + (r - v.left[oy])], (int)kMfmaVScaleLog2);
+                    const uint16_t wa = f16_bits(w), wb = f16_bits(w - f16_value(wa));
+                    const size_t base = ((((size_t)s * 2 + set) * 2) * 64 + lane) * 4 + jj / 2;
+                    out.vw[base] |= (uint32_t)wa << (16 * (jj & 1u));
+                    out.vw[base + 64 * 4] |= (uint32_t)wb << (16 * (jj & 1u));
+                }
+            }
+        }
+        out.vmeta[out.tiles[j].kb_last] = (out.vmeta[out.tiles[j].kb_last] & 0xffff0000u) | j;
+    }
+    out.ntiles = NT; out.nkb = NKB; out.y0 = cy; out.rows = ch;
+
+    // ---- horizontal: strips of <= 2048 source bytes -----------------------------------------------------------------
+    float maxw = 0.0f;
+    for (uint32_t x = cx; x < cx + cw; ++x)
+        for (uint32_t k = 0; k < h.count[x]; ++k) maxw = std::max(maxw, fabsf(h.weights[h.woff[x] + k]));
+    int hs = 17;
+    while (hs >= 14 && ldexp((double)maxw, hs) > 32000.0) --hs;
+    if (hs < 14) return;
+    // fewest equal strips that fit
+    uint32_t per = 0;
+    for (uint32_t ns = std::max(1u, (cw + kMfmaMaxStripPx - 1u) / kMfmaMaxStripPx); ns <= cw; ++ns) {
+        per = (cw + ns - 1u) / ns;
+        bool fits = true;
+        for (uint32_t x0 = cx; x0 < cx + cw && fits; x0 += per) {
+            const uint32_t x1 = std::min(x0 + per, cx + cw);
+            uint32_t L = 0xffffffffu, R = 0;
+            for (uint32_t x = x0; x < x1; ++x) { L = std::min(L, h.left[x]); R = std::max(R, h.left[x] + h.count[x]); }
+            const uint32_t byte0 = (3u * L) / 16u * 16u;
+            if (3u * R - byte0 > kMfmaStripBytes) fits = false;
+        }
+        if (fits) break;
+        per = 0;
+    }
+    if (!per) return;
+    // quantised weights, one vector per output column; the largest tap absorbs the rounding so that the sum is exactly 2^hs
+    std::vector<std::vector<int32_t>> hq(cw);
+    for (uint32_t x = cx; x < cx + cw; ++x) {
+        std::vector<int32_t> &q = hq[x - cx];
+        q.resize(h.count[x]);
+        int64_t sum = 0;
+        uint32_t big = 0;
+        for (uint32_t k = 0; k < h.count[x]; ++k) {
+            q[k] = (int32_t)llround(ldexp((double)h.weights[h.woff[x] + k], hs));
+            sum += q[k];
+            if (abs(q[k]) > abs(q[big])) big = k;
+        }
+        q[big] += (int32_t)(((int64_t)1 << hs) - sum);
+        if (abs(q[big]) > 32639) return;
+    }
+    for (uint32_t x0 = cx; x0 < cx + cw; x0 += per) {
+        HostMfmaPlan::Strip S;
+        const uint32_t x1 = std::min(x0 + per, cx + cw);
+        uint32_t L = 0xffffffffu;
+        for (uint32_t x = x0; x < x1; ++x) L = std::min(L, h.left[x]);
+        S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (3u * L) / 16u * 16u; S.hdr.nout = (x1 - x0) * 3u; S.hdr.hs = (uint32_t)hs;
+        const int32_t nout = (int32_t)S.hdr.nout;
+        S.ctab.assign(kMfmaWaves * 4 * 3 * 3, -1);
+        std::map<std::string, uint32_t> seen;
+        auto weight_of = [&](int32_t o, uint32_t col) -> int32_t { // weight of strip byte column `col` in output o
+            if (o < 0 || o >= nout) return 0;
+            const uint32_t abs_b = S.hdr.byte0 + col;
+            if (abs_b >= 3u * sw) return 0;
+            const uint32_t px = abs_b / 3u, chn = abs_b % 3u, x = x0 + (uint32_t)o / 3u;
+            if ((uint32_t)o % 3u != chn || px < h.left[x] || px >= h.left[x] + h.count[x]) return 0;
+            return hq[x - cx][px - h.left[x]];
+        };
+        for (uint32_t w = 0; w < kMfmaWaves; ++w)
+            for (uint32_t c = 0; c < 4; ++c) {
+                const uint32_t col0 = kMfmaWaveCols * w + 64u * c;
+                int32_t omin = 0x7fffffff, omax = -1;
+                for (int32_t o = 0; o < nout; ++o)
+                    for (uint32_t col = col0; col < col0 + 64u; ++col)
+                        if (weight_of(o, col) != 0) { omin = std::min(omin, o); omax = std::max(omax, o); break; }
+                if (omax < 0) continue;
+                const uint32_t nt = (uint32_t)(omax - omin) / 16u + 1u;
+                if (nt > 3) return;
+                for (uint32_t t = 0; t < nt; ++t) {
+                    const int32_t base = omin + 16 * (int32_t)t;
+                    std::string op[2] = {std::string(1024, '\0'), std::string(1024, '\0')};
+                    for (uint32_t lane = 0; lane < 64; ++lane) {
+                        const uint32_t g = lane >> 4, n = lane & 15u;
+                        for (uint32_t a = 0; a < 4; ++a)
+                            for (uint32_t r = 0; r < 4; ++r) {
+                                const int32_t q = weight_of(base + (int32_t)n, col0 + 16u * a + 4u * g + r);
+                                const int32_t lo = ((q + 128) & 255) - 128, hi = (q - lo) / 256;
+                                op[0][lane * 16 + 4 * a + r] = (char)(int8_t)hi;
+                                op[1][lane * 16 + 4 * a + r] = (char)(int8_t)lo;
+                            }
+                    }
+                    int32_t *e = &S.ctab[((w * 4 + c) * 3 + t) * 3];
+                    e[0] = base;
+                    for (int d = 0; d < 2; ++d) {
+                        auto it = seen.find(op[d]);
+                        if (it == seen.end()) {
+                            it = seen.emplace(op[d], (uint32_t)seen.size()).first;
+                            S.ops.resize((size_t)seen.size() * 256);
+                            memcpy(S.ops.data() + (size_t)it->second * 256, op[d].data(), 1024);
+                        }
+                        e[1 + d] = (int32_t)it->second;
+                    }
+                }
+            }
+        S.hdr.n_ops = (uint32_t)seen.size();
+        out.strips.push_back(std::move(S));
+    }
+    out.ok = true;
+}
+
+} // namespace fl

@@ -186,6 +186,7 @@ typedef struct flgpu_stats {
     uint64_t jpeg_sources;        /* FLGPU_IMG_JPEG_SOURCE pictures decoded on the device */
     uint64_t jpeg_file_bytes;     /* their file bytes ... */
     uint64_t jpeg_upload_bytes;   /* ... and what crossed PCIe for them (coefficient blobs) */
+    uint64_t mfma_launches;       /* of resample_launches: launches of the matrix-pipe kernel (fl_mfma.hip) */
 } flgpu_stats;
 
 typedef struct flgpu_ctx flgpu_ctx;
