@@ -240,7 +240,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     const char *env_generic = getenv("FLGPU_FORCE_GENERIC");
     const char *env_bands = getenv("FLGPU_FORCE_BANDS");
     const bool force_generic = env_generic && env_generic[0] == '1';
-    static const bool no_mfma = [] { const char *e = getenv("FLGPU_NO_MFMA"); return e && e[0] == '1'; }(); // tests / A-B runs: keep the streaming kernel
+    const char *env_no_mfma = getenv("FLGPU_NO_MFMA"); // tests / A-B runs: keep the streaming kernel (read per batch, so a test can flip it)
+    const bool no_mfma = env_no_mfma && env_no_mfma[0] == '1';
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool full = false;
         size_t n_resample = 0;
@@ -264,7 +265,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
                 else if (n_resample < 128) nbands = (uint32_t)std::min<size_t>(16, (256 + n_resample * 3 - 1) / (n_resample * 3));
                 const MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, nbands);
-                if (c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
+                if (mp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
                 if (mp->ok) { w.s1 = S1_MFMA; w.mplan = mp; continue; }
             }
             if (stream_supported(w.cs, w.pre) && aligned && !force_generic) {

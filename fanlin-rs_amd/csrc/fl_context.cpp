@@ -117,6 +117,17 @@ const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &v
     HostMfmaPlan hp;
     build_mfma_plan(va, ha, cx, cy, cw, ch, hp);
     bool ok = hp.ok;
+    if (ok) { // all or nothing: whether a geometry gets this kernel must not depend on how full the arena happens to be
+        size_t need = sizeof(MfmaVPlan) / 4 + hp.vmeta.size() + hp.vw.size() + 64;
+        for (auto &S : hp.strips) need += sizeof(MfmaStrip) / 4 + S.ctab.size() + S.ops.size() + 64;
+        if (c->h_arena.size() + need + 2048 > c->arena_cap_words) {
+            static thread_local MfmaPlan full_plan;
+            full_plan = MfmaPlan();
+            full_plan.arena_full = need + 4096 <= c->arena_cap_words; // (tables larger than the whole arena: the geometry never gets the kernel)
+            if (full_plan.arena_full) return &full_plan;
+            ok = false;
+        }
+    }
     uint32_t vplan_off = 0;
     if (ok) {
         MfmaVPlan vp{};
@@ -152,6 +163,12 @@ const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &v
     }
     plan.ok = ok;
     if (!ok) plan.items.clear();
+    if (getenv("FLGPU_DEBUG_MFMA")) {
+        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, %zu items, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d;",
+                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, plan.items.size(), hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds);
+        for (auto &S : hp.strips) fprintf(stderr, " strip [%u,%u) byte0 %u hs %u ops %u", S.hdr.x0, S.hdr.x1, S.hdr.byte0, S.hdr.hs, S.hdr.n_ops);
+        fprintf(stderr, "\n");
+    }
     auto res = c->mfma_plans.emplace(key, std::move(plan));
     return &res.first->second;
 }

@@ -85,6 +85,7 @@ struct MfmaPlan {
     std::vector<MfmaItem> items;
     uint32_t max_nout = 0;
     bool ops_in_lds = false;
+    bool arena_full = false; // the tables did not fit what is left of the arena: not cached, the caller resets the arena and plans again
 };
 
 struct PinBlock {

@@ -57,7 +57,8 @@ struct MfmaVPlan {
     uint32_t ntiles, nkb;
     uint32_t y0, rows;     // first kept output row (resized coordinates) and how many
     uint32_t meta_off, w_off;
-    uint32_t pad0, pad1;
+    uint32_t pad0;
+    uint32_t pad1;
 };
 
 // Horizontal plan of one strip.

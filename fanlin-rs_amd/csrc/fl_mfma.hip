@@ -21,14 +21,25 @@ constexpr uint32_t THREADS = kMfmaWaves * 64;
 constexpr uint32_t RING_BYTES = kMfmaKRows * kMfmaWaveCols; // one K-block of one wave
 constexpr uint32_t CNT_BYTES = 16;                          // add_cnt[2], conv_cnt[2]
 
+__shared__ __attribute__((aligned(16))) uint8_t mfma_ring[kMfmaWaves * RING_BYTES]; // the rows' landing zone (static), everything else is dynamic
 extern __shared__ __attribute__((aligned(16))) uint8_t mfma_lds[];
 
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0)
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); } // lgkmcnt(0)
 
+// Counters that order the waves' traffic on the LDS output tiles.  Everything they guard lives in LDS, so the fences name
+// the local address space only: a plain workgroup-scope acquire or release also drains vmcnt, i.e. waits for the K-block
+// that has just been requested from HBM -- the one latency this kernel is built to hide.
 __device__ __forceinline__ uint32_t lds_counter(const uint32_t *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    return v;
+}
+__device__ __forceinline__ void lds_counter_bump(uint32_t *p)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // LB: the destination is Rgba8 with the picture placed on a fill frame.  HLDS: the strip's horizontal operands sit in LDS.
@@ -36,6 +47,13 @@ template <bool LB, bool HLDS>
 __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
                                                                    const uint32_t *__restrict__ arena, uint32_t ot_words)
 {
+    // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh): 1 = no horizontal MFMAs / LDS adds, 2 = no conversion of
+    // finished tiles, 32 = conversion without its global stores, 4 = no horizontal stage at all, 8 = no vertical MFMAs
+#ifdef FL_ABLATE
+    constexpr uint32_t ablate = FL_ABLATE;
+#else
+    constexpr uint32_t ablate = 0;
+#endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u, g = lane >> 4, i = lane & 15u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const MfmaItem it = items[blockIdx.x];
@@ -47,9 +65,8 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     uint32_t *otile = reinterpret_cast<uint32_t *>(mfma_lds);
     uint32_t *add_cnt = reinterpret_cast<uint32_t *>(mfma_lds + 2u * ot_words * 4u);
     uint32_t *conv_cnt = add_cnt + 2;
-    constexpr uint32_t OPS_BYTES = HLDS ? kMfmaLdsOperands * 1024u : 0u;
     const u32x4 *ops_lds = reinterpret_cast<const u32x4 *>(mfma_lds + 2u * ot_words * 4u + CNT_BYTES);
-    uint8_t *ring = mfma_lds + 2u * ot_words * 4u + CNT_BYTES + OPS_BYTES + wave * RING_BYTES;
+    uint8_t *ring = mfma_ring + wave * RING_BYTES;
     const u32x4 *ops_glb = reinterpret_cast<const u32x4 *>(arena + sp.ops_off);
 
     for (uint32_t k = tid; k < 2u * ot_words + CNT_BYTES / 4u; k += THREADS) otile[k] = 0u;
@@ -94,13 +111,17 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         for (uint32_t par = 0; par < 2; ++par)
             coff[hh][par] = min(sp.byte0 + wave * kMfmaWaveCols + hh * 128u + ((lt ^ par) * 16u), pitch - 16u);
     const uint32_t last_row = jb.sh - 1u;
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring);
     auto issue = [&](uint32_t s) {
 #pragma unroll
         for (uint32_t u = 0; u < 8; ++u) {
             const uint32_t ro = u >> 1, hh = u & 1u;
             const uint32_t row = min(s * kMfmaKRows + ro * 8u + lq, last_row);
             const uint8_t *gp = jb.src + (size_t)row * pitch + coff[hh][ro & 1u];
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)gp, (void __attribute__((address_space(3))) *)(ring + u * 1024u), 16, 0, 0);
+            // (inline asm: hipcc orders EVERY later LDS access behind a global_load_lds it knows about -- s_waitcnt vmcnt(0) in
+            // front of the first counter or operand read -- which would park the whole horizontal stage behind the K-block just
+            // requested.  The transfers are waited for by hand, wait_vm0() in front of the transposed reads.)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gp), "s"(ring_lds + u * 1024u) : "memory");
         }
     };
 
@@ -112,7 +133,13 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 
     const uint32_t traddr = (i >> 1) * 16u + (i & 1u) * 8u;
     const u32x4 *vw = reinterpret_cast<const u32x4 *>(arena + vp.w_off);
-    const int32_t *ctab = reinterpret_cast<const int32_t *>(arena + sp.ctab_off) + wave * 36u;
+    // this wave's 4 chunks x 3 tiles x { first output, operand of the high digit, of the low digit }, kept in SGPRs
+    int32_t ctab[36];
+    {
+        const int32_t *cp = reinterpret_cast<const int32_t *>(arena + sp.ctab_off) + wave * 36u;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) ctab[k] = __builtin_amdgcn_readfirstlane(cp[k]);
+    }
     const uint32_t hs = sp.hs;
     const int32_t round_add = (int32_t)((128u << hs) + (1u << (hs + kMfmaXFracBits - 1u)));
     const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     c8[c] = (uint32_t)min(max(q + 128, 0), 255);
                     o[c] = 0u;
                 }
-                if (live) {
+                if (live && !(ablate & 32u)) {
                     if (LB) reinterpret_cast<uint32_t *>(jb.dst)[pix_base + oy * jb.dw + xo] = c8[0] | (c8[1] << 8) | (c8[2] << 16) | 0xff000000u;
                     else {
                         uint8_t *p = jb.dst + (size_t)(pix_base + oy * jb.dw + xo) * 3u;
@@ -146,6 +173,12 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         }
     };
 
+    auto do_convert = [&](uint32_t tile) __attribute__((always_inline)) {
+        const uint32_t li = tile - it.tile0, buf = li & 1u;
+        while (lds_counter(&add_cnt[buf]) < kMfmaWaves * ((li >> 1) + 1u)) __builtin_amdgcn_s_sleep(1);
+        if (!(ablate & 2u)) convert_rows(tile, buf);
+        if (lane == 0) lds_counter_bump(&conv_cnt[buf]);
+    };
     issue(it.kb0);
     for (uint32_t s = it.kb0; s < it.kb1; ++s) {
         const uint32_t meta = __builtin_amdgcn_readfirstlane(arena[vp.meta_off + s]);
@@ -169,6 +202,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             a[2] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][1], 0x04010400u);
             a[3] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][1], 0x04030402u);
             const f16x8 av = __builtin_bit_cast(f16x8, a);
+            if (ablate & 8u) { acc[0][ct][0] += (float)a[0]; acc[1][ct][1] += (float)a[1]; acc[0][ct][2] += (float)a[2]; acc[1][ct][3] += (float)a[3]; continue; }
             acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[0]), acc[0][ct], 0, 0, 0);
             acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[1]), acc[0][ct], 0, 0, 0);
             acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[2]), acc[1][ct], 0, 0, 0);
@@ -177,7 +211,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         const uint32_t ft = meta & 0xffffu;
         if (ft != 0xffffu) { // output tile ft is complete
             const uint32_t set = ft & 1u;
-            const bool mine = ft >= it.tile0 && ft < it.tile1;
+            const bool mine = ft >= it.tile0 && ft < it.tile1 && !(ablate & 4u);
             if (mine) {
                 const uint32_t li = ft - it.tile0, buf = li & 1u;
                 uint32_t *ot = otile + buf * ot_words;
@@ -199,10 +233,9 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     }
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        const int32_t *e = ctab + (c * 3 + t) * 3;
-                        const int32_t obase = __builtin_amdgcn_readfirstlane(e[0]);
-                        const uint32_t i1 = __builtin_amdgcn_readfirstlane((uint32_t)e[1]), i0 = __builtin_amdgcn_readfirstlane((uint32_t)e[2]);
-                        if (i1 == 0xffffffffu) continue;
+                        const int32_t obase = ctab[(c * 3 + t) * 3];
+                        const uint32_t i1 = (uint32_t)ctab[(c * 3 + t) * 3 + 1], i0 = (uint32_t)ctab[(c * 3 + t) * 3 + 2];
+                        if (i1 == 0xffffffffu || (ablate & 1u)) continue;
                         const u32x4 h1 = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
                         const u32x4 h0 = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
                         i32x4 t2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, ahi), __builtin_bit_cast(i32x4, h1), i32x4{0, 0, 0, 0}, 0, 0, 0);
@@ -218,27 +251,22 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                         }
                     }
                 }
-                if (lane == 0) __hip_atomic_fetch_add(&add_cnt[buf], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (li >= 1u) { // this wave's two rows of the previous tile, once every wave has added its sums
-                    const uint32_t pb = buf ^ 1u;
-                    while (lds_counter(&add_cnt[pb]) < kMfmaWaves * (((li - 1u) >> 1) + 1u)) __builtin_amdgcn_s_sleep(1);
-                    convert_rows(ft - 1u, pb);
-                    if (lane == 0) __hip_atomic_fetch_add(&conv_cnt[pb], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                if (lane == 0) lds_counter_bump(&add_cnt[buf]);
+                if (li >= 1u) do_convert(ft - 1u); // this wave's two rows of the previous tile: every wave has added its sums long ago
             }
 #pragma unroll
             for (int ct = 0; ct < 16; ++ct) { if (set) acc[1][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; else acc[0][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
         }
     }
     __syncthreads(); // every wave has added its sums of the last tile
-    convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
+    if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
 }
 
 } // namespace
 
 size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds)
 {
-    return (size_t)2 * 16 * (max_nout + 1u) * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u) + kMfmaWaves * RING_BYTES;
+    return (size_t)2 * 16 * (max_nout + 1u) * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u); // dynamic part; the rows' 64 KB are static
 }
 
 template <bool LB, bool HLDS>

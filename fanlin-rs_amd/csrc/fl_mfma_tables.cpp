@@ -71,12 +71,13 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t
     }
     out.tiles.resize(NT);
     for (uint32_t j = 0; j < NT; ++j) out.tiles[j] = {A[j] / kMfmaKRows, (B[j] - 1u) / kMfmaKRows};
-    for (uint32_t j = 0; j + 2 < NT; ++j)
-        if (out.tiles[j + 2].kb_first <= out.tiles[j].kb_last) return; // the accumulator set of tile j is free again before tile j + 2 starts
     for (uint32_t j = 0; j + 1 < NT; ++j)
         if (out.tiles[j + 1].kb_last == out.tiles[j].kb_last) return;  // one tile finishes per K-block at most
-    out.vmeta.assign(NKB, 0xffffu);
-    out.vw.assign((size_t)NKB * 2 * 2 * 64 * 4, 0u);
+    for (uint32_t j = 0; j + 2 < NT; ++j)
+        if (out.tiles[j + 2].kb_first <= out.tiles[j].kb_last) return; // the accumulator set of tile j is free again before tile j + 2 starts
+    // (one K-block more than the picture has: all-zero weights, for the kernel's passes after the last rows)
+    out.vmeta.assign(NKB + 1u, 0xffffu);
+    out.vw.assign((size_t)(NKB + 1u) * 2 * 2 * 64 * 4, 0u);
     for (uint32_t j = 0; j < NT; ++j) {
         const uint32_t set = j & 1u;
         for (uint32_t s = out.tiles[j].kb_first; s <= out.tiles[j].kb_last; ++s) {

@@ -1,0 +1,85 @@
+"""The bars a resampled result has to clear, shared by the GPU tests.
+
+Two kernels produce resampled pixels:
+  * the streaming kernel (f32 FMA chains): required to be BIT-EXACT against the oracle's ARITH_FMA mode (same taps, same
+    order, one fused multiply-add per tap), which pins every index, weight and rounding decision, and within 1 LSB of the
+    reference arithmetic ARITH_REF (separate multiply and add, as rustc emits);
+  * the matrix-pipe kernel (fl_mfma.hip; Rgb8 down-scales with 16-byte-aligned rows): its vertical sums are accumulated by
+    the matrix unit in an order no CPU restatement can pin bit for bit, and its horizontal weights are 16-17 bit fixed point,
+    so its bar is the north-star tolerance itself -- EVERY byte within 1 LSB of ARITH_REF -- plus a bound on how many bytes
+    may differ at all (they are the bytes whose exact value lies within ~0.01 of a rounding boundary), plus equality with
+    itself: the same request gives the same bytes alone, in a batch, through the queue and on every device shard.
+Which kernel ran is read from the context's statistics, never assumed."""
+import os
+
+import numpy as np
+
+import oracle_lib
+
+TOL_LSB = 1              # north_star: "+-1 LSB per channel for resample/blur"
+MFMA_OFF_BY_ONE = 0.006  # matrix-pipe kernel: at most 0.6 % of the bytes may differ from ARITH_REF (measured: 0.03-0.25 %)
+
+
+def maxdiff(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return int(np.abs(a.astype(np.int16) - b.astype(np.int16)).max()) if a.size else 0
+
+
+def oracle_kwargs(kw):
+    return dict(w=kw.get("w"), h=kw.get("h"), fill=kw.get("fill", (32, 32, 32)), crop=kw.get("crop", False),
+                blur_sigma=kw.get("blur_sigma", 0.0), grayscale=kw.get("grayscale", False), inverse=kw.get("inverse", False),
+                orientation=kw.get("orientation", 0))
+
+
+def check_pixels(oracle, got, img, used_mfma, **okw):
+    """`got` = device pixels of the request described by okw (oracle.process_pixels keywords)."""
+    want_ref = oracle.process_pixels(img, arith=oracle_lib.ARITH_REF, **okw)
+    assert got.shape == want_ref.shape, (got.shape, want_ref.shape)
+    d = np.abs(got.astype(np.int16) - want_ref.astype(np.int16))
+    assert int(d.max()) <= TOL_LSB, f"> {TOL_LSB} LSB vs reference arithmetic {okw}"
+    if used_mfma:
+        if got.size >= 20000:   # (a rate means little on a handful of pixels)
+            assert float((d > 0).mean()) <= MFMA_OFF_BY_ONE, f"{100 * float((d > 0).mean()):.2f} % of the bytes differ from the reference arithmetic {okw}"
+    else:
+        want_fma = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **okw)
+        assert np.array_equal(got, want_fma), f"not bit-exact vs fused oracle: maxdiff {maxdiff(got, want_fma)} {okw}"
+
+
+def device_pixels(fl, st, img, **kw):
+    """Pixels of one request sent alone, and whether the matrix-pipe kernel produced them."""
+    before = st.stats()["mfma_launches"]
+    got = st.process_pixels(img, fl.make_params(**kw))
+    return got, st.stats()["mfma_launches"] > before
+
+
+def check_resample(fl, st, oracle, img, **kw):
+    """One request through the device, against the bars of whichever kernel served it; then the SAME request with the
+    matrix-pipe kernel switched off (FLGPU_NO_MFMA=1, read per batch), so that the streaming kernel keeps its own,
+    bit-exact bar on every geometry the tests use."""
+    got, used = device_pixels(fl, st, img, **kw)
+    check_pixels(oracle, got, img, used, **oracle_kwargs(kw))
+    if used:
+        os.environ["FLGPU_NO_MFMA"] = "1"
+        try:
+            other, used2 = device_pixels(fl, st, img, **kw)
+        finally:
+            del os.environ["FLGPU_NO_MFMA"]
+        assert not used2
+        check_pixels(oracle, other, img, False, **oracle_kwargs(kw))
+        assert maxdiff(got, other) <= TOL_LSB
+    return got
+
+
+def expected_pixels(fl, st, oracle, img, **kw):
+    """What a batch / queue / shard / encoder test compares against: the pixels this request gives when sent alone -- after
+    they have cleared their own bar against the oracle.  For the streaming kernel these ARE the oracle's ARITH_FMA pixels."""
+    got, used = device_pixels(fl, st, img, **kw)
+    check_pixels(oracle, got, img, used, **oracle_kwargs(kw))
+    return got
+
+
+def check_pixels_any_kernel(oracle, got, img, **okw):
+    """For results whose context is out of reach (another process): bit-exact against ARITH_FMA, or else the matrix-pipe
+    kernel's bars."""
+    want_fma = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **okw)
+    check_pixels(oracle, got, img, not np.array_equal(got, want_fma), **okw)

@@ -15,37 +15,14 @@ import synth
 
 pytestmark = pytest.mark.gpu
 
-TOL_LSB = 1  # north_star: "+-1 LSB per channel for resample/blur"
+from parity import TOL_LSB, check_resample, expected_pixels, maxdiff  # the bars themselves: tests/parity.py
 
 
-def maxdiff(a, b):
-    assert a.shape == b.shape, (a.shape, b.shape)
-    return int(np.abs(a.astype(np.int16) - b.astype(np.int16)).max()) if a.size else 0
-
-
-def both_bars(oracle, got, img, **okw):
-    """The two bars of every resampled result: bit-exact against the oracle's restatement of the kernel's own summation
-    order (ARITH_FMA) AND within 1 LSB of the reference arithmetic (ARITH_REF) -- the second is the independent one."""
-    want_fma = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **okw)
-    want_ref = oracle.process_pixels(img, arith=oracle_lib.ARITH_REF, **okw)
-    assert got.shape == want_ref.shape
-    assert np.array_equal(got, want_fma), f"not bit-exact vs fused oracle: maxdiff {maxdiff(got, want_fma)} {okw}"
-    assert maxdiff(got, want_ref) <= TOL_LSB, f"> {TOL_LSB} LSB vs reference arithmetic {okw}"
-
-
-def check_resample(fl, st, oracle, img, **kw):
-    fe_kw = dict(kw)
-    p = fl.make_params(**fe_kw)
-    got = st.process_pixels(img, p)
-    okw = dict(w=kw.get("w"), h=kw.get("h"), fill=kw.get("fill", (32, 32, 32)), crop=kw.get("crop", False),
-               blur_sigma=kw.get("blur_sigma", 0.0), grayscale=kw.get("grayscale", False), inverse=kw.get("inverse", False),
-               orientation=kw.get("orientation", 0))
-    want_fma = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **okw)
-    want_ref = oracle.process_pixels(img, arith=oracle_lib.ARITH_REF, **okw)
-    assert got.shape == want_ref.shape
-    assert np.array_equal(got, want_fma), f"not bit-exact vs fused oracle: maxdiff {maxdiff(got, want_fma)} {kw}"
-    assert maxdiff(got, want_ref) <= TOL_LSB, f"> {TOL_LSB} LSB vs reference arithmetic {kw}"
-    return got
+def both_bars(fl, st, oracle, got, img, **kw):
+    """A result that came out of a batch, the queue or a band split: equal to the same request sent alone, which in turn
+    has cleared the bars of the kernel that served it (parity.expected_pixels)."""
+    want = expected_pixels(fl, st, oracle, img, **kw)
+    assert got.shape == want.shape and np.array_equal(got, want), f"differs from the same request sent alone: maxdiff {maxdiff(got, want)} {kw}"
 
 
 # ---------------------------------------------------------------- pointwise (bit-exact) --
@@ -195,7 +172,7 @@ def test_unaligned_row_pitch_uses_the_fused_kernel(fl, gpu_state, oracle, w):
     view = buf[1:].reshape(img.shape)
     view[...] = img
     got = gpu_state.process_batch([view], [fl.make_params(300, 200)])[0]
-    both_bars(oracle, got, img, w=300, h=200)
+    both_bars(fl, gpu_state, oracle, got, img, w=300, h=200)
 
 
 @pytest.mark.parametrize("c,kw", [(1, {}), (1, dict(inverse=True)), (2, {}), (2, dict(inverse=True)), (1, dict(grayscale=True))])
@@ -260,7 +237,7 @@ def test_blur_wide_image_tiles(fl, gpu_state, oracle):
 
 def test_jfif444_front_end(fl, gpu_state, oracle):
     img = synth.uniform(360, 640, 3, index=30)
-    pix = oracle.process_pixels(img, 300, 200, arith=oracle_lib.ARITH_FMA)
+    pix = expected_pixels(fl, gpu_state, oracle, img, w=300, h=200)
     planes = gpu_state.process_pixels(img, fl.make_params(300, 200, front_end=fl.FE_JFIF444))
     y, cb, cr = oracle.jpeg_ycbcr444(pix)
     assert planes.y.shape == (200, 304)
@@ -302,7 +279,7 @@ def test_many_geometries_overflow_the_table_arena(fl, oracle, monkeypatch):
             h, w = 200 + 13 * i, 320 + 17 * i
             img = synth.uniform(h, w, 3, index=300 + i)
             got = st.process_pixels(img, fl.make_params(120 + i, 90, blur_sigma=10.0 if i % 7 == 0 else 0.0))
-            both_bars(oracle, got, img, w=120 + i, h=90, blur_sigma=10.0 if i % 7 == 0 else 0.0)
+            both_bars(fl, st, oracle, got, img, w=120 + i, h=90, blur_sigma=10.0 if i % 7 == 0 else 0.0)
         assert st.stats()["tables_built"] > 80
 
 
@@ -317,7 +294,7 @@ def test_batch_mixed_requests(fl, gpu_state, oracle):
     for img, r, got in zip(imgs, reqs, outs):
         okw = dict(w=r.get("w"), h=r.get("h"), fill=r.get("fill", (32, 32, 32)), crop=r.get("crop", False),
                    grayscale=r.get("grayscale", False), inverse=r.get("inverse", False))
-        both_bars(oracle, got, img, **okw)
+        both_bars(fl, gpu_state, oracle, got, img, **okw)
 
 
 def test_request_queue_concurrent_callers(fl, gpu_state, oracle):
@@ -334,7 +311,7 @@ def test_request_queue_concurrent_callers(fl, gpu_state, oracle):
     [t.join() for t in ts]
     after = gpu_state.stats()
     for g, im in zip(got, imgs):
-        both_bars(oracle, g, im, w=300, h=200)
+        both_bars(fl, gpu_state, oracle, g, im, w=300, h=200)
     # 24 concurrent requests must have shared launches
     assert after["queue_flushes"] - before["queue_flushes"] < len(imgs)
 
@@ -364,7 +341,7 @@ def test_device_resident_batch_properties(fl, gpu_state, oracle):
         else:
             assert np.array_equal(out[i], out[i % 4]), i
     for i in range(4):
-        both_bars(oracle, out[i], base[i].numpy(), w=300, h=200, fill=(5, 6, 7))
+        both_bars(fl, gpu_state, oracle, out[i], base[i].numpy(), w=300, h=200, fill=(5, 6, 7))
 
 
 def _full_size_batch(fl, gpu_state, params, n=1024):
@@ -413,8 +390,7 @@ def test_config1_at_bench_size(fl, gpu_state, oracle):
         else:
             first[k] = i
     for k, i in first.items():                                                           # every distinct picture against the oracle chain
-        px = oracle.process_pixels(base[k], 300, 200, arith=oracle_lib.ARITH_FMA)
-        assert maxdiff(px, oracle.process_pixels(base[k], 300, 200, arith=oracle_lib.ARITH_REF)) <= TOL_LSB
+        px = expected_pixels(fl, gpu_state, oracle, base[k], w=300, h=200)     # (checked against the reference arithmetic in there)
         assert out[i, :res[i][1]].tobytes() == oracle.jpeg_encode(px, 75)
     i = 15                                                                                # a constant picture: flat 300x169 on the fill colour
     v = (i * 29) % 256
@@ -440,7 +416,7 @@ def test_config2_at_bench_size(fl, gpu_state, oracle):
         else:
             first[k] = i
     for k, i in first.items():
-        both_bars(oracle, out[i], base[k], w=300, h=200, grayscale=True, blur_sigma=10.0)
+        both_bars(fl, gpu_state, oracle, out[i], base[k], w=300, h=200, grayscale=True, blur_sigma=10.0)
     assert (out[..., 3] == 255).all()
 
 
@@ -454,7 +430,7 @@ def test_mixed_size_batch_with_webp_front_end(fl, gpu_state, oracle):
     assert fmt == fl.OUT_WEBP and p.front_end == fl.FE_WEBP420
     outs = gpu_state.process_batch(imgs, [p] * len(imgs))
     for img, planes in zip(imgs, outs):
-        pix = oracle.process_pixels(img, 300, 200, arith=oracle_lib.ARITH_FMA)
+        pix = expected_pixels(fl, gpu_state, oracle, img, w=300, h=200)
         y, u, v, has_alpha = oracle.webp_yuv420(pix)
         assert not has_alpha and planes.y.shape == (200, 300) and planes.u.shape == (100, 150)
         assert np.array_equal(planes.y, y) and np.array_equal(planes.u, u) and np.array_equal(planes.v, v)
@@ -464,15 +440,17 @@ def test_band_split_small_batch_matches(fl, gpu_state, oracle, monkeypatch):
     img = synth.uniform(1080, 1920, 3, index=60)
     for bands in ("1", "3", "7"):
         monkeypatch.setenv("FLGPU_FORCE_BANDS", bands)
-        both_bars(oracle, gpu_state.process_pixels(img, fl.make_params(300, 200)), img, w=300, h=200)
+        both_bars(fl, gpu_state, oracle, gpu_state.process_pixels(img, fl.make_params(300, 200)), img, w=300, h=200)
 
 
 def test_generic_and_stream_kernels_agree(fl, gpu_state, monkeypatch):
     img = synth.uniform(720, 1280, 3, index=61)
-    a = gpu_state.process_pixels(img, fl.make_params(300, 200))
+    m = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the matrix-pipe kernel (1280-pixel rows are 16-byte aligned)
+    monkeypatch.setenv("FLGPU_NO_MFMA", "1")
+    a = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the streaming kernel
     monkeypatch.setenv("FLGPU_FORCE_GENERIC", "1")
-    b = gpu_state.process_pixels(img, fl.make_params(300, 200))
-    assert np.array_equal(a, b)
+    b = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the two-pass generic kernels
+    assert np.array_equal(a, b) and maxdiff(m, a) <= TOL_LSB and not np.array_equal(m, a)
 
 
 def test_errors_are_reported_not_swallowed(fl, gpu_state):
@@ -519,4 +497,4 @@ def test_seeded_sweep_as_one_mixed_batch(fl, gpu_state, oracle):
     ps = [fl.make_params(**kw) for _, _, kw in cases]
     outs = gpu_state.process_batch(imgs, ps)
     for (i, shape, kw), img, got in zip(cases, imgs, outs):
-        both_bars(oracle, got, img, **kw)
+        both_bars(fl, gpu_state, oracle, got, img, **kw)

