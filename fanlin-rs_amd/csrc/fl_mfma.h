@@ -35,6 +35,7 @@ constexpr uint32_t kMfmaKRows = 32;         // source rows per K-block
 constexpr uint32_t kMfmaWaveCols = 256;     // byte columns per wave
 constexpr uint32_t kMfmaStripBytes = kMfmaWaves * kMfmaWaveCols;
 constexpr uint32_t kMfmaMaxStripPx = 128;   // output pixels per strip (bounds the LDS output tiles)
+constexpr uint32_t kMfmaOutPitch = 3 * kMfmaMaxStripPx + 1; // words per row of an LDS output tile: 384 outputs + a dummy column (odd: rows spread over the banks)
 constexpr uint32_t kMfmaVScaleLog2 = 8;     // vertical weights are stored times 2^8 (keeps the low f16 term normal)
 constexpr uint32_t kMfmaXFracBits = 6;      // intermediate rows: (value - 128) * 64 as i16
 constexpr uint32_t kMfmaLdsOperands = 40;   // horizontal operands (1 KB each) kept in LDS when a strip has no more distinct ones
@@ -63,7 +64,7 @@ struct MfmaVPlan {
 
 // Horizontal plan of one strip.
 //   ctab[8 waves][4 chunks][3]: { first output index of the tile (may be negative or past nout: lanes outside go to the
-//                  dummy column), operand index of the high weight digit, of the low digit }; operand index 0xffffffff = tile unused
+//                  dummy column), operand index of the high weight digit, of the low digit }; unused tile slots: operand 0 (all zeros), first output 2^30
 //   ops[n_ops][64 lanes] x 16 bytes: B operands of v_mfma_i32_16x16x64_i8, deduplicated
 struct MfmaStrip {
     uint32_t x0, x1;       // output columns [x0, x1) in resized coordinates

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <type_traits>
 
 #include "fl_mfma.h"
 
@@ -23,6 +25,16 @@ constexpr uint32_t CNT_BYTES = 16;                          // add_cnt[2], conv_
 
 __shared__ __attribute__((aligned(16))) uint8_t mfma_ring[kMfmaWaves * RING_BYTES]; // the rows' landing zone (static), everything else is dynamic
 extern __shared__ __attribute__((aligned(16))) uint8_t mfma_lds[];
+
+// (a << 8) + b, opaque to the optimiser: left alone hipcc re-associates the digit sums' Horner form into two shifts and a
+// three-operand add.  (An empty asm, not an asm instruction: the operands come straight out of the matrix unit and only
+// instructions the compiler knows get the wait states that requires.)
+__device__ __forceinline__ uint32_t shl8_add(uint32_t a, uint32_t b)
+{
+    uint32_t r = (a << 8) + b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0)
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); } // lgkmcnt(0)
@@ -45,8 +57,20 @@ __device__ __forceinline__ void lds_counter_bump(uint32_t *p)
 // LB: the destination is Rgba8 with the picture placed on a fill frame.  HLDS: the strip's horizontal operands sit in LDS.
 template <bool LB, bool HLDS>
 __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
-                                                                   const uint32_t *__restrict__ arena, uint32_t ot_words)
+                                                                   const uint32_t *__restrict__ arena, uint32_t ot_words
+#ifdef FL_MFMA_TIMING
+                                                                   , unsigned long long *__restrict__ dbg
+#endif
+)
 {
+#ifdef FL_MFMA_TIMING // development aid (tools/build_ablate.sh ... -DFL_MFMA_TIMING): shader-clock cycles per phase of one workgroup's waves
+    unsigned long long tm_wait = 0, tm_read = 0, tm_mfma = 0, tm_flush = 0, tm_t0 = __builtin_readcyclecounter(), tm_a, tm_b;
+#define TM_A() tm_a = __builtin_readcyclecounter()
+#define TM_B(acc_) do { tm_b = __builtin_readcyclecounter(); acc_ += tm_b - tm_a; tm_a = tm_b; } while (0)
+#else
+#define TM_A() do { } while (0)
+#define TM_B(acc_) do { } while (0)
+#endif
     // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh): 1 = no horizontal MFMAs / LDS adds, 2 = no conversion of
     // finished tiles, 32 = conversion without its global stores, 4 = no horizontal stage at all, 8 = no vertical MFMAs
 #ifdef FL_ABLATE
@@ -60,7 +84,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const Job jb = jobs[it.job];
     const MfmaVPlan vp = *reinterpret_cast<const MfmaVPlan *>(arena + it.vplan_off);
     const MfmaStrip sp = *reinterpret_cast<const MfmaStrip *>(arena + it.strip_off);
-    const uint32_t np = sp.nout + 1u; // words per output-tile row: the outputs and one dummy column
+    constexpr uint32_t np = kMfmaOutPitch; // words per output-tile row (compile-time: the row offsets of the LDS adds become immediates); column sp.nout is a dummy
 
     uint32_t *otile = reinterpret_cast<uint32_t *>(mfma_lds);
     uint32_t *add_cnt = reinterpret_cast<uint32_t *>(mfma_lds + 2u * ot_words * 4u);
@@ -179,13 +203,25 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         if (!(ablate & 2u)) convert_rows(tile, buf);
         if (lane == 0) lds_counter_bump(&conv_cnt[buf]);
     };
+#ifdef FL_MFMA_TIMING
+    const unsigned long long tm_loop0 = __builtin_readcyclecounter();
+#endif
+    // A K-block's weights (64 bytes per lane, served by the L2) and its meta word are fetched one K-block ahead, in front
+    // of the request for the rows: the vmcnt(0) in front of the transposed reads covers them for free, while fetched at
+    // the top of their own K-block they would add one L2 round trip to every pass of the loop.
+    u32x4 wvn[4];
+    uint32_t meta_n = arena[vp.meta_off + it.kb0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wvn[k] = vw[(it.kb0 * 4u + k) * 64u + lane];
     issue(it.kb0);
     for (uint32_t s = it.kb0; s < it.kb1; ++s) {
-        const uint32_t meta = __builtin_amdgcn_readfirstlane(arena[vp.meta_off + s]);
+        TM_A();
+        wait_vm0();
+        TM_B(tm_wait);
+        const uint32_t meta = __builtin_amdgcn_readfirstlane(meta_n);
         u32x4 wv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wv[k] = vw[(s * 4u + k) * 64u + lane];
-        wait_vm0();
+        for (int k = 0; k < 4; ++k) wv[k] = wvn[k];
         v2i raw[16];
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
@@ -193,7 +229,13 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             raw[ct] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + off));
         }
         wait_lgkm0();
-        if (s + 1u < it.kb1) issue(s + 1u);
+        if (s + 1u < it.kb1) {
+            meta_n = arena[vp.meta_off + s + 1u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wvn[k] = vw[((s + 1u) * 4u + k) * 64u + lane];
+            issue(s + 1u);
+        }
+        TM_B(tm_read);
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             u32x4 a;
@@ -208,6 +250,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[2]), acc[1][ct], 0, 0, 0);
             acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[3]), acc[1][ct], 0, 0, 0);
         }
+        TM_B(tm_mfma);
         const uint32_t ft = meta & 0xffffu;
         if (ft != 0xffffu) { // output tile ft is complete
             const uint32_t set = ft & 1u;
@@ -235,7 +278,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     for (int t = 0; t < 3; ++t) {
                         const int32_t obase = ctab[(c * 3 + t) * 3];
                         const uint32_t i1 = (uint32_t)ctab[(c * 3 + t) * 3 + 1], i0 = (uint32_t)ctab[(c * 3 + t) * 3 + 2];
-                        if (i1 == 0xffffffffu || (ablate & 1u)) continue;
+                        if ((ablate & 1u) || (t == 2 && obase == 0x40000000)) continue; // (slot not in use; slots 0 and 1 run regardless, on the all-zero operand if need be: fewer branches, longer schedules)
                         const u32x4 h1 = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
                         const u32x4 h0 = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
                         i32x4 t2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, ahi), __builtin_bit_cast(i32x4, h1), i32x4{0, 0, 0, 0}, 0, 0, 0);
@@ -246,7 +289,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                         const uint32_t col = o < sp.nout ? o : sp.nout; // lanes outside the strip's outputs add into the dummy column
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const uint32_t p = ((uint32_t)t2[r] << 16) + ((uint32_t)t1[r] << 8) + (uint32_t)t0[r];
+                            const uint32_t p = shl8_add(shl8_add((uint32_t)t2[r], (uint32_t)t1[r]), (uint32_t)t0[r]);
                             __hip_atomic_fetch_add(&ot[(4u * g + r) * np + col], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
@@ -256,8 +299,16 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             }
 #pragma unroll
             for (int ct = 0; ct < 16; ++ct) { if (set) acc[1][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; else acc[0][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+            TM_B(tm_flush);
         }
     }
+#ifdef FL_MFMA_TIMING
+    if (blockIdx.x == 1500u && lane == 0) {
+        dbg[wave * 8 + 0] = tm_wait; dbg[wave * 8 + 1] = tm_read; dbg[wave * 8 + 2] = tm_mfma; dbg[wave * 8 + 3] = tm_flush;
+        dbg[wave * 8 + 4] = __builtin_readcyclecounter() - tm_t0;
+        dbg[wave * 8 + 5] = tm_loop0 - tm_t0;
+    }
+#endif
     __syncthreads(); // every wave has added its sums of the last tile
     if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
 }
@@ -266,7 +317,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 
 size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds)
 {
-    return (size_t)2 * 16 * (max_nout + 1u) * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u); // dynamic part; the rows' 64 KB are static
+    return (size_t)2 * 16 * kMfmaOutPitch * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u); // dynamic part; the rows' 64 KB are static
 }
 
 template <bool LB, bool HLDS>
@@ -275,7 +326,21 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
     const size_t lds = mfma_lds_bytes(m.max_nout, HLDS);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<LB, HLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    resample_mfma_kernel<LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (m.max_nout + 1u));
+#ifdef FL_MFMA_TIMING
+    static unsigned long long *dbg = nullptr;
+    static int launches = 0;
+    if (!dbg) { (void)hipMalloc(&dbg, 64 * 8); (void)hipMemset(dbg, 0, 64 * 8); }
+    resample_mfma_kernel<LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch, dbg);
+    if (++launches == 20 && m.nitems > 1500) {
+        unsigned long long h[64];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "mfma timing wave %d: wait %llu, reads+request %llu, vertical mfma %llu, tile stage %llu, total %llu cycles, of which %llu before the first request\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+    }
+#else
+    resample_mfma_kernel<LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch);
+#endif
     return hipGetLastError();
 }
 

@@ -146,8 +146,13 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t
         for (uint32_t x = x0; x < x1; ++x) L = std::min(L, h.left[x]);
         S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (3u * L) / 16u * 16u; S.hdr.nout = (x1 - x0) * 3u; S.hdr.hs = (uint32_t)hs;
         const int32_t nout = (int32_t)S.hdr.nout;
-        S.ctab.assign(kMfmaWaves * 4 * 3 * 3, -1);
+        // operand 0 is all zeros: the tile slots a chunk does not need multiply by it and add into the dummy column, which keeps
+        // the kernel's horizontal stage free of branches (12 matrix instructions back to back per chunk instead of 4 + a wait)
+        S.ctab.assign(kMfmaWaves * 4 * 3 * 3, 0);
+        for (size_t k = 0; k < S.ctab.size(); k += 3) S.ctab[k] = 0x40000000;
         std::map<std::string, uint32_t> seen;
+        seen.emplace(std::string(1024, '\0'), 0u);
+        S.ops.assign(256, 0u);
         auto weight_of = [&](int32_t o, uint32_t col) -> int32_t { // weight of strip byte column `col` in output o
             if (o < 0 || o >= nout) return 0;
             const uint32_t abs_b = S.hdr.byte0 + col;
