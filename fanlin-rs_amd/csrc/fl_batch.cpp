@@ -83,6 +83,44 @@ void fill_job(const Work &w, Job &j)
     }
 }
 
+
+// XCD-aware numbering: workgroups are dealt to the 8 XCDs round-robin in launch order and each XCD has its own L2.
+// The strips of one picture re-read each other's halo columns, so inside every run of equally long workgroups the
+// items of 8 pictures are interleaved: picture p's strips get launch indices congruent modulo 8 (same XCD, close
+// in time) and the halo is served by that XCD's L2 instead of HBM.  Speed only; any placement is correct.
+template <class Item, class Len>
+void xcd_interleave(Item *first, uint32_t nitems, Len len_of)
+{
+    static const bool no_xcd_order = [] { const char *e = getenv("FLGPU_NO_XCD_ORDER"); return e && e[0] == '1'; }(); // A/B experiments
+    std::vector<Item> tmp;
+    for (uint32_t a = 0; a < nitems && !no_xcd_order;) {
+        uint32_t b = a;
+        const uint32_t len = len_of(first[a]);
+        while (b < nitems && len_of(first[b]) == len) ++b;
+        // items of one job are consecutive inside the run (stable sort): collect up to 8 jobs at a time
+        for (uint32_t g0 = a; g0 < b;) {
+            uint32_t g1 = g0, njob = 0, prev = 0xffffffffu, per = 0, cur = 0;
+            bool uniform = true;
+            while (g1 < b) {
+                if (first[g1].job != prev) {
+                    if (njob == 8) break;
+                    if (njob >= 1) { if (per == 0) per = cur; else if (cur != per) uniform = false; }
+                    ++njob; prev = first[g1].job; cur = 0;
+                }
+                ++cur; ++g1;
+            }
+            if (per == 0) per = cur; else if (cur != per) uniform = false;
+            if (uniform && njob > 1 && per > 1) {
+                tmp.assign(first + g0, first + g1);
+                for (uint32_t s2 = 0; s2 < per; ++s2)
+                    for (uint32_t j2 = 0; j2 < njob; ++j2) first[g0 + s2 * njob + j2] = tmp[j2 * per + s2];
+            }
+            g0 = g1;
+        }
+        a = b;
+    }
+}
+
 } // namespace
 
 namespace fl {
@@ -409,47 +447,17 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             L.njobs++;
         }
         if ((k.kind & 255u) == S1_MFMA && L.nitems > 1) {
-            // longest workgroups first, as below; the strips of one picture share only a few halo bytes, so no XCD shuffle
+            // longest workgroups first and strips of a picture on one XCD, as for the streaming kernel below
             auto first = mitems.begin() + L.item_base;
             std::stable_sort(first, first + L.nitems, [](const MfmaItem &a, const MfmaItem &b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
+            xcd_interleave(&*first, L.nitems, [](const MfmaItem &x) { return x.kb1 - x.kb0; });
         }
         if ((k.kind & 255u) == S1_STREAM && L.nitems > 1) {
             // longest workgroups first: in a mixed batch a 4K band walks four times the rows of a 1080p one, and the
             // hardware hands out workgroups in index order -- started last, the long ones would be the launch's tail
             auto first = items.begin() + L.item_base;
             std::stable_sort(first, first + L.nitems, [](const StreamItem &a, const StreamItem &b) { return a.r1 - a.r0 > b.r1 - b.r0; });
-            // XCD-aware numbering: workgroups are dealt to the 8 XCDs round-robin in launch order and each XCD has its own L2.
-            // The strips of one picture re-read each other's halo columns, so inside every run of equally long workgroups the
-            // items of 8 pictures are interleaved: picture p's strips get launch indices congruent modulo 8 (same XCD, close
-            // in time) and the halo is served by that XCD's L2 instead of HBM.  Speed only; any placement is correct.
-            std::vector<StreamItem> tmp;
-            static const bool no_xcd_order = [] { const char *e = getenv("FLGPU_NO_XCD_ORDER"); return e && e[0] == '1'; }(); // A/B experiments
-            for (uint32_t a = 0; a < L.nitems && !no_xcd_order;) {
-                uint32_t b = a;
-                const uint32_t len = first[a].r1 - first[a].r0;
-                while (b < L.nitems && first[b].r1 - first[b].r0 == len) ++b;
-                // items of one job are consecutive inside the run (stable sort): collect up to 8 jobs at a time
-                for (uint32_t g0 = a; g0 < b;) {
-                    uint32_t g1 = g0, njob = 0, prev = 0xffffffffu, per = 0, cur = 0;
-                    bool uniform = true;
-                    while (g1 < b) {
-                        if (first[g1].job != prev) {
-                            if (njob == 8) break;
-                            if (njob >= 1) { if (per == 0) per = cur; else if (cur != per) uniform = false; }
-                            ++njob; prev = first[g1].job; cur = 0;
-                        }
-                        ++cur; ++g1;
-                    }
-                    if (per == 0) per = cur; else if (cur != per) uniform = false;
-                    if (uniform && njob > 1 && per > 1) {
-                        tmp.assign(first + g0, first + g1);
-                        for (uint32_t s2 = 0; s2 < per; ++s2)
-                            for (uint32_t j2 = 0; j2 < njob; ++j2) first[g0 + s2 * njob + j2] = tmp[j2 * per + s2];
-                    }
-                    g0 = g1;
-                }
-                a = b;
-            }
+            xcd_interleave(&*first, L.nitems, [](const StreamItem &x) { return x.r1 - x.r0; });
         }
         s1_launches.push_back(L);
     }

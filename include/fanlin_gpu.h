@@ -172,7 +172,7 @@ typedef struct flgpu_stats {
     uint64_t batches;             /* kernel batches launched */
     uint64_t queue_flushes;       /* request-queue flushes */
     uint64_t tables_built;        /* weight tables built (cache misses) */
-    uint64_t resample_launches;   /* launches of the fused resample kernel */
+    uint64_t resample_launches;   /* launches of the fused resample kernels (streaming + matrix-pipe) */
     double resample_ms;           /* summed HIP-event time of those launches (profile = 1) */
     uint64_t resample_src_bytes;  /* algorithmic bytes read by those launches */
     uint64_t resample_dst_bytes;  /* algorithmic bytes written by those launches */

@@ -22,6 +22,7 @@ run rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetc
 run rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
 run rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -o p -- $B --steps 2 --warmup 1 > $O/pmc_sq.log 2>&1
 run rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- $B --steps 2 --warmup 1 > $O/pmc_sq2.log 2>&1
+run rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_mfma -o p -- $B --steps 2 --warmup 1 > $O/pmc_mfma.log 2>&1
 # plain bench lines (no profiler attached)
 cd $R
 for name_args in "config1:" "config1_resize_only:--frontend none" "config1_crop:--crop --frontend none" "config2_gray_blur:--blur 10 --grayscale --frontend none" "config1_jfif444:--frontend jfif444" "config1_webp420:--frontend webp420"; do

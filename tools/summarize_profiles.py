@@ -48,12 +48,16 @@ def main():
             break
     except Exception:
         pass
+    bench = json.load(open(os.path.join(RAW, "bench_config1.json")))
+    kernel = bench["roofline"].get("kernel", "resample_stream_kernel")   # the dominant kernel of config 1, as bench.py names it
     vals, nd = {}, 0
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-        v, n = counters(sub, "resample_stream_kernel")
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mfma"):
+        try:
+            v, n = counters(sub, kernel)
+        except OSError:
+            continue          # (an optional pass whose counters this rocprofv3 does not know)
         vals.update(v)
         nd = max(nd, n)
-    bench = json.load(open(os.path.join(RAW, "bench_config1.json")))
     workload = bench["config"]["workload"]
     alg = bench["roofline"]["algorithmic_bytes_per_launch"]
     # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports half of wide coalesced reads -> FETCH x 2
@@ -62,8 +66,8 @@ def main():
     with open(os.path.join(OUT, f"{tag}_config1_pmc.txt"), "w") as f:
         f.write("rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-images 0 --latency-requests 0\n")
         f.write("separate passes: {FETCH_SIZE} {WRITE_SIZE} {SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY} "
-                "{SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE}\n")
-        f.write(f"per-dispatch averages of fl::resample_stream_kernel ({workload}), {nd} dispatches each\n\n")
+                "{SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE} {SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES}\n")
+        f.write(f"per-dispatch averages of fl::{kernel} ({workload}), {nd} dispatches each\n\n")
         for k in sorted(vals):
             f.write(f"{k:28s} {vals[k]:16.1f}\n")
         f.write(f"\nHBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB = {hbm / 1e9:.3f} GB (FETCH_SIZE doubled: gfx950 reports half of wide coalesced reads)\n")
@@ -76,7 +80,7 @@ def main():
         traffic_all = json.load(open(os.path.join(OUT, "traffic.json")))
     except (OSError, ValueError):
         traffic_all = {}
-    traffic = {workload: {"kernel": "resample_stream_kernel", "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"],
+    traffic = {workload: {"kernel": kernel, "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"],
                           "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE as is; separate --pmc passes",
                           "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
                           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-images 0 --latency-requests 0",
