@@ -131,7 +131,7 @@ const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &v
     uint32_t vplan_off = 0;
     if (ok) {
         MfmaVPlan vp{};
-        vp.ntiles = hp.ntiles; vp.nkb = hp.nkb; vp.y0 = hp.y0; vp.rows = hp.rows;
+        vp.ntiles = hp.ntiles; vp.nkb = hp.nkb; vp.y0 = hp.y0; vp.rows = hp.rows; vp.tail = hp.tail;
         vplan_off = arena_append(c, nullptr, sizeof(MfmaVPlan) / 4);
         vp.meta_off = arena_append(c, hp.vmeta.data(), hp.vmeta.size());
         vp.w_off = arena_append(c, hp.vw.data(), hp.vw.size());
@@ -160,6 +160,11 @@ const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &v
             }
         }
         if (ok && mfma_lds_bytes(plan.max_nout, plan.ops_in_lds) > 160 * 1024) ok = false;
+        // Where the kernel pays (tools/experiments/resample_sweep.py, 1080p sources): every strip requests 2048 bytes per row
+        // whatever it needs, and horizontal operands that do not fit the LDS cache come from the L2 behind the K-block in
+        // flight.  With both handicaps (four strips where 2.8 would do, ~100 distinct operands) the streaming kernel is as
+        // fast or faster (256x144: 1.03 vs 1.06 ms, 512x288: 1.77 vs 1.63); with either one alone the matrix pipe wins by 20-28 %.
+        if (ok && !plan.ops_in_lds && (uint64_t)hp.strips.size() * kMfmaStripBytes * 10u > (uint64_t)ha.in_size * 3u * 11u) ok = false;
     }
     plan.ok = ok;
     if (!ok) plan.items.clear();

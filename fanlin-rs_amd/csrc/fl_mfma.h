@@ -51,14 +51,15 @@ struct alignas(16) MfmaItem {
 };
 
 // Vertical plan of one (axis, kept rows) pair.  All offsets are arena word offsets.
-//   kb_meta[nkb]   per K-block: bits 0-15 = tile that is complete after it (0xffff: none), bit 16/17 = set 0/1 has weights in it
+//   kb_meta[nkb + 1] per K-block: bits 0-15 = tile that is complete after it (0xffff: none), bit 16/17 = set 0/1 has weights in it;
+//                  entry nkb = the all-zero K-block the kernel appends when `tail` is set (it completes the last tile)
 //   kb_w[nkb][2 sets][2 terms][64 lanes] x 16 bytes: B operand of v_mfma_f32_16x16x32_f16: lane 16g + n holds the
 //                  weights of source rows 32 s + 8 g .. + 7 towards output row 16 tile + n as 8 f16
 struct MfmaVPlan {
     uint32_t ntiles, nkb;
     uint32_t y0, rows;     // first kept output row (resized coordinates) and how many
     uint32_t meta_off, w_off;
-    uint32_t pad0;
+    uint32_t tail;         // the last tile ends in the same K-block as the one before it: one more pass, on the all-zero K-block, completes it
     uint32_t pad1;
 };
 
@@ -78,7 +79,7 @@ struct MfmaStrip {
 struct HostMfmaPlan {
     bool ok = false;
     std::vector<uint32_t> vmeta, vw;     // MfmaVPlan tables
-    uint32_t ntiles = 0, nkb = 0, y0 = 0, rows = 0;
+    uint32_t ntiles = 0, nkb = 0, y0 = 0, rows = 0, tail = 0;
     struct Tile { uint32_t kb_first, kb_last; };
     std::vector<Tile> tiles;
     struct Strip { MfmaStrip hdr; std::vector<int32_t> ctab; std::vector<uint32_t> ops; };

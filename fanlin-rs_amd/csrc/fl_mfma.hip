@@ -214,7 +214,17 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #pragma unroll
     for (int k = 0; k < 4; ++k) wvn[k] = vw[(it.kb0 * 4u + k) * 64u + lane];
     issue(it.kb0);
-    for (uint32_t s = it.kb0; s < it.kb1; ++s) {
+    // (kb_end: one pass more than the band has K-blocks when the picture's short last tile ends together with the tile before
+    // it -- that pass runs on the table's all-zero K-block, index vp.nkb, whose meta word names the last tile: the matrix unit
+    // adds zeros to whatever the transposed reads deliver, nothing is requested, and the loop body stays as it is)
+    const uint32_t kb_end = it.kb1 + ((vp.tail && it.tile1 == vp.ntiles) ? 1u : 0u);
+    for (uint32_t s = it.kb0; s < kb_end; ++s) {
+        if (!HLDS && s != it.kb0) { // (this variant has no registers to spare for the look-ahead: it fetches its weights here, one L2 round trip per pass)
+            const uint32_t sc = s < it.kb1 ? s : vp.nkb;
+            meta_n = arena[vp.meta_off + sc];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wvn[k] = vw[(sc * 4u + k) * 64u + lane];
+        }
         TM_A();
         wait_vm0();
         TM_B(tm_wait);
@@ -229,11 +239,14 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             raw[ct] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + off));
         }
         wait_lgkm0();
-        if (s + 1u < it.kb1) {
-            meta_n = arena[vp.meta_off + s + 1u];
+        if (s + 1u < kb_end) {
+            if (HLDS) {
+                const uint32_t sn = s + 1u < it.kb1 ? s + 1u : vp.nkb;
+                meta_n = arena[vp.meta_off + sn];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wvn[k] = vw[((s + 1u) * 4u + k) * 64u + lane];
-            issue(s + 1u);
+                for (int k = 0; k < 4; ++k) wvn[k] = vw[(sn * 4u + k) * 64u + lane];
+            }
+            if (s + 1u < it.kb1) issue(s + 1u);
         }
         TM_B(tm_read);
 #pragma unroll

@@ -71,8 +71,13 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t
     }
     out.tiles.resize(NT);
     for (uint32_t j = 0; j < NT; ++j) out.tiles[j] = {A[j] / kMfmaKRows, (B[j] - 1u) / kMfmaKRows};
+    // one tile finishes per K-block -- except that a short last tile may end in the same K-block as its predecessor (both
+    // windows are cut off by the picture's last row): the kernel then takes one more pass, on the all-zero K-block, for it
     for (uint32_t j = 0; j + 1 < NT; ++j)
-        if (out.tiles[j + 1].kb_last == out.tiles[j].kb_last) return;  // one tile finishes per K-block at most
+        if (out.tiles[j + 1].kb_last == out.tiles[j].kb_last) {
+            if (j + 2 != NT) return;
+            out.tail = 1;
+        }
     for (uint32_t j = 0; j + 2 < NT; ++j)
         if (out.tiles[j + 2].kb_first <= out.tiles[j].kb_last) return; // the accumulator set of tile j is free again before tile j + 2 starts
     // (one K-block more than the picture has: all-zero weights, for the kernel's passes after the last rows)
@@ -97,7 +102,10 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t
                 }
             }
         }
-        out.vmeta[out.tiles[j].kb_last] = (out.vmeta[out.tiles[j].kb_last] & 0xffff0000u) | j;
+        {   // the K-block that completes the tile (the extra, all-zero one for a last tile that ends with its predecessor)
+            uint32_t &m = out.vmeta[(out.tail && j + 1 == NT) ? NKB : out.tiles[j].kb_last];
+            m = (m & 0xffff0000u) | j;
+        }
     }
     out.ntiles = NT; out.nkb = NKB; out.y0 = cy; out.rows = ch;
 

@@ -444,8 +444,8 @@ def test_band_split_small_batch_matches(fl, gpu_state, oracle, monkeypatch):
 
 
 def test_generic_and_stream_kernels_agree(fl, gpu_state, monkeypatch):
-    img = synth.uniform(720, 1280, 3, index=61)
-    m = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the matrix-pipe kernel (1280-pixel rows are 16-byte aligned)
+    img = synth.uniform(1080, 1920, 3, index=61)
+    m = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the matrix-pipe kernel
     monkeypatch.setenv("FLGPU_NO_MFMA", "1")
     a = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the streaming kernel
     monkeypatch.setenv("FLGPU_FORCE_GENERIC", "1")

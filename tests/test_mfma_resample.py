@@ -24,9 +24,14 @@ GEOMETRIES = [
     (1080, 1920, 480, 270, False),   # ratio 4: tiles finish every second K-block
     (1088, 1936, 333, 222, True),    # odd targets, windows of irregular length
     (600, 800, 100, 100, False),     # letterboxed on the sides
-    (333, 1024, 90, 30, False),      # short picture: two tiles
-    (4000, 6000, 300, 200, False),   # ratio 20: 120-tap windows
+    (1080, 1920, 317, 200, False),   # 317 x 178: the short last tile ends in the same K-block as the tile before it (one extra pass)
+    (1080, 1920, 320, 240, False),   # horizontal operands that do not repeat: read from the L2, not from LDS
+    (1080, 1920, 150, 100, False),   # ratio 12.8 on 1080p: four strips
 ]
+
+# geometries the planner leaves to the streaming kernel although the matrix-pipe kernel could run them (it would not pay:
+# csrc/fl_context.cpp get_mfma_plan); they must of course still be right
+NOT_WORTH_IT = [(333, 1024, 90, 30), (4000, 6000, 300, 200), (1080, 1920, 256, 144), (1080, 1920, 512, 288)]
 
 
 @pytest.mark.parametrize("h,w,ow,oh,crop", GEOMETRIES)
@@ -37,6 +42,14 @@ def test_geometry_against_the_oracle_and_the_streaming_kernel(fl, gpu_state, ora
     assert gpu_state.stats()["mfma_launches"] > before, "this geometry is meant to reach the matrix-pipe kernel"
     again, used = parity.device_pixels(fl, gpu_state, img, w=ow, h=oh, crop=crop)
     assert used and np.array_equal(got, again)                                       # same request, same bytes
+
+
+@pytest.mark.parametrize("h,w,ow,oh", NOT_WORTH_IT)
+def test_geometries_left_to_the_streaming_kernel(fl, gpu_state, oracle, h, w, ow, oh):
+    img = synth.uniform(h, w, 3, index=h + ow)
+    got, used = parity.device_pixels(fl, gpu_state, img, w=ow, h=oh)
+    assert not used
+    parity.check_pixels(oracle, got, img, False, w=ow, h=oh)
 
 
 def test_photo_like_input_and_constant_input(fl, gpu_state, oracle):
