@@ -34,8 +34,8 @@ constexpr uint32_t kMfmaWaves = 8;          // waves per workgroup
 constexpr uint32_t kMfmaKRows = 32;         // source rows per K-block
 constexpr uint32_t kMfmaWaveCols = 256;     // byte columns per wave
 constexpr uint32_t kMfmaStripBytes = kMfmaWaves * kMfmaWaveCols;
-constexpr uint32_t kMfmaMaxStripPx = 128;   // output pixels per strip (bounds the LDS output tiles)
-constexpr uint32_t kMfmaOutPitch = 3 * kMfmaMaxStripPx + 1; // words per row of an LDS output tile: 384 outputs + a dummy column (odd: rows spread over the banks)
+constexpr uint32_t kMfmaMaxStripPx = 136;   // output pixels per strip (bounds the LDS output tiles: 2 x 16 x 409 words = 52 KB)
+constexpr uint32_t kMfmaOutPitch = 3 * kMfmaMaxStripPx + 1; // words per row of an LDS output tile: 408 outputs + a dummy column (odd: rows spread over the banks)
 constexpr uint32_t kMfmaVScaleLog2 = 8;     // vertical weights are stored times 2^8 (keeps the low f16 term normal)
 constexpr uint32_t kMfmaXFracBits = 6;      // intermediate rows: (value - 128) * 64 as i16
 constexpr uint32_t kMfmaLdsOperands = 40;   // horizontal operands (1 KB each) kept in LDS when a strip has no more distinct ones

@@ -40,3 +40,4 @@ for (w, h, crop) in targets:
             gbs = (s["resample_src_bytes"] + s["resample_dst_bytes"]) / max(s["resample_launches"], 1) / (ms * 1e-3) / 1e9
             line += f"  {'mfma' if s['mfma_launches'] else 'stream'} {ms:.3f} ms ({gbs / 8000:.3f} of peak)"
     print(line, flush=True)
+    open(os.path.join(ROOT, "gpurun_out", "resample_sweep.txt"), "a").write(line + "\n") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
