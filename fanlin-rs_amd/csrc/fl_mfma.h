@@ -17,7 +17,7 @@
 //                    commute, so the result does not depend on the order); rounding, clamping and the store follow.
 //
 // Arithmetic: vertical weights are the reference's f32 weights split into two f16 terms, summed in f32 by the matrix
-// unit (error < 2^-12 of a pixel step); horizontal weights are rounded to 2^-hs (hs = 15..17, sums forced to exactly
+// unit (error < 2^-12 of a pixel step); horizontal weights are rounded to 2^-hs (hs = 14..17: the largest that keeps every weight below 2^15; sums forced to exactly
 // 1) and the intermediate to 1/64.  Worst case |error| < 0.1 before the final rounding, so every output byte is
 // within 1 of the reference's (tests/test_mfma_resample.py measures the rate of such off-by-one bytes).
 #pragma once
