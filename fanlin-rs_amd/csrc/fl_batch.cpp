@@ -294,15 +294,15 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             // rows that are not dword aligned: Rgb8 has a funnel-shift variant of the kernel, others use the generic path
             w.unaligned = ((w.sw * w.cs) % 4u != 0) || ((uintptr_t)w.src % 4u != 0);
             const bool aligned = (!w.unaligned || w.cs == 3) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
-            // The matrix-pipe kernel takes Rgb8 down-scales whose rows are 16-byte aligned (it moves 16-byte pieces of a row
+            // The matrix-pipe kernel takes down-scales (any channel count, no pre-op) whose rows are 16-byte aligned (it moves 16-byte pieces of a row
             // straight into LDS).  The choice depends on the request's geometry only, never on the batch around it.
-            if (w.cs == 3 && w.pre == PRE_NONE && !force_generic && !no_mfma && (w.sw * 3u) % 16u == 0 && (uintptr_t)w.src % 16u == 0 &&
-                (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0) && w.sw * 3u >= 64u) {
+            if (w.pre == PRE_NONE && !force_generic && !no_mfma && (w.sw * w.cs) % 16u == 0 && (uintptr_t)w.src % 16u == 0 &&
+                (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0) && w.sw * w.cs >= 64u) {
                 Job jtmp; fill_job(w, jtmp);
                 uint32_t nbands = 1;
                 if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
                 else if (n_resample < 128) nbands = (uint32_t)std::min<size_t>(16, (256 + n_resample * 3 - 1) / (n_resample * 3));
-                const MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, nbands);
+                const MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, nbands, w.cs);
                 if (mp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
                 if (mp->ok) { w.s1 = S1_MFMA; w.mplan = mp; continue; }
             }
@@ -602,7 +602,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         } else if ((L.k.kind & 255u) == S1_MFMA) {
             LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
             m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
-            m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.max_nout = L.max_nout;
+            m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.max_nout = L.max_nout;
             {
                 ProfileScope ps(c, st, 0);
                 FL_HIP(c, launch_mfma(m, st), "matrix-pipe resample kernel");

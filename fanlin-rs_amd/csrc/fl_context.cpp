@@ -108,14 +108,14 @@ uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma
 
 // Tables and workgroup list of the matrix-pipe kernel for one geometry; bands are runs of whole 16-row tiles.
 const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
-                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands)
+                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs)
 {
-    MfmaPlanKey key{vk, hk, cx, cy, cw, ch, nbands};
+    MfmaPlanKey key{vk, hk, cx, cy, cw, ch, nbands, cs};
     auto it = c->mfma_plans.find(key);
     if (it != c->mfma_plans.end()) return &it->second;
     MfmaPlan plan;
     HostMfmaPlan hp;
-    build_mfma_plan(va, ha, cx, cy, cw, ch, hp);
+    build_mfma_plan(va, ha, cs, cx, cy, cw, ch, hp);
     bool ok = hp.ok;
     if (ok) { // all or nothing: whether a geometry gets this kernel must not depend on how full the arena happens to be
         size_t need = sizeof(MfmaVPlan) / 4 + hp.vmeta.size() + hp.vw.size() + 64;
@@ -164,7 +164,7 @@ const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &v
         // whatever it needs, and horizontal operands that do not fit the LDS cache come from the L2 behind the K-block in
         // flight.  With both handicaps (four strips where 2.8 would do, ~100 distinct operands) the streaming kernel is as
         // fast or faster (256x144: 1.03 vs 1.06 ms, 512x288: 1.77 vs 1.63); with either one alone the matrix pipe wins by 20-28 %.
-        if (ok && !plan.ops_in_lds && (uint64_t)hp.strips.size() * kMfmaStripBytes * 10u > (uint64_t)ha.in_size * 3u * 11u) ok = false;
+        if (ok && !plan.ops_in_lds && (uint64_t)hp.strips.size() * kMfmaStripBytes * 10u > (uint64_t)ha.in_size * cs * 11u) ok = false;
     }
     plan.ok = ok;
     if (!ok) plan.items.clear();

@@ -75,8 +75,8 @@ struct StreamPlan {
 
 struct MfmaPlanKey {
     AxisKey v, h;
-    uint32_t cx, cy, cw, ch, nbands;
-    bool operator<(const MfmaPlanKey &o) const { return std::tie(v, h, cx, cy, cw, ch, nbands) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.nbands); }
+    uint32_t cx, cy, cw, ch, nbands, cs;
+    bool operator<(const MfmaPlanKey &o) const { return std::tie(v, h, cx, cy, cw, ch, nbands, cs) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.nbands, o.cs); }
 };
 
 // Workgroups of the matrix-pipe resample kernel for one geometry (fl_mfma.h); job field unset.
@@ -235,7 +235,7 @@ void arena_reset(flgpu_ctx *c);
 int arena_flush(flgpu_ctx *c, hipStream_t st);
 uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma, AxisKey *key_out, const HostAxis **host_out);
 const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
-                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands);
+                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs);
 const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
                                   uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs, uint32_t pre);
 hipEvent_t get_event(flgpu_ctx *c);

@@ -64,29 +64,6 @@ __device__ __forceinline__ uint32_t round_u8(float t)
     return (uint32_t)f;
 }
 
-// image::color `impl Blend for Rgba<u8>` onto an opaque background (the letterbox
-// fill), f32 src-over with truncating casts; alpha 0 keeps the background, 255 replaces it.
-__device__ __forceinline__ uint32_t blend_over_fill(uint32_t fill, uint32_t r, uint32_t g, uint32_t b, uint32_t a)
-{
-    if (a == 0u) return fill;
-    if (a == 255u) return r | (g << 8) | (b << 16) | (255u << 24);
-    const float max_t = 255.0f;
-    float bg_r = (float)(fill & 255u) / max_t, bg_g = (float)((fill >> 8) & 255u) / max_t,
-          bg_b = (float)((fill >> 16) & 255u) / max_t, bg_a = (float)(fill >> 24) / max_t;
-    float fg_r = (float)r / max_t, fg_g = (float)g / max_t, fg_b = (float)b / max_t, fg_a = (float)a / max_t;
-    float alpha_final = bg_a + fg_a - bg_a * fg_a;
-    if (alpha_final == 0.0f) return fill;
-    float bg_r_a = bg_r * bg_a, bg_g_a = bg_g * bg_a, bg_b_a = bg_b * bg_a;
-    float fg_r_a = fg_r * fg_a, fg_g_a = fg_g * fg_a, fg_b_a = fg_b * fg_a;
-    float out_r_a = fg_r_a + bg_r_a * (1.0f - fg_a);
-    float out_g_a = fg_g_a + bg_g_a * (1.0f - fg_a);
-    float out_b_a = fg_b_a + bg_b_a * (1.0f - fg_a);
-    float out_r = out_r_a / alpha_final, out_g = out_g_a / alpha_final, out_b = out_b_a / alpha_final;
-    uint32_t o_r = (uint32_t)(max_t * out_r), o_g = (uint32_t)(max_t * out_g), o_b = (uint32_t)(max_t * out_b),
-             o_a = (uint32_t)(max_t * alpha_final);
-    return (o_r & 255u) | ((o_g & 255u) << 8) | ((o_b & 255u) << 16) | ((o_a & 255u) << 24);
-}
-
 // One dword / byte to global memory, invisible to hipcc's s_waitcnt bookkeeping (see load_row below).
 __device__ __forceinline__ void store_hidden_b32(void *p, uint32_t v)
 {

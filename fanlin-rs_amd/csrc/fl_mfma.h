@@ -34,8 +34,8 @@ constexpr uint32_t kMfmaWaves = 8;          // waves per workgroup
 constexpr uint32_t kMfmaKRows = 32;         // source rows per K-block
 constexpr uint32_t kMfmaWaveCols = 256;     // byte columns per wave
 constexpr uint32_t kMfmaStripBytes = kMfmaWaves * kMfmaWaveCols;
-constexpr uint32_t kMfmaMaxStripPx = 136;   // output pixels per strip (bounds the LDS output tiles: 2 x 16 x 409 words = 52 KB)
-constexpr uint32_t kMfmaOutPitch = 3 * kMfmaMaxStripPx + 1; // words per row of an LDS output tile: 408 outputs + a dummy column (odd: rows spread over the banks)
+constexpr uint32_t kMfmaMaxStripOutputs = 408; // outputs (pixels x channels) per strip: 136 Rgb8 pixels (bounds the LDS output tiles: 2 x 16 x 409 words = 52 KB)
+constexpr uint32_t kMfmaOutPitch = kMfmaMaxStripOutputs + 1; // words per row of an LDS output tile: 408 outputs + a dummy column (odd: rows spread over the banks)
 constexpr uint32_t kMfmaVScaleLog2 = 8;     // vertical weights are stored times 2^8 (keeps the low f16 term normal)
 constexpr uint32_t kMfmaXFracBits = 6;      // intermediate rows: (value - 128) * 64 as i16
 constexpr uint32_t kMfmaLdsOperands = 40;   // horizontal operands (1 KB each) kept in LDS when a strip has no more distinct ones
@@ -70,7 +70,7 @@ struct MfmaVPlan {
 struct MfmaStrip {
     uint32_t x0, x1;       // output columns [x0, x1) in resized coordinates
     uint32_t byte0;        // first source byte of the strip inside a row (multiple of 16)
-    uint32_t nout;         // (x1 - x0) * 3
+    uint32_t nout;         // (x1 - x0) * channels
     uint32_t hs;           // horizontal weights are scaled by 2^hs
     uint32_t n_ops;
     uint32_t ctab_off, ops_off;
@@ -86,16 +86,17 @@ struct HostMfmaPlan {
     std::vector<Strip> strips;
 };
 
-// Builds the tables for output rows [cy, cy+ch) x columns [cx, cx+cw) of an Rgb8 picture (3 bytes per pixel).
+// Builds the tables for output rows [cy, cy+ch) x columns [cx, cx+cw) of a picture with cs interleaved 8-bit channels.
 // ok = false when the geometry does not fit the kernel (more than two tiles alive in a K-block, horizontal windows
 // that touch more than three 16-output tiles per 64-byte chunk, weights too large for the digit planes).
-void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out);
+void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out);
 
 struct LaunchMfma {
     const Job *jobs;
     const MfmaItem *items;
     const uint32_t *arena;
     uint32_t nitems;
+    uint32_t cs;           // channels of the source (1..4)
     uint32_t letterbox;
     uint32_t ops_in_lds;   // every strip of the launch has <= kMfmaLdsOperands distinct operands
     uint32_t max_nout;

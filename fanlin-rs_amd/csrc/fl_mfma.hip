@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "fl_mfma.h"
+#include "fl_pixel.h"
 
 namespace fl {
 
@@ -54,8 +55,10 @@ __device__ __forceinline__ void lds_counter_bump(uint32_t *p)
     __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// CS: interleaved 8-bit channels of the source (the vertical pass does not care; the horizontal tables carry the channel
+// structure; only the last step, bytes -> destination pixel, is written per channel count).
 // LB: the destination is Rgba8 with the picture placed on a fill frame.  HLDS: the strip's horizontal operands sit in LDS.
-template <bool LB, bool HLDS>
+template <int CS, bool LB, bool HLDS>
 __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
                                                                    const uint32_t *__restrict__ arena, uint32_t ot_words
 #ifdef FL_MFMA_TIMING
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // octet, 16-byte column tile t = lane >> 3 of the half; the data lands lane-linear, i.e. as eight [8 rows][16 bytes]
     // tiles of 128 bytes, which is the block ds_read_b64_tr_b8 transposes.  Odd octets swap neighbouring tiles so that
     // the two 16-lane groups of a transposed read hit different banks.
-    const uint32_t pitch = jb.sw * 3u;
+    const uint32_t pitch = jb.sw * (uint32_t)CS;
     const uint32_t lq = lane & 7u, lt = lane >> 3;
     uint32_t coff[2][2]; // [column half][octet parity]: byte offset inside the row, clamped so that 16 bytes stay inside it
 #pragma unroll
@@ -178,19 +181,27 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             const uint32_t oy = vp.y0 + 16u * tile + row;
             const bool live = 16u * tile + row < vp.rows;
             for (uint32_t xo = lane; xo < npx; xo += 64u) {
-                uint32_t *o = ot + row * np + 3u * xo;
-                uint32_t c8[3];
+                uint32_t *o = ot + row * np + (uint32_t)CS * xo;
+                uint32_t c8[CS];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int c = 0; c < CS; ++c) {
                     const int32_t q = ((int32_t)o[c] + round_add) >> (hs + kMfmaXFracBits);
                     c8[c] = (uint32_t)min(max(q + 128, 0), 255);
                     o[c] = 0u;
                 }
                 if (live && !(ablate & 32u)) {
-                    if (LB) reinterpret_cast<uint32_t *>(jb.dst)[pix_base + oy * jb.dw + xo] = c8[0] | (c8[1] << 8) | (c8[2] << 16) | 0xff000000u;
-                    else {
-                        uint8_t *p = jb.dst + (size_t)(pix_base + oy * jb.dw + xo) * 3u;
-                        p[0] = (uint8_t)c8[0]; p[1] = (uint8_t)c8[1]; p[2] = (uint8_t)c8[2];
+                    const uint32_t pix = pix_base + oy * jb.dw + xo;
+                    if (LB) { // DynamicImage -> Rgba8 (to_rgba8) and imageops::overlay onto the fill colour, as in the streaming kernel
+                        uint32_t v;
+                        if (CS == 1) v = c8[0] | (c8[0] << 8) | (c8[0] << 16) | 0xff000000u;
+                        else if (CS == 2) v = blend_over_fill(jb.fill, c8[0], c8[0], c8[0], c8[CS > 1 ? 1 : 0]);
+                        else if (CS == 3) v = c8[0] | (c8[CS > 1 ? 1 : 0] << 8) | (c8[CS > 2 ? 2 : 0] << 16) | 0xff000000u;
+                        else v = blend_over_fill(jb.fill, c8[0], c8[CS > 1 ? 1 : 0], c8[CS > 2 ? 2 : 0], c8[CS > 3 ? 3 : 0]);
+                        reinterpret_cast<uint32_t *>(jb.dst)[pix] = v;
+                    } else {
+                        uint8_t *p = jb.dst + (size_t)pix * CS;
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) p[c] = (uint8_t)c8[c];
                     }
                 }
             }
@@ -333,17 +344,17 @@ size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds)
     return (size_t)2 * 16 * kMfmaOutPitch * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u); // dynamic part; the rows' 64 KB are static
 }
 
-template <bool LB, bool HLDS>
+template <int CS, bool LB, bool HLDS>
 static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 {
     const size_t lds = mfma_lds_bytes(m.max_nout, HLDS);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<LB, HLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
 #ifdef FL_MFMA_TIMING
     static unsigned long long *dbg = nullptr;
     static int launches = 0;
     if (!dbg) { (void)hipMalloc(&dbg, 64 * 8); (void)hipMemset(dbg, 0, 64 * 8); }
-    resample_mfma_kernel<LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch, dbg);
+    resample_mfma_kernel<CS, LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch, dbg);
     if (++launches == 20 && m.nitems > 1500) {
         unsigned long long h[64];
         (void)hipDeviceSynchronize();
@@ -352,16 +363,28 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
             fprintf(stderr, "mfma timing wave %d: wait %llu, reads+request %llu, vertical mfma %llu, tile stage %llu, total %llu cycles, of which %llu before the first request\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
     }
 #else
-    resample_mfma_kernel<LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch);
+    resample_mfma_kernel<CS, LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch);
 #endif
     return hipGetLastError();
+}
+
+template <int CS>
+static hipError_t launch_mfma_c(const LaunchMfma &m, hipStream_t st)
+{
+    if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<CS, true, true>(m, st) : launch_mfma_t<CS, true, false>(m, st);
+    return m.ops_in_lds ? launch_mfma_t<CS, false, true>(m, st) : launch_mfma_t<CS, false, false>(m, st);
 }
 
 hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st)
 {
     if (m.nitems == 0) return hipSuccess;
-    if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<true, true>(m, st) : launch_mfma_t<true, false>(m, st);
-    return m.ops_in_lds ? launch_mfma_t<false, true>(m, st) : launch_mfma_t<false, false>(m, st);
+    switch (m.cs) {
+    case 1: return launch_mfma_c<1>(m, st);
+    case 2: return launch_mfma_c<2>(m, st);
+    case 3: return launch_mfma_c<3>(m, st);
+    case 4: return launch_mfma_c<4>(m, st);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 } // namespace fl

@@ -50,9 +50,10 @@ double f16_value(uint16_t h)
 
 } // namespace
 
-void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out)
+void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out)
 {
     out = HostMfmaPlan();
+    if (cs < 1 || cs > 4) return;
     if (cw == 0 || ch == 0 || cy + ch > v.out_size || cx + cw > h.out_size) return;
     const uint32_t sh = v.in_size, sw = h.in_size;
     // ---- vertical: tiles of 16 output rows, K-blocks of 32 source rows --------------------------------------------
@@ -118,15 +119,16 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t
     if (hs < 14) return;
     // fewest equal strips that fit
     uint32_t per = 0;
-    for (uint32_t ns = std::max(1u, (cw + kMfmaMaxStripPx - 1u) / kMfmaMaxStripPx); ns <= cw; ++ns) {
+    const uint32_t max_px = kMfmaMaxStripOutputs / cs;
+    for (uint32_t ns = std::max(1u, (cw + max_px - 1u) / max_px); ns <= cw; ++ns) {
         per = (cw + ns - 1u) / ns;
         bool fits = true;
         for (uint32_t x0 = cx; x0 < cx + cw && fits; x0 += per) {
             const uint32_t x1 = std::min(x0 + per, cx + cw);
             uint32_t L = 0xffffffffu, R = 0;
             for (uint32_t x = x0; x < x1; ++x) { L = std::min(L, h.left[x]); R = std::max(R, h.left[x] + h.count[x]); }
-            const uint32_t byte0 = (3u * L) / 16u * 16u;
-            if (3u * R - byte0 > kMfmaStripBytes) fits = false;
+            const uint32_t byte0 = (cs * L) / 16u * 16u;
+            if (cs * R - byte0 > kMfmaStripBytes) fits = false;
         }
         if (fits) break;
         per = 0;
@@ -152,7 +154,7 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t
         const uint32_t x1 = std::min(x0 + per, cx + cw);
         uint32_t L = 0xffffffffu;
         for (uint32_t x = x0; x < x1; ++x) L = std::min(L, h.left[x]);
-        S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (3u * L) / 16u * 16u; S.hdr.nout = (x1 - x0) * 3u; S.hdr.hs = (uint32_t)hs;
+        S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (cs * L) / 16u * 16u; S.hdr.nout = (x1 - x0) * cs; S.hdr.hs = (uint32_t)hs;
         const int32_t nout = (int32_t)S.hdr.nout;
         // operand 0 is all zeros: the tile slots a chunk does not need multiply by it and add into the dummy column, which keeps
         // the kernel's horizontal stage free of branches (12 matrix instructions back to back per chunk instead of 4 + a wait)
@@ -164,9 +166,9 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cx, uint32_t
         auto weight_of = [&](int32_t o, uint32_t col) -> int32_t { // weight of strip byte column `col` in output o
             if (o < 0 || o >= nout) return 0;
             const uint32_t abs_b = S.hdr.byte0 + col;
-            if (abs_b >= 3u * sw) return 0;
-            const uint32_t px = abs_b / 3u, chn = abs_b % 3u, x = x0 + (uint32_t)o / 3u;
-            if ((uint32_t)o % 3u != chn || px < h.left[x] || px >= h.left[x] + h.count[x]) return 0;
+            if (abs_b >= cs * sw) return 0;
+            const uint32_t px = abs_b / cs, chn = abs_b % cs, x = x0 + (uint32_t)o / cs;
+            if ((uint32_t)o % cs != chn || px < h.left[x] || px >= h.left[x] + h.count[x]) return 0;
             return hq[x - cx][px - h.left[x]];
         };
         for (uint32_t w = 0; w < kMfmaWaves; ++w)

@@ -181,7 +181,8 @@ def test_luma_sources_use_the_fused_kernel(fl, gpu_state, oracle, c, kw):
     before = gpu_state.stats()
     check_resample(fl, gpu_state, oracle, img, w=300, h=200, **kw)
     after = gpu_state.stats()
-    assert after["resample_launches"] == before["resample_launches"] + 1
+    # one fused launch -- or two: where the matrix-pipe kernel serves the request, check_resample repeats it on the streaming kernel
+    assert after["resample_launches"] - before["resample_launches"] in (1, 2) and after["generic_launches"] == before["generic_launches"]
 
 
 def test_constant_image_stays_constant(fl, gpu_state):

@@ -52,6 +52,28 @@ def test_geometries_left_to_the_streaming_kernel(fl, gpu_state, oracle, h, w, ow
     parity.check_pixels(oracle, got, img, False, w=ow, h=oh)
 
 
+@pytest.mark.parametrize("c,h,w,ow,oh,crop", [
+    (4, 1080, 1920, 300, 200, False),   # Rgba8 with random alpha: letterboxed -> every pixel is blended onto the fill colour
+    (4, 1080, 1920, 300, 169, False),   # Rgba8 -> Rgba8, no letterbox
+    (4, 1080, 1920, 300, 200, True),
+    (1, 1080, 1920, 300, 200, False),   # Luma8 (grey JPEG sources)
+    (1, 2160, 3840, 640, 360, False),
+    (2, 1080, 1920, 300, 200, False),   # LumaA8
+    (2, 1200, 1600, 250, 188, False),
+])
+def test_other_channel_counts(fl, gpu_state, oracle, c, h, w, ow, oh, crop):
+    img = synth.uniform(h, w, c, index=c * 100 + ow)
+    got = parity.check_resample(fl, gpu_state, oracle, img, w=ow, h=oh, crop=crop)
+    again, used = parity.device_pixels(fl, gpu_state, img, w=ow, h=oh, crop=crop)
+    assert used and np.array_equal(got, again)
+    if c == 4:                                                                        # opaque Rgba8 must equal the Rgb8 result
+        opaque = img.copy()
+        opaque[..., 3] = 255
+        a, _ = parity.device_pixels(fl, gpu_state, opaque, w=ow, h=oh, crop=crop)
+        b, _ = parity.device_pixels(fl, gpu_state, np.ascontiguousarray(opaque[..., :3]), w=ow, h=oh, crop=crop)
+        assert np.array_equal(a[..., :3], b[..., :3])
+
+
 def test_photo_like_input_and_constant_input(fl, gpu_state, oracle):
     img = synth.photo(1080, 1920, 3, index=5)
     parity.check_resample(fl, gpu_state, oracle, img, w=300, h=200)
@@ -81,10 +103,10 @@ def test_band_splits_and_batches_give_the_same_bytes(fl, gpu_state, oracle, monk
 
 
 def test_requests_the_kernel_does_not_take(fl, gpu_state, oracle):
-    """Unaligned rows, other channel counts, pre-ops and mild ratios stay with the streaming / generic kernels."""
+    """Unaligned rows, pre-ops and mild ratios stay with the streaming / generic kernels."""
     cases = [(synth.uniform(540, 961, 3, index=1), dict(w=300, h=200)),            # 2883-byte rows
-             (synth.uniform(540, 960, 4, index=2), dict(w=300, h=200)),            # Rgba8
-             (synth.uniform(540, 960, 1, index=3), dict(w=300, h=200)),            # Luma8
+             (synth.uniform(540, 962, 4, index=2), dict(w=150, h=100)),            # Rgba8, 3848-byte rows: not a multiple of 16
+             (synth.uniform(540, 1000, 1, index=3), dict(w=150, h=100)),           # Luma8, 1000-byte rows
              (synth.uniform(540, 960, 3, index=4), dict(w=300, h=200, grayscale=True)),
              (synth.uniform(540, 960, 3, index=5), dict(w=300, h=200, inverse=True)),
              (synth.uniform(540, 960, 3, index=6), dict(w=600, h=400)),            # ratio 1.6: more than two tiles alive per K-block
