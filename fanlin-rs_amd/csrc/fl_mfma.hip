@@ -277,7 +277,6 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         TM_B(tm_mfma);
         const uint32_t ft = meta & 0xffffu;
         if (ft != 0xffffu) { // output tile ft is complete
-            const uint32_t set = ft & 1u;
             const bool mine = ft >= it.tile0 && ft < it.tile1 && !(ablate & 4u);
             if (mine) {
                 const uint32_t li = ft - it.tile0, buf = li & 1u;
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     u32x4 ahi, alo;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        const f32x4 v = set ? acc[1][4 * c + a] : acc[0][4 * c + a];
+                        const f32x4 v = acc[0][4 * c + a]; // (the older of the two live tiles always sits in set 0, see below)
                         // acc = 256 * (1024 + value); 1.5 * 2^23 - 64 * (1024 + 128) = 12509184: the sum's low 16 bits are
                         // round((value - 128) * 64) in two's complement
                         const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[0], 0.25f, 12509184.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[1], 0.25f, 12509184.0f)),
@@ -321,8 +320,18 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 if (lane == 0) lds_counter_bump(&add_cnt[buf]);
                 if (li >= 1u) do_convert(ft - 1u); // this wave's two rows of the previous tile: every wave has added its sums long ago
             }
+            // The younger tile becomes the older one: set 0 <- set 1, set 1 <- 0.  Done by the matrix unit (0 x 0 + C, exact), which has
+            // time to spare here, instead of 128 vector moves -- and with the finished tile always in set 0 the stage above indexes
+            // its accumulators at compile time (selecting the set at run time cost a v_cndmask per register and tile; a second copy of
+            // the stage per set made hipcc spill).  The host orders each K-block's weights the same way: older tile first.
+            {
+                const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int ct = 0; ct < 16; ++ct) { if (set) acc[1][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; else acc[0][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+                for (int ct = 0; ct < 16; ++ct) {
+                    acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(z, z, acc[1][ct], 0, 0, 0);
+                    acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(z, z, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                }
+            }
             TM_B(tm_flush);
         }
     }

@@ -85,8 +85,10 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
     out.vmeta.assign(NKB + 1u, 0xffffu);
     out.vw.assign((size_t)(NKB + 1u) * 2 * 2 * 64 * 4, 0u);
     for (uint32_t j = 0; j < NT; ++j) {
-        const uint32_t set = j & 1u;
         for (uint32_t s = out.tiles[j].kb_first; s <= out.tiles[j].kb_last; ++s) {
+            // accumulator set of tile j during K-block s: 0 if it is the older (lower) of the K-block's live tiles, 1 if the tile
+            // before it is still alive -- when that one completes, the kernel moves set 1 to set 0
+            const uint32_t set = (j > 0 && out.tiles[j - 1].kb_last >= s) ? 1u : 0u;
             out.vmeta[s] |= 1u << (16 + set);
             for (uint32_t lane = 0; lane < 64; ++lane) {
                 const uint32_t g = lane >> 4, n = lane & 15u;
