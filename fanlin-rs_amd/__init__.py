@@ -110,7 +110,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
     "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version", "flgpu_build_info",
-    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob",
+    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob", "flgpu_debug_mfma_plan",
 )
 
 _lib = None
@@ -194,6 +194,7 @@ def load_library() -> C.CDLL:
     lib.flgpu_debug_axis_table.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_uint64)]
     lib.flgpu_debug_stream_schedulable.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
+    lib.flgpu_debug_mfma_plan.argtypes = [C.c_uint32] * 9 + [C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -409,6 +410,21 @@ def debug_axis_table(in_size: int, out_size: int, gaussian: bool = False, sigma:
     total = C.c_uint64()
     _check(lib.flgpu_debug_axis_table(in_size, out_size, int(gaussian), sigma, left, count, w, cap, C.byref(total)))
     return (np.array(left, dtype=np.uint32), np.array(count, dtype=np.uint32), np.array(w[: total.value], dtype=np.float32))
+
+
+def debug_mfma_plan(sw: int, sh: int, channels: int, rw: int, rh: int, crop=None) -> Optional[dict]:
+    """Builds and self-checks the matrix-pipe kernel's tables on the host (csrc/fl_query.cpp flgpu_debug_mfma_plan); None if
+    the geometry does not fit the kernel.  crop = (cx, cy, cw, ch) in resized coordinates, default the whole picture."""
+    lib = load_library()
+    cx, cy, cw, ch = crop if crop else (0, 0, rw, rh)
+    info = (C.c_uint32 * 8)()
+    err = (C.c_double * 2)()
+    if not lib.flgpu_debug_mfma_plan(sw, sh, channels, rw, rh, cx, cy, cw, ch, info, err):
+        return None
+    keys = ("tiles", "k_blocks", "strips", "max_operands", "hs", "tail", "bad_horizontal", "bad_vertical")
+    d = dict(zip(keys, (int(x) for x in info)))
+    d["vertical_weight_error"], d["horizontal_weight_error"] = float(err[0]), float(err[1])
+    return d
 
 
 def debug_stream_schedulable(in_size: int, out_size: int, y0: int = 0, y1: Optional[int] = None) -> Tuple[bool, int]:

@@ -2,6 +2,7 @@
 // content::Format (src/content.rs) and the geometry decisions of
 // State::process_image (src/handler.rs:224-261).  No device code.
 #include <errno.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -12,6 +13,7 @@
 #include "../../include/fanlin_gpu.h"
 #include "fl_jpeg_tables.h"
 #include "fl_jpegdec.h"
+#include "fl_mfma.h"
 #include "fl_tables.h"
 
 namespace {
@@ -481,3 +483,99 @@ const char *flgpu_strerror(int status)
 uint32_t flgpu_abi_version(void) { return FLGPU_ABI_VERSION; }
 
 } // extern "C"
+
+// Host-side self-check of the matrix-pipe kernel's tables: everything the kernel will read is decoded again here, the way the
+// kernel uses it, and compared with the axis tables it was built from (tests/test_mfma_tables.py, no device needed).
+int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
+                          uint32_t cw, uint32_t ch, uint32_t info[8], double err[2])
+{
+    using namespace fl;
+    if (!sw || !sh || !rw || !rh || !info || !err) return 0;
+    HostAxis v, h;
+    build_axis(sh, rh, FILTER_LANCZOS3, 0.0f, v);
+    build_axis(sw, rw, FILTER_LANCZOS3, 0.0f, h);
+    HostMfmaPlan p;
+    build_mfma_plan(v, h, channels, cx, cy, cw, ch, p);
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    err[0] = err[1] = 0.0;
+    if (!p.ok) return 0;
+    auto f16 = [](uint32_t hbits) -> double {
+        const int sgn = (hbits & 0x8000u) ? -1 : 1, e = (hbits >> 10) & 31, m = hbits & 0x3ff;
+        return e == 0 ? sgn * ldexp((double)m, -24) : sgn * ldexp((double)(m | 0x400), e - 25);
+    };
+    info[0] = p.ntiles; info[1] = p.nkb; info[2] = (uint32_t)p.strips.size(); info[5] = p.tail;
+    // ---- vertical: walk the K-blocks as the kernel does (older live tile = set 0, the set moves down when a tile completes)
+    uint32_t bad_rows = 0;
+    {
+        std::vector<std::vector<double>> got(p.rows, std::vector<double>(sh, 0.0)); // [kept output row][source row]
+        int cur[2] = {-1, -1};                                                        // tile held by each accumulator set
+        uint32_t next_tile = 0;
+        for (uint32_t s = 0; s <= p.nkb; ++s) {                                       // the last pass is the all-zero K-block
+            if (s == p.nkb && !p.tail) break;
+            for (int set = 0; set < 2; ++set) {
+                bool any = false;
+                for (uint32_t k = 0; k < 2u * 64u * 4u && !any; ++k) any = p.vw[(((size_t)s * 2 + set) * 2) * 64 * 4 + k] != 0u;
+                if (!any) continue;
+                if (cur[set] < 0) { cur[set] = (int)next_tile++; }
+                for (uint32_t lane = 0; lane < 64; ++lane)
+                    for (uint32_t jj = 0; jj < 8; ++jj) {
+                        const size_t base = ((((size_t)s * 2 + set) * 2) * 64 + lane) * 4 + jj / 2;
+                        const double w = (f16((p.vw[base] >> (16 * (jj & 1))) & 0xffffu) + f16((p.vw[base + 256] >> (16 * (jj & 1))) & 0xffffu)) / 256.0;
+                        const uint32_t r = kMfmaKRows * s + 8 * (lane >> 4) + jj, row = 16u * (uint32_t)cur[set] + (lane & 15u);
+                        if (w != 0.0) { if (row >= p.rows || r >= sh) ++bad_rows; else got[row][r] += w; }
+                    }
+            }
+            const uint32_t ft = p.vmeta[s] & 0xffffu;
+            if (ft != 0xffffu) { if (cur[0] != (int)ft) ++bad_rows; cur[0] = cur[1]; cur[1] = -1; }
+        }
+        for (uint32_t row = 0; row < p.rows; ++row) {
+            const uint32_t oy = cy + row;
+            for (uint32_t r = 0; r < sh; ++r) {
+                const bool in = r >= v.left[oy] && r < v.left[oy] + v.count[oy];
+                const double want = in ? (double)v.weights[v.woff[oy] + r - v.left[oy]] : 0.0;
+                if (!in && got[row][r] != 0.0) ++bad_rows;
+                err[0] = std::max(err[0], fabs(got[row][r] - want));
+            }
+        }
+    }
+    info[7] = bad_rows;
+    // ---- horizontal: decode every operand through the tile tables into a dense [output][strip byte column] matrix
+    uint32_t bad_h = 0;
+    for (auto &S : p.strips) {
+        const uint32_t nout = S.hdr.nout;
+        info[3] = std::max(info[3], S.hdr.n_ops); info[4] = S.hdr.hs;
+        std::vector<int32_t> dense((size_t)nout * kMfmaStripBytes, 0);
+        std::vector<uint8_t> hits((size_t)nout * kMfmaStripBytes, 0);
+        for (uint32_t w = 0; w < kMfmaWaves; ++w)
+            for (uint32_t c = 0; c < 4; ++c)
+                for (uint32_t t = 0; t < 3; ++t) {
+                    const int32_t *e = &S.ctab[((w * 4 + c) * 3 + t) * 3];
+                    const int8_t *o1 = reinterpret_cast<const int8_t *>(S.ops.data() + (size_t)e[1] * 256), *o0 = reinterpret_cast<const int8_t *>(S.ops.data() + (size_t)e[2] * 256);
+                    for (uint32_t lane = 0; lane < 64; ++lane)
+                        for (uint32_t b = 0; b < 16; ++b) {
+                            const int32_t q = 256 * (int32_t)o1[lane * 16 + b] + (int32_t)o0[lane * 16 + b];
+                            if (q == 0) continue;
+                            const int64_t o = (int64_t)e[0] + (lane & 15u);
+                            const uint32_t col = kMfmaWaveCols * w + 64u * c + 16u * (b >> 2) + 4u * (lane >> 4) + (b & 3u);
+                            if (o < 0 || o >= (int64_t)nout) { ++bad_h; continue; }
+                            dense[(size_t)o * kMfmaStripBytes + col] += q;
+                            if (++hits[(size_t)o * kMfmaStripBytes + col] > 1) ++bad_h;
+                        }
+                }
+        for (uint32_t o = 0; o < nout; ++o) {
+            const uint32_t x = S.hdr.x0 + o / channels, chn = o % channels;
+            int64_t sum = 0;
+            for (uint32_t col = 0; col < kMfmaStripBytes; ++col) {
+                const uint32_t ab = S.hdr.byte0 + col, px = ab / channels;
+                const bool in = ab < channels * sw && ab % channels == chn && px >= h.left[x] && px < h.left[x] + h.count[x];
+                const int32_t q = dense[(size_t)o * kMfmaStripBytes + col];
+                sum += q;
+                if (!in) { if (q != 0) ++bad_h; continue; }
+                err[1] = std::max(err[1], fabs(ldexp((double)q, -(int)S.hdr.hs) - (double)h.weights[h.woff[x] + px - h.left[x]]));
+            }
+            if (sum != ((int64_t)1 << S.hdr.hs)) ++bad_h; // every tap present exactly once, and the fixed-point weights sum to exactly 1
+        }
+    }
+    info[6] = bad_h;
+    return 1;
+}

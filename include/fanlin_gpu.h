@@ -383,6 +383,15 @@ int flgpu_debug_axis_table(uint32_t in_size, uint32_t out_size, int filter, floa
 int flgpu_debug_jpeg_blob(const uint8_t *jpeg, uint64_t n, uint8_t *blob, uint64_t capacity, uint64_t *used);
 
 int flgpu_debug_stream_schedulable(uint32_t in_size, uint32_t out_size, uint32_t y0, uint32_t y1, uint32_t *max_live);
+/* Builds the matrix-pipe kernel's tables (csrc/fl_mfma.h) for a source of sw x sh pixels with `channels` interleaved bytes,
+ * resized to rw x rh, kept rows [cy, cy+ch) x columns [cx, cx+cw), and checks them on the host against the plain weight
+ * tables: returns 1 if the geometry fits the kernel, 0 if not.  info[0..7] = tiles, K-blocks, strips, largest number of
+ * distinct horizontal operands of a strip, log2 of the horizontal weight scale, 1 if the short last tile needs the extra
+ * pass, weights of the horizontal tables that are missing / wrong / doubled (must be 0), rows of the vertical tables that
+ * are wrong (must be 0).  err[0] = largest |f32 weight - (sum of its two f16 terms)| of the vertical tables, err[1] = largest
+ * |weight - fixed-point weight| of the horizontal ones.  Needs no device. */
+int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
+                          uint32_t cw, uint32_t ch, uint32_t info[8], double err[2]);
 
 const char *flgpu_strerror(int status);
 const char *flgpu_last_error(flgpu_ctx *ctx); /* detail of the last FLGPU_ERR_DEVICE on this context */

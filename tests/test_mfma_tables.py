@@ -1,0 +1,54 @@
+"""Host logic of the matrix-pipe resample kernel (csrc/fl_mfma_tables.cpp), checked WITHOUT a device: flgpu_debug_mfma_plan
+builds the tables for a geometry and decodes them again the way the kernel reads them -- K-block by K-block with the
+accumulator sets moving as tiles complete, operand by operand through the tile tables -- and compares the result with the
+plain per-axis weight tables (image 0.25.6 imageops/sample.rs index and weight maths, tests/test_tables.py):
+  * every vertical tap lands in the right output row exactly once, as two f16 terms that give back the f32 weight to 2^-24;
+  * every horizontal tap lands on the right (output, source byte) pair exactly once, channel structure included, as a
+    fixed-point weight within one rounding of the f32 weight, and each output's weights sum to exactly 1;
+  * nothing else is non-zero (rows and columns outside a window, outputs outside a strip, lanes of unused tile slots)."""
+import pytest
+
+GEOMETRIES = [
+    # sw, sh, channels, rw, rh, crop (cx, cy, cw, ch) or None
+    (1920, 1080, 3, 300, 169, None),                # BASELINE config 1
+    (1920, 1080, 3, 356, 200, (28, 0, 300, 200)),   # crop=true: resize_to_fill + centre crop
+    (1920, 1080, 3, 317, 178, None),                # short last tile (2 rows): the extra all-zero pass
+    (1920, 1080, 3, 320, 180, None),
+    (1920, 1080, 3, 400, 225, None),
+    (1920, 1080, 3, 480, 270, None),
+    (1920, 1080, 3, 150, 84, None),
+    (3840, 2160, 3, 300, 169, None),                # 4K: 68 K-blocks, 7 strips
+    (3840, 2160, 3, 640, 360, None),
+    (1280, 720, 3, 160, 90, None),
+    (1936, 1088, 3, 395, 222, (31, 0, 333, 222)),
+    (800, 600, 3, 100, 75, None),
+    (1920, 1080, 4, 300, 169, None),                # Rgba8
+    (1920, 1080, 1, 300, 169, None),                # Luma8
+    (1600, 1200, 2, 250, 188, None),                # LumaA8
+    (6000, 4000, 3, 300, 200, None),                # ratio 20
+    (1024, 333, 3, 90, 29, None),                   # two tiles
+]
+
+
+@pytest.mark.parametrize("sw,sh,c,rw,rh,crop", GEOMETRIES)
+def test_tables_decode_back_to_the_axis_weights(fl, sw, sh, c, rw, rh, crop):
+    d = fl.debug_mfma_plan(sw, sh, c, rw, rh, crop)
+    assert d is not None, "this geometry is meant to fit the kernel"
+    assert d["bad_vertical"] == 0 and d["bad_horizontal"] == 0, d
+    assert d["vertical_weight_error"] < 2.0 ** -24, d           # two f16 terms carry 22 bits of a weight < 1/2
+    # fixed point with 2^-hs steps; the largest tap of an output absorbs the rounding of the others (so the sum is exactly 1)
+    assert 14 <= d["hs"] <= 17 and d["horizontal_weight_error"] < 64 * 2.0 ** -(d["hs"] + 1), d
+    rows = crop[3] if crop else rh
+    assert d["tiles"] == (rows + 15) // 16 and d["k_blocks"] == (sh + 31) // 32 and d["strips"] >= 1
+
+
+def test_geometries_the_kernel_refuses(fl):
+    assert fl.debug_mfma_plan(1920, 1080, 3, 1200, 675) is None       # ratio 1.6: more than two tiles alive per K-block
+    assert fl.debug_mfma_plan(320, 200, 3, 640, 400) is None          # up-scale
+    assert fl.debug_mfma_plan(1920, 1080, 3, 300, 169, (0, 0, 301, 169)) is None   # crop outside the resized picture
+    assert fl.debug_mfma_plan(1920, 1080, 5, 300, 169) is None        # not a channel count
+
+
+def test_short_last_tile_is_flagged(fl):
+    assert fl.debug_mfma_plan(1920, 1080, 3, 317, 178)["tail"] == 1   # rows 176-177 end with the tile before them
+    assert fl.debug_mfma_plan(1920, 1080, 3, 300, 169)["tail"] == 0
