@@ -49,6 +49,13 @@ __device__ __forceinline__ uint32_t lds_counter(const uint32_t *p)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     return v;
 }
+// Waits until the counter has reached `target`.  By construction the wait is short or none (the slowest wave never waits,
+// see the kernel), but a wait inside a kernel gets a bound all the same: a wave that gives up produces wrong pixels,
+// which the tests catch, instead of a grid that never drains.
+__device__ __forceinline__ void lds_counter_wait(const uint32_t *p, uint32_t target)
+{
+    for (uint32_t spin = 0; lds_counter(p) < target && spin < (1u << 22); ++spin) __builtin_amdgcn_s_sleep(2);
+}
 __device__ __forceinline__ void lds_counter_bump(uint32_t *p)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 
     auto do_convert = [&](uint32_t tile) __attribute__((always_inline)) {
         const uint32_t li = tile - it.tile0, buf = li & 1u;
-        while (lds_counter(&add_cnt[buf]) < kMfmaWaves * ((li >> 1) + 1u)) __builtin_amdgcn_s_sleep(1);
+        lds_counter_wait(&add_cnt[buf], kMfmaWaves * ((li >> 1) + 1u));
         if (!(ablate & 2u)) convert_rows(tile, buf);
         if (lane == 0) lds_counter_bump(&conv_cnt[buf]);
     };
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 const uint32_t li = ft - it.tile0, buf = li & 1u;
                 uint32_t *ot = otile + buf * ot_words;
                 // the tile that used this buffer two tiles ago must have been converted by every wave
-                while (lds_counter(&conv_cnt[buf]) < kMfmaWaves * (li >> 1)) __builtin_amdgcn_s_sleep(1);
+                lds_counter_wait(&conv_cnt[buf], kMfmaWaves * (li >> 1));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     u32x4 ahi, alo;
