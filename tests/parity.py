@@ -83,3 +83,44 @@ def check_pixels_any_kernel(oracle, got, img, **okw):
     kernel's bars."""
     want_fma = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **okw)
     check_pixels(oracle, got, img, not np.array_equal(got, want_fma), **okw)
+
+
+def mfma_model(fl, img, rw, rh):
+    """A numpy restatement of the matrix-pipe kernel's arithmetic for a plain resize_exact of `img` to rw x rh (no crop, no
+    letterbox): vertical weights as two f16 terms of 256 w (csrc/fl_mfma_tables.cpp), exact vertical sums, the intermediate
+    rounded to 1/64 around 128, horizontal weights round(w 2^hs) with the largest tap absorbing the rounding, exact integer
+    horizontal sums, round half up, clamp.  The device differs from it only where the matrix unit's f32 accumulation (error
+    ~1e-4 of a pixel step) tips the 1/64 rounding of an intermediate value AND that tips a final rounding: a few bytes in
+    ten thousand.  Far sharper than the 1 LSB bar: it pins every index, weight and rounding rule of the kernel and its tables."""
+    sh, sw, c = img.shape
+    d = fl.debug_mfma_plan(sw, sh, c, rw, rh)
+    assert d is not None
+    hs = d["hs"]
+    vl, vc, vw = fl.debug_axis_table(sh, rh)
+    hl, hc, hw = fl.debug_axis_table(sw, rw)
+    rows = img.reshape(sh, sw * c).astype(np.float64)
+    x16 = np.empty((rh, sw * c), np.int64)
+    o = 0
+    for y in range(rh):
+        n, l = int(vc[y]), int(vl[y])
+        w = vw[o:o + n].astype(np.float64) * 256.0
+        o += n
+        wa = w.astype(np.float16).astype(np.float64)
+        wb = (w - wa).astype(np.float16).astype(np.float64)
+        x = ((wa + wb)[:, None] * rows[l:l + n]).sum(axis=0) / 256.0      # exact in float64: 22-bit weights x 8-bit pixels x <= 120 taps
+        x16[y] = np.rint((x - 128.0) * 64.0).astype(np.int64)
+    x16 = x16.reshape(rh, sw, c)
+    out = np.empty((rh, rw, c), np.uint8)
+    o = 0
+    for x in range(rw):
+        n, l = int(hc[x]), int(hl[x])
+        w = hw[o:o + n].astype(np.float64)
+        o += n
+        q = np.rint(np.ldexp(w, hs))
+        q = np.where(np.abs(np.ldexp(w, hs) - np.trunc(np.ldexp(w, hs))) == 0.5, np.sign(w) * np.ceil(np.abs(np.ldexp(w, hs))), q).astype(np.int64)  # llround: halves away from zero
+        big = int(np.argmax(np.abs(q)))
+        q[big] += (1 << hs) - int(q.sum())
+        acc = (q[None, :, None] * x16[:, l:l + n, :]).sum(axis=1)           # [rh][c]
+        v = ((acc + (1 << (hs + 5))) >> (hs + 6)) + 128
+        out[:, x, :] = np.clip(v, 0, 255).astype(np.uint8)
+    return out
