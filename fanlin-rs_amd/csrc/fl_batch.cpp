@@ -31,6 +31,7 @@ struct Work {
     uint32_t vtab = 0, htab = 0;
     const StreamPlan *splan = nullptr;
     const MfmaPlan *mplan = nullptr;
+    const std::vector<MfmaItem> *mitems = nullptr; // its workgroups for the band count of this batch
     bool unaligned = false;
     size_t jpeg_coef_off = 0, jpeg_off_off = 0, jpeg_raw_off = 0; // FE_JPEG scratch (bytes)
     uint32_t jpeg_tab = 0;
@@ -302,9 +303,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 uint32_t nbands = 1;
                 if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
                 else if (n_resample < 128) nbands = (uint32_t)std::min<size_t>(16, (256 + n_resample * 3 - 1) / (n_resample * 3));
-                const MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, nbands, w.cs);
+                MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
                 if (mp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
-                if (mp->ok) { w.s1 = S1_MFMA; w.mplan = mp; continue; }
+                if (mp->ok) { w.s1 = S1_MFMA; w.mplan = mp; w.mitems = &mp->items_for(nbands); continue; }
             }
             if (stream_supported(w.cs, w.pre) && aligned && !force_generic) {
                 Job jtmp; fill_job(w, jtmp);
@@ -429,8 +430,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
             L.g.max_dw = std::max(L.g.max_dw, j.dw); L.g.max_dh = std::max(L.g.max_dh, j.dh);
             if ((k.kind & 255u) == S1_MFMA) {
-                for (MfmaItem it2 : w.mplan->items) { it2.job = (uint32_t)jobs.size(); mitems.push_back(it2); }
-                L.nitems += (uint32_t)w.mplan->items.size();
+                for (MfmaItem it2 : *w.mitems) { it2.job = (uint32_t)jobs.size(); mitems.push_back(it2); }
+                L.nitems += (uint32_t)w.mitems->size();
                 L.max_nout = std::max(L.max_nout, w.mplan->max_nout);
                 c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
                 c->stats.resample_dst_bytes += w.plan.pixel_bytes;

@@ -106,17 +106,50 @@ uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma
     return hoff;
 }
 
-// Tables and workgroup list of the matrix-pipe kernel for one geometry; bands are runs of whole 16-row tiles.
-const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
-                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs)
+// Workgroups of one geometry for a given number of bands (runs of whole 16-row tiles), longest K-block ranges first is the
+// launcher's business; the list is cached per band count.
+const std::vector<MfmaItem> &MfmaPlan::items_for(uint32_t nbands)
 {
-    MfmaPlanKey key{vk, hk, cx, cy, cw, ch, nbands, cs};
+    const uint32_t nt = (uint32_t)tiles.size(), nb = std::max(1u, std::min(nbands, nt));
+    auto it = items_by_bands.find(nb);
+    if (it != items_by_bands.end()) return it->second;
+    std::vector<MfmaItem> items;
+    for (uint32_t soff : strip_offs)
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t t0 = (uint32_t)((uint64_t)nt * b / nb), t1 = (uint32_t)((uint64_t)nt * (b + 1) / nb);
+            if (t1 <= t0) continue;
+            MfmaItem mi{};
+            mi.vplan_off = vplan_off; mi.strip_off = soff; mi.tile0 = t0; mi.tile1 = t1;
+            mi.kb0 = tiles[t0].kb_first; mi.kb1 = tiles[t1 - 1].kb_last + 1u;
+            items.push_back(mi);
+        }
+    return items_by_bands.emplace(nb, std::move(items)).first->second;
+}
+
+// Tables of the matrix-pipe kernel for one geometry, or ok = false if the kernel cannot or should not take it.
+MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
+                        uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs)
+{
+    MfmaPlanKey key{vk, hk, cx, cy, cw, ch, cs};
     auto it = c->mfma_plans.find(key);
     if (it != c->mfma_plans.end()) return &it->second;
     MfmaPlan plan;
     HostMfmaPlan hp;
     build_mfma_plan(va, ha, cs, cx, cy, cw, ch, hp);
     bool ok = hp.ok;
+    if (ok) {
+        plan.ops_in_lds = true;
+        for (auto &S : hp.strips) {
+            plan.max_nout = std::max(plan.max_nout, S.hdr.nout);
+            if (S.hdr.n_ops > kMfmaLdsOperands) plan.ops_in_lds = false;
+        }
+        if (mfma_lds_bytes(plan.max_nout, plan.ops_in_lds) > 160 * 1024) ok = false;
+        // Where the kernel pays (tools/experiments/resample_sweep.py, 1080p sources): every strip requests 2048 bytes per row
+        // whatever it needs, and horizontal operands that do not fit the LDS cache come from the L2 behind the K-block in
+        // flight.  With both handicaps (four strips where 2.8 would do, ~100 distinct operands) the streaming kernel is as
+        // fast or faster (256x144: 1.03 vs 1.06 ms, 512x288: 1.77 vs 1.63); with either one alone the matrix pipe wins by 20-28 %.
+        if (ok && !plan.ops_in_lds && (uint64_t)hp.strips.size() * kMfmaStripBytes * 10u > (uint64_t)ha.in_size * cs * 11u) ok = false;
+    }
     if (ok) { // all or nothing: whether a geometry gets this kernel must not depend on how full the arena happens to be
         size_t need = sizeof(MfmaVPlan) / 4 + hp.vmeta.size() + hp.vw.size() + 64;
         for (auto &S : hp.strips) need += sizeof(MfmaStrip) / 4 + S.ctab.size() + S.ops.size() + 64;
@@ -128,19 +161,17 @@ const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &v
             ok = false;
         }
     }
-    uint32_t vplan_off = 0;
     if (ok) {
         MfmaVPlan vp{};
         vp.ntiles = hp.ntiles; vp.nkb = hp.nkb; vp.y0 = hp.y0; vp.rows = hp.rows; vp.tail = hp.tail;
-        vplan_off = arena_append(c, nullptr, sizeof(MfmaVPlan) / 4);
+        plan.vplan_off = arena_append(c, nullptr, sizeof(MfmaVPlan) / 4);
         vp.meta_off = arena_append(c, hp.vmeta.data(), hp.vmeta.size());
         vp.w_off = arena_append(c, hp.vw.data(), hp.vw.size());
-        if (!vplan_off || !vp.meta_off || !vp.w_off) ok = false;
-        else memcpy(c->h_arena.data() + vplan_off, &vp, sizeof(vp));
+        if (!plan.vplan_off || !vp.meta_off || !vp.w_off) ok = false;
+        else memcpy(c->h_arena.data() + plan.vplan_off, &vp, sizeof(vp));
     }
     if (ok) {
-        plan.ops_in_lds = true;
-        const uint32_t nb = std::max(1u, std::min(nbands, hp.ntiles));
+        plan.tiles = hp.tiles;
         for (auto &S : hp.strips) {
             MfmaStrip sh = S.hdr;
             const uint32_t soff = arena_append(c, nullptr, sizeof(MfmaStrip) / 4);
@@ -148,29 +179,13 @@ const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &v
             sh.ops_off = arena_append(c, S.ops.data(), S.ops.size());
             if (!soff || !sh.ctab_off || !sh.ops_off) { ok = false; break; }
             memcpy(c->h_arena.data() + soff, &sh, sizeof(sh));
-            plan.max_nout = std::max(plan.max_nout, sh.nout);
-            if (sh.n_ops > kMfmaLdsOperands) plan.ops_in_lds = false;
-            for (uint32_t b = 0; b < nb; ++b) {
-                const uint32_t t0 = (uint32_t)((uint64_t)hp.ntiles * b / nb), t1 = (uint32_t)((uint64_t)hp.ntiles * (b + 1) / nb);
-                if (t1 <= t0) continue;
-                MfmaItem mi{};
-                mi.vplan_off = vplan_off; mi.strip_off = soff; mi.tile0 = t0; mi.tile1 = t1;
-                mi.kb0 = hp.tiles[t0].kb_first; mi.kb1 = hp.tiles[t1 - 1].kb_last + 1u;
-                plan.items.push_back(mi);
-            }
+            plan.strip_offs.push_back(soff);
         }
-        if (ok && mfma_lds_bytes(plan.max_nout, plan.ops_in_lds) > 160 * 1024) ok = false;
-        // Where the kernel pays (tools/experiments/resample_sweep.py, 1080p sources): every strip requests 2048 bytes per row
-        // whatever it needs, and horizontal operands that do not fit the LDS cache come from the L2 behind the K-block in
-        // flight.  With both handicaps (four strips where 2.8 would do, ~100 distinct operands) the streaming kernel is as
-        // fast or faster (256x144: 1.03 vs 1.06 ms, 512x288: 1.77 vs 1.63); with either one alone the matrix pipe wins by 20-28 %.
-        if (ok && !plan.ops_in_lds && (uint64_t)hp.strips.size() * kMfmaStripBytes * 10u > (uint64_t)ha.in_size * cs * 11u) ok = false;
     }
     plan.ok = ok;
-    if (!ok) plan.items.clear();
     if (getenv("FLGPU_DEBUG_MFMA")) {
-        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, %zu items, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d;",
-                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, plan.items.size(), hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds);
+        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d;",
+                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds);
         for (auto &S : hp.strips) fprintf(stderr, " strip [%u,%u) byte0 %u hs %u ops %u", S.hdr.x0, S.hdr.x1, S.hdr.byte0, S.hdr.hs, S.hdr.n_ops);
         fprintf(stderr, "\n");
     }

@@ -75,14 +75,19 @@ struct StreamPlan {
 
 struct MfmaPlanKey {
     AxisKey v, h;
-    uint32_t cx, cy, cw, ch, nbands, cs;
-    bool operator<(const MfmaPlanKey &o) const { return std::tie(v, h, cx, cy, cw, ch, nbands, cs) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.nbands, o.cs); }
+    uint32_t cx, cy, cw, ch, cs;
+    bool operator<(const MfmaPlanKey &o) const { return std::tie(v, h, cx, cy, cw, ch, cs) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.cs); }
 };
 
-// Workgroups of the matrix-pipe resample kernel for one geometry (fl_mfma.h); job field unset.
+// Tables of the matrix-pipe resample kernel for one geometry (fl_mfma.h) and its workgroup lists (job field unset), one per
+// band count: the tables do not depend on how a picture is cut into bands, so they are built and stored once.
 struct MfmaPlan {
     bool ok = false;
-    std::vector<MfmaItem> items;
+    uint32_t vplan_off = 0;
+    std::vector<uint32_t> strip_offs;
+    std::vector<HostMfmaPlan::Tile> tiles;
+    std::map<uint32_t, std::vector<MfmaItem>> items_by_bands;
+    const std::vector<MfmaItem> &items_for(uint32_t nbands);
     uint32_t max_nout = 0;
     bool ops_in_lds = false;
     bool arena_full = false; // the tables did not fit what is left of the arena: not cached, the caller resets the arena and plans again
@@ -234,8 +239,8 @@ uint32_t arena_append(flgpu_ctx *c, const void *data, size_t words, size_t align
 void arena_reset(flgpu_ctx *c);
 int arena_flush(flgpu_ctx *c, hipStream_t st);
 uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma, AxisKey *key_out, const HostAxis **host_out);
-const MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
-                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs);
+MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
+                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs);
 const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
                                   uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs, uint32_t pre);
 hipEvent_t get_event(flgpu_ctx *c);
