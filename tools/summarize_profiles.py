@@ -109,6 +109,9 @@ def main():
                                             verification, extras, the three latency probes and the CPU baseline)
 {tag}_latency_sweep.txt              tools/experiments/latency_sweep.sh + tools/latency/latency_probe <threads> 4096 1920 1080 "w=300&h=200"
 {tag}_microbench_valu_rate.txt       tools/microbench/valu_rate.hip
+{tag}_resample_sweep.txt            tools/experiments/resample_sweep.py 1024 (matrix-pipe vs streaming kernel over target sizes)
+{tag}_mfma_model_rate.txt            tools/experiments/mfma_model_rate.py (device vs the numpy model of the matrix-pipe arithmetic vs the reference arithmetic)
+{tag}_microbench_*_probe.txt         tools/microbench/{mfma,vstage,hfirst,tr8,mfma_pipeline}_probe.hip (the skeletons timed before the kernel was built)
 (only rows of this repository's kernels, fl::*, are kept in the kernel statistics)
 """.replace("{tag}", tag))
     print("profiles/ updated:", sorted(os.listdir(OUT)))
