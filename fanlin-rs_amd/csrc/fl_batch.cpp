@@ -37,6 +37,8 @@ struct Work {
     uint32_t jpeg_tab = 0;
     uint32_t orient = 0, raw_w = 0, raw_h = 0; // EXIF orientation pre-pass (2..8), source size before it
     size_t orient_off = 0;
+    size_t align_off = 0;       // misaligned device source of a matrix-pipe geometry: offset of its aligned copy in d_tmp_al
+    bool align_copy = false;
     const uint8_t *raw_src = nullptr;
 };
 
@@ -151,6 +153,7 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
         if (H->nc == 4) scratch += align_up((px + 3) / 4 * 12, 256); // the Rgb8 picture after the CMYK table
     }
     if (!nj) return FLGPU_OK;
+    { const int brc = clut_batch_begin(c); if (brc) return brc; } // tables selected below stay resident until the batch's kernels are launched
     FL_HIP(c, c->d_dec.reserve(scratch), "JPEG decode scratch");
     FL_HIP(c, c->h_decjobs.reserve(nj * sizeof(JpegDecJob)), "JPEG decode descriptors");
     FL_HIP(c, c->d_decjobs.reserve(nj * sizeof(JpegDecJob)), "JPEG decode descriptors");
@@ -215,7 +218,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     // ---- plan every image ------------------------------------------------
     std::unique_ptr<RoctxRange> range_plan(new RoctxRange("flgpu plan + tables"));
     std::vector<Work> work(n);
-    size_t tmp_a_bytes = 0, tmp_b_bytes = 0, tmp_o_bytes = 0, jpeg_coef_bytes = 0, jpeg_off_bytes = 0, jpeg_raw_bytes = 0;
+    size_t tmp_a_bytes = 0, tmp_b_bytes = 0, tmp_o_bytes = 0, tmp_al_bytes = 0, jpeg_coef_bytes = 0, jpeg_off_bytes = 0, jpeg_raw_bytes = 0;
     for (size_t i = 0; i < n; ++i) {
         Work &w = work[i];
         const flgpu_image &s = srcs[i];
@@ -240,6 +243,15 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (pl.resampled) w.s1 = w.p->filter == FLGPU_FILTER_NEAREST ? S1_NEAREST : S1_GENERIC;
         else if (pre_changes || pl.letterboxed || cropped) w.s1 = S1_PLACE;
         else w.s1 = S1_NONE;
+        // Which resample kernel serves a request is a function of the REQUEST (geometry, channels, pre-op), never of where the
+        // caller's buffer happens to start: the matrix-pipe kernel moves 16-byte pieces of a row, so a source whose rows qualify
+        // but whose base is not 16-byte aligned (only possible through the device-batch entry point; staged and decoded sources
+        // are 256-byte aligned) is copied to aligned scratch first.  The two kernels may differ by 1 LSB; an HTTP cache in front of
+        // the service must not see that difference come and go with an address.
+        if (pl.resampled && w.s1 == S1_GENERIC && !pre_changes && !w.orient && ((size_t)w.sw * w.cs) % 16u == 0 && (uintptr_t)s.data % 16u != 0) {
+            w.align_off = tmp_al_bytes; w.align_copy = true;
+            tmp_al_bytes += align_up((size_t)s.width * s.height * s.channels, 256);
+        }
         const bool blur = w.p->blur_sigma > 0.0f;
         const bool fe = w.p->front_end != FLGPU_FE_NONE;
         // buffer chain
@@ -265,6 +277,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     FL_HIP(c, c->d_tmp_o.reserve(tmp_o_bytes), "orientation scratch");
     for (auto &w : work)
         if (w.orient) { w.raw_src = w.src; w.src = static_cast<uint8_t *>(c->d_tmp_o.p) + w.orient_off; }
+    FL_HIP(c, c->d_tmp_al.reserve(tmp_al_bytes), "alignment scratch");
+    for (auto &w : work)
+        if (w.align_copy) {
+            uint8_t *al = static_cast<uint8_t *>(c->d_tmp_al.p) + w.align_off;
+            FL_HIP(c, hipMemcpyAsync(al, w.src, (size_t)w.sw * w.sh * w.cs, hipMemcpyDeviceToDevice, st), "alignment copy");
+            w.src = al;
+        }
     FL_HIP(c, c->d_tmp_a.reserve(tmp_a_bytes), "scratch A");
     FL_HIP(c, c->d_tmp_b.reserve(tmp_b_bytes), "scratch B");
     for (auto &w : work) {
@@ -501,11 +520,17 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         blur_launches.push_back(L);
     }
     // result words: two per image of the batch, see flgpu_ctx::last_fe
+    // ... followed by the batch's device error word (fl_mfma.h FLGPU_DEVERR_*): kernels that wait on one another inside a
+    // workgroup bound their waits and report an expired one here instead of delivering pixels that were never synchronised
     const bool has_results = !fe_groups.empty();
-    if (has_results) {
-        FL_HIP(c, c->d_status.reserve(n * 8), "result words");
-        FL_HIP(c, hipMemsetAsync(c->d_status.p, 0, n * 8, st), "result clear");
+    bool has_err_word = false;
+    for (auto &L : s1_launches) has_err_word |= (L.k.kind & 255u) == S1_MFMA;
+    if (has_results || has_err_word) {
+        FL_HIP(c, c->d_status.reserve(n * 8 + 8), "result words");
+        FL_HIP(c, hipMemsetAsync(c->d_status.p, 0, n * 8 + 8, st), "result clear");
     }
+    uint32_t mfma_spin_limit = kMfmaDefaultSpinLimit;
+    if (const char *e = getenv("FLGPU_MFMA_SPIN_LIMIT")) mfma_spin_limit = (uint32_t)strtoul(e, nullptr, 10); // tests: 0 = every bounded wait expires
     std::vector<JpegJob> jjobs;
     uint32_t jpeg_max_blocks = 0;
     for (auto &kv : fe_groups) {
@@ -604,6 +629,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
             m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
             m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.max_nout = L.max_nout;
+            m.spin_limit = mfma_spin_limit; m.err_word = static_cast<uint32_t *>(c->d_status.p) + 2 * n;
             {
                 ProfileScope ps(c, st, 0);
                 FL_HIP(c, launch_mfma(m, st), "matrix-pipe resample kernel");
@@ -668,6 +694,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     }
     c->last_n = n;
     c->last_has_results = has_results;
+    c->last_has_err_word = has_err_word;
     c->last_fe.resize(n);
     for (size_t i = 0; i < n; ++i) c->last_fe[i] = work[i].p->front_end;
     c->stats.images += n;
@@ -679,11 +706,18 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
 // the alpha flag of the WebP front end, the length of an encoded stream.
 int collect_results(flgpu_ctx *c, size_t n, flgpu_image *dsts, hipStream_t st)
 {
-    if (!c->last_has_results || n != c->last_n) { FL_HIP(c, hipStreamSynchronize(st), "batch sync"); return FLGPU_OK; }
-    FL_HIP(c, c->h_results.reserve(n * 8), "pinned result words");
-    FL_HIP(c, hipMemcpyAsync(c->h_results.p, c->d_status.p, n * 8, hipMemcpyDeviceToHost, st), "result words D2H");
+    if ((!c->last_has_results && !c->last_has_err_word) || n != c->last_n) { FL_HIP(c, hipStreamSynchronize(st), "batch sync"); return FLGPU_OK; }
+    FL_HIP(c, c->h_results.reserve(n * 8 + 8), "pinned result words");
+    if (c->last_has_results) FL_HIP(c, hipMemcpyAsync(c->h_results.p, c->d_status.p, n * 8 + 8, hipMemcpyDeviceToHost, st), "result words D2H");
+    else FL_HIP(c, hipMemcpyAsync(static_cast<char *>(c->h_results.p) + n * 8, static_cast<char *>(c->d_status.p) + n * 8, 8, hipMemcpyDeviceToHost, st), "error word D2H");
     FL_HIP(c, hipStreamSynchronize(st), "batch sync");
     const uint32_t *r = static_cast<const uint32_t *>(c->h_results.p);
+    if (c->last_has_err_word && r[2 * n]) {
+        c->set_error((r[2 * n] & FLGPU_DEVERR_MFMA_WAIT) ? "matrix-pipe resample kernel: a bounded wait on an LDS hand-off expired; the batch's pixels are not valid"
+                                                         : "device error word set");
+        return FLGPU_ERR_DEVICE;
+    }
+    if (!c->last_has_results) return FLGPU_OK;
     int rc = FLGPU_OK;
     for (size_t i = 0; i < n; ++i) {
         if (c->last_fe[i] == FLGPU_FE_WEBP420 && (r[2 * i] & 1u)) dsts[i].flags |= FLGPU_IMG_HAS_ALPHA;

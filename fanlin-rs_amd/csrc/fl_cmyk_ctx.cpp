@@ -19,6 +19,7 @@ using namespace fl;
 namespace {
 
 constexpr size_t kClutNodes = (size_t)kCmykGrid * kCmykGrid * kCmykGrid * kCmykGrid;
+constexpr size_t kClutCacheEntries = 8; // baked tables of embedded profiles kept per context (653 KB each)
 
 int upload_clut(flgpu_ctx *c, flgpu_ctx::Clut &t)
 {
@@ -39,12 +40,19 @@ int select_clut_impl(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const v
         if (it == c->cmyk_embedded.end()) {
             std::vector<uint16_t> nodes;
             if (bake_cmyk_clut(icc, icc_len, nodes) == 0) {
-                if (c->cmyk_embedded.size() >= 8) { // evict the least recently used table
-                    auto old = c->cmyk_embedded.begin();
-                    for (auto i2 = c->cmyk_embedded.begin(); i2 != c->cmyk_embedded.end(); ++i2) if (i2->second.stamp < old->second.stamp) old = i2;
-                    FL_HIP(c, hipStreamSynchronize(c->stream), "CLUT evict sync");
-                    old->second.dev.release();
-                    c->cmyk_embedded.erase(old);
+                if (c->cmyk_embedded.size() >= kClutCacheEntries) {
+                    // Evict the least recently used table -- but never one handed out since clut_batch_begin(): a batch selects
+                    // the tables of ALL its pictures first and launches their conversions afterwards, so a table chosen for
+                    // picture 1 must survive the selection for picture 9.  If every cached table is pinned that way the cache
+                    // grows for this batch and is trimmed when the next one begins.
+                    auto old = c->cmyk_embedded.end();
+                    for (auto i2 = c->cmyk_embedded.begin(); i2 != c->cmyk_embedded.end(); ++i2)
+                        if (i2->second.stamp <= c->cmyk_pin_floor && (old == c->cmyk_embedded.end() || i2->second.stamp < old->second.stamp)) old = i2;
+                    if (old != c->cmyk_embedded.end()) {
+                        FL_HIP(c, hipDeviceSynchronize(), "CLUT evict sync"); // earlier batches may have run on a caller's stream
+                        old->second.dev.release();
+                        c->cmyk_embedded.erase(old);
+                    }
                 }
                 flgpu_ctx::Clut &t = c->cmyk_embedded[h];
                 t.host.swap(nodes);
@@ -163,6 +171,23 @@ int install_default(flgpu_ctx *c)
 namespace fl {
 
 int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev) { return select_clut_impl(c, icc, icc_len, dev); }
+
+// Called before a batch (or a single conversion) selects its tables: everything selected from here on stays resident until
+// the next call.  A cache that grew past its size because one batch used more distinct embedded profiles is trimmed here.
+int clut_batch_begin(flgpu_ctx *c)
+{
+    if (c->cmyk_embedded.size() > kClutCacheEntries) {
+        FL_HIP(c, hipDeviceSynchronize(), "CLUT trim sync");
+        while (c->cmyk_embedded.size() > kClutCacheEntries) {
+            auto old = c->cmyk_embedded.begin();
+            for (auto i2 = c->cmyk_embedded.begin(); i2 != c->cmyk_embedded.end(); ++i2) if (i2->second.stamp < old->second.stamp) old = i2;
+            old->second.dev.release();
+            c->cmyk_embedded.erase(old);
+        }
+    }
+    c->cmyk_pin_floor = c->cmyk_stamp;
+    return FLGPU_OK;
+}
 
 void release_cmyk(flgpu_ctx *c)
 {
@@ -288,6 +313,7 @@ int flgpu_cmyk_to_rgb(flgpu_ctx *c, const uint8_t *cmyk, uint64_t n_pixels, uint
     }
     FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
     const void *clut = nullptr;
+    { const int brc = clut_batch_begin(c); if (brc) return brc; }
     const int rc = select_clut_impl(c, embedded_icc, icc_len, &clut);
     if (rc) return rc;
     return cmyk_range(c, clut, cmyk, n_pixels, rgb, flags);

@@ -145,7 +145,7 @@ struct flgpu_ctx {
 
     fl::DescSlot slots[4];
     int next_slot = 0;
-    fl::DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_tmp_o, d_status;
+    fl::DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_tmp_o, d_tmp_al, d_status;
     fl::DeviceBuf d_in, d_out;
     fl::DeviceBuf d_dec, d_decjobs;                    // JPEG decode: planes + decoded pixels of a batch, job descriptors
     fl::PinnedBuf h_decjobs;
@@ -155,6 +155,7 @@ struct flgpu_ctx {
     // end, FL_JPEG_RESULT_OVERFLOW), [2i + 1] bytes of an encoded stream
     size_t last_n = 0;
     bool last_has_results = false;
+    bool last_has_err_word = false; // a kernel of the batch reports through the device error word that follows the result words
     std::vector<uint8_t> last_fe;
     fl::PinnedBuf h_results;
     fl::PinnedBuf h_stage_in, h_stage_out;
@@ -177,6 +178,7 @@ struct flgpu_ctx {
     bool has_cmyk_default = false;
     std::map<uint64_t, Clut> cmyk_embedded;
     uint64_t cmyk_stamp = 0;
+    uint64_t cmyk_pin_floor = 0;   // tables stamped later than this were handed out in the current batch: not evictable
 
     // pinned staging blocks recycled between requests (power-of-two size classes)
     std::mutex pin_mu;
@@ -277,6 +279,7 @@ int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, siz
 // fl_cmyk_ctx.cpp: the device-link table for one conversion on context c: the embedded profile's if given and usable
 // (baked once, cached on c), else the configured one (c's own, or its clut_owner's)
 int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev);
+int clut_batch_begin(flgpu_ctx *c);
 
 // ---- fl_queue.cpp ----------------------------------------------------------------------------------------------------
 // contiguous split of n weighted items into n_shards shards of about equal weight: shard_of[i] is non-decreasing

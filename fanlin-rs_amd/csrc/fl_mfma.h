@@ -34,8 +34,15 @@ constexpr uint32_t kMfmaWaves = 8;          // waves per workgroup
 constexpr uint32_t kMfmaKRows = 32;         // source rows per K-block
 constexpr uint32_t kMfmaWaveCols = 256;     // byte columns per wave
 constexpr uint32_t kMfmaStripBytes = kMfmaWaves * kMfmaWaveCols;
-constexpr uint32_t kMfmaMaxStripOutputs = 408; // outputs (pixels x channels) per strip: 136 Rgb8 pixels (bounds the LDS output tiles: 2 x 16 x 409 words = 52 KB)
-constexpr uint32_t kMfmaOutPitch = kMfmaMaxStripOutputs + 1; // words per row of an LDS output tile: 408 outputs + a dummy column (odd: rows spread over the banks)
+constexpr uint32_t kMfmaMaxStripOutputs = 408; // outputs (pixels x channels) per strip: 136 Rgb8 pixels (bounds the LDS output tiles: 2 x 16 x 428 words = 53.5 KB)
+// Words per row of an LDS output tile: 408 outputs + 16 dummy columns (one per lane of a 16-lane group, for lanes whose output lies
+// outside the strip), rounded up to 4 (mod 8): an LDS add goes to row 4g + r, column base + i of lane (g, i), and with
+// 4 x pitch = 16 (mod 32) the two 16-lane groups that share an LDS cycle fall on disjoint halves of the 32 banks
+// (pitch 409 put them 4 banks apart: 12 of 16 banks hit twice).
+constexpr uint32_t kMfmaOutPitch = 428;
+static_assert(kMfmaOutPitch >= kMfmaMaxStripOutputs + 16 && (4 * kMfmaOutPitch) % 32 == 16, "LDS output tile pitch");
+constexpr uint32_t kMfmaDefaultSpinLimit = 1u << 22; // polls of an LDS counter before a wave gives up and reports FLGPU_DEVERR_MFMA_WAIT
+constexpr uint32_t FLGPU_DEVERR_MFMA_WAIT = 1u;      // bit of the batch's device error word
 constexpr uint32_t kMfmaVScaleLog2 = 8;     // vertical weights are stored times 2^8 (keeps the low f16 term normal)
 constexpr uint32_t kMfmaXFracBits = 6;      // intermediate rows: (value - 128) * 64 as i16
 constexpr uint32_t kMfmaLdsOperands = 40;   // horizontal operands (1 KB each) kept in LDS when a strip has no more distinct ones
@@ -100,6 +107,8 @@ struct LaunchMfma {
     uint32_t letterbox;
     uint32_t ops_in_lds;   // every strip of the launch has <= kMfmaLdsOperands distinct operands
     uint32_t max_nout;
+    uint32_t spin_limit;   // bound of the kernel's LDS counter waits (kMfmaDefaultSpinLimit; tests force 0 = every wait expires)
+    uint32_t *err_word;    // device word of the batch: the kernel ORs FLGPU_DEVERR_MFMA_WAIT into it when a wait expired
 };
 size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds);
 hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st);

@@ -19,6 +19,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Pointers read from a descriptor have no address space the compiler could know, so stores through them become flat_store --
+// which counts on lgkmcnt as well as vmcnt and completes out of order with LDS traffic: one pending pixel store turns every LDS
+// wait behind it into lgkmcnt(0).  The destination is device memory by contract; saying so makes them global_store.
+typedef __attribute__((address_space(1))) uint32_t *gptr32;
+typedef __attribute__((address_space(1))) uint8_t *gptr8;
 
 constexpr uint32_t THREADS = kMfmaWaves * 64;
 constexpr uint32_t RING_BYTES = kMfmaKRows * kMfmaWaveCols; // one K-block of one wave
@@ -33,41 +38,27 @@ extern __shared__ __attribute__((aligned(16))) uint8_t mfma_lds[];
 __device__ __forceinline__ uint32_t shl8_add(uint32_t a, uint32_t b)
 {
     uint32_t r = (a << 8) + b;
-    asm volatile("" : "+v"(r));
+    asm("" : "+v"(r)); // (not volatile: the scheduler may interleave the digit sums of different tiles)
     return r;
 }
 
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0f70); }   // vmcnt(0)
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); } // lgkmcnt(0)
 
-// Counters that order the waves' traffic on the LDS output tiles.  Everything they guard lives in LDS, so the fences name
-// the local address space only: a plain workgroup-scope acquire or release also drains vmcnt, i.e. waits for the K-block
-// that has just been requested from HBM -- the one latency this kernel is built to hide.
-__device__ __forceinline__ uint32_t lds_counter(const uint32_t *p)
-{
-    const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    return v;
-}
-// Waits until the counter has reached `target`.  By construction the wait is short or none (the slowest wave never waits,
-// see the kernel), but a wait inside a kernel gets a bound all the same: a wave that gives up produces wrong pixels,
-// which the tests catch, instead of a grid that never drains.
-__device__ __forceinline__ void lds_counter_wait(const uint32_t *p, uint32_t target)
-{
-    for (uint32_t spin = 0; lds_counter(p) < target && spin < (1u << 22); ++spin) __builtin_amdgcn_s_sleep(2);
-}
-__device__ __forceinline__ void lds_counter_bump(uint32_t *p)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+// Two counters per LDS output tile order the waves' traffic on it (add_cnt: waves that have added their sums, conv_cnt: waves
+// that have converted their rows).  Everything they guard lives in LDS, so the fences name the local address space only: a
+// plain workgroup-scope acquire or release also drains vmcnt, i.e. waits for the K-block that has just been requested from
+// HBM -- the one latency this kernel is built to hide.  Every wait is bounded (spin_limit): by construction it is short or
+// none (the slowest wave never waits), but a wave that gives up sets the launch's error word and the host returns
+// FLGPU_ERR_DEVICE for the batch instead of pixels that were never synchronised.
 
 // CS: interleaved 8-bit channels of the source (the vertical pass does not care; the horizontal tables carry the channel
 // structure; only the last step, bytes -> destination pixel, is written per channel count).
 // LB: the destination is Rgba8 with the picture placed on a fill frame.  HLDS: the strip's horizontal operands sit in LDS.
 template <int CS, bool LB, bool HLDS>
 __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
-                                                                   const uint32_t *__restrict__ arena, uint32_t ot_words
+                                                                   const uint32_t *__restrict__ arena, uint32_t ot_words, uint32_t spin_limit,
+                                                                   uint32_t *__restrict__ err_word
 #ifdef FL_MFMA_TIMING
                                                                    , unsigned long long *__restrict__ dbg
 #endif
@@ -75,6 +66,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 {
 #ifdef FL_MFMA_TIMING // development aid (tools/build_ablate.sh ... -DFL_MFMA_TIMING): shader-clock cycles per phase of one workgroup's waves
     unsigned long long tm_wait = 0, tm_read = 0, tm_mfma = 0, tm_flush = 0, tm_t0 = __builtin_readcyclecounter(), tm_a, tm_b;
+    const unsigned long long tm_rt0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
 #define TM_A() tm_a = __builtin_readcyclecounter()
 #define TM_B(acc_) do { tm_b = __builtin_readcyclecounter(); acc_ += tm_b - tm_a; tm_a = tm_b; } while (0)
 #else
@@ -82,13 +74,15 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #define TM_B(acc_) do { } while (0)
 #endif
     // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh): 1 = no horizontal MFMAs / LDS adds, 2 = no conversion of
-    // finished tiles, 32 = conversion without its global stores, 4 = no horizontal stage at all, 8 = no vertical MFMAs
+    // finished tiles, 32 = conversion without its global stores, 4 = no horizontal stage at all, 8 = no vertical MFMAs,
+    // 128 = no LDS adds, 8192 (with 4) = the vertical pass alone, its sums kept alive
 #ifdef FL_ABLATE
     constexpr uint32_t ablate = FL_ABLATE;
 #else
     constexpr uint32_t ablate = 0;
 #endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u, g = lane >> 4, i = lane & 15u;
+    uint32_t wg_error = 0u; // a bounded wait expired in this lane's wave
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const MfmaItem it = items[blockIdx.x];
     const Job jb = jobs[it.job];
@@ -114,7 +108,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         const uint32_t dx1 = sp.x1 == jb.cx + jb.cw ? jb.dw : jb.ox + sp.x1 - jb.cx;
         const uint32_t dy0 = y_first == jb.cy ? 0u : jb.oy + y_first - jb.cy;
         const uint32_t dy1 = y_end == jb.cy + jb.ch ? jb.dh : jb.oy + y_end - jb.cy;
-        uint32_t *d32 = reinterpret_cast<uint32_t *>(jb.dst);
+        gptr32 d32 = (gptr32)(uintptr_t)jb.dst;
         const uint32_t wcols = dx1 - dx0;
         const uint32_t top_rows = dy0 < jb.oy ? min(dy1, jb.oy) - dy0 : 0u;
         for (uint32_t k = tid; k < top_rows * wcols; k += THREADS) d32[(dy0 + k / wcols) * jb.dw + dx0 + k % wcols] = jb.fill;
@@ -146,16 +140,29 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             coff[hh][par] = min(sp.byte0 + wave * kMfmaWaveCols + hh * 128u + ((lt ^ par) * 16u), pitch - 16u);
     const uint32_t last_row = jb.sh - 1u;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring);
-    auto issue = [&](uint32_t s) {
+    // (addresses: the picture's base pointer in SGPRs + a 32-bit byte offset per lane -- descriptors promise < 4 GiB per picture.
+    // The offsets of a K-block are computed ahead of time (request_offsets, in front of the wait for the rows in flight), and the
+    // requests go out the moment the transposed reads have returned: between "the rows have landed" and "the next rows are
+    // requested" the wave's 8 KB of LDS are not in flight, and with one K-block in flight per wave every such cycle is missing
+    // bandwidth.)
+    auto request_offsets = [&](uint32_t s, uint32_t (&goff)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (uint32_t u = 0; u < 8; ++u) {
             const uint32_t ro = u >> 1, hh = u & 1u;
             const uint32_t row = min(s * kMfmaKRows + ro * 8u + lq, last_row);
-            const uint8_t *gp = jb.src + (size_t)row * pitch + coff[hh][ro & 1u];
+            goff[u] = row * pitch + coff[hh][ro & 1u];
+        }
+    };
+    auto request = [&](const uint32_t (&goff)[8]) __attribute__((always_inline)) {
+        // (in slot order: slots 2 ro and 2 ro + 1 are the two 128-byte halves of the same eight 256-byte row pieces, and memory
+        // serves them best back to back -- requesting the even slots as soon as "their" transposed reads had returned and the odd
+        // ones later measured 6 % SLOWER)
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
             // (inline asm: hipcc orders EVERY later LDS access behind a global_load_lds it knows about -- s_waitcnt vmcnt(0) in
             // front of the first counter or operand read -- which would park the whole horizontal stage behind the K-block just
             // requested.  The transfers are waited for by hand, wait_vm0() in front of the transposed reads.)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gp), "s"(ring_lds + u * 1024u) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(goff[u]), "s"(jb.src), "s"(ring_lds + u * 1024u) : "memory");
         }
     };
 
@@ -179,59 +186,89 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
     const uint32_t npx = sp.x1 - sp.x0;
 
-    // One wave's share (2 of the 16 rows) of a finished output tile: i32 sums -> bytes -> destination.
-    auto convert_rows = [&](uint32_t tile, uint32_t buf) {
+    // One wave's share (2 of the 16 rows) of a finished output tile: i32 sums -> bytes -> destination.  A strip row has at most
+    // kMfmaMaxStripOutputs / CS pixels = CONV_G groups of 64 lanes.  All LDS reads of the share are issued before the first of
+    // them is used; lanes past the row's end repeat its last pixel (same words read, same value stored to the same address), so
+    // nothing here switches lanes off; rows past the picture's end (short last tile) are skipped as a whole -- their LDS words
+    // are not cleared, the workgroup does not use the buffer again.
+    constexpr uint32_t CONV_G = (kMfmaMaxStripOutputs / (uint32_t)CS + 63u) / 64u;
+    // One wave's share (2 of the 16 rows) of a finished output tile: i32 sums -> bytes -> destination.  A strip row has
+    // at most kMfmaMaxStripOutputs / CS pixels = CONV_G groups of 64 lanes.  All LDS reads of the share are issued before the first of
+    // them is used; lanes past the row's end repeat its last pixel (same words read, same value stored to the same address), so
+    // nothing here switches lanes off; rows past the picture's end (short last tile) are skipped as a whole -- their LDS words
+    // are not cleared, the workgroup does not use the buffer again.
+    auto convert_rows = [&](uint32_t tile, uint32_t buf) __attribute__((always_inline)) {
         uint32_t *ot = otile + buf * ot_words;
+        const uint32_t ngrp = (npx + 63u) >> 6; // lane groups in use (wave-uniform)
+        uint32_t sums[2][CONV_G][CS];
+#pragma unroll
+        for (uint32_t rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (uint32_t k = 0; k < CONV_G; ++k) {
+                const uint32_t xo = min(lane + 64u * k, npx - 1u);
+                const uint32_t *o = ot + (2u * wave + rr) * np + (uint32_t)CS * xo;
+#pragma unroll
+                for (int c = 0; c < CS; ++c) sums[rr][k][c] = o[c];
+            }
 #pragma unroll
         for (uint32_t rr = 0; rr < 2; ++rr) {
             const uint32_t row = 2u * wave + rr;
-            const uint32_t oy = vp.y0 + 16u * tile + row;
             const bool live = 16u * tile + row < vp.rows;
-            for (uint32_t xo = lane; xo < npx; xo += 64u) {
+#pragma unroll
+            for (uint32_t k = 0; k < CONV_G; ++k) {
+                if (k >= ngrp || !live) continue;
+                const uint32_t xo = min(lane + 64u * k, npx - 1u);
                 uint32_t *o = ot + row * np + (uint32_t)CS * xo;
                 uint32_t c8[CS];
 #pragma unroll
                 for (int c = 0; c < CS; ++c) {
-                    const int32_t q = ((int32_t)o[c] + round_add) >> (hs + kMfmaXFracBits);
+                    const int32_t q = ((int32_t)sums[rr][k][c] + round_add) >> (hs + kMfmaXFracBits);
                     c8[c] = (uint32_t)min(max(q + 128, 0), 255);
                     o[c] = 0u;
                 }
-                if (live && !(ablate & 32u)) {
-                    const uint32_t pix = pix_base + oy * jb.dw + xo;
-                    if (LB) { // DynamicImage -> Rgba8 (to_rgba8) and imageops::overlay onto the fill colour, as in the streaming kernel
-                        uint32_t v;
-                        if (CS == 1) v = c8[0] | (c8[0] << 8) | (c8[0] << 16) | 0xff000000u;
-                        else if (CS == 2) v = blend_over_fill(jb.fill, c8[0], c8[0], c8[0], c8[CS > 1 ? 1 : 0]);
-                        else if (CS == 3) v = c8[0] | (c8[CS > 1 ? 1 : 0] << 8) | (c8[CS > 2 ? 2 : 0] << 16) | 0xff000000u;
-                        else v = blend_over_fill(jb.fill, c8[0], c8[CS > 1 ? 1 : 0], c8[CS > 2 ? 2 : 0], c8[CS > 3 ? 3 : 0]);
-                        reinterpret_cast<uint32_t *>(jb.dst)[pix] = v;
-                    } else {
-                        uint8_t *p = jb.dst + (size_t)pix * CS;
+                uint32_t v;
+                if (LB) { // DynamicImage -> Rgba8 (to_rgba8) and imageops::overlay onto the fill colour, as in the streaming kernel
+                    if (CS == 1) v = c8[0] | (c8[0] << 8) | (c8[0] << 16) | 0xff000000u;
+                    else if (CS == 2) v = blend_over_fill(jb.fill, c8[0], c8[0], c8[0], c8[CS > 1 ? 1 : 0]);
+                    else if (CS == 3) v = c8[0] | (c8[CS > 1 ? 1 : 0] << 8) | (c8[CS > 2 ? 2 : 0] << 16) | 0xff000000u;
+                    else v = blend_over_fill(jb.fill, c8[0], c8[CS > 1 ? 1 : 0], c8[CS > 2 ? 2 : 0], c8[CS > 3 ? 3 : 0]);
+                } else {
+                    v = c8[0] | (c8[CS > 1 ? 1 : 0] << 8) | (c8[CS > 2 ? 2 : 0] << 16) | (c8[CS > 3 ? 3 : 0] << 24);
+                }
+                if (ablate & 32u) { asm volatile("" : : "v"(v)); continue; } // (experiment: everything but the store itself)
+                // (a pointer read from a descriptor has no address space the compiler could know; the destination is device
+                // memory by contract, see gptr32)
+                const uint32_t pix = pix_base + (vp.y0 + 16u * tile + row) * jb.dw + xo;
+                if (LB) ((gptr32)(uintptr_t)jb.dst)[pix] = v;
+                else {
+                    gptr8 p = (gptr8)(uintptr_t)jb.dst + (size_t)pix * CS;
 #pragma unroll
-                        for (int c = 0; c < CS; ++c) p[c] = (uint8_t)c8[c];
-                    }
+                    for (int c = 0; c < CS; ++c) p[c] = (uint8_t)(v >> (8 * c));
                 }
             }
         }
     };
 
-    auto do_convert = [&](uint32_t tile) __attribute__((always_inline)) {
-        const uint32_t li = tile - it.tile0, buf = li & 1u;
-        lds_counter_wait(&add_cnt[buf], kMfmaWaves * ((li >> 1) + 1u));
-        if (!(ablate & 2u)) convert_rows(tile, buf);
-        if (lane == 0) lds_counter_bump(&conv_cnt[buf]);
-    };
 #ifdef FL_MFMA_TIMING
     const unsigned long long tm_loop0 = __builtin_readcyclecounter();
 #endif
     // A K-block's weights (64 bytes per lane, served by the L2) and its meta word are fetched one K-block ahead, in front
     // of the request for the rows: the vmcnt(0) in front of the transposed reads covers them for free, while fetched at
     // the top of their own K-block they would add one L2 round trip to every pass of the loop.
+    // (the meta word comes through the VECTOR memory path like the weights, its index made opaque to the compiler: a scalar load
+    // left in flight across the tile stage shares lgkmcnt with the stage's LDS traffic, and since scalar loads return out of
+    // order every LDS wait of the stage then becomes lgkmcnt(0) -- behind all the LDS adds issued so far)
+    uint32_t vzero = 0u;
+    asm("" : "+v"(vzero));
     u32x4 wvn[4];
-    uint32_t meta_n = arena[vp.meta_off + it.kb0];
+    uint32_t meta_n = arena[vp.meta_off + it.kb0 + vzero];
 #pragma unroll
     for (int k = 0; k < 4; ++k) wvn[k] = vw[(it.kb0 * 4u + k) * 64u + lane];
-    issue(it.kb0);
+    {
+        uint32_t g0[8];
+        request_offsets(it.kb0, g0);
+        request(g0);
+    }
     // (kb_end: one pass more than the band has K-blocks when the picture's short last tile ends together with the tile before
     // it -- that pass runs on the table's all-zero K-block, index vp.nkb, whose meta word names the last tile: the matrix unit
     // adds zeros to whatever the transposed reads deliver, nothing is requested, and the loop body stays as it is)
@@ -239,11 +276,15 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     for (uint32_t s = it.kb0; s < kb_end; ++s) {
         if (!HLDS && s != it.kb0) { // (this variant has no registers to spare for the look-ahead: it fetches its weights here, one L2 round trip per pass)
             const uint32_t sc = s < it.kb1 ? s : vp.nkb;
-            meta_n = arena[vp.meta_off + sc];
+            meta_n = arena[vp.meta_off + sc + vzero];
 #pragma unroll
             for (int k = 0; k < 4; ++k) wvn[k] = vw[(sc * 4u + k) * 64u + lane];
         }
+        const bool have_next = s + 1u < it.kb1;
+        uint32_t gnext[8];
+        if (have_next) request_offsets(s + 1u, gnext);
         TM_A();
+        __builtin_amdgcn_s_setprio(3); // (from here to the next request this wave's instructions go first on its SIMD: its LDS is not in flight)
         wait_vm0();
         TM_B(tm_wait);
         const uint32_t meta = __builtin_amdgcn_readfirstlane(meta_n);
@@ -257,16 +298,21 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             raw[ct] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + off));
         }
         wait_lgkm0();
+        if (have_next) request(gnext);
+        __builtin_amdgcn_s_setprio(0);
         if (s + 1u < kb_end) {
             if (HLDS) {
                 const uint32_t sn = s + 1u < it.kb1 ? s + 1u : vp.nkb;
-                meta_n = arena[vp.meta_off + sn];
+                meta_n = arena[vp.meta_off + sn + vzero];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) wvn[k] = vw[(sn * 4u + k) * 64u + lane];
             }
-            if (s + 1u < it.kb1) issue(s + 1u);
         }
         TM_B(tm_read);
+        // (the meta word says whether the K-block has weights for a second, younger tile (set 1) at all: about a third of the
+        // K-blocks touch one tile only, and a matrix instruction on zeros costs the same time and nearly the same power --
+        // this kernel runs at the socket's power limit, so what it does not compute is what makes it faster)
+        const bool both_sets = ((meta >> 17) & 1u) != 0u;
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             u32x4 a;
@@ -278,21 +324,30 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             if (ablate & 8u) { acc[0][ct][0] += (float)a[0]; acc[1][ct][1] += (float)a[1]; acc[0][ct][2] += (float)a[2]; acc[1][ct][3] += (float)a[3]; continue; }
             acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[0]), acc[0][ct], 0, 0, 0);
             acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[1]), acc[0][ct], 0, 0, 0);
-            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[2]), acc[1][ct], 0, 0, 0);
-            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[3]), acc[1][ct], 0, 0, 0);
+            if (both_sets) {
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[2]), acc[1][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[3]), acc[1][ct], 0, 0, 0);
+            }
         }
         TM_B(tm_mfma);
         const uint32_t ft = meta & 0xffffu;
         if (ft != 0xffffu) { // output tile ft is complete
             const bool mine = ft >= it.tile0 && ft < it.tile1 && !(ablate & 4u);
+            if (ablate & 8192u) { // (experiment, with 4: the vertical pass alone -- its sums are kept alive, nothing is done with them)
+#pragma unroll
+                for (int ct = 0; ct < 16; ++ct) asm volatile("" : : "v"(acc[0][ct][0]), "v"(acc[0][ct][1]), "v"(acc[0][ct][2]), "v"(acc[0][ct][3]));
+            }
             if (mine) {
                 const uint32_t li = ft - it.tile0, buf = li & 1u;
                 uint32_t *ot = otile + buf * ot_words;
-                // the tile that used this buffer two tiles ago must have been converted by every wave
-                lds_counter_wait(&conv_cnt[buf], kMfmaWaves * (li >> 1));
+                // The stage is written for instruction-level parallelism -- two waves per SIMD run it at the same time, so nothing else
+                // hides its latencies: (1) all A operands first (vector work only), (2) a chunk's B operands are requested one chunk
+                // ahead, in front of the LDS adds of the chunk before (LDS executes a wave's instructions in order: behind 12 adds
+                // they would return ~12 adds late), (3) both counters are read in ONE round trip at the top, (4) the previous tile's
+                // rows are read before this tile's adds are issued and converted while its matrix instructions run.
+                u32x4 ahi[4], alo[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    u32x4 ahi, alo;
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const f32x4 v = acc[0][4 * c + a]; // (the older of the two live tiles always sits in set 0, see below)
@@ -301,56 +356,91 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                         const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[0], 0.25f, 12509184.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[1], 0.25f, 12509184.0f)),
                                        x2 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[2], 0.25f, 12509184.0f)), x3 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[3], 0.25f, 12509184.0f));
                         const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x3, x2, 0x05010400u); // (x0.b0, x1.b0, x0.b1, x1.b1)
-                        alo[a] = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u; // low bytes, as signed value - 128
-                        ahi[a] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);               // high bytes (signed)
+                        alo[c][a] = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u; // low bytes, as signed value - 128
+                        ahi[c][a] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);               // high bytes (signed)
                     }
+                // units u = 3 c + t (chunk c, tile slot t): operands of unit u + 2 are requested, and the matrix instructions of
+                // unit u + 1 issued, in front of the digit sums and LDS adds of unit u
+                u32x4 h1[3], h0[3];
+                i32x4 t2[2], t1[2], t0[2];
+                auto load_ops = [&](int u) __attribute__((always_inline)) {
+                    uint32_t i1 = (uint32_t)ctab[u * 3 + 1], i0 = (uint32_t)ctab[u * 3 + 2];
+                    asm volatile("" : "+s"(i1), "+s"(i0)); // (keeps hipcc from hoisting the 24 operand addresses out of the row loop into 24 VGPRs)
+                    h1[u % 3] = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
+                    h0[u % 3] = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
+                };
+                auto unit_mfma = [&](int u) __attribute__((always_inline)) {
+                    const i32x4 bh = __builtin_bit_cast(i32x4, h1[u % 3]), bl = __builtin_bit_cast(i32x4, h0[u % 3]);
+                    const i32x4 ah = __builtin_bit_cast(i32x4, ahi[u / 3]), al = __builtin_bit_cast(i32x4, alo[u / 3]);
+                    t2[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah, bh, i32x4{0, 0, 0, 0}, 0, 0, 0);
+                    t1[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah, bl, i32x4{0, 0, 0, 0}, 0, 0, 0);
+                    t0[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, bl, i32x4{0, 0, 0, 0}, 0, 0, 0);
+                    t1[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, bh, t1[u & 1], 0, 0, 0);
+                };
+                if (!(ablate & 1u)) { load_ops(0); load_ops(1); }
+                // the tile that used this buffer two tiles ago must have been converted by every wave, and every wave must have added
+                // its sums of the previous tile (both long since true in practice: the slowest wave never waits)
+                {
+                    const uint32_t need_conv = kMfmaWaves * (li >> 1), need_add = li ? kMfmaWaves * (((li - 1u) >> 1) + 1u) : 0u;
+                    uint32_t spin = 0;
+                    for (;;) {
+                        const uint32_t cv = __hip_atomic_load(&conv_cnt[buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t ad = __hip_atomic_load(&add_cnt[buf ^ 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                        if ((cv >= need_conv && ad >= need_add) || ++spin >= spin_limit) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (spin >= spin_limit) wg_error = 1u;
+                }
+                if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u); // this wave's two rows of the previous tile
+                if (!(ablate & 1u)) {
+                    unit_mfma(0);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const int32_t obase = ctab[(c * 3 + t) * 3];
-                        const uint32_t i1 = (uint32_t)ctab[(c * 3 + t) * 3 + 1], i0 = (uint32_t)ctab[(c * 3 + t) * 3 + 2];
-                        if ((ablate & 1u) || (t == 2 && obase == 0x40000000)) continue; // (slot not in use; slots 0 and 1 run regardless, on the all-zero operand if need be: fewer branches, longer schedules)
-                        const u32x4 h1 = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
-                        const u32x4 h0 = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
-                        i32x4 t2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, ahi), __builtin_bit_cast(i32x4, h1), i32x4{0, 0, 0, 0}, 0, 0, 0);
-                        i32x4 t1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, ahi), __builtin_bit_cast(i32x4, h0), i32x4{0, 0, 0, 0}, 0, 0, 0);
-                        t1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, alo), __builtin_bit_cast(i32x4, h1), t1, 0, 0, 0);
-                        i32x4 t0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, alo), __builtin_bit_cast(i32x4, h0), i32x4{0, 0, 0, 0}, 0, 0, 0);
-                        const uint32_t o = (uint32_t)(obase + (int32_t)i);
-                        const uint32_t col = o < sp.nout ? o : sp.nout; // lanes outside the strip's outputs add into the dummy column
+                    for (int u = 0; u < 12; ++u) {
+                        if (u + 2 < 12) load_ops(u + 2);
+                        if (u + 1 < 12) unit_mfma(u + 1);
+                        // lanes outside the strip's outputs (and every lane of a slot not in use: operand 0, first output 2^30) add
+                        // into dummy columns of their own, nout + i: no lane is switched off, no two lanes share an address
+                        const uint32_t o = (uint32_t)(ctab[u * 3] + (int32_t)i);
+                        const uint32_t col = o < sp.nout ? o : sp.nout + i;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const uint32_t p = shl8_add(shl8_add((uint32_t)t2[r], (uint32_t)t1[r]), (uint32_t)t0[r]);
+                            const uint32_t p = shl8_add(shl8_add((uint32_t)t2[u & 1][r], (uint32_t)t1[u & 1][r]), (uint32_t)t0[u & 1][r]);
+                            if (ablate & 128u) { asm volatile("" : : "v"(p), "v"(col)); continue; }
                             __hip_atomic_fetch_add(&ot[(4u * g + r) * np + col], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 }
-                if (lane == 0) lds_counter_bump(&add_cnt[buf]);
-                if (li >= 1u) do_convert(ft - 1u); // this wave's two rows of the previous tile: every wave has added its sums long ago
-            }
-            // The younger tile becomes the older one: set 0 <- set 1, set 1 <- 0.  Done by the matrix unit (0 x 0 + C, exact), which has
-            // time to spare here, instead of 128 vector moves -- and with the finished tile always in set 0 the stage above indexes
-            // its accumulators at compile time (selecting the set at run time cost a v_cndmask per register and tile; a second copy of
-            // the stage per set made hipcc spill).  The host orders each K-block's weights the same way: older tile first.
-            {
-                const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int ct = 0; ct < 16; ++ct) {
-                    acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(z, z, acc[1][ct], 0, 0, 0);
-                    acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(z, z, f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                if (lane == 0) { // one release for both counters
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __hip_atomic_fetch_add(&add_cnt[buf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (li >= 1u) __hip_atomic_fetch_add(&conv_cnt[buf ^ 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+            }
+            // The younger tile becomes the older one: set 0 <- set 1, set 1 <- 0, so that the finished tile is always read from
+            // compile-time registers (set 0).  Plain moves: at the power limit 128 moves are cheaper than the 32 matrix
+            // instructions (0 x 0 + C) that did this before.
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct) {
+                acc[0][ct] = acc[1][ct];
+                acc[1][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
             TM_B(tm_flush);
         }
     }
 #ifdef FL_MFMA_TIMING
-    if (blockIdx.x == 1500u && lane == 0) {
-        dbg[wave * 8 + 0] = tm_wait; dbg[wave * 8 + 1] = tm_read; dbg[wave * 8 + 2] = tm_mfma; dbg[wave * 8 + 3] = tm_flush;
-        dbg[wave * 8 + 4] = __builtin_readcyclecounter() - tm_t0;
-        dbg[wave * 8 + 5] = tm_loop0 - tm_t0;
+    if ((blockIdx.x == 8u || blockIdx.x == 1500u || blockIdx.x == 2900u) && lane == 0) {
+        unsigned long long *d = dbg + ((blockIdx.x == 8u ? 0u : blockIdx.x == 1500u ? 1u : 2u) * 8u + wave) * 8u;
+        d[0] = tm_wait; d[1] = tm_read; d[2] = tm_mfma; d[3] = tm_flush;
+        d[4] = __builtin_readcyclecounter() - tm_t0;
+        d[5] = tm_loop0 - tm_t0;
+        d[6] = __builtin_amdgcn_s_memrealtime() - tm_rt0;
+        d[7] = tm_rt0;
     }
 #endif
     __syncthreads(); // every wave has added its sums of the last tile
     if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
+    if (wg_error && lane == 0) atomicOr(err_word, FLGPU_DEVERR_MFMA_WAIT);
 }
 
 } // namespace
@@ -369,17 +459,21 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 #ifdef FL_MFMA_TIMING
     static unsigned long long *dbg = nullptr;
     static int launches = 0;
-    if (!dbg) { (void)hipMalloc(&dbg, 64 * 8); (void)hipMemset(dbg, 0, 64 * 8); }
-    resample_mfma_kernel<CS, LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch, dbg);
-    if (++launches == 20 && m.nitems > 1500) {
-        unsigned long long h[64];
+    if (!dbg) { (void)hipMalloc(&dbg, 3 * 64 * 8); (void)hipMemset(dbg, 0, 3 * 64 * 8); }
+    resample_mfma_kernel<CS, LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch, m.spin_limit, m.err_word, dbg);
+    if ((++launches == 5 || launches == 100) && m.nitems > 2900) {
+        unsigned long long h[3 * 64];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-        for (int w = 0; w < 8; ++w)
-            fprintf(stderr, "mfma timing wave %d: wait %llu, reads+request %llu, vertical mfma %llu, tile stage %llu, total %llu cycles, of which %llu before the first request\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+        for (int b = 0; b < 3; ++b)
+            for (int w = 0; w < 8; ++w) {
+                const unsigned long long *d = h + (b * 8 + w) * 8;
+                fprintf(stderr, "mfma timing launch %d wg %d wave %d: wait %llu, reads+request %llu, vertical mfma %llu, tile stage %llu, total %llu cycles (%llu before the loop) in %.2f us = %.0f MHz, started at %.2f us\n",
+                        launches, b, w, d[0], d[1], d[2], d[3], d[4], d[5], d[6] * 0.01, d[6] ? d[4] / (d[6] * 0.01) : 0.0, (d[7] - h[7]) * 0.01);
+            }
     }
 #else
-    resample_mfma_kernel<CS, LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch);
+    resample_mfma_kernel<CS, LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch, m.spin_limit, m.err_word);
 #endif
     return hipGetLastError();
 }

@@ -113,6 +113,7 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
     for (size_t i = 0; i < n; ++i) encoded |= ps[i].front_end == FLGPU_FE_JPEG;
     int rrc = FLGPU_OK;
     if (encoded) rrc = collect_results(c, n, ddst.data(), st);
+    if (rrc == FLGPU_ERR_DEVICE) return rrc;
     for (size_t i = 0; i < n; ++i) {
         const bool jpeg = ps[i].front_end == FLGPU_FE_JPEG;
         const uint64_t nb = jpeg ? ddst[i].bytes : batch[i]->out_bytes;
@@ -127,8 +128,8 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
         batch[i]->dst->bytes = ddst[i].bytes;
         if (ps[i].front_end == FLGPU_FE_JPEG && !ddst[i].bytes && batch[i]->status == FLGPU_OK) batch[i]->status = FLGPU_ERR_BUFFER_TOO_SMALL;
     }
-    (void)rrc; // per-request status above: one oversized stream must not fail its batch mates
-    return FLGPU_OK;
+    if (rrc == FLGPU_ERR_DEVICE) return rrc; // the device error word: no result of this batch is valid
+    return FLGPU_OK; // otherwise the per-request status above: one oversized stream must not fail its batch mates
 }
 
 // `slot` = index of this lane's device in the context's device list (0 for a single-device context)

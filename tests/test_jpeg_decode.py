@@ -260,6 +260,35 @@ def test_embedded_profile_of_a_cmyk_file(fl, oracle):
 
 
 @pytest.mark.gpu
+def test_more_embedded_profiles_in_one_batch_than_the_table_cache_holds(fl, oracle):
+    """A batch selects the tables of all its pictures before it launches their conversions, and the cache of baked embedded
+    profiles holds 8: with 11 distinct profiles in ONE batch no table handed out for an earlier picture may be evicted (and
+    freed) by a later one.  Every picture must equal what liblcms2 makes of its own profile; the same batch again (cache
+    trimmed in between) and each file alone must give the same bytes."""
+    import lcms2_lib
+    import synth_icc
+    from conftest import require_device
+    require_device()
+    if lcms2_lib.load() is None:
+        pytest.skip("liblcms2 not installed")
+    iccs = [synth_icc.cmyk_profile(seed=40 + k) for k in range(11)]
+    assert len({bytes(i) for i in iccs}) == 11
+    files = [make_cmyk_jpeg(40, 56, icc=iccs[k], index=60 + k) for k in range(11)]
+    wants = [lcms2_lib.Cmyk2Rgb(iccs[k]).convert(oracle.jpeg_decode(files[k]).reshape(-1, 4)).reshape(40, 56, 3) for k in range(11)]
+    with fl.State(device=0, use_embedded_profile=True) as st:
+        st.set_cmyk_clut(np.random.default_rng(23).integers(0, 65536, (17, 17, 17, 17, 3), dtype=np.uint16))
+        p = fl.make_params(28, 20)
+        alone = [st.process_pixels(wants[k], p) for k in range(11)]  # the pipeline on liblcms2's pixels
+        for rep in range(2):
+            outs = st.process_batch(files, [p] * 11)
+            for k in range(11):
+                assert np.array_equal(outs[k], alone[k]), (rep, k)
+        assert st.stats()["cmyk_tables_baked"] >= 11
+        for k in (0, 5, 10):
+            assert np.array_equal(st.decode_jpeg(files[k]), wants[k])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
 def test_device_decode_is_bit_identical_to_the_oracle(fl, gpu_state, oracle, case):
     h, w, c, q, sub, rst = case

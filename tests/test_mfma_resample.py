@@ -136,3 +136,53 @@ def test_switch_keeps_the_streaming_kernel(fl, gpu_state, oracle, monkeypatch):
     got, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)
     assert not used
     parity.check_pixels(oracle, got, img, False, w=300, h=200)
+
+
+def test_expired_wait_is_an_error_not_a_picture(fl, gpu_state, monkeypatch):
+    """The kernel's waves hand tiles to one another through LDS counters; every wait on one is bounded, and a wave whose wait
+    expires sets the batch's device error word.  FLGPU_MFMA_SPIN_LIMIT=0 makes every such wait expire at once: the request
+    must come back as FLGPU_ERR_DEVICE -- through flgpu_transform and through flgpu_transform_batch_device +
+    flgpu_batch_results -- never as FLGPU_OK with pixels that were not synchronised (reference: any Err of process_image
+    makes the handler serve its fallback, src/main.rs:185-195)."""
+    import torch
+    img = synth.uniform(1080, 1920, 3, index=123)
+    good, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)
+    assert used
+    monkeypatch.setenv("FLGPU_MFMA_SPIN_LIMIT", "0")
+    with pytest.raises(fl.FanlinError) as e:
+        gpu_state.process_pixels(img, fl.make_params(300, 200))
+    assert e.value.status == fl.ERR_DEVICE and "wait" in str(e.value)
+    src = torch.from_numpy(img).cuda()
+    dst = torch.zeros(240000, dtype=torch.uint8, device="cuda")
+    gpu_state.process_batch_device([src.data_ptr()], [img.shape], fl.make_params(300, 200), [dst.data_ptr()], [240000])
+    with pytest.raises(fl.FanlinError) as e:
+        gpu_state.batch_results()
+    assert e.value.status == fl.ERR_DEVICE
+    monkeypatch.delenv("FLGPU_MFMA_SPIN_LIMIT")
+    again, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)   # the context is fine afterwards
+    assert used and np.array_equal(again, good)
+    gpu_state.process_batch_device([src.data_ptr()], [img.shape], fl.make_params(300, 200), [dst.data_ptr()], [240000])
+    gpu_state.batch_results()
+    assert np.array_equal(dst.cpu().numpy().reshape(200, 300, 4), good)
+
+
+def test_bytes_do_not_depend_on_the_base_address_of_a_device_source(fl, gpu_state):
+    """Which resample kernel serves a request is decided by the request alone: the same picture at device addresses 0, 4, 8
+    and 12 bytes past a 16-byte boundary gives identical bytes through flgpu_transform_batch_device (misaligned sources of a
+    matrix-pipe geometry are copied to aligned scratch; the two kernels may differ by 1 LSB, an address must not choose)."""
+    import torch
+    img = synth.uniform(1080, 1920, 3, index=321)
+    flat = torch.zeros(img.size + 64, dtype=torch.uint8, device="cuda")
+    base = flat.data_ptr()
+    assert base % 16 == 0
+    outs = []
+    for off in (0, 4, 8, 12, 1, 7):
+        flat[off:off + img.size] = torch.from_numpy(img.reshape(-1)).cuda()
+        dst = torch.zeros(240000, dtype=torch.uint8, device="cuda")
+        before = gpu_state.stats()["mfma_launches"]
+        gpu_state.process_batch_device([base + off], [img.shape], fl.make_params(300, 200), [dst.data_ptr()], [240000])
+        gpu_state.batch_results()
+        assert gpu_state.stats()["mfma_launches"] == before + 1, off
+        outs.append(dst.cpu().numpy())
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
