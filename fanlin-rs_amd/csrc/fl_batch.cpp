@@ -128,6 +128,32 @@ void xcd_interleave(Item *first, uint32_t nitems, Len len_of)
 
 namespace fl {
 
+// What a JPEG file's own header may make this library allocate is decided here, before anything is allocated: the header
+// must describe the picture the caller announced, the decoded picture must respect the limit the reference's decoder runs
+// under (image::Limits::default(): max_alloc 512 MiB -- ImageReader rejects larger pictures, handler.rs:205-220), and the file
+// must be long enough to hold that many blocks at all (a block costs at least a DC and an end-of-block code, two bits), so a
+// few hundred hostile bytes cannot reserve gigabytes of pinned or host memory.
+int jpeg_source_precheck(flgpu_ctx *c, const flgpu_image *src, const JpegInfo &info)
+{
+    if (info.width != src->width || info.height != src->height) {
+        c->set_error("FLGPU_IMG_JPEG_SOURCE: width / height do not match the file (see flgpu_jpeg_info_of)");
+        return FLGPU_ERR_INVALID_ARG;
+    }
+    const uint64_t decoded = (uint64_t)info.width * info.height * std::max<uint32_t>(info.components, 1u);
+    if (decoded > (512ull << 20)) {
+        c->set_error("JPEG source: the decoded picture exceeds the 512 MiB the reference's decoder allows (image::Limits)");
+        return FLGPU_ERR_UNSUPPORTED;
+    }
+    const uint64_t blocks = ((uint64_t)(info.width + 7u) / 8u) * ((info.height + 7u) / 8u) * std::max<uint32_t>(info.components, 1u);
+    if (blocks > 4ull * src->capacity + 64ull) { // (chroma sub-sampling only lowers the count)
+        if (((uint64_t)(info.width + 15u) / 16u) * ((info.height + 15u) / 16u) * 3u > 4ull * src->capacity + 64ull) {
+            c->set_error("malformed JPEG stream: shorter than its header's picture needs");
+            return FLGPU_ERR_INVALID_ARG;
+        }
+    }
+    return FLGPU_OK;
+}
+
 int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used)
 {
     const int rc = jpeg_entropy_decode(src->data, (size_t)src->capacity, blob, cap, used);
@@ -752,6 +778,8 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
             JpegInfo info;
             if (jpeg_parse_info(srcs[i].data, (size_t)srcs[i].capacity, info) != 0) return FLGPU_ERR_INVALID_ARG;
             if (!info.supported) return FLGPU_ERR_UNSUPPORTED;
+            rc = jpeg_source_precheck(c, &srcs[i], info);
+            if (rc) return rc;
             blobs[i].resize(jpeg_blob_bound(info));
             size_t used = 0;
             rc = jpeg_source_to_blob(c, &srcs[i], blobs[i].data(), blobs[i].size(), &jh[i], &used);

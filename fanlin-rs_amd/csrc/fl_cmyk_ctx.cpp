@@ -207,7 +207,7 @@ void release_cmyk(flgpu_ctx *c)
 extern "C" {
 
 int flgpu_set_cmyk_profile(flgpu_ctx *c, const uint8_t *icc, uint64_t n)
-{
+try {
     if (!c || !icc || !n) return FLGPU_ERR_INVALID_ARG;
     std::vector<uint16_t> nodes;
     const int rc = bake_cmyk_clut(icc, n, nodes);
@@ -218,10 +218,10 @@ int flgpu_set_cmyk_profile(flgpu_ctx *c, const uint8_t *icc, uint64_t n)
     const int u = install_default(c);
     if (u == FLGPU_OK) c->stats.cmyk_tables_baked++;
     return u;
-}
+} FL_ABI_CATCH
 
 int flgpu_set_cmyk_clut(flgpu_ctx *c, uint32_t grid, const uint16_t *rgb_nodes)
-{
+try {
     if (!c || !rgb_nodes) return FLGPU_ERR_INVALID_ARG;
     if (grid != kCmykGrid) return FLGPU_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> g(c->mu);
@@ -229,7 +229,7 @@ int flgpu_set_cmyk_clut(flgpu_ctx *c, uint32_t grid, const uint16_t *rgb_nodes)
     for (size_t i = 0; i < kClutNodes; ++i)
         for (int k = 0; k < 3; ++k) c->cmyk_default.host[i * 4 + k] = rgb_nodes[i * 3 + k];
     return install_default(c);
-}
+} FL_ABI_CATCH
 
 int flgpu_get_cmyk_clut(flgpu_ctx *c, uint16_t *rgb_nodes, uint64_t capacity_entries, uint32_t *grid)
 {
@@ -252,7 +252,7 @@ int flgpu_cmyk_distribution(flgpu_ctx *c)
 }
 
 int flgpu_cmyk_to_rgb_device(flgpu_ctx *c, const void *d_cmyk, void *d_rgb, uint64_t n_pixels, uint32_t flags, void *hip_stream)
-{
+try {
     if (!c || ((!d_cmyk || !d_rgb) && n_pixels)) return FLGPU_ERR_INVALID_ARG;
     if (n_pixels == 0) return FLGPU_OK;
     if (n_pixels >= (1ull << 32)) return FLGPU_ERR_UNSUPPORTED;
@@ -266,7 +266,7 @@ int flgpu_cmyk_to_rgb_device(flgpu_ctx *c, const void *d_cmyk, void *d_rgb, uint
     FL_HIP(c, launch_cmyk_clut(d_cmyk, d_rgb, clut, kCmykGrid, n_pixels, (flags & FLGPU_CMYK_INPUT_YCCK) != 0, st), "CMYK kernel");
     c->stats.cmyk_pixels += n_pixels;
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 // one contiguous range of pixels on one device context (its mutex held by the caller)
 static int cmyk_range(flgpu_ctx *c, const void *clut, const uint8_t *cmyk, uint64_t n_pixels, uint8_t *rgb, uint32_t flags)
@@ -285,7 +285,7 @@ static int cmyk_range(flgpu_ctx *c, const void *clut, const uint8_t *cmyk, uint6
 
 int flgpu_cmyk_to_rgb(flgpu_ctx *c, const uint8_t *cmyk, uint64_t n_pixels, uint8_t *rgb, const uint8_t *embedded_icc,
                       uint64_t icc_len, uint32_t flags)
-{
+try {
     if (!c || ((!cmyk || !rgb) && n_pixels)) return FLGPU_ERR_INVALID_ARG;
     if (n_pixels == 0) return FLGPU_OK;
     if (n_pixels >= (1ull << 30)) return FLGPU_ERR_UNSUPPORTED;
@@ -317,7 +317,7 @@ int flgpu_cmyk_to_rgb(flgpu_ctx *c, const uint8_t *cmyk, uint64_t n_pixels, uint
     const int rc = select_clut_impl(c, embedded_icc, icc_len, &clut);
     if (rc) return rc;
     return cmyk_range(c, clut, cmyk, n_pixels, rgb, flags);
-}
+} FL_ABI_CATCH
 
 int flgpu_cmyk_bake_available(void) { return cmyk_bake_available() ? 1 : 0; }
 

@@ -442,7 +442,7 @@ void flgpu_host_free(flgpu_ctx *c, void *p)
 }
 
 int flgpu_export_tables(flgpu_ctx *c, void **device_ptr, uint64_t *bytes)
-{
+try {
     if (!c || !device_ptr || !bytes) return FLGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
@@ -452,10 +452,10 @@ int flgpu_export_tables(flgpu_ctx *c, void **device_ptr, uint64_t *bytes)
     *device_ptr = c->d_arena;
     *bytes = (uint64_t)c->h_arena.size() * 4;
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 int flgpu_copy_tables(flgpu_ctx *c, void *dst_device, uint64_t capacity, uint64_t *bytes)
-{
+try {
     if (!c || !dst_device || !bytes) return FLGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
@@ -466,10 +466,10 @@ int flgpu_copy_tables(flgpu_ctx *c, void *dst_device, uint64_t capacity, uint64_
     FL_HIP(c, hipMemcpyAsync(dst_device, c->d_arena, *bytes, hipMemcpyDeviceToDevice, c->stream), "table copy");
     FL_HIP(c, hipStreamSynchronize(c->stream), "table sync");
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 int flgpu_import_tables(flgpu_ctx *c, const void *src_device, uint64_t bytes)
-{
+try {
     if (!c || !src_device) return FLGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     FL_HIP(c, hipSetDevice(c->device), "hipSetDevice");
@@ -479,7 +479,7 @@ int flgpu_import_tables(flgpu_ctx *c, const void *src_device, uint64_t bytes)
     FL_HIP(c, hipMemcpyAsync(c->d_arena, src_device, bytes, hipMemcpyDeviceToDevice, c->stream), "table import");
     FL_HIP(c, hipStreamSynchronize(c->stream), "table sync");
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 static void add_stats(flgpu_stats *out, const flgpu_stats &ls)
 {

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/fanlin_gpu.h"
+#include "fl_abi.h"
 #include "fl_cmyk.h"
 #include "fl_jpeg_tables.h"
 #include "fl_jpegdec.h"
@@ -280,6 +281,7 @@ int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, siz
 // (baked once, cached on c), else the configured one (c's own, or its clut_owner's)
 int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev);
 int clut_batch_begin(flgpu_ctx *c);
+int jpeg_source_precheck(flgpu_ctx *c, const flgpu_image *src, const fl::JpegInfo &info);
 
 // ---- fl_queue.cpp ----------------------------------------------------------------------------------------------------
 // contiguous split of n weighted items into n_shards shards of about equal weight: shard_of[i] is non-decreasing

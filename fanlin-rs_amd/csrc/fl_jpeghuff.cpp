@@ -143,7 +143,9 @@ int exif_orientation(const uint8_t *p, size_t len)
     for (uint32_t i = 0; i < cnt; ++i) {
         const size_t e = ifd + 2 + 12u * i;
         if (e + 12 > n) return 0;
-        if (rd16(e) == 0x0112) { const uint32_t v = rd16(e + 8); return v >= 1 && v <= 8 ? (int)v : 0; }
+        // (the tag counts only as what the specification makes it, one SHORT: an entry of another type or count is skipped and
+        // the search goes on, as far as is known what image 0.25.6's Orientation::from_exif_chunk does)
+        if (rd16(e) == 0x0112 && rd16(e + 2) == 3 && rd32(e + 4) == 1) { const uint32_t v = rd16(e + 8); return v >= 1 && v <= 8 ? (int)v : 0; }
     }
     return 0;
 }
@@ -200,7 +202,7 @@ int parse(const uint8_t *d, size_t n, Parsed &P, bool want_tables)
                 o += 17 + (uint32_t)total;
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
-            if (pl < 6) return -1;
+            if (pl < 6 || got_sof) return -1; // (a second frame header: T.81 allows one per image; zune-jpeg rejects it too)
             P.info.progressive = m == 0xC2;
             P.info.precision = p[0];
             P.info.height = be16(p + 1);

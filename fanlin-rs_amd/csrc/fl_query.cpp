@@ -3,6 +3,7 @@
 // State::process_image (src/handler.rs:224-261).  No device code.
 #include <errno.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -11,6 +12,7 @@
 #include <vector>
 
 #include "../../include/fanlin_gpu.h"
+#include "fl_abi.h"
 #include "fl_jpeg_tables.h"
 #include "fl_jpegdec.h"
 #include "fl_mfma.h"
@@ -75,7 +77,7 @@ bool parse_bool(const std::string &v, uint8_t *out)
 extern "C" {
 
 int flgpu_query_parse(const char *query_string, flgpu_query *out)
-{
+try {
     if (!query_string || !out) return FLGPU_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
     const char *q = query_string;
@@ -97,7 +99,29 @@ int flgpu_query_parse(const char *query_string, flgpu_query *out)
 #define FL_DUP(flag) do { if (out->flag) return FLGPU_ERR_PARSE; } while (0)
             if (key == "w") { FL_DUP(has_w); if (!parse_uint(val, UINT32_MAX, &u)) return FLGPU_ERR_PARSE; out->w = (uint32_t)u; out->has_w = 1; }
             else if (key == "h") { FL_DUP(has_h); if (!parse_uint(val, UINT32_MAX, &u)) return FLGPU_ERR_PARSE; out->h = (uint32_t)u; out->has_h = 1; }
-            else if (key == "rgb") { FL_DUP(has_rgb); strncpy(out->rgb, val.c_str(), sizeof(out->rgb) - 1); out->has_rgb = 1; }
+            else if (key == "rgb") {
+                FL_DUP(has_rgb);
+                out->has_rgb = 1;
+                if (val.size() < sizeof(out->rgb)) memcpy(out->rgb, val.c_str(), val.size() + 1);
+                else {
+                    // query.rs:35-49 reads the WHOLE string (a u8 field may carry any number of leading zeros); a value that does
+                    // not fit the fixed field is reduced here to the colour it means, spelled canonically, so nothing is cut off
+                    flgpu_query tmp{};
+                    tmp.has_rgb = 1;
+                    uint8_t c3[3] = {kDefaultColor, kDefaultColor, kDefaultColor}, t3[3];
+                    int nf = 0;
+                    size_t a = 0;
+                    while (nf < 3) {
+                        const size_t e = val.find(',', a);
+                        uint64_t v = 0;
+                        t3[nf++] = parse_uint(val.substr(a, e == std::string::npos ? std::string::npos : e - a), 255, &v) ? (uint8_t)v : kDefaultColor;
+                        if (e == std::string::npos) break;
+                        a = e + 1;
+                    }
+                    if (nf == 3) { c3[0] = t3[0]; c3[1] = t3[1]; c3[2] = t3[2]; }
+                    snprintf(out->rgb, sizeof(out->rgb), "%u,%u,%u", c3[0], c3[1], c3[2]);
+                }
+            }
             else if (key == "quality") { FL_DUP(has_quality); if (!parse_uint(val, 255, &u)) return FLGPU_ERR_PARSE; out->quality = (uint8_t)u; out->has_quality = 1; }
             else if (key == "crop") { FL_DUP(has_crop); if (!parse_bool(val, &out->crop)) return FLGPU_ERR_PARSE; out->has_crop = 1; }
             else if (key == "blur") { FL_DUP(has_blur); if (!parse_uint(val, 255, &u)) return FLGPU_ERR_PARSE; out->blur = (uint8_t)u; out->has_blur = 1; }
@@ -111,7 +135,7 @@ int flgpu_query_parse(const char *query_string, flgpu_query *out)
         pos = end + 1;
     }
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 /* query.rs:28-33 */
 int flgpu_query_dimensions(const flgpu_query *q, uint32_t *w, uint32_t *h)
@@ -168,7 +192,7 @@ int flgpu_query_unsupported_scale_size(const flgpu_query *q)
 }
 
 int flgpu_params_from_query(const flgpu_query *q, uint32_t accept_flags, int input_is_jpeg, flgpu_params *p, int *out_format)
-{
+try {
     if (!q || !p) return FLGPU_ERR_INVALID_ARG;
     memset(p, 0, sizeof(*p));
     p->has_dims = (uint32_t)flgpu_query_dimensions(q, &p->w, &p->h);
@@ -190,7 +214,7 @@ int flgpu_params_from_query(const flgpu_query *q, uint32_t accept_flags, int inp
     else if (fmt == FLGPU_OUT_KEEP && input_is_jpeg) p->front_end = input_is_jpeg == 2 ? FLGPU_FE_JPEG : FLGPU_FE_JFIF444;
     else p->front_end = FLGPU_FE_NONE;
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 /* Everything State::process_image decides before it touches pixels (handler.rs:198-261). */
 static int plan_request(const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string, uint32_t accept_flags,
@@ -228,14 +252,14 @@ static int plan_request(const flgpu_image *decoded, uint8_t exif_orientation, co
 
 int flgpu_process_image_plan(const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string, uint32_t accept_flags,
                              int input_format, flgpu_plan *plan, int *result_kind)
-{
+try {
     flgpu_params p;
     return plan_request(decoded, exif_orientation, query_string, accept_flags, input_format, &p, plan, result_kind, nullptr);
-}
+} FL_ABI_CATCH
 
 int flgpu_process_image(flgpu_ctx *ctx, const flgpu_image *decoded, uint8_t exif_orientation, const char *query_string,
                         uint32_t accept_flags, int input_format, flgpu_image *dst, flgpu_plan *plan, int *result_kind, int *out_format)
-{
+try {
     if (!ctx || !dst) return FLGPU_ERR_INVALID_ARG;
     flgpu_params p;
     flgpu_plan local;
@@ -244,10 +268,10 @@ int flgpu_process_image(flgpu_ctx *ctx, const flgpu_image *decoded, uint8_t exif
     if (result_kind) *result_kind = kind;
     if (rc || kind == FLGPU_RESULT_AS_IS) return rc;
     return flgpu_transform(ctx, decoded, &p, dst);
-}
+} FL_ABI_CATCH
 
 int flgpu_jpeg_info_of(const uint8_t *jpeg, uint64_t n, flgpu_jpeg_info *info)
-{
+try {
     if (!jpeg || !info) return FLGPU_ERR_INVALID_ARG;
     fl::JpegInfo I;
     if (fl::jpeg_parse_info(jpeg, (size_t)n, I) != 0) return FLGPU_ERR_PARSE;
@@ -260,7 +284,7 @@ int flgpu_jpeg_info_of(const uint8_t *jpeg, uint64_t n, flgpu_jpeg_info *info)
     info->h_max = I.hmax; info->v_max = I.vmax;
     info->exif_orientation = I.exif_orientation; info->supported = I.supported;
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 static int plan_jpeg(const uint8_t *jpeg, uint64_t n, const char *query_string, uint32_t accept_flags, flgpu_image *src, uint8_t *orientation,
                      flgpu_params *p, flgpu_plan *plan, int *kind, int *out_format)
@@ -281,16 +305,16 @@ static int plan_jpeg(const uint8_t *jpeg, uint64_t n, const char *query_string, 
 }
 
 int flgpu_process_jpeg_plan(const uint8_t *jpeg, uint64_t n, const char *query_string, uint32_t accept_flags, flgpu_plan *plan, int *result_kind)
-{
+try {
     flgpu_image src;
     flgpu_params p;
     uint8_t o = 1;
     return plan_jpeg(jpeg, n, query_string, accept_flags, &src, &o, &p, plan, result_kind, nullptr);
-}
+} FL_ABI_CATCH
 
 int flgpu_process_jpeg(flgpu_ctx *ctx, const uint8_t *jpeg, uint64_t n, const char *query_string, uint32_t accept_flags,
                        flgpu_image *dst, flgpu_plan *plan, int *result_kind, int *out_format)
-{
+try {
     if (!ctx || !dst) return FLGPU_ERR_INVALID_ARG;
     flgpu_image src;
     flgpu_params p;
@@ -301,10 +325,10 @@ int flgpu_process_jpeg(flgpu_ctx *ctx, const uint8_t *jpeg, uint64_t n, const ch
     if (result_kind) *result_kind = kind;
     if (rc || kind == FLGPU_RESULT_AS_IS) return rc;
     return flgpu_transform(ctx, &src, &p, dst);
-}
+} FL_ABI_CATCH
 
 int flgpu_debug_jpeg_blob(const uint8_t *jpeg, uint64_t n, uint8_t *blob, uint64_t capacity, uint64_t *used)
-{
+try {
     if (!jpeg || !used) return FLGPU_ERR_INVALID_ARG;
     fl::JpegInfo I;
     if (fl::jpeg_parse_info(jpeg, (size_t)n, I) != 0) return FLGPU_ERR_PARSE;
@@ -316,10 +340,10 @@ int flgpu_debug_jpeg_blob(const uint8_t *jpeg, uint64_t n, uint8_t *blob, uint64
     const int rc = fl::jpeg_entropy_decode(jpeg, (size_t)n, blob, (size_t)capacity, &u);
     *used = u;
     return rc == 0 ? FLGPU_OK : rc == -2 ? FLGPU_ERR_UNSUPPORTED : FLGPU_ERR_INVALID_ARG;
-}
+} FL_ABI_CATCH
 
 int flgpu_decode_jpeg(flgpu_ctx *ctx, const uint8_t *jpeg, uint64_t n, flgpu_image *dst)
-{
+try {
     if (!ctx || !dst || !dst->data) return FLGPU_ERR_INVALID_ARG;
     flgpu_jpeg_info info;
     int rc = flgpu_jpeg_info_of(jpeg, n, &info);
@@ -332,7 +356,7 @@ int flgpu_decode_jpeg(flgpu_ctx *ctx, const uint8_t *jpeg, uint64_t n, flgpu_ima
     flgpu_params p;
     memset(&p, 0, sizeof(p)); /* no dimensions, no operation: the pipeline is the identity, the result the decoded picture */
     return flgpu_transform(ctx, &src, &p, dst);
-}
+} FL_ABI_CATCH
 
 int flgpu_plan_output(const flgpu_params *p, uint32_t sw, uint32_t sh, uint32_t sc, flgpu_plan *plan)
 {

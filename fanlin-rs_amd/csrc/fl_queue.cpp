@@ -38,6 +38,8 @@ void split_by_weight(const uint64_t *weight, size_t n, uint32_t n_shards, uint32
     }
 }
 
+constexpr size_t kPinPoolMaxBlock = (size_t)64 << 20; // page-locked staging blocks above this size are freed after use, not pooled
+
 PinBlock pin_acquire(flgpu_ctx *c, size_t bytes)
 {
     size_t cap = 64 * 1024;
@@ -58,6 +60,7 @@ PinBlock pin_acquire(flgpu_ctx *c, size_t bytes)
 void pin_release(flgpu_ctx *c, PinBlock &b)
 {
     if (!b.p) return;
+    if (b.cap > kPinPoolMaxBlock) { (void)hipHostFree(b.p); b.p = nullptr; return; } // a rare huge picture must not pin its block for the context's lifetime
     std::lock_guard<std::mutex> g(c->pin_mu);
     c->pin_free.emplace(b.cap, b.p);
     b.p = nullptr;
@@ -279,7 +282,7 @@ extern "C" {
 
 int flgpu_plan_shards(uint32_t n_shards, size_t n, const flgpu_image *srcs, const flgpu_params *ps, uint32_t flags,
                       uint32_t *shard_of, uint64_t *shard_bytes)
-{
+try {
     if (n_shards == 0 || n_shards > FLGPU_MAX_DEVICES || (n && (!srcs || !ps || !shard_of))) return FLGPU_ERR_INVALID_ARG;
     std::vector<uint64_t> w(n);
     for (size_t i = 0; i < n; ++i) {
@@ -295,11 +298,11 @@ int flgpu_plan_shards(uint32_t n_shards, size_t n, const flgpu_image *srcs, cons
         for (size_t i = 0; i < n; ++i) shard_bytes[shard_of[i]] += w[i];
     }
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 int flgpu_transform_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts,
                                  void *hip_stream, uint32_t flags)
-{
+try {
     if (!c) return FLGPU_ERR_INVALID_ARG;
     const bool same = (flags & FLGPU_BATCH_SAME_PARAMS) != 0;
     if (c->shard_ctx.empty()) {
@@ -335,10 +338,10 @@ int flgpu_transform_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs
     c->last_shards = ranges;
     c->last_n = n;
     return rc;
-}
+} FL_ABI_CATCH
 
 int flgpu_transform_batch(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_params *ps, flgpu_image *dsts)
-{
+try {
     if (!c) return FLGPU_ERR_INVALID_ARG;
     if (c->shard_ctx.empty()) {
         std::lock_guard<std::mutex> g(c->mu);
@@ -355,10 +358,10 @@ int flgpu_transform_batch(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const
         std::lock_guard<std::mutex> gs(s->mu);
         return run_batch_host(s, b - a, srcs + a, ps + a, dsts + a);
     });
-}
+} FL_ABI_CATCH
 
 int flgpu_batch_results(flgpu_ctx *c, size_t n, flgpu_image *dsts)
-{
+try {
     if (!c || (!dsts && n)) return FLGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     if (n != c->last_n) { c->set_error("flgpu_batch_results: n differs from the last device batch"); return FLGPU_ERR_INVALID_ARG; }
@@ -377,10 +380,10 @@ int flgpu_batch_results(flgpu_ctx *c, size_t n, flgpu_image *dsts)
         if (r2 && !rc) { rc = r2; c->set_error(s->get_error()); }
     }
     return rc;
-}
+} FL_ABI_CATCH
 
 int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p, flgpu_image *dst)
-{
+try {
     if (!c || !src || !p || !dst || !src->data || !dst->data) return FLGPU_ERR_INVALID_ARG;
     // validate on the caller's thread so that one bad request cannot fail a shared batch
     flgpu_plan plan;
@@ -391,6 +394,8 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
     if (jsrc) {
         if (jpeg_parse_info(src->data, (size_t)src->capacity, jinfo) != 0) return FLGPU_ERR_INVALID_ARG;
         if (!jinfo.supported) { c->set_error("JPEG stream not covered by the device decoder"); return FLGPU_ERR_UNSUPPORTED; }
+        const int prc = jpeg_source_precheck(c, src, jinfo); // before any block is reserved on the file's say-so
+        if (prc) return prc;
     } else if (src->capacity < (uint64_t)src->width * src->height * src->channels) return FLGPU_ERR_INVALID_ARG;
     const bool jpeg = p->front_end == FLGPU_FE_JPEG;
     if (!jpeg && dst->capacity < plan.out_bytes) return FLGPU_ERR_BUFFER_TOO_SMALL;
@@ -452,10 +457,10 @@ int flgpu_transform(flgpu_ctx *c, const flgpu_image *src, const flgpu_params *p,
     give_back();
     if (dst_pinned) dst->flags |= FLGPU_IMG_PINNED;
     return r.status;
-}
+} FL_ABI_CATCH
 
 int flgpu_ycck_to_cmyk(flgpu_ctx *c, uint8_t *raw, uint64_t n_pixels)
-{
+try {
     if (!c || (!raw && n_pixels)) return FLGPU_ERR_INVALID_ARG;
     if (n_pixels == 0) return FLGPU_OK;
     if (n_pixels >= (1ull << 30)) return FLGPU_ERR_UNSUPPORTED;
@@ -468,6 +473,6 @@ int flgpu_ycck_to_cmyk(flgpu_ctx *c, uint8_t *raw, uint64_t n_pixels)
     FL_HIP(c, hipMemcpyAsync(raw, c->d_in.p, bytes, hipMemcpyDeviceToHost, c->stream), "D2H");
     FL_HIP(c, hipStreamSynchronize(c->stream), "sync");
     return FLGPU_OK;
-}
+} FL_ABI_CATCH
 
 } // extern "C"

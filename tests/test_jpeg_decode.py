@@ -260,6 +260,36 @@ def test_embedded_profile_of_a_cmyk_file(fl, oracle):
 
 
 @pytest.mark.gpu
+def test_a_hostile_header_cannot_reserve_gigabytes(fl, gpu_state):
+    """A file's own SOF header decides how much staging memory a JPEG source needs, so it is checked before anything is
+    reserved: a small file that announces 26,000 x 26,000 pixels is malformed (too short for that many blocks), one that
+    announces more than the reference decoder's 512 MiB limit (image::Limits::default, handler.rs:205-220) is unsupported --
+    through the queue (flgpu_transform) and through the batch call alike, and the context keeps working."""
+    data = bytearray(make_jpeg(64, 64, 3, 85, 2, 0, index=3))
+    sof = data.find(b"\xff\xc0")
+    assert sof > 0
+
+    def with_size(h, w):
+        d = bytearray(data)
+        d[sof + 5:sof + 7] = h.to_bytes(2, "big")
+        d[sof + 7:sof + 9] = w.to_bytes(2, "big")
+        return bytes(d)
+
+    before = gpu_state.stats()
+    for h, w, status in ((26000, 26000, fl.ERR_UNSUPPORTED), (12000, 12000, fl.ERR_INVALID_ARG), (20000, 30000, fl.ERR_UNSUPPORTED)):
+        bad = with_size(h, w)
+        assert fl.jpeg_info(bad)["width"] == w
+        with pytest.raises(fl.FanlinError) as e:
+            gpu_state.process_jpeg_pixels(bad, fl.make_params(300, 200))
+        assert e.value.status == status, (h, w, e.value.status)
+        with pytest.raises(fl.FanlinError) as e:
+            gpu_state.process_batch([bad], [fl.make_params(300, 200)])
+        assert e.value.status == status
+    good = gpu_state.process_jpeg_pixels(bytes(data), fl.make_params(32, 32))
+    assert good.shape[:2] == (32, 32)
+
+
+@pytest.mark.gpu
 def test_more_embedded_profiles_in_one_batch_than_the_table_cache_holds(fl, oracle):
     """A batch selects the tables of all its pictures before it launches their conversions, and the cache of baked embedded
     profiles holds 8: with 11 distinct profiles in ONE batch no table handed out for an earlier picture may be evicted (and

@@ -76,6 +76,12 @@ def test_query_blur_clamp_and_odd_values(fl):
     assert fl.Query.parse("rgb=1%2C2%2C3").fill_color() == (1, 2, 3)
     assert fl.Query.parse("rgb=1,,3").fill_color() == (1, 32, 3)
     assert fl.Query.parse("rgb=300,2,3").fill_color() == (32, 2, 3)  # u8 parse failure -> default per field
+    # query.rs:35-49 parses the whole string, however long: u8::from_str takes any number of leading zeros, so a value longer
+    # than the ABI's fixed field must not be cut off (it is reduced to the colour it means)
+    assert fl.Query.parse("rgb=" + "0" * 150 + "7,8," + "0" * 90 + "9").fill_color() == (7, 8, 9)
+    assert fl.Query.parse("rgb=" + "0" * 150 + "7,8").fill_color() == (32, 32, 32)      # two fields: the default colour
+    assert fl.Query.parse("rgb=1,2,3," + "x" * 200).fill_color() == (1, 2, 3)            # fields past the third are ignored
+    assert fl.Query.parse("rgb=1,2," + "3" * 120).fill_color() == (1, 2, 32)             # a field that overflows u8
     assert fl.Query.parse("").as_is()
     assert fl.Query.parse("crop=false").cropping() is False
 
