@@ -74,11 +74,67 @@ def cpu_baseline(n_images: int, workload: dict, max_threads: int = 16):
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(one, range(n_images)))
     dt = time.perf_counter() - t0
-    return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "single_thread_ms_per_image": t1 * 1e3,
+    return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "host_cores_visible": avail, "single_thread_ms_per_image": t1 * 1e3,
             "sample": f"{n_images} synthetic 1920x1080 RGB8 images (uniform bytes), oracle/libfanlin_oracle.so "
                       f"(C restatement of image 0.25.6, reference arithmetic), resize + letterbox"
                       + (" + JPEG encode (q 75)" if workload.get("jpeg") else "") + f", one image per thread on {cores} threads"}
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def config0(fl, st, runs: int = 200):
+    """BASELINE.json configs[0]: the reference's own demo request, images/lenna.jpg (512x512) -> w=300&h=200 (200x200 Lanczos3,
+    letterboxed to 300x200, JPEG quality 75), once on the CPU path and once through the library, from the FILE bytes on
+    (decode + resize + letterbox + encode), one request at a time, p50 over `runs`.  The reference's README quotes 18.06 ms
+    p50 for this request INCLUDING its HTTP stack and file fetch on an i7-13700HX (/root/reference/README.md:111-114)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle = oracle_lib.load()
+    path = os.path.join(ROOT, "tests", "golden", "lenna_reference.jpg")
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+
+    def cpu_once():
+        px = oracle.process_pixels(oracle.jpeg_decode(data), REQ_W, REQ_H, arith=oracle_lib.ARITH_REF)
+        return oracle.jpeg_encode(px, 75)
+
+    def p50(fn):
+        fn()
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        a = np.sort(np.array(ts))
+        return float(a[len(a) // 2]), float(a[min(len(a) - 1, int(len(a) * 0.99))])
+
+    out = {"request": "tests/golden/lenna_reference.jpg (the reference's images/lenna.jpg, 512x512, 343,160 B) -> w=300&h=200, JPEG q 75, from the file bytes on",
+           "runs": runs, "reference_readme_p50_ms": 18.06,
+           "reference_readme_note": "whole HTTP path incl. local-file fetch, i7-13700HX, README.md:111-114 -- context only"}
+    c50, c99 = p50(cpu_once)
+    out["cpu_oracle"] = {"p50_ms": c50, "p99_ms": c99, "threads": 1, "kind": "port", "cpu_model": cpu_model(),
+                         "path": "oracle: zune-jpeg-style decode + Lanczos3 (reference arithmetic) + letterbox + JPEG encode"}
+    try:
+        q = f"w={REQ_W}&h={REQ_H}"
+        body = st.process_jpeg(data, q)[2]
+        g50, g99 = p50(lambda: st.process_jpeg(data, q))
+        out["gpu_single_request"] = {"p50_ms": g50, "p99_ms": g99, "stream_bytes": len(body),
+                                     "path": "flgpu_process_jpeg: host Huffman decode on the caller's thread, IDCT + colour + resize + letterbox + JPEG encode on the device, one request in flight"}
+    except Exception as e:
+        out["gpu_single_request"] = {"skipped": repr(e)[:160]}
+    return out
 
 
 def measured_traffic(workload: str):
@@ -284,8 +340,93 @@ def timed_loop(run, stream, steps, warmup, st, world, dist, cdev):
     return elapsed, st.stats()
 
 
+def main_one_context(args):
+    """--one-context: ONE process and ONE flgpu context over N GPUs (flgpu_config.devices[], the drop-in's mode: one Arc<State>
+    for all workers, src/main.rs:108-112).  The batch of N x --batch images is cut by flgpu_plan_shards (contiguous shards balanced
+    by algorithmic bytes), shard k is resident on device k, and one flgpu_transform_batch_device call per step runs all shards
+    concurrently and returns when every one is done.  No torch.distributed, no collective (the library hands the CMYK table
+    round with one ncclBroadcast of its own when a profile is set).  Same JSON line as the per-rank mode."""
+    import numpy as np
+    import torch
+    fl = load_package()
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    N = args.gpus
+    devices = [k % ndev for k in range(N)]  # fewer GPUs than asked for: shards share them (rehearsal on a 1-GPU box)
+    FE = {"none": fl.FE_NONE, "jfif444": fl.FE_JFIF444, "webp420": fl.FE_WEBP420, "jpeg": fl.FE_JPEG}
+    fe = FE[args.frontend]
+    params = fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fe, quality=args.quality)
+    plan = fl.plan_output(params, SRC_W, SRC_H, SRC_C)
+    n = args.batch * N
+    src_bytes = SRC_W * SRC_H * SRC_C
+    out_stride = (int(plan.max_out_bytes) + 255) // 256 * 256
+    shapes = [(SRC_H, SRC_W, SRC_C)] * n
+    shard_of, shard_bytes = fl.plan_shards(N, shapes, params)
+    srcp, dstp, keep = [0] * n, [0] * n, []
+    for k in range(N):
+        idx = [i for i in range(n) if int(shard_of[i]) == k]
+        dev = torch.device("cuda", devices[k])
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0xFA171200 + k)
+        s_k = torch.empty((len(idx), SRC_H, SRC_W, SRC_C), dtype=torch.uint8, device=dev)
+        for i in range(0, len(idx), 64):
+            s_k[i:i + 64] = torch.randint(0, 256, (min(64, len(idx) - i), SRC_H, SRC_W, SRC_C), dtype=torch.uint8, device=dev, generator=gen)
+        d_k = torch.zeros((len(idx), out_stride), dtype=torch.uint8, device=dev)
+        keep.append((s_k, d_k))
+        for j, i in enumerate(idx):
+            srcp[i] = s_k.data_ptr() + j * src_bytes
+            dstp[i] = d_k.data_ptr() + j * out_stride
+    st = fl.State(devices=devices, profile=True) if N > 1 else fl.State(device=devices[0], profile=True)
+    run = st.prepared_batch(srcp, shapes, params, dstp, [out_stride] * n)
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    for _ in range(max(args.warmup, 1)):
+        run(0)
+    sync_all()
+    st.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run(0)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    stats = st.stats()
+    ok, err = 1, None
+    if fe == fl.FE_JPEG:
+        srcs_c, dsts_c, _ = run._keep
+        fl._check(st._lib.flgpu_batch_results(st._ctx, n, dsts_c), st._ctx)
+        if any(d.bytes == 0 for d in dsts_c):
+            ok, err = 0, "an encoded stream did not fit its destination"
+    launches = max(int(stats["resample_launches"]), 1)
+    k_ms = stats["resample_ms"] / launches
+    alg_bytes = (stats["resample_src_bytes"] + stats["resample_dst_bytes"]) / launches
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    line = {"metric": baseline_metric(), "value": n * args.steps / elapsed, "unit": "images/s", "n_gpus": N, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 x f16-pair weights -> f32 acc; i16 x 17-bit fixed weights -> i32" if stats.get("mfma_launches") else "f32", "data": "synthetic",
+            "config": {"workload": f"{n} x {SRC_W}x{SRC_H} RGB8 (uniform bytes, HBM-resident, shard k on device k) -> w={REQ_W}&h={REQ_H} Lanczos3 + letterbox RGBA8"
+                                   + (f" + baseline JPEG encode (q {args.quality}) on the device" if fe == fl.FE_JPEG else ""),
+                       "mode": "one process, one context over the node's GPUs (flgpu_config.devices[]), shards by flgpu_plan_shards",
+                       "devices": devices, "shard_images": [int((shard_of == k).sum()) for k in range(N)], "images_per_gpu_per_step": args.batch},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "resample_mfma_kernel" if stats.get("mfma_launches") else "resample_stream_kernel", "kernel_ms": k_ms,
+                         "note": "per launch and device: average over the shards' launches"},
+            "cpu_baseline": None}
+    if err:
+        line["error"] = err
+    print(json.dumps(line), flush=True)
+    st.close()
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--one-context", action="store_true",
+                    help="one process, one flgpu context over --gpus devices (the drop-in's mode) instead of one process per GPU; do not launch under torch.distributed.run")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400, help="timed steps (the default keeps the timed region above one second)")
     ap.add_argument("--warmup", type=int, default=3)
@@ -305,9 +446,12 @@ def main():
     ap.add_argument("--latency-requests", type=int, default=1024,
                     help="requests of the per-image latency probe through flgpu_transform (0 = skip)")
     ap.add_argument("--latency-threads", type=int, default=64, help="concurrent caller threads of the latency probe")
+    ap.add_argument("--config0-runs", type=int, default=200, help="runs of BASELINE config 0 (lenna.jpg, CPU oracle and one GPU request at a time); 0 = skip")
     ap.add_argument("--queue-lanes", type=int, default=0, help="batches the request queue keeps in flight (0 = library default)")
     ap.add_argument("--queue-max-batch", type=int, default=0, help="largest batch the request queue forms (0 = library default)")
     args = ap.parse_args()
+    if args.one_context:
+        return main_one_context(args)
 
     import torch
     import torch.distributed as dist
@@ -419,6 +563,18 @@ def main():
         if fe != fl.FE_NONE:
             extra["resize_only (config 1 without the encode)"] = measure(
                 fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fl.FE_NONE))
+        # the same resize with the reference's own arithmetic width: the streaming kernel (f32 accumulation, bit-exact against the
+        # oracle's fused-order mode) serves the request when the matrix-pipe kernel is switched off
+        os.environ["FLGPU_NO_MFMA"] = "1"
+        try:
+            f32m = measure(fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fl.FE_NONE))
+        finally:
+            del os.environ["FLGPU_NO_MFMA"]
+        alg = SRC_W * SRC_H * SRC_C * n + int(fl.plan_output(fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale), SRC_W, SRC_H, SRC_C).pixel_bytes) * n
+        f32m["roofline"] = {"bound": "hbm", "kernel": "resample_stream_kernel", "kernel_ms": f32m["stage_ms_per_step"]["resample"],
+                            "achieved": alg / (f32m["stage_ms_per_step"]["resample"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (f32m["stage_ms_per_step"]["resample"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        extra["f32 arithmetic (FLGPU_NO_MFMA=1), resize only"] = f32m
         if not (args.grayscale and args.blur):
             extra["config2 (grayscale + blur sigma 10, pixels out)"] = measure(
                 fl.make_params(REQ_W, REQ_H, blur_sigma=10.0, grayscale=True, front_end=fl.FE_NONE))
@@ -435,11 +591,15 @@ def main():
         alg_bytes = (stats["resample_src_bytes"] + stats["resample_dst_bytes"]) / launches
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         workload = {"blur_sigma": args.blur, "grayscale": args.grayscale, "crop": args.crop, "jpeg": fe == fl.FE_JPEG, "quality": args.quality}
+        # the arithmetic the dominant kernel really computes in (not a precision claim: every byte is checked to lie within
+        # 1 LSB of the reference's f32 arithmetic, see verified_against)
+        kernel_dtype = ("u8 x f16-pair weights (22 bit) -> f32 acc (vertical, MFMA); i16 (1/64 steps) x 17-bit fixed weights -> i32 exact (horizontal, MFMA)"
+                        if stats.get("mfma_launches") else "f32 (one fused multiply-add per tap, vertical then horizontal)")
         line = {
             "metric": baseline_metric(),
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": kernel_dtype, "data": "synthetic",
             "config": {"workload": f"{n} x {SRC_W}x{SRC_H} RGB8 (uniform bytes, HBM-resident) -> w={REQ_W}&h={REQ_H} Lanczos3"
                                    + (" crop" if args.crop else " + letterbox RGBA8")
                                    + (" + grayscale" if args.grayscale else "") + (f" + blur sigma {args.blur:g}" if args.blur else "")
@@ -482,6 +642,8 @@ def main():
                     line["latency_jpeg_sources"] = jp
             except Exception as e:  # Pillow missing: the probe is optional
                 line["latency_jpeg_sources"] = {"skipped": repr(e)[:120]}
+        if args.config0_runs > 0 and args.cpu_images > 0 and world == 1 and ok_flag:  # (--cpu-images 0 switches every CPU leg off)
+            line["config0"] = config0(fl, st, args.config0_runs)
         if args.cpu_images > 0 and world == 1 and ok_flag:
             line["cpu_baseline"] = cpu_baseline(args.cpu_images, workload, args.cpu_threads)
         else:
