@@ -105,7 +105,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_query_use_avif", "flgpu_query_use_webp", "flgpu_query_as_is", "flgpu_query_unsupported_scale_size",
     "flgpu_params_from_query", "flgpu_plan_output", "flgpu_process_image", "flgpu_process_image_plan", "flgpu_create", "flgpu_destroy", "flgpu_transform",
     "flgpu_transform_batch", "flgpu_transform_batch_device", "flgpu_batch_results", "flgpu_plan_shards", "flgpu_devices",
-    "flgpu_cmyk_distribution", "flgpu_jpeg_info_of", "flgpu_decode_jpeg", "flgpu_process_jpeg", "flgpu_process_jpeg_plan", "flgpu_host_alloc", "flgpu_host_free", "flgpu_ycck_to_cmyk",
+    "flgpu_cmyk_distribution", "flgpu_rccl_selftest", "flgpu_jpeg_info_of", "flgpu_decode_jpeg", "flgpu_process_jpeg", "flgpu_process_jpeg_plan", "flgpu_host_alloc", "flgpu_host_free", "flgpu_ycck_to_cmyk",
     "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
@@ -174,6 +174,8 @@ def load_library() -> C.CDLL:
     lib.flgpu_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32]
     lib.flgpu_devices.restype = C.c_uint32
     lib.flgpu_cmyk_distribution.argtypes = [C.c_void_p]
+    lib.flgpu_rccl_selftest.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
+    lib.flgpu_rccl_selftest.restype = C.c_int
     lib.flgpu_ycck_to_cmyk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.flgpu_set_cmyk_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     lib.flgpu_set_cmyk_clut.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
@@ -350,6 +352,13 @@ def plan_output(params: flgpu_params, sw: int, sh: int, sc: int) -> flgpu_plan:
     plan = flgpu_plan()
     _check(load_library().flgpu_plan_output(C.byref(params), sw, sh, sc, C.byref(plan)))
     return plan
+
+
+def rccl_selftest(device: int = 0) -> dict:
+    """flgpu_rccl_selftest: the RCCL path of the CMYK table distribution, exercised with one rank on one device."""
+    info = (C.c_uint32 * 4)()
+    status = load_library().flgpu_rccl_selftest(device, info)
+    return {"status": status, "rccl_version": info[0], "bytes_intact": info[1], "tail_untouched": bool(info[2]), "communicator_destroyed": bool(info[3])}
 
 
 def jpeg_info(data: bytes) -> dict:

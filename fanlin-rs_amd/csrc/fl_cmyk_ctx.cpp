@@ -82,6 +82,25 @@ struct Rccl {
     std::vector<void *> comms; // one per device of the context, in device-list order
 };
 
+// ncclDataType_t of one byte (nccl.h: ncclInt8 = ncclChar = 0, ncclUint8 = 1); flgpu_rccl_selftest checks on the box that a
+// broadcast of n elements of this type moves exactly n bytes
+constexpr int kNcclUint8 = 1;
+
+// The five entry points the table distribution uses, resolved from the RCCL of the host (prototypes as in rccl's nccl.h:
+// ncclResult_t == int, ncclComm_t == an opaque pointer).  false = no usable RCCL here.
+bool rccl_load(Rccl *r)
+{
+    for (const char *name : {"librccl.so.1", "librccl.so"}) { r->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (r->lib) break; }
+    if (!r->lib) return false;
+    r->CommInitAll = reinterpret_cast<int (*)(void **, int, const int *)>(dlsym(r->lib, "ncclCommInitAll"));
+    r->CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(r->lib, "ncclCommDestroy"));
+    r->GroupStart = reinterpret_cast<int (*)()>(dlsym(r->lib, "ncclGroupStart"));
+    r->GroupEnd = reinterpret_cast<int (*)()>(dlsym(r->lib, "ncclGroupEnd"));
+    r->Broadcast = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(dlsym(r->lib, "ncclBroadcast"));
+    if (!r->CommInitAll || !r->CommDestroy || !r->GroupStart || !r->GroupEnd || !r->Broadcast) { dlclose(r->lib); r->lib = nullptr; return false; }
+    return true;
+}
+
 Rccl *rccl_for(flgpu_ctx *c)
 {
     if (c->rccl) return static_cast<Rccl *>(c->rccl);
@@ -89,17 +108,9 @@ Rccl *rccl_for(flgpu_ctx *c)
     std::set<int> distinct(c->devices.begin(), c->devices.end());
     if (n < 2 || distinct.size() != n) return nullptr; // RCCL wants one rank per physical GPU
     Rccl *r = new Rccl();
-    for (const char *name : {"librccl.so.1", "librccl.so"}) { r->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (r->lib) break; }
-    if (r->lib) {
-        r->CommInitAll = reinterpret_cast<int (*)(void **, int, const int *)>(dlsym(r->lib, "ncclCommInitAll"));
-        r->CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(r->lib, "ncclCommDestroy"));
-        r->GroupStart = reinterpret_cast<int (*)()>(dlsym(r->lib, "ncclGroupStart"));
-        r->GroupEnd = reinterpret_cast<int (*)()>(dlsym(r->lib, "ncclGroupEnd"));
-        r->Broadcast = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(dlsym(r->lib, "ncclBroadcast"));
-    }
-    if (!r->lib || !r->CommInitAll || !r->CommDestroy || !r->GroupStart || !r->GroupEnd || !r->Broadcast) { if (r->lib) dlclose(r->lib); delete r; return nullptr; }
+    if (!rccl_load(r)) { delete r; return nullptr; }
     r->comms.assign(n, nullptr);
-    if (r->CommInitAll(r->comms.data(), (int)n, c->devices.data()) != 0) { dlclose(r->lib); delete r; return nullptr; }
+    if (r->CommInitAll(r->comms.data(), (int)n, c->devices.data()) != 0) { delete r; return nullptr; } // (the library stays loaded)
     c->rccl = r;
     return r;
 }
@@ -128,7 +139,7 @@ int distribute_clut(flgpu_ctx *c, int *how)
         for (size_t k = 0; ok && k < c->shard_ctx.size(); ++k) {
             flgpu_ctx *s = c->shard_ctx[k];
             ok = hipSetDevice(s->device) == hipSuccess &&
-                 r->Broadcast(s->cmyk_default.dev.p, s->cmyk_default.dev.p, bytes, /*ncclUint8*/ 1, /*root*/ 0, r->comms[k], s->stream) == 0;
+                 r->Broadcast(s->cmyk_default.dev.p, s->cmyk_default.dev.p, bytes, kNcclUint8, /*root*/ 0, r->comms[k], s->stream) == 0;
         }
         ok = (r->GroupEnd() == 0) && ok;
         for (flgpu_ctx *s : c->shard_ctx) { (void)hipSetDevice(s->device); ok = (hipStreamSynchronize(s->stream) == hipSuccess) && ok; }
@@ -320,5 +331,48 @@ try {
 } FL_ABI_CATCH
 
 int flgpu_cmyk_bake_available(void) { return cmyk_bake_available() ? 1 : 0; }
+
+// One GPU is enough to prove everything about the RCCL path except the wires: the library loads, the five symbols resolve,
+// the hand-written prototypes and the ncclUint8 value are the ones this RCCL understands (a one-rank communicator from
+// ncclCommInitAll, an out-of-place one-rank ncclBroadcast of n "uint8" elements between group calls must move exactly n bytes
+// and not one more), and the communicator can be destroyed.
+int flgpu_rccl_selftest(int device, uint32_t info[4])
+try {
+    if (info) info[0] = info[1] = info[2] = info[3] = 0;
+    Rccl r;
+    if (!rccl_load(&r)) return FLGPU_ERR_UNSUPPORTED; // no RCCL on this host: the distribution falls back to copies
+    if (auto ver = reinterpret_cast<int (*)(int *)>(dlsym(r.lib, "ncclGetVersion"))) { int v = 0; if (ver(&v) == 0 && info) info[0] = (uint32_t)v; }
+    if (hipSetDevice(device) != hipSuccess) return FLGPU_ERR_NO_DEVICE;
+    void *comm = nullptr;
+    const int devs[1] = {device};
+    if (r.CommInitAll(&comm, 1, devs) != 0 || !comm) return FLGPU_ERR_DEVICE;
+    const size_t n = 250563, pad = 4096; // 17^4 x 3 bytes: an odd count, so a wider element type cannot pass by accident
+    std::vector<uint8_t> h(n + pad), back(n + pad, 0);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (uint8_t)(i * 2654435761u >> 24);
+    uint8_t *src = nullptr, *dst = nullptr;
+    hipStream_t st = nullptr;
+    int rc = FLGPU_ERR_DEVICE;
+    if (hipMalloc(&src, n + pad) == hipSuccess && hipMalloc(&dst, n + pad) == hipSuccess && hipStreamCreate(&st) == hipSuccess &&
+        hipMemcpy(src, h.data(), n + pad, hipMemcpyHostToDevice) == hipSuccess && hipMemset(dst, 0xA5, n + pad) == hipSuccess) {
+        bool ok = r.GroupStart() == 0;
+        ok = ok && r.Broadcast(src, dst, n, kNcclUint8, /*root*/ 0, comm, st) == 0;
+        ok = (r.GroupEnd() == 0) && ok;
+        ok = ok && hipStreamSynchronize(st) == hipSuccess && hipMemcpy(back.data(), dst, n + pad, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok) {
+            size_t good = 0;
+            while (good < n && back[good] == h[good]) ++good;
+            bool tail_untouched = true;
+            for (size_t i = n; i < n + pad; ++i) tail_untouched = tail_untouched && back[i] == 0xA5;
+            if (info) { info[1] = (uint32_t)good; info[2] = tail_untouched ? 1u : 0u; }
+            rc = (good == n && tail_untouched) ? FLGPU_OK : FLGPU_ERR_DEVICE;
+        }
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (r.CommDestroy(comm) != 0 && rc == FLGPU_OK) rc = FLGPU_ERR_DEVICE;
+    if (info) info[3] = 1; // the communicator was created and destroyed
+    return rc;
+} FL_ABI_CATCH
 
 } // extern "C"

@@ -241,6 +241,12 @@ int flgpu_get_cmyk_clut(flgpu_ctx *ctx, uint16_t *rgb_nodes, uint64_t capacity_e
  * ncclBroadcast (RCCL over xGMI; one rank per distinct GPU, librccl loaded on demand), 1 = by plain copies (shards sharing
  * a GPU, or no RCCL on the host), 0 = single-device context or no table yet. */
 int flgpu_cmyk_distribution(flgpu_ctx *ctx);
+/* Self-test of that RCCL path on ONE device: loads librccl as the distribution does, resolves the same five symbols, creates
+ * a one-rank communicator (ncclCommInitAll), broadcasts 250,563 bytes out of place as "ncclUint8" between group calls,
+ * checks that exactly those bytes arrived, destroys the communicator.  FLGPU_ERR_UNSUPPORTED = no RCCL on this host (the
+ * distribution then uses copies).  info (may be NULL): [0] RCCL version, [1] bytes that arrived intact, [2] 1 if nothing was
+ * written past them, [3] 1 once the communicator has been destroyed. */
+int flgpu_rccl_selftest(int device, uint32_t info[4]);
 /* Replaces CMYK2RGB::convert = lcms2 transform_pixels (src/handler.rs:490-492) and, with
  * FLGPU_CMYK_INPUT_YCCK, the YCCK loop in front of it (423-438).  n_pixels x 4 bytes in, n_pixels x 3 bytes out.
  * `embedded_icc` (may be NULL) is the JPEG's own profile when use_embedded_profile is set: it is baked once and

@@ -167,3 +167,19 @@ def test_cmyk_table_reaches_every_shard(fl, two_shards):
         want = one.cmyk_to_rgb(px)
     assert np.array_equal(two_shards.cmyk_to_rgb(px), want)
     assert np.array_equal(two_shards.get_cmyk_clut(), clut)
+
+
+@pytest.mark.gpu
+def test_rccl_path_of_the_table_distribution_on_one_device(fl):
+    """A context over several distinct GPUs hands its CMYK table round with one ncclBroadcast through a dlopen-ed RCCL and five
+    hand-declared prototypes (csrc/fl_cmyk_ctx.cpp).  No multi-GPU box has run that yet; everything but the wires is proven here
+    with one rank: library found, symbols resolved, a communicator from ncclCommInitAll, 250,563 "ncclUint8" elements broadcast
+    out of place between group calls arrive as exactly 250,563 bytes, the communicator is destroyed."""
+    from conftest import require_device
+    require_device()
+    r = fl.rccl_selftest(0)
+    if r["status"] == fl.ERR_UNSUPPORTED:
+        pytest.skip("no librccl on this host: the distribution uses copies")
+    assert r["status"] == fl.OK, r
+    assert r["bytes_intact"] == 250563 and r["tail_untouched"] and r["communicator_destroyed"], r
+    assert r["rccl_version"] > 20000, r
