@@ -134,17 +134,20 @@ __device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, false);
 }
 
-// Inclusive prefix sum over the 64 lanes: four DPP steps inside the rows of 16, then the three row totals
-// (VALU latency only; ds_bpermute based shuffles cost an LDS round trip per step).
+// Inclusive prefix sum over the 64 lanes in six DPP adds: four steps inside the rows of 16, then the row totals travel by
+// row_bcast:15 (rows 1 and 3 take the last lane of the row before) and row_bcast:31 (rows 2 and 3 take lane 31).
+// (VALU latency only; ds_bpermute based shuffles cost an LDS round trip per step, v_readlane + v_cndmask per row six more
+// vector instructions -- this kernel runs at 97 % VALU issue, profiles/r03_jpeg_pmc.txt, so instructions are its time.)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 {
+    (void)lane;
     v += dpp_row_shr<1>(v);
     v += dpp_row_shr<2>(v);
     v += dpp_row_shr<4>(v);
     v += dpp_row_shr<8>(v);
-    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), s1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
-                   s2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
-    return v + (lane >= 16u ? s0 : 0u) + (lane >= 32u ? s1 : 0u) + (lane >= 48u ? s2 : 0u);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 row_mask:0xa
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 row_mask:0xc
+    return v;
 }
 
 // LDS traffic that stays inside one wave needs no hardware barrier (a wave's DS instructions execute in order);
@@ -253,9 +256,8 @@ __device__ __forceinline__ void stage_ac_luts(uint32_t *s_ac)
     __syncthreads();
 }
 
-__device__ __forceinline__ uint32_t block_pixel(const JpegJob &jb, uint32_t blk, uint32_t r, uint32_t c)
+__device__ __forceinline__ uint32_t block_pixel(const JpegJob &jb, uint32_t brow, uint32_t bcol, uint32_t r, uint32_t c)
 {
-    const uint32_t brow = blk / jb.bx, bcol = blk - brow * jb.bx;
     // copy_blocks_ycbcr / pixel_at_or_near: pixels past the right / bottom edge repeat the last column / row
     uint32_t px = bcol * 8u + c, py = brow * 8u + r;
     px = px < jb.w ? px : jb.w - 1u;
@@ -267,17 +269,62 @@ __device__ __forceinline__ uint32_t block_pixel(const JpegJob &jb, uint32_t blk,
     return pr | (pg << 8) | (pb << 16);
 }
 
+// Forward DCT + quantisation of one component of one block: lane (r, c) in, lane k = zig-zag coefficient k out.
+__device__ __forceinline__ int32_t dct_quant_unit(uint32_t sample, uint32_t lane, uint32_t r, uint32_t c, const uint32_t (&m1)[4], const uint32_t (&m2)[4],
+                                                  uint4 k1, uint32_t q, uint32_t magic, uint32_t zz, int16_t *ta16, int16_t *tb16, int32_t *ta)
+{
+    ta16[lane] = (int16_t)sample;
+    wave_lds_sync();
+    // Pass 1 (rows): lane (r, c) produces horizontal frequency c of row r
+    const int32_t p = dot8_i16(m1, *reinterpret_cast<const uint4 *>(ta16 + r * 8)); // one 16-byte read: the row's 8 samples
+    // transform.rs: c = 0: (p - 8 * 128) << PASS1_BITS (level shift folded in), c = 4: p << PASS1_BITS, else (p + 2^10) >> 11
+    // (CONST_BITS - PASS1_BITS).  One form for all lanes, (p << s1 + a1) >> 11 with per-lane s1 = 13 or 0 (the sums of columns 0
+    // and 4 are below 2^12, so nothing is shifted out): no lane-dependent branches in a kernel whose time is its vector instructions.
+    const int32_t v1 = ((p << k1.x) + (int32_t)k1.y) >> 11;
+    tb16[c * 8 + r] = (int16_t)v1;                // |v1| <= 255 * 8 * 4; transposed: the column pass reads 8 consecutive values
+    wave_lds_sync();
+    // Pass 2 (columns): lane (r, c) produces vertical frequency r of column c: rows 0 and 4 (p2 + 2) >> 2, else (p2 + 2^14) >> 15
+    const int32_t p2 = dot8_i16(m2, *reinterpret_cast<const uint4 *>(tb16 + c * 8));
+    const int32_t d = (p2 + (int32_t)k1.z) >> k1.w;
+    // encode_rgb "Quantization": ((d / 8) as f32 / f32::from(q)).round() as i32.  |d / 8| <= 2048 and q <= 255,
+    // so the f32 quotient cannot round onto or across a half (nearest miss: 1 / (2q) >= 2^-9 away, f32 error
+    // <= 2^-14): it equals the exact round-half-away  sign(n) * floor((2|n| + q) / 2q), taken with the
+    // per-coefficient reciprocal ceil(2^32 / 2q) from the table block (exact for 2|n| + q < 2^13).
+    // i32 division truncates toward zero: |d / 8| = |d| >> 3, and the sign of a non-zero quotient is d's.
+    const int32_t sg = d >> 31;
+    const uint32_t an = (uint32_t)((d ^ sg) - sg) >> 3;
+    const uint32_t rq = __umulhi(2u * an + q, magic);
+    const int32_t qv = ((int32_t)rq ^ sg) - sg;
+    // natural -> zig-zag order through LDS: lane k then owns zig-zag coefficient k
+    ta[zz] = qv;
+    wave_lds_sync();
+    const int32_t zv = ta[lane];
+    wave_lds_sync();
+    return zv;
+}
+
+// One wave per block; the three components of a block are transformed one after the other, then Huffman-coded TOGETHER:
+// the kernel is bound by vector-instruction issue (97 % VALU, profiles/r03_jpeg_pmc.txt), a block's three 64-coefficient
+// units rarely hold more than a few dozen non-zero coefficients between them, and coding works on non-zero coefficients
+// only -- so they are compacted into one list (rank of a lane among its unit's non-zero lanes = v_mbcnt of the ballot), one
+// lane per code word: (run, size) lookup, value bits, ZRL prefixes, a segmented prefix sum for the bit positions and the LDS
+// ORs then run once per block instead of once per component.  A block with more than 64 code words (non-zero coefficients
+// plus end-of-block codes) takes the per-component path, code_ac_block, which is also what every stream is checked against
+// (the oracle encoder codes blocks the reference's way, one BitWriter call after the other).
 __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__restrict__ jobs, const uint32_t *__restrict__ arena,
                                                              uint32_t job_base)
 {
     __shared__ int32_t s_a[4][64];                       // zig-zag exchange
     __shared__ __attribute__((aligned(16))) int16_t s_a16[4][64], s_b16[4][64]; // samples / pass-1 results (both fit 16 bits)
-    __shared__ uint32_t s_ac[512], s_u[4][64];
+    __shared__ uint32_t s_ac[512], s_u[4][3][64];        // AC code tables (luma, chroma); per wave and component: the unit's AC bits
+    __shared__ uint32_t s_ent[4][72];                    // per wave: [0] a pad entry, then the block's compacted code-word list
     const JpegJob jb = jobs[job_base + blockIdx.y];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, r = lane >> 3, c = lane & 7u;
     const uint32_t nblocks = jb.bx * jb.by;
     if (blockIdx.x * kBlocksPerWg >= nblocks) return; // whole workgroup idle (uniform)
-    s_u[wave][lane] = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_u[wave][k][lane] = 0u;
+    if (lane == 0) s_ent[wave][0] = 7u << 24;          // (component 7: no real entry continues it)
     stage_ac_luts(s_ac);
     const uint32_t first = blockIdx.x * kBlocksPerWg + wave * kBlocksPerWave;
     if (first >= nblocks) return;                      // wave-uniform; from here on waves never synchronise with each other
@@ -294,53 +341,114 @@ __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__re
     const uint32_t ml = magic[lane], mc = magic[64 + lane];
     const uint32_t lt_lo = lane >= 32u ? 0xffffffffu : (1u << lane) - 1u, lt_hi = lane >= 32u ? (1u << (lane - 32u)) - 1u : 0u;
     const uint32_t zz = kZigzagPos[lane];
+    // per-lane shift / rounding constants of the two passes (see dct_quant_unit)
+    const uint4 k1 = {(c == 0u || c == 4u) ? 13u : 0u, c == 0u ? (uint32_t)(-(8 * 128) * 8192) : (c == 4u ? 0u : 1u << 10),
+                      (r == 0u || r == 4u) ? 2u : 1u << 14, (r == 0u || r == 4u) ? 2u : 15u};
     int32_t *ta = s_a[wave];
     int16_t *ta16 = s_a16[wave], *tb16 = s_b16[wave];
-    uint32_t *tu = s_u[wave];
-    uint32_t rgb = block_pixel(jb, first, r, c);
+    uint32_t *ent = s_ent[wave];
+    uint32_t brow = first / jb.bx, bcol = first - brow * jb.bx; // (one division per wave; the walk below steps them)
+    uint32_t rgb = block_pixel(jb, brow, bcol, r, c);
     for (uint32_t blk = first; blk < last; ++blk) {
         uint32_t smp[3];
         jfif_px(rgb, smp[0], smp[1], smp[2]);
-        if (blk + 1u < last) rgb = block_pixel(jb, blk + 1u, r, c); // in flight while this block is transformed
+        if (++bcol == jb.bx) { bcol = 0; ++brow; }
+        if (blk + 1u < last) rgb = block_pixel(jb, brow, bcol, r, c); // in flight while this block is transformed
+        int32_t zv[3];
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) zv[comp] = dct_quant_unit(smp[comp], lane, r, c, m1, m2, k1, comp ? qc : ql, comp ? mc : ml, zz, ta16, tb16, ta);
+        // ---- the block's code words: per component its non-zero AC coefficients in zig-zag order, then an end-of-block code
+        // unless coefficient 63 is coded (BitWriter::write_block) ----
+        uint64_t mask[3];
+        uint32_t base[3], total = 0;
 #pragma unroll
         for (int comp = 0; comp < 3; ++comp) {
-            ta16[lane] = (int16_t)smp[comp];
-            wave_lds_sync();
-            // Pass 1 (rows): lane (r, c) produces horizontal frequency c of row r
-            const int32_t p = dot8_i16(m1, *reinterpret_cast<const uint4 *>(ta16 + r * 8)); // one 16-byte read: the row's 8 samples
-            int32_t v1;
-            if (c == 0) v1 = (p - 8 * 128) << 2;          // level shift folded in, scaled by 2^PASS1_BITS
-            else if (c == 4) v1 = p << 2;
-            else v1 = (p + (1 << 10)) >> 11;              // CONST_BITS - PASS1_BITS
-            tb16[c * 8 + r] = (int16_t)v1;                   // |v1| <= 255 * 8 * 4; transposed: the column pass reads 8 consecutive values
-            wave_lds_sync();
-            // Pass 2 (columns): lane (r, c) produces vertical frequency r of column c
-            const int32_t p2 = dot8_i16(m2, *reinterpret_cast<const uint4 *>(tb16 + c * 8));
-            int32_t d;
-            if (r == 0 || r == 4) d = (p2 + 2) >> 2;
-            else d = (p2 + (1 << 14)) >> 15;              // CONST_BITS + PASS1_BITS
-            // encode_rgb "Quantization": ((d / 8) as f32 / f32::from(q)).round() as i32.  |d / 8| <= 2048 and q <= 255,
-            // so the f32 quotient cannot round onto or across a half (nearest miss: 1 / (2q) >= 2^-9 away, f32 error
-            // <= 2^-14): it equals the exact round-half-away  sign(n) * floor((2|n| + q) / 2q), taken with the
-            // per-coefficient reciprocal ceil(2^32 / 2q) from the table block (exact for 2|n| + q < 2^13).
-            const int32_t n = (d + ((d >> 31) & 7)) >> 3;                       // i32 division truncates toward zero
-            const uint32_t an = (uint32_t)(n < 0 ? -n : n);
-            const uint32_t rq = __umulhi(2u * an + (comp ? qc : ql), comp ? mc : ml);
-            const int32_t qv = n < 0 ? -(int32_t)rq : (int32_t)rq;
-            // natural -> zig-zag order through LDS: lane k then owns zig-zag coefficient k
-            ta[zz] = qv;
-            wave_lds_sync();
-            const int32_t zv = ta[lane];
-            wave_lds_sync();
-            const uint32_t unit = blk * 3u + comp;
-            // the block's AC code, assembled from bit 0 of a private buffer: the pack kernel shifts it into place
-            const uint32_t ac_bits = code_ac_block(zv, lane, lt_lo, lt_hi, s_ac + (comp ? 256 : 0), tu);
-            wave_lds_sync();
-            const uint32_t nw = (ac_bits + 31u) >> 5;                // <= 52 words: 63 * 26 bits
-            if (lane < nw) { jb.acbits[(size_t)unit * kAcWordsPerUnit + lane] = tu[lane]; tu[lane] = 0u; }
-            if (lane == 0u) jb.meta[unit] = ((uint32_t)zv & 0xffffu) | (ac_bits << 16); // quantised DC, AC bit count
-            wave_lds_sync();
+            mask[comp] = __ballot(zv[comp] != 0 && lane != 0u);
+            base[comp] = total;
+            total += (uint32_t)__popcll(mask[comp]) + ((mask[comp] >> 63) ? 0u : 1u);
         }
+        uint32_t ac_bits[3];
+        if (total <= 64u) {
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) {
+                const uint32_t lo = (uint32_t)mask[comp], hi = (uint32_t)(mask[comp] >> 32);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u)); // non-zero lanes below this one
+                if (zv[comp] != 0 && lane != 0u) ent[1u + base[comp] + rank] = ((uint32_t)zv[comp] & 0xffffu) | (lane << 16) | ((uint32_t)comp << 24); // value, zig-zag position, component
+                if (lane == 0u && !(mask[comp] >> 63)) ent[base[comp] + (uint32_t)__popcll(mask[comp]) + 1u] = (64u << 16) | ((uint32_t)comp << 24); // position 64: end of block
+            }
+            wave_lds_sync();
+            const bool act = lane < total;
+            const uint32_t prev = ent[lane], cur = act ? ent[lane + 1u] : (64u << 16);
+            wave_lds_sync();
+            const uint32_t comp = (cur >> 24) & 3u, pos = (cur >> 16) & 127u;
+            const bool is_eob = pos == 64u;
+            const uint32_t prevpos = ((prev ^ cur) >> 24) ? 0u : ((prev >> 16) & 127u); // a unit's first code word: its run starts behind the DC term
+            const uint32_t run = pos - prevpos - 1u;
+            const int32_t v = (int32_t)(int16_t)(cur & 0xffffu);
+            const uint32_t mag = (uint32_t)(v < 0 ? -v : v);
+            const uint32_t size = is_eob ? 0u : 32u - (uint32_t)__clz(mag | 1u); // encode_coefficient (a listed coefficient is not zero)
+            const uint32_t value = (uint32_t)(v + (v >> 31)) & ((1u << size) - 1u);                 // negative: (v - 1) & mask
+            const uint32_t *tab = s_ac + (comp ? 256u : 0u);
+            const uint32_t e = tab[is_eob ? 0u : (((run & 15u) << 4) | size)];
+            uint32_t nb = act ? (e >> 16) + size : 0u;              // <= 16 + 10
+            const uint32_t code = ((e & 0xffffu) << size) | value;
+            const uint32_t nzrl = (act && !is_eob) ? run >> 4 : 0u; // "while zero_run > 15 { huffman_encode(0xF0) }": up to three in front
+            uint32_t *tuc = s_u[wave][comp];
+            uint32_t inc, pbit;
+            if (__ballot(nzrl != 0u) == 0ull) {
+                // no ZRL anywhere in the block: every code word fits one 32-bit word
+                inc = wave_inclusive_scan(nb, lane);
+                const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)base[1] - 1), s2 = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)base[2] - 1);
+                pbit = inc - nb - (comp == 0u ? 0u : (comp == 1u ? s1 : s2));
+                if (nb) {
+                    const uint32_t wi = pbit >> 5, sh = pbit & 31u;
+                    const uint32_t left = code << (32u - nb);
+                    const uint32_t w1 = (left << 1) << (31u - sh);
+                    atomicOr(&tuc[wi], left >> sh);
+                    if (w1) atomicOr(&tuc[wi + 1u], w1);
+                }
+                ac_bits[0] = s1; ac_bits[1] = s2 - s1;
+            } else {
+                const uint32_t zrl = tab[0xF0], zl = zrl >> 16, zc = zrl & 0xffffu;
+                uint64_t pre = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 3; ++i) if (i < nzrl) pre = (pre << zl) | zc;
+                const uint64_t bits = (pre << nb) | code; // <= 3 * 16 + 26 bits
+                nb += nzrl * zl;
+                inc = wave_inclusive_scan(nb, lane);
+                const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)base[1] - 1), s2 = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)base[2] - 1);
+                pbit = inc - nb - (comp == 0u ? 0u : (comp == 1u ? s1 : s2));
+                if (nb) {
+                    const uint32_t wi = pbit >> 5, sh = pbit & 31u;
+                    const uint64_t left = bits << (64u - nb);
+                    const uint64_t a2 = left >> sh;
+                    const uint32_t w0 = (uint32_t)(a2 >> 32), w1 = (uint32_t)a2, w2 = sh ? (uint32_t)((left << (64u - sh)) >> 32) : 0u;
+                    if (w0) atomicOr(&tuc[wi], w0);
+                    if (w1) atomicOr(&tuc[wi + 1u], w1);
+                    if (w2) atomicOr(&tuc[wi + 2u], w2);
+                }
+                ac_bits[0] = s1; ac_bits[1] = s2 - s1;
+            }
+            ac_bits[2] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63) - ac_bits[0] - ac_bits[1];
+            wave_lds_sync();
+        } else {
+            // more code words than lanes: component by component, as the reference writes them
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) {
+                ac_bits[comp] = code_ac_block(zv[comp], lane, lt_lo, lt_hi, s_ac + (comp ? 256 : 0), s_u[wave][comp]);
+                wave_lds_sync();
+            }
+        }
+        // ---- out: the units' AC bits (from bit 0 of their own buffers: the pack kernel shifts them into place), quantised DC, AC bit count
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) {
+            const uint32_t unit = blk * 3u + (uint32_t)comp;
+            uint32_t *tu = s_u[wave][comp];
+            const uint32_t nw = (ac_bits[comp] + 31u) >> 5;          // <= 52 words: 63 * 26 bits
+            if (lane < nw) { jb.acbits[(size_t)unit * kAcWordsPerUnit + lane] = tu[lane]; tu[lane] = 0u; }
+            if (lane == 0u) jb.meta[unit] = ((uint32_t)zv[comp] & 0xffffu) | (ac_bits[comp] << 16); // quantised DC, AC bit count
+        }
+        wave_lds_sync();
     }
 }
 

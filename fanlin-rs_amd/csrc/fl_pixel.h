@@ -15,11 +15,12 @@ __device__ __forceinline__ void load_rgba(const uint8_t *p, uint32_t c, uint32_t
     else { r = p[0]; g = p[1]; b = p[2]; a = p[3]; }
 }
 
+// Rust's `f32 as u8`: truncates, saturates, NaN -> 0.  v_cvt_u32_f32 truncates toward zero and gives 0 for negative values and
+// NaN, so one conversion and one minimum do it (three compares and selects before: these run once per pixel and component in
+// kernels whose time is their vector instructions).
 __device__ __forceinline__ uint8_t sat_u8(float v)
 {
-    if (!(v > 0.0f)) return 0;
-    if (v >= 255.0f) return 255;
-    return (uint8_t)v;
+    return (uint8_t)min(__float2uint_rz(v), 255u);
 }
 
 // image::color `impl Blend for Rgba<u8>` onto an opaque background (the letterbox
