@@ -158,7 +158,10 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// exclusive scan across the 256 threads of the workgroup; *total = sum.  s_w: 4 words of LDS.
+constexpr uint32_t kPackThreads = 512; // jpeg_pack_kernel: one workgroup per picture; its phases are chains of short dependent steps
+constexpr uint32_t kPackWaves = kPackThreads / 64;
+
+// exclusive scan across the threads of the pack workgroup; *total = sum.  s_w: kPackWaves words of LDS.
 __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_w, uint32_t *total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -168,7 +171,7 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_w,
     __syncthreads();
     uint32_t base = 0, sum = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) { const uint32_t t = s_w[i]; if (i < wave) base += t; sum += t; }
+    for (uint32_t i = 0; i < kPackWaves; ++i) { const uint32_t t = s_w[i]; if (i < wave) base += t; sum += t; }
     *total = sum;
     return base + inc - v;
 }
@@ -478,19 +481,20 @@ __device__ __forceinline__ uint32_t dc_code(const JpegJob &jb, uint32_t u, uint3
     return (((e & 0xffffu) << size) | value) << (32u - *len);  // left-aligned
 }
 
-__global__ __launch_bounds__(256) void jpeg_pack_kernel(const JpegJob *__restrict__ jobs, const uint32_t *__restrict__ arena,
-                                                        uint32_t job_base)
+__global__ __launch_bounds__(kPackThreads) void jpeg_pack_kernel(const JpegJob *__restrict__ jobs, const uint32_t *__restrict__ arena,
+                                                                 uint32_t job_base)
 {
     __shared__ uint32_t s_win[kWinWords];
-    __shared__ uint32_t s_w[4], s_carry, s_lo, s_hi;
+    __shared__ uint32_t s_w[kPackWaves], s_carry, s_lo, s_hi;
     const JpegJob jb = jobs[job_base + blockIdx.x];
     const uint32_t tid = threadIdx.x;
     const uint32_t nunits = jb.bx * jb.by * 3u;
+    constexpr uint32_t T = kPackThreads;
 
     // ---- bit offset of every block: DC code size (needs the previous block) + AC size, exclusive scan ----
     if (tid == 0u) s_carry = 0u;
     __syncthreads();
-    for (uint32_t base = 0; base < nunits; base += 256u) {
+    for (uint32_t base = 0; base < nunits; base += T) {
         const uint32_t u = base + tid;
         uint32_t len = 0;
         if (u < nunits) {
@@ -514,14 +518,19 @@ __global__ __launch_bounds__(256) void jpeg_pack_kernel(const JpegJob *__restric
     const uint32_t nbytes = (total_bits + 7u) >> 3, limit = jb.dst_cap;
     // everything in front of the scan data
     const uint8_t *hdr = reinterpret_cast<const uint8_t *>(arena + jb.tab_off);
-    for (uint32_t i = tid; i < kJpegHeaderBytes; i += 256u) if (i < limit) jb.dst[i] = hdr[i];
+    for (uint32_t i = tid; i < kJpegHeaderBytes; i += T) if (i < limit) jb.dst[i] = hdr[i];
 
     uint32_t ff_before = 0; // stuffed bytes emitted by earlier windows (same value in every thread)
+    const bool one_window = (uint64_t)total_bits <= (uint64_t)kWinWords * 32u; // (every 300 x 200 picture: ~12 KB of 32)
     for (uint32_t wbase = 0; wbase * 32ull < total_bits; wbase += kWinWords) {
         const uint64_t wb = (uint64_t)wbase * 32u, we = wb + (uint64_t)kWinWords * 32u;
-        for (uint32_t i = tid; i < kWinWords; i += 256u) s_win[i] = 0u;
-        // blocks that touch this window: offsets are ascending, so two binary searches bound them
-        if (tid == 0u) {
+        // only the words this window will hold are cleared (the stream's words, not all 8192)
+        const uint32_t win_words = (uint32_t)min((uint64_t)kWinWords, (((uint64_t)total_bits + 31u) >> 5) - wbase) + 1u;
+        for (uint32_t i = tid; i < min(win_words, kWinWords); i += T) s_win[i] = 0u;
+        // blocks that touch this window: offsets are ascending, so two binary searches bound them (a stream that fits one
+        // window needs none: two chains of a dozen dependent loads by one thread while 511 wait)
+        if (one_window) { if (tid == 0u) { s_lo = 0u; s_hi = nunits; } }
+        else if (tid == 0u) {
             uint32_t lo = 0, hi = nunits;            // first u with unit_off[u + 1] > wb
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (jb.unit_off[mid + 1u] > wb) hi = mid; else lo = mid + 1u; }
             s_lo = lo;
@@ -531,16 +540,16 @@ __global__ __launch_bounds__(256) void jpeg_pack_kernel(const JpegJob *__restric
         }
         __syncthreads();
         const uint32_t u_lo = s_lo, u_hi = s_hi;
-        // 8 lanes per block: lane 0 of the group also places the DC code, all of them shift AC words into place
-        for (uint32_t ub = u_lo; ub < u_hi; ub += 32u) {
-            const uint32_t u = ub + (tid >> 3), j = tid & 7u;
+        // 2 lanes per block (a block's AC code is 1-3 words in ordinary pictures): lane 0 of the pair also places the DC code
+        for (uint32_t ub = u_lo; ub < u_hi; ub += T / 2u) {
+            const uint32_t u = ub + (tid >> 1), j = tid & 1u;
             if (u < u_hi) {
                 const uint32_t m = jb.meta[u], off = jb.unit_off[u];
                 uint32_t dl;
                 const uint32_t dcw = dc_code(jb, u, m, &dl);
                 if (j == 0u) win_or(s_win, wbase, off, dcw);
                 const uint32_t nw = ((m >> 16) + 31u) >> 5;
-                for (uint32_t w = j; w < nw; w += 8u)
+                for (uint32_t w = j; w < nw; w += 2u)
                     win_or(s_win, wbase, (uint64_t)off + dl + 32u * w, jb.acbits[(size_t)u * kAcWordsPerUnit + w]);
             }
         }
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(256) void jpeg_pack_kernel(const JpegJob *__restric
         const uint32_t win_bytes = (uint32_t)min((uint64_t)kWinWords * 4u, (uint64_t)nbytes - (uint64_t)wbase * 4u);
         if (tid == 0u) s_carry = 0u;
         __syncthreads();
-        for (uint32_t base = 0; base < win_bytes; base += 1024u) {
+        for (uint32_t base = 0; base < win_bytes; base += 4u * T) {
             const uint32_t i = base + tid * 4u;
             const uint32_t word = i < win_bytes ? s_win[i >> 2] : 0u;     // stream order = most significant byte first
             const uint32_t valid = i < win_bytes ? (win_bytes - i < 4u ? win_bytes - i : 4u) : 0u;
@@ -602,7 +611,7 @@ hipError_t launch_jpeg_encode(const JpegJob *jobs, const uint32_t *arena, uint32
     if (!njobs || !max_blocks) return hipSuccess;
     hipLaunchKernelGGL(jpeg_dct_quant_kernel, dim3((max_blocks + kBlocksPerWg - 1) / kBlocksPerWg, njobs), dim3(256), 0, st, jobs, arena, job_base);
     FL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jpeg_pack_kernel, dim3(njobs), dim3(256), 0, st, jobs, arena, job_base);
+    hipLaunchKernelGGL(jpeg_pack_kernel, dim3(njobs), dim3(kPackThreads), 0, st, jobs, arena, job_base);
     FL_LAUNCH_CHECK();
     return hipSuccess;
 }
