@@ -491,22 +491,35 @@ __global__ __launch_bounds__(kPackThreads) void jpeg_pack_kernel(const JpegJob *
     const uint32_t nunits = jb.bx * jb.by * 3u;
     constexpr uint32_t T = kPackThreads;
 
-    // ---- bit offset of every block: DC code size (needs the previous block) + AC size, exclusive scan ----
+    // ---- bit offset of every block: DC code size (needs the previous block) + AC size, exclusive scan -- and, in the same pass,
+    // the block's code goes into the first window of the stream (win_or drops what lies beyond it): the words a thread will
+    // place are requested together with its meta word, BEFORE the scan, so that a picture whose stream fits one window (every
+    // 300 x 200 picture) costs one chain of dependent loads per 512 blocks instead of three ----
+    for (uint32_t i = tid; i < kWinWords; i += T) s_win[i] = 0u;
     if (tid == 0u) s_carry = 0u;
     __syncthreads();
     for (uint32_t base = 0; base < nunits; base += T) {
         const uint32_t u = base + tid;
-        uint32_t len = 0;
+        uint32_t len = 0, dl = 0, dcw = 0, nw = 0, a0 = 0, a1 = 0;
         if (u < nunits) {
             const uint32_t m = jb.meta[u];
-            uint32_t dl;
-            (void)dc_code(jb, u, m, &dl);
+            nw = ((m >> 16) + 31u) >> 5;
+            if (nw > 0u) a0 = jb.acbits[(size_t)u * kAcWordsPerUnit];
+            if (nw > 1u) a1 = jb.acbits[(size_t)u * kAcWordsPerUnit + 1u];
+            dcw = dc_code(jb, u, m, &dl);
             len = dl + (m >> 16);
         }
         uint32_t chunk;
         const uint32_t ex = wg_exclusive_scan(len, s_w, &chunk);
         const uint32_t carry = s_carry;
-        if (u < nunits) jb.unit_off[u] = carry + ex;
+        if (u < nunits) {
+            const uint32_t off = carry + ex;
+            jb.unit_off[u] = off;
+            win_or(s_win, 0u, off, dcw);
+            if (nw > 0u) win_or(s_win, 0u, (uint64_t)off + dl, a0);
+            if (nw > 1u) win_or(s_win, 0u, (uint64_t)off + dl + 32u, a1);
+            for (uint32_t w = 2; w < nw; ++w) win_or(s_win, 0u, (uint64_t)off + dl + 32u * w, jb.acbits[(size_t)u * kAcWordsPerUnit + w]);
+        }
         __syncthreads();
         if (tid == 0u) s_carry = carry + chunk;
         __syncthreads();
@@ -521,23 +534,20 @@ __global__ __launch_bounds__(kPackThreads) void jpeg_pack_kernel(const JpegJob *
     for (uint32_t i = tid; i < kJpegHeaderBytes; i += T) if (i < limit) jb.dst[i] = hdr[i];
 
     uint32_t ff_before = 0; // stuffed bytes emitted by earlier windows (same value in every thread)
-    const bool one_window = (uint64_t)total_bits <= (uint64_t)kWinWords * 32u; // (every 300 x 200 picture: ~12 KB of 32)
     for (uint32_t wbase = 0; wbase * 32ull < total_bits; wbase += kWinWords) {
         const uint64_t wb = (uint64_t)wbase * 32u, we = wb + (uint64_t)kWinWords * 32u;
-        // only the words this window will hold are cleared (the stream's words, not all 8192)
-        const uint32_t win_words = (uint32_t)min((uint64_t)kWinWords, (((uint64_t)total_bits + 31u) >> 5) - wbase) + 1u;
-        for (uint32_t i = tid; i < min(win_words, kWinWords); i += T) s_win[i] = 0u;
-        // blocks that touch this window: offsets are ascending, so two binary searches bound them (a stream that fits one
-        // window needs none: two chains of a dozen dependent loads by one thread while 511 wait)
-        if (one_window) { if (tid == 0u) { s_lo = 0u; s_hi = nunits; } }
-        else if (tid == 0u) {
-            uint32_t lo = 0, hi = nunits;            // first u with unit_off[u + 1] > wb
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (jb.unit_off[mid + 1u] > wb) hi = mid; else lo = mid + 1u; }
-            s_lo = lo;
-            uint32_t lo2 = lo, hi2 = nunits;         // first u with unit_off[u] >= we
-            while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (jb.unit_off[mid] >= we) hi2 = mid; else lo2 = mid + 1u; }
-            s_hi = lo2;
-        }
+        if (wbase != 0u) { // (the first window was filled by the pass above)
+            for (uint32_t i = tid; i < kWinWords; i += T) s_win[i] = 0u;
+            // blocks that touch this window: offsets are ascending, so two binary searches bound them
+            if (tid == 0u) {
+                uint32_t lo = 0, hi = nunits;            // first u with unit_off[u + 1] > wb
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (jb.unit_off[mid + 1u] > wb) hi = mid; else lo = mid + 1u; }
+                s_lo = lo;
+                uint32_t lo2 = lo, hi2 = nunits;         // first u with unit_off[u] >= we
+                while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (jb.unit_off[mid] >= we) hi2 = mid; else lo2 = mid + 1u; }
+                s_hi = lo2;
+            }
+        } else if (tid == 0u) { s_lo = 0u; s_hi = 0u; }
         __syncthreads();
         const uint32_t u_lo = s_lo, u_hi = s_hi;
         // 2 lanes per block (a block's AC code is 1-3 words in ordinary pictures): lane 0 of the pair also places the DC code

@@ -135,6 +135,9 @@ def test_gpu_noise_and_flat_pictures(fl, gpu_state, oracle):
     noise = synth.uniform(64, 96, 3)
     for q in (50, 100):                                             # long codes, ZRL runs, many stuffed bytes
         assert gpu_jpeg(fl, gpu_state, noise, q) == oracle.jpeg_encode(noise, q)
+    big = synth.uniform(200, 300, 3, index=9)                      # streams of several 32 KB windows; at q 100 every block has more code
+    for q in (75, 100):                                             # words than a wave has lanes (the per-component coding path)
+        assert gpu_jpeg(fl, gpu_state, big, q) == oracle.jpeg_encode(big, q)
     for v in (0, 128, 255):                                         # DC only: every block is DC + EOB
         flat = np.full((40, 40, 3), v, np.uint8)
         assert gpu_jpeg(fl, gpu_state, flat, 75) == oracle.jpeg_encode(flat, 75)
