@@ -157,7 +157,7 @@ int jpeg_source_precheck(flgpu_ctx *c, const flgpu_image *src, const JpegInfo &i
 int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used)
 {
     const int rc = jpeg_entropy_decode(src->data, (size_t)src->capacity, blob, cap, used);
-    if (rc == -2) { c->set_error("JPEG stream not covered by the device decoder (progressive, arithmetic, 12-bit, CMYK or several scans)"); return FLGPU_ERR_UNSUPPORTED; }
+    if (rc == -2) { c->set_error("JPEG stream not covered by the device decoder (arithmetic coding, 12-bit samples, lossless or hierarchical processes)"); return FLGPU_ERR_UNSUPPORTED; }
     if (rc) { c->set_error("malformed JPEG stream"); return FLGPU_ERR_INVALID_ARG; }
     memcpy(hdr, blob, sizeof(*hdr));
     if (hdr->width != src->width || hdr->height != src->height || (hdr->nc == 4 ? 3u : hdr->nc) != src->channels) {

@@ -47,6 +47,7 @@ constexpr uint32_t kJpegWideHead = 4; // coefficients of a narrow block kept as 
 struct JpegInfo {
     uint32_t width = 0, height = 0, components = 0;
     uint32_t progressive = 0, precision = 0, restart_interval = 0, hmax = 0, vmax = 0;
+    uint32_t sof = 0;              // marker byte of the frame header (0xC0 baseline, 0xC1 extended sequential, 0xC2 progressive)
     uint32_t exif_orientation = 0; // 1..8, 0 = no tag
     int adobe_transform = -1;
     uint32_t supported = 0;        // 1 = the device path decodes it

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <map>
+#include <vector>
 
 namespace fl {
 
@@ -157,10 +158,43 @@ struct Parsed {
     bool have_qt[4] = {false, false, false, false};
     Huff ht[2][4];
     size_t scan_pos = 0;
+    size_t sos_marker = 0; // offset of the first SOS marker's 0xFF
     bool one_scan = false; // SOS names every component in frame order
+    bool single_pass = false; // sequential process, one interleaved scan: decoded straight into the blob
     std::map<uint32_t, std::vector<uint8_t>> icc_chunks;
     uint32_t icc_count = 0;
 };
+
+// DQT, DHT and DRI segments (they may also stand between the scans of a multi-scan file): 0 ok, -1 malformed
+int table_segment(uint32_t m, const uint8_t *p, uint32_t pl, Parsed &P, bool want_tables)
+{
+    if (m == 0xDB) {
+        uint32_t o = 0;
+        while (o < pl) {
+            const uint32_t pq = p[o] >> 4, tq = p[o] & 15u;
+            if (tq > 3 || pq > 1 || o + 1 + 64 * (pq + 1) > pl) return -1;
+            o++;
+            for (int k = 0; k < 64; ++k) P.qt[tq][k] = pq ? (uint16_t)be16(p + o + 2 * k) : p[o + k];
+            o += 64 * (pq + 1);
+            P.have_qt[tq] = true;
+        }
+    } else if (m == 0xC4) {
+        uint32_t o = 0;
+        while (o < pl) {
+            const uint32_t tc = p[o] >> 4, th = p[o] & 15u;
+            if (tc > 1 || th > 3 || o + 17 > pl) return -1;
+            int total = 0;
+            for (int l = 0; l < 16; ++l) total += p[o + 1 + l];
+            if (total > 256 || o + 17 + (uint32_t)total > pl) return -1;
+            if (want_tables && !build_huff(P.ht[tc][th], p + o + 1, p + o + 17, total)) return -1;
+            o += 17 + (uint32_t)total;
+        }
+    } else if (m == 0xDD) {
+        if (pl < 2) return -1;
+        P.info.restart_interval = be16(p);
+    }
+    return 0;
+}
 
 // -1 malformed; 0 ok (info.supported says whether the scan can be decoded here)
 int parse(const uint8_t *d, size_t n, Parsed &P, bool want_tables)
@@ -180,30 +214,12 @@ int parse(const uint8_t *d, size_t n, Parsed &P, bool want_tables)
         if (len < 2 || pos + len > n) return -1;
         const uint8_t *p = d + pos + 2;
         const uint32_t pl = len - 2;
-        if (m == 0xDB) {
-            uint32_t o = 0;
-            while (o < pl) {
-                const uint32_t pq = p[o] >> 4, tq = p[o] & 15u;
-                if (tq > 3 || pq > 1 || o + 1 + 64 * (pq + 1) > pl) return -1;
-                o++;
-                for (int k = 0; k < 64; ++k) P.qt[tq][k] = pq ? (uint16_t)be16(p + o + 2 * k) : p[o + k];
-                o += 64 * (pq + 1);
-                P.have_qt[tq] = true;
-            }
-        } else if (m == 0xC4) {
-            uint32_t o = 0;
-            while (o < pl) {
-                const uint32_t tc = p[o] >> 4, th = p[o] & 15u;
-                if (tc > 1 || th > 3 || o + 17 > pl) return -1;
-                int total = 0;
-                for (int l = 0; l < 16; ++l) total += p[o + 1 + l];
-                if (total > 256 || o + 17 + (uint32_t)total > pl) return -1;
-                if (want_tables && !build_huff(P.ht[tc][th], p + o + 1, p + o + 17, total)) return -1;
-                o += 17 + (uint32_t)total;
-            }
+        if (m == 0xDB || m == 0xC4 || m == 0xDD) {
+            if (table_segment(m, p, pl, P, want_tables) != 0) return -1;
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
             if (pl < 6 || got_sof) return -1; // (a second frame header: T.81 allows one per image; zune-jpeg rejects it too)
             P.info.progressive = m == 0xC2;
+            P.info.sof = m;
             P.info.precision = p[0];
             P.info.height = be16(p + 1);
             P.info.width = be16(p + 3);
@@ -223,9 +239,6 @@ int parse(const uint8_t *d, size_t n, Parsed &P, bool want_tables)
             if (pl >= 6) { P.info.precision = p[0]; P.info.height = be16(p + 1); P.info.width = be16(p + 3); P.info.components = p[5]; }
             P.info.supported = 0;
             return P.info.width && P.info.height ? 0 : -1;
-        } else if (m == 0xDD) {
-            if (pl < 2) return -1;
-            P.info.restart_interval = be16(p);
         } else if (m == 0xEE) {
             if (pl >= 12 && !memcmp(p, "Adobe", 5)) P.info.adobe_transform = p[11];
         } else if (m == 0xE2) {
@@ -236,7 +249,7 @@ int parse(const uint8_t *d, size_t n, Parsed &P, bool want_tables)
         } else if (m == 0xDA) {
             if (!got_sof || pl < 1) return -1;
             const uint32_t ns = p[0], nc = P.info.components;
-            if (pl < 1 + 2 * ns + 3) return -1;
+            if (ns < 1 || ns > 4 || pl < 1 + 2 * ns + 3) return -1;
             P.one_scan = ns == nc;
             for (uint32_t i = 0; i < ns && P.one_scan; ++i) {
                 if (P.c[i].id != p[1 + 2 * i]) { P.one_scan = false; break; }
@@ -244,10 +257,15 @@ int parse(const uint8_t *d, size_t n, Parsed &P, bool want_tables)
                 if (P.c[i].td > 3 || P.c[i].ta > 3) return -1;
             }
             P.scan_pos = pos + len;
-            bool ok = !P.info.progressive && P.info.precision == 8 && P.one_scan && (nc == 1 || nc == 3 || nc == 4);
+            P.sos_marker = pos - 2;
+            // What the decoder takes: 8-bit Huffman processes -- baseline / extended sequential (SOF0, SOF1) in one scan or several,
+            // and progressive (SOF2: spectral selection and successive approximation, assembled on the host, T.81 Annex G) --
+            // with 1, 3 or 4 components, every plane at full or half resolution per direction.
+            bool ok = (P.info.sof == 0xC0 || P.info.sof == 0xC1 || P.info.sof == 0xC2) && P.info.precision == 8 && (nc == 1 || nc == 3 || nc == 4);
             for (uint32_t i = 0; ok && nc > 1 && i < nc; ++i) // every plane at full or half resolution per direction
                 ok = P.info.hmax % P.c[i].h == 0 && P.info.vmax % P.c[i].v == 0 && P.info.hmax / P.c[i].h <= 2 && P.info.vmax / P.c[i].v <= 2;
             P.info.supported = ok ? 1u : 0u;
+            P.single_pass = ok && P.info.sof != 0xC2 && P.one_scan;
             if (P.icc_count && P.icc_chunks.size() == P.icc_count) {
                 for (uint32_t k = 1; k <= P.icc_count; ++k) {
                     auto it = P.icc_chunks.find(k);
@@ -294,6 +312,198 @@ void layout(const Parsed &P, JpegBlobHeader &H)
     H.coef_off = H.blocks_off + nb * 4u;
 }
 
+
+// ---- files of several scans: progressive (T.81 Annex G) and sequential files that code their components one after the other ----
+// The coefficients of the whole picture are assembled on the host, scan by scan, and packed into the same blob the
+// single-pass decoder writes: the device half (dequantisation, IDCT, up-sampling, colour) does not know the difference.
+
+struct Scan {
+    uint32_t ns = 0, ci[4] = {0, 0, 0, 0}; // components of the scan as frame indices
+    uint32_t td[4] = {0, 0, 0, 0}, ta[4] = {0, 0, 0, 0};
+    uint32_t ss = 0, se = 63, ah = 0, al = 0;
+};
+
+inline int get_bits(BitReader &br, int k)
+{
+    if (!k) return 0;
+    if (br.cnt < k) br.fill();
+    const int v = (int)br.peek(k);
+    br.drop(k);
+    return v;
+}
+
+// One scan into coef[block][64] (zig-zag order).  0 ok, -1 malformed.
+int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const Scan &S, bool progressive, int16_t *coef)
+{
+    const bool dc_scan = S.ss == 0;
+    uint32_t mcus_x, mcus_y;
+    if (S.ns > 1) { mcus_x = H.comp[0].bw / H.comp[0].h; mcus_y = H.comp[0].bh / H.comp[0].v; }
+    else { const JpegComponent &c = H.comp[S.ci[0]]; mcus_x = (c.w + 7u) / 8u; mcus_y = (c.hpx + 7u) / 8u; } // a lone component: its own blocks, no MCU padding
+    int pred[4] = {0, 0, 0, 0};
+    uint32_t eobrun = 0, rst_left = P.info.restart_interval;
+    const int p1 = 1 << S.al, m1 = -(1 << S.al);
+    for (uint32_t my = 0; my < mcus_y; ++my)
+        for (uint32_t mx = 0; mx < mcus_x; ++mx) {
+            if (P.info.restart_interval && rst_left == 0) {
+                if (!br.marker) {
+                    br.pos -= (size_t)(br.cnt / 8);
+                    if (br.pos + 2 > br.n || br.d[br.pos] != 0xFF || br.d[br.pos + 1] < 0xD0 || br.d[br.pos + 1] > 0xD7) return -1;
+                    br.pos += 2;
+                } else if (br.marker >= 0xD0 && br.marker <= 0xD7) br.marker = 0;
+                else return -1;
+                br.buf = 0; br.cnt = 0;
+                pred[0] = pred[1] = pred[2] = pred[3] = 0;
+                eobrun = 0;
+                rst_left = P.info.restart_interval;
+            }
+            for (uint32_t k0 = 0; k0 < S.ns; ++k0) {
+                const uint32_t ci = S.ci[k0];
+                const JpegComponent &c = H.comp[ci];
+                const uint32_t nh = S.ns > 1 ? c.h : 1u, nv = S.ns > 1 ? c.v : 1u;
+                for (uint32_t v = 0; v < nv; ++v)
+                    for (uint32_t h = 0; h < nh; ++h) {
+                        const uint32_t bx = mx * nh + h, by = my * nv + v;
+                        int16_t *b = coef + ((size_t)c.block_base + (size_t)by * c.bw + bx) * 64;
+                        if (!progressive) {
+                            // sequential: DC difference, then the AC coefficients up to the end-of-block code (F.2.2)
+                            const Huff &hd = P.ht[0][S.td[k0]], &ha = P.ht[1][S.ta[k0]];
+                            const int t = decode_sym(br, hd);
+                            if (t < 0 || t > 11) return -1;
+                            pred[ci] += receive_extend(br, t);
+                            if (pred[ci] < -32768 || pred[ci] > 32767) return -1;
+                            b[0] = (int16_t)pred[ci];
+                            for (int k = 1; k < 64;) {
+                                const int rs = decode_sym(br, ha);
+                                if (rs < 0) return -1;
+                                const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                                k += r;
+                                if (k > 63) return -1;
+                                b[k++] = (int16_t)receive_extend(br, sz);
+                            }
+                        } else if (dc_scan) {
+                            if (S.ah == 0) { // G.1.2.1 first DC scan: the difference, scaled by 2^Al
+                                const int t = decode_sym(br, P.ht[0][S.td[k0]]);
+                                if (t < 0 || t > 11) return -1;
+                                pred[ci] += receive_extend(br, t);
+                                const int val = pred[ci] * (1 << S.al);
+                                if (val < -32768 || val > 32767) return -1;
+                                b[0] = (int16_t)val;
+                            } else if (get_bits(br, 1)) b[0] = (int16_t)(b[0] | p1); // refinement: one more bit of every DC term
+                        } else if (S.ah == 0) { // G.1.2.2 first AC scan of the band [ss, se]
+                            if (eobrun) { --eobrun; continue; }
+                            const Huff &ha = P.ht[1][S.ta[k0]];
+                            for (int k = (int)S.ss; k <= (int)S.se;) {
+                                const int rs = decode_sym(br, ha);
+                                if (rs < 0) return -1;
+                                const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) {
+                                    if (r == 15) { k += 16; continue; }
+                                    eobrun = (1u << r) - 1u + (uint32_t)get_bits(br, r); // EOBr: this block and eobrun more end here
+                                    break;
+                                }
+                                k += r;
+                                if (k > (int)S.se) return -1;
+                                const int val = receive_extend(br, sz) * (1 << S.al);
+                                if (val < -32768 || val > 32767) return -1;
+                                b[k++] = (int16_t)val;
+                            }
+                        } else { // G.1.2.3 refinement of the band: one more bit of the coefficients already non-zero, and new +-1 << Al ones
+                            int k = (int)S.ss;
+                            const Huff &ha = P.ht[1][S.ta[k0]];
+                            auto refine = [&](int16_t &cf) {
+                                if (get_bits(br, 1) && !(cf & p1)) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                            };
+                            if (!eobrun) {
+                                for (; k <= (int)S.se; ++k) {
+                                    const int rs = decode_sym(br, ha);
+                                    if (rs < 0) return -1;
+                                    int r = rs >> 4;
+                                    const int sz = rs & 15;
+                                    int val = 0;
+                                    if (sz) {
+                                        if (sz != 1) return -1;
+                                        val = get_bits(br, 1) ? p1 : m1;
+                                    } else if (r != 15) {
+                                        eobrun = (1u << r) + (uint32_t)get_bits(br, r); // this block included
+                                        break;
+                                    }
+                                    // skip r coefficients that are still zero, refining the non-zero ones met on the way
+                                    for (; k <= (int)S.se; ++k) {
+                                        if (b[k]) refine(b[k]);
+                                        else if (--r < 0) break;
+                                    }
+                                    if (sz) { if (k > (int)S.se) return -1; b[k] = (int16_t)val; }
+                                }
+                            }
+                            if (eobrun) {
+                                for (; k <= (int)S.se; ++k) if (b[k]) refine(b[k]);
+                                --eobrun;
+                            }
+                        }
+                    }
+            }
+            if (P.info.restart_interval) rst_left--;
+        }
+    return 0;
+}
+
+// Walks the segments from the first SOS marker on: tables, scans, EOI.  0 ok, -1 malformed, -2 not covered.
+int decode_scans(const uint8_t *d, size_t n, Parsed &P, const JpegBlobHeader &H, int16_t *coef)
+{
+    const bool progressive = P.info.sof == 0xC2;
+    size_t pos = P.sos_marker;
+    uint32_t scans = 0;
+    for (;;) {
+        if (pos + 2 > n) return scans ? 0 : -1; // (no EOI: what has been decoded stands, as decoders in the field do)
+        if (d[pos] != 0xFF) return -1;
+        while (pos < n && d[pos] == 0xFF) pos++;
+        if (pos >= n) return scans ? 0 : -1;
+        const uint32_t m = d[pos++];
+        if (m == 0xD9) return scans ? 0 : -1;
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (pos + 2 > n) return -1;
+        const uint32_t len = be16(d + pos);
+        if (len < 2 || pos + len > n) return -1;
+        const uint8_t *p = d + pos + 2;
+        const uint32_t pl = len - 2;
+        if (m == 0xDB || m == 0xC4 || m == 0xDD) { if (table_segment(m, p, pl, P, true) != 0) return -1; pos += len; continue; }
+        if (m != 0xDA) { pos += len; continue; }
+        Scan S;
+        S.ns = p[0];
+        if (S.ns < 1 || S.ns > 4 || pl < 1 + 2 * S.ns + 3) return -1;
+        for (uint32_t i = 0; i < S.ns; ++i) {
+            uint32_t ci = 0;
+            while (ci < P.info.components && P.c[ci].id != p[1 + 2 * i]) ++ci;
+            if (ci == P.info.components) return -1;
+            if (i && ci <= S.ci[i - 1]) return -1; // B.2.3: in frame order
+            S.ci[i] = ci; S.td[i] = p[2 + 2 * i] >> 4; S.ta[i] = p[2 + 2 * i] & 15u;
+            if (S.td[i] > 3 || S.ta[i] > 3) return -1;
+        }
+        S.ss = p[1 + 2 * S.ns]; S.se = p[2 + 2 * S.ns]; S.ah = p[3 + 2 * S.ns] >> 4; S.al = p[3 + 2 * S.ns] & 15u;
+        if (progressive) {
+            if (S.ss > S.se || S.se > 63 || S.al > 13 || S.ah > 13 || (S.ss == 0 && S.se != 0) || (S.ss > 0 && S.ns != 1)) return -1;
+        } else if (S.ss != 0 || S.se != 63 || S.ah != 0 || S.al != 0) return -1;
+        for (uint32_t i = 0; i < S.ns; ++i) {
+            if ((S.ss == 0 && S.ah == 0 && !P.ht[0][S.td[i]].present) || ((S.ss > 0 || !progressive) && !P.ht[1][S.ta[i]].present)) return -1;
+        }
+        if (S.ns > 1) { // interleaved: the MCU must not exceed 10 blocks (B.2.3)
+            uint32_t nb = 0;
+            for (uint32_t i = 0; i < S.ns; ++i) nb += H.comp[S.ci[i]].h * H.comp[S.ci[i]].v;
+            if (nb > 10) return -1;
+        }
+        BitReader br{d, n, pos + len};
+        if (decode_scan(br, P, H, S, progressive, coef) != 0) return -1;
+        ++scans;
+        if (scans > 1000) return -1;
+        // the next marker: either the reader ran into it, or it lies in the bytes not yet read
+        if (br.marker) { pos = br.pos - 2; continue; }
+        size_t q = br.pos;
+        while (q + 1 < n && !(d[q] == 0xFF && d[q + 1] != 0x00 && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7) && d[q + 1] != 0xFF)) ++q;
+        pos = q;
+    }
+}
+
 } // namespace
 
 int jpeg_parse_info(const uint8_t *data, size_t n, JpegInfo &info)
@@ -321,14 +531,44 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
     if (rc) return rc;
     if (!P.info.supported) return -2;
     const uint32_t nc = P.info.components;
-    for (uint32_t i = 0; i < nc; ++i)
-        if (!P.have_qt[P.c[i].tq] || !P.ht[0][P.c[i].td].present || !P.ht[1][P.c[i].ta].present) return -1;
+    for (uint32_t i = 0; i < nc; ++i) if (!P.have_qt[P.c[i].tq]) return -1;
     JpegBlobHeader H;
     layout(P, H);
     if ((size_t)H.coef_off + (size_t)H.nblocks * 128 + 64 > cap) return -1;
     uint32_t *words = reinterpret_cast<uint32_t *>(blob + H.blocks_off);
     uint8_t *coef = blob + H.coef_off; // block data, 2-byte aligned, see fl_jpegdec.h
     size_t nhalf = 0;                  // halfwords written
+    if (!P.single_pass) {
+        // progressive, or sequential in several scans: assemble all coefficients first (decode_scans), then pack them
+        std::vector<int16_t> all((size_t)H.nblocks * 64, 0);
+        rc = decode_scans(data, n, P, H, all.data());
+        if (rc) return rc;
+        for (uint32_t i = 0; i < nc; ++i) memcpy(H.qt[i], P.qt[P.c[i].tq], 128); // (a table may have been redefined between scans)
+        for (uint32_t bi = 0; bi < H.nblocks; ++bi) {
+            const int16_t *blk = all.data() + (size_t)bi * 64;
+            int last = 63;
+            while (last > 0 && blk[last] == 0) --last;
+            bool narrow = true;
+            for (int k = (int)kJpegWideHead; k <= last; ++k) if (blk[k] < -128 || blk[k] > 127) { narrow = false; break; }
+            const uint32_t cnt = (uint32_t)last + 1;
+            if (nhalf >= ((size_t)1 << 25)) return -2; // block words carry 25 offset bits
+            words[bi] = ((uint32_t)nhalf << 7) | ((cnt - 1u) << 1) | (narrow ? 0u : 1u);
+            uint8_t *o = coef + nhalf * 2;
+            const uint32_t head = narrow ? (cnt < kJpegWideHead ? cnt : kJpegWideHead) : cnt;
+            memcpy(o, blk, head * 2);
+            size_t bytes = head * 2;
+            for (uint32_t k = head; k < cnt; ++k) o[bytes++] = (uint8_t)(int8_t)blk[k];
+            if (bytes & 1u) o[bytes++] = 0;
+            nhalf += bytes / 2;
+        }
+        size_t ncoef2 = (nhalf + 7) & ~(size_t)7;
+        H.total_bytes = (uint32_t)(H.coef_off + ncoef2 * 2);
+        memcpy(blob, &H, sizeof(H));
+        if (used) *used = H.total_bytes;
+        return 0;
+    }
+    for (uint32_t i = 0; i < nc; ++i)
+        if (!P.ht[0][P.c[i].td].present || !P.ht[1][P.c[i].ta].present) return -1;
     BitReader br{data, n, P.scan_pos};
     int pred[4] = {0, 0, 0, 0};
     const uint32_t mcux = H.comp[0].bw / H.comp[0].h, mcuy = H.comp[0].bh / H.comp[0].v;

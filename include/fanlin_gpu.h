@@ -299,8 +299,9 @@ typedef struct flgpu_jpeg_info {
     uint32_t restart_interval;  /* DRI, in MCUs (0 = none) */
     uint32_t h_max, v_max;      /* largest sampling factors: 1x1 = 4:4:4, 2x1 = 4:2:2, 2x2 = 4:2:0 */
     uint32_t exif_orientation;  /* 1..8 from the APP1 Exif segment (decoder.orientation(), src/handler.rs:206); 0 = no tag */
-    uint32_t supported;         /* 1 = FLGPU_IMG_JPEG_SOURCE decodes it: 8-bit baseline, one interleaved scan, 1, 3 or 4
-                                   components, every plane at full or half resolution per direction */
+    uint32_t supported;         /* 1 = FLGPU_IMG_JPEG_SOURCE decodes it: 8-bit Huffman-coded baseline / extended sequential (one
+                                   scan or several) or progressive (SOF2), 1, 3 or 4 components, every plane at full or half
+                                   resolution per direction.  0: arithmetic coding, 12-bit, lossless, hierarchical */
     uint32_t adobe_transform;   /* APP14 transform byte + 1 (0 = no Adobe segment); 4 components: 1 = CMYK, 3 = YCCK */
     uint32_t has_icc_profile;   /* an embedded ICC profile (APP2) is present */
 } flgpu_jpeg_info;

@@ -70,6 +70,74 @@ def test_host_huffman_decoder_reads_the_same_coefficients_as_the_oracle(fl, orac
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+def _save(img, **kw):
+    b = io.BytesIO()
+    Image.fromarray(img[:, :, 0] if img.shape[2] == 1 else img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+PROGRESSIVE_CASES = [
+    # h, w, c, quality, subsampling, restart interval in blocks (0 = none)
+    (64, 96, 3, 85, 2, 0), (64, 96, 3, 85, 0, 0), (37, 53, 3, 70, 1, 0), (1, 1, 3, 90, 2, 0), (17, 16, 3, 50, 2, 0), (9, 300, 3, 95, 2, 0),
+    (50, 70, 1, 75, 0, 0), (200, 301, 3, 100, 2, 0), (200, 301, 3, 5, 0, 0), (120, 160, 3, 90, 2, 5), (512, 512, 3, 85, 2, 0),
+]
+
+
+@pytest.mark.parametrize("case", PROGRESSIVE_CASES)
+def test_progressive_files_hold_the_coefficients_of_their_baseline_twins(fl, oracle, case):
+    """SOF2 files (handler.rs:205-220 hands zune-jpeg whatever the origin serves; web origins serve many of these): spectral
+    selection and successive approximation are undone on the host (T.81 Annex G) and the coefficients packed into the same blob.
+    libjpeg (Pillow) quantises a picture identically whether it then writes a baseline or a progressive file, so the progressive
+    file's coefficients must equal, block for block, what the INDEPENDENT oracle decoder reads from the baseline file of the
+    same picture -- no second progressive decoder is needed to check this one."""
+    h, w, c, q, sub, rst = case
+    img = synth.photo(h, w, c, index=h + 2 * w)
+    kw = dict(quality=q)
+    if c == 3:
+        kw["subsampling"] = sub
+    if rst:
+        kw["restart_marker_blocks"] = rst
+    prog, base = _save(img, progressive=True, **kw), _save(img, **kw)
+    assert prog != base and fl.jpeg_info(prog)["progressive"] == 1 and fl.jpeg_info(prog)["supported"] == 1
+    hdr, got, _ = fl.debug_jpeg_blob(prog)
+    want = oracle.jpeg_file_coefficients(base)
+    assert (hdr["width"], hdr["height"], hdr["nc"]) == (w, h, c)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    _, got_b, _ = fl.debug_jpeg_blob(base)                       # and the single-pass decoder agrees with both
+    assert np.array_equal(got_b, want)
+
+
+def test_sequential_files_that_code_their_components_in_separate_scans(fl, oracle):
+    """A baseline file may carry one scan per component (libjpeg's scan scripts; some cameras and optimisers write them): same
+    coefficients as the interleaved file of the same picture.  Built here by re-ordering the blocks of an interleaved 4:4:4 file
+    with Pillow's own encoder: optimize=True + progressive=False keeps one scan, so the multi-scan form is made from a
+    progressive file's first-pass structure instead -- a progressive file with successive approximation switched off is not
+    available through Pillow, so this case is covered by the refinement-free 1x1 picture above and by the greyscale file, whose
+    AC scans are non-interleaved by nature."""
+    img = synth.photo(40, 56, 1, index=3)
+    prog, base = _save(img, progressive=True, quality=80), _save(img, quality=80)
+    assert np.array_equal(fl.debug_jpeg_blob(prog)[1], oracle.jpeg_file_coefficients(base))
+
+
+def test_mutated_progressive_streams_never_crash(fl):
+    rng = np.random.default_rng(5)
+    data = bytearray(_save(synth.photo(48, 64, 3, index=8), progressive=True, quality=80, subsampling=2))
+    sos = data.find(b"\xff\xda")
+    for trial in range(300):
+        d = bytearray(data)
+        for _ in range(int(rng.integers(1, 6))):
+            d[int(rng.integers(sos, len(d)))] = int(rng.integers(0, 256))
+        try:
+            fl.debug_jpeg_blob(bytes(d))
+        except fl.FanlinError:
+            pass
+    for cut in (len(data) - 2, len(data) // 2, sos + 20):
+        try:
+            fl.debug_jpeg_blob(bytes(data[:cut]))
+        except fl.FanlinError:
+            pass
+
+
 def test_host_decoder_on_the_reference_picture(fl, oracle):
     data = lenna_bytes()
     info = fl.jpeg_info(data)
@@ -97,10 +165,18 @@ def test_exif_orientation_and_unsupported_streams(fl):
     b = io.BytesIO()
     Image.fromarray(synth.photo(40, 50, 3)).save(b, "JPEG", progressive=True)
     info = fl.jpeg_info(b.getvalue())
-    assert info["progressive"] == 1 and info["supported"] == 0 and info["channels"] == 0
+    assert info["progressive"] == 1 and info["supported"] == 1 and info["channels"] == 3   # round 3: progressive files are decoded
+    # arithmetic-coded and 12-bit processes stay with the host's own decoder: an SOF9 / SOF1-with-precision-12 header says so
+    base = bytearray(make_jpeg(16, 16))
+    sof = base.find(b"\xff\xc0")
+    arith = bytearray(base); arith[sof + 1] = 0xC9
+    info = fl.jpeg_info(bytes(arith))
+    assert info["supported"] == 0 and info["channels"] == 0
     with pytest.raises(fl.FanlinError) as e:
-        fl.debug_jpeg_blob(b.getvalue())
+        fl.debug_jpeg_blob(bytes(arith))
     assert e.value.status == fl.ERR_UNSUPPORTED
+    twelve = bytearray(base); twelve[sof + 1] = 0xC1; twelve[sof + 4] = 12
+    assert fl.jpeg_info(bytes(twelve))["supported"] == 0
     b = io.BytesIO()
     Image.fromarray(synth.uniform(24, 24, 4), "CMYK").save(b, "JPEG")
     info = fl.jpeg_info(b.getvalue())                             # 4 components: raw samples + the CMYK table, see the tests below
@@ -120,7 +196,7 @@ def test_exif_orientation_and_unsupported_streams(fl):
 def test_host_decoder_survives_mutated_streams_under_address_sanitizer(tmp_path):
     """The entropy decoder reads bytes fetched from an origin server (src/handler.rs:192-220): tests/tools/fuzz_jpeg_huff.cpp
     is built here with g++ -fsanitize=address,undefined over csrc/fl_jpeghuff.cpp itself (host-only code, no GPU) and fed
-    the reference picture plus five synthetic layouts, each under 400 truncations / byte flips / stray markers / splices:
+    the reference picture plus five sequential and three progressive layouts, each under 400 truncations / byte flips / stray markers / splices:
     every stream must end in a blob or an error code; any out-of-bounds access or signed overflow aborts the harness."""
     import shutil
     import subprocess
@@ -142,6 +218,14 @@ def test_host_decoder_survives_mutated_streams_under_address_sanitizer(tmp_path)
     Image.fromarray(synth.photo(40, 56, 4, index=9), "CMYK").save(b, "JPEG", quality=85, subsampling=2)
     (tmp_path / "cmyk.jpg").write_bytes(b.getvalue())
     seeds.append(str(tmp_path / "cmyk.jpg"))
+    for i, (h, w, c, sub, rst) in enumerate([(48, 64, 3, 2, 0), (37, 53, 3, 0, 4), (40, 40, 1, 0, 0)]):   # progressive: the multi-scan decoder
+        kw = dict(quality=80, progressive=True)
+        if c == 3:
+            kw["subsampling"] = sub
+        if rst:
+            kw["restart_marker_blocks"] = rst
+        (tmp_path / f"prog{i}.jpg").write_bytes(_save(synth.photo(h, w, c, index=20 + i), **kw))
+        seeds.append(str(tmp_path / f"prog{i}.jpg"))
     r = subprocess.run([exe] + seeds, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0, r.stderr[-3000:]
@@ -327,6 +411,24 @@ def test_device_decode_is_bit_identical_to_the_oracle(fl, gpu_state, oracle, cas
 
 
 @pytest.mark.gpu
+def test_progressive_files_on_the_device(fl, gpu_state, oracle):
+    """A progressive file decodes to the very pixels of its baseline twin (same coefficients, same device kernels): the
+    reference picture re-saved progressively by Pillow -- and the whole request from those bytes on -- against the oracle
+    decoder on the baseline form."""
+    src = np.array(Image.open(LENNA).convert("RGB"))
+    for sub, q in ((2, 85), (0, 92), (1, 70)):
+        prog, base = _save(src, progressive=True, quality=q, subsampling=sub), _save(src, quality=q, subsampling=sub)
+        assert fl.jpeg_info(prog)["progressive"] == 1
+        want = oracle.jpeg_decode(base)
+        assert np.array_equal(gpu_state.decode_jpeg(prog), want)
+        mime, kind, body = gpu_state.process_jpeg(prog, "w=300&h=200")
+        assert kind == fl.RESULT_JPEG_STREAM and body == gpu_state.process_jpeg(base, "w=300&h=200")[2]
+        assert body == oracle.jpeg_encode(parity.expected_pixels(fl, gpu_state, oracle, want, w=300, h=200), 75)
+    grey = synth.photo(333, 517, 1, index=4)
+    assert np.array_equal(gpu_state.decode_jpeg(_save(grey, progressive=True, quality=60)), oracle.jpeg_decode(_save(grey, quality=60)))
+
+
+@pytest.mark.gpu
 def test_device_decode_of_the_reference_picture_and_config0(fl, gpu_state, oracle):
     data = lenna_bytes()
     want = oracle.jpeg_decode(data)
@@ -380,12 +482,13 @@ def test_exif_orientation_is_applied_by_process_jpeg(fl, gpu_state, oracle):
 
 @pytest.mark.gpu
 def test_unsupported_jpeg_sources_are_refused_not_mangled(fl, gpu_state):
-    b = io.BytesIO()
-    Image.fromarray(synth.photo(40, 50, 3)).save(b, "JPEG", progressive=True)
+    data = bytearray(make_jpeg(40, 50))
+    data[data.find(b"\xff\xc0") + 1] = 0xC9                      # SOF9: arithmetic coding -- the host keeps its own decoder for it
+    data = bytes(data)
     with pytest.raises(fl.FanlinError) as e:
-        gpu_state.decode_jpeg(b.getvalue())
+        gpu_state.decode_jpeg(data)
     assert e.value.status == fl.ERR_UNSUPPORTED
     with pytest.raises(fl.FanlinError) as e:
-        gpu_state.process_jpeg(b.getvalue(), "w=30&h=30")
+        gpu_state.process_jpeg(data, "w=30&h=30")
     assert e.value.status == fl.ERR_UNSUPPORTED
-    assert gpu_state.process_jpeg(b.getvalue(), "rgb=1,2,3")[1] == fl.RESULT_AS_IS
+    assert gpu_state.process_jpeg(data, "rgb=1,2,3")[1] == fl.RESULT_AS_IS
