@@ -15,14 +15,16 @@ namespace {
 
 inline uint32_t be16(const uint8_t *p) { return ((uint32_t)p[0] << 8) | p[1]; }
 
+constexpr int kFastBits = 9; // lookahead of the one-step tables (11 bits resolve a few more symbols at once and cost as much again in L1 misses: measured equal)
+
 struct Huff {
-    // 9-bit lookahead: (length << 8) | symbol, 0 = longer than 9 bits
-    uint16_t fast[512];
+    // kFastBits lookahead: (length << 8) | symbol, 0 = longer than that
+    uint16_t fast[1 << kFastBits];
     int32_t maxcode[18];  // per length, -1 = none; [17] = sentinel
     int32_t valoff[17];   // symbol index of the first code of a length minus that code
     uint8_t vals[256];
-    // AC tables only: code AND magnitude bits inside the 9-bit lookahead -> (value << 8) | (run << 4) | total bits, 0 = slow path
-    int16_t fastac[512];
+    // AC tables only: code AND magnitude bits inside the lookahead -> (value << 8) | (run << 4) | total bits, 0 = slow path
+    int16_t fastac[1 << kFastBits];
     bool present = false;
 };
 
@@ -34,9 +36,9 @@ bool build_huff(Huff &h, const uint8_t *bits /*[16] counts of lengths 1..16*/, c
     for (int l = 1; l <= 16; ++l) {
         h.valoff[l] = k - code;
         for (int i = 0; i < bits[l - 1]; ++i, ++k, ++code) {
-            if (l <= 9) {
-                const int first = code << (9 - l), cnt = 1 << (9 - l);
-                if (first + cnt > 512) return false;
+            if (l <= kFastBits) {
+                const int first = code << (kFastBits - l), cnt = 1 << (kFastBits - l);
+                if (first + cnt > (1 << kFastBits)) return false;
                 for (int f = 0; f < cnt; ++f) h.fast[first + f] = (uint16_t)((l << 8) | vals[k]);
             }
         }
@@ -46,13 +48,13 @@ bool build_huff(Huff &h, const uint8_t *bits /*[16] counts of lengths 1..16*/, c
     }
     h.maxcode[17] = 0x7fffffff;
     // short code + short magnitude in one lookup (the common case of AC coefficients: small values after short runs)
-    for (int i = 0; i < 512; ++i) {
+    for (int i = 0; i < (1 << kFastBits); ++i) {
         h.fastac[i] = 0;
         const uint32_t f = h.fast[i];
         if (!f) continue;
         const int len = (int)(f >> 8), rs = (int)(f & 255u), run = rs >> 4, mag = rs & 15;
-        if (mag == 0 || len + mag > 9) continue;
-        int v = ((i << len) & 511) >> (9 - mag);           // the magnitude bits that follow the code
+        if (mag == 0 || len + mag > kFastBits) continue;
+        int v = ((i << len) & ((1 << kFastBits) - 1)) >> (kFastBits - mag);           // the magnitude bits that follow the code
         if (v < (1 << (mag - 1))) v += (int)(~0u << mag) + 1; // F.2.2.1 EXTEND
         if (v >= -128 && v <= 127) h.fastac[i] = (int16_t)((v * 256) | (run << 4) | (len + mag));
     }
@@ -104,11 +106,11 @@ struct BitReader {
 inline int decode_sym(BitReader &br, const Huff &h)
 {
     if (br.cnt < 16) br.fill();
-    const uint32_t f = h.fast[br.peek(9)];
+    const uint32_t f = h.fast[br.peek(kFastBits)];
     if (f) { br.drop((int)(f >> 8)); return (int)(f & 255u); }
-    // longer than 9 bits: canonical search
-    uint32_t code = br.peek(10);
-    int l = 10;
+    // longer than the lookahead: canonical search
+    uint32_t code = br.peek(kFastBits + 1);
+    int l = kFastBits + 1;
     while (l <= 16 && (int32_t)code > h.maxcode[l]) { ++l; code = br.peek(l); }
     if (l > 16) return -1;
     br.drop(l);
@@ -600,17 +602,19 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                         if (t < 0 || t > 11) return -1;
                         pred[i] += receive_extend(br, t);
                         if (pred[i] < -32768 || pred[i] > 32767) return -1;
+                        // (the block starts as zeros and only the coded coefficients are written: one 128-byte clear instead of a
+                        // store per zero of every run)
+                        memset(blk, 0, sizeof(blk));
                         blk[0] = (int16_t)pred[i];
                         int last = 0;
-                        bool narrow = true;
+                        uint32_t wide = 0; // becomes non-zero when a coefficient from kJpegWideHead on does not fit a byte
                         for (int k = 1; k < 64;) {
-                            if (br.cnt < 16) br.fill();
-                            const int fa = ha.fastac[br.peek(9)];
-                            if (fa) { // code + magnitude in one step
+                            if (br.cnt < 32) br.fill();
+                            const int fa = ha.fastac[br.peek(kFastBits)];
+                            if (fa) { // code + magnitude in one step (the value fits a byte by construction)
                                 k += (fa >> 4) & 15;
                                 if (k > 63) return -1;
                                 br.drop(fa & 15);
-                                while (last + 1 < k) blk[++last] = 0;
                                 blk[k] = (int16_t)(fa >> 8);
                                 last = k;
                                 ++k;
@@ -625,13 +629,13 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                             }
                             k += r;
                             if (k > 63) return -1;
-                            while (last + 1 < k) blk[++last] = 0;
                             const int val = receive_extend(br, s);
                             blk[k] = (int16_t)val;
-                            if (k >= (int)kJpegWideHead && (val < -128 || val > 127)) narrow = false;
+                            wide |= (k >= (int)kJpegWideHead) ? ((uint32_t)(val + 128) >> 8) : 0u;
                             last = k;
                             ++k;
                         }
+                        const bool narrow = wide == 0;
                         const uint32_t cnt = (uint32_t)last + 1;
                         if (nhalf >= ((size_t)1 << 25)) return -2; // block words carry 25 offset bits
                         words[c.block_base + by * c.bw + bx] = ((uint32_t)nhalf << 7) | ((cnt - 1u) << 1) | (narrow ? 0u : 1u);
