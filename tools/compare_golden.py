@@ -31,6 +31,12 @@ EXTRA = {
     "orient6_resize": (60, 90, 3, "photo", dict(w=30, h=30, orientation=6)),
     "orient3_only": (17, 23, 3, "uniform", dict(orientation=3)),
     "lenna_like_512_to_300x200": (512, 512, 3, "photo", dict(w=300, h=200)),
+    # the shapes the matrix-pipe kernel serves (fl_mfma.hip: 22-bit vertical weights, 1/64 intermediate, 17-bit horizontal
+    # weights): the first environment with cargo measures THAT kernel's distance to the crate too, not only the oracle's
+    "config1_1080p_uniform_to_300x200": (1080, 1920, 3, "uniform", dict(w=300, h=200)),
+    "config1_1080p_photo_to_300x200": (1080, 1920, 3, "photo", dict(w=300, h=200)),
+    "config1_1080p_photo_crop": (1080, 1920, 3, "photo", dict(w=300, h=200, crop=True)),
+    "rgba_1080p_to_300x169": (1080, 1920, 4, "uniform", dict(w=300, h=169)),
 }
 EXACT = {"inverse_only", "letterbox_only_rgb", "gray_only_rgba", "orient3_only"}  # no f32 resampling involved
 JPEG_QUALITIES = (75, 85)
