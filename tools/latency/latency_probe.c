@@ -32,10 +32,13 @@ static double now_ms(void)
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+static uint8_t **g_dst; /* one result buffer per caller thread, allocated BEFORE the clock starts: round 2 allocated (and
+                           freed) them inside the timed region, and 64 hipHostMalloc / hipHostFree calls behind the driver's
+                           lock were what made the page-locked run look slower than the pageable one */
+
 static void *caller(void *arg)
 {
-    (void)arg;
-    uint8_t *dst = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, g_plan.max_out_bytes) : malloc(g_plan.max_out_bytes));
+    uint8_t *dst = g_dst[(size_t)(uintptr_t)arg];
     const uint32_t fl = g_pinned ? FLGPU_IMG_PINNED : 0u;
     for (;;) {
         pthread_mutex_lock(&g_mu);
@@ -47,7 +50,6 @@ static void *caller(void *arg)
         if (flgpu_transform(g_ctx, &in, &g_params, &out) != FLGPU_OK) { pthread_mutex_lock(&g_mu); g_failed++; pthread_mutex_unlock(&g_mu); }
         g_lat[i] = now_ms() - t0;
     }
-    if (g_pinned) flgpu_host_free(g_ctx, dst); else free(dst);
     return NULL;
 }
 
@@ -102,15 +104,17 @@ int main(int argc, char **argv)
     }
     g_lat = (double *)calloc((size_t)(g_requests > threads * 2 ? g_requests : threads * 2), sizeof(double));
     pthread_t *ts = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    g_dst = (uint8_t **)calloc((size_t)threads, sizeof(uint8_t *));
+    for (int t = 0; t < threads; ++t) g_dst[t] = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, g_plan.max_out_bytes) : malloc(g_plan.max_out_bytes));
     /* warm up: tables, pinned blocks, lanes */
     const int total = g_requests;
     g_requests = threads * 2; g_next = 0;
-    for (int t = 0; t < threads; ++t) pthread_create(&ts[t], NULL, caller, NULL);
+    for (int t = 0; t < threads; ++t) pthread_create(&ts[t], NULL, caller, (void *)(uintptr_t)t);
     for (int t = 0; t < threads; ++t) pthread_join(ts[t], NULL);
     g_requests = total; g_next = 0;
     flgpu_reset_stats(g_ctx);
     const double t0 = now_ms();
-    for (int t = 0; t < threads; ++t) pthread_create(&ts[t], NULL, caller, NULL);
+    for (int t = 0; t < threads; ++t) pthread_create(&ts[t], NULL, caller, (void *)(uintptr_t)t);
     for (int t = 0; t < threads; ++t) pthread_join(ts[t], NULL);
     const double wall = now_ms() - t0;
     flgpu_stats stats;
