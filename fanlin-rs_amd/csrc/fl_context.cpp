@@ -144,11 +144,10 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
             if (S.hdr.n_ops > kMfmaLdsOperands) plan.ops_in_lds = false;
         }
         if (mfma_lds_bytes(plan.max_nout, plan.ops_in_lds) > 160 * 1024) ok = false;
-        // Where the kernel pays (tools/experiments/resample_sweep.py, 1080p sources): every strip requests 2048 bytes per row
-        // whatever it needs, and horizontal operands that do not fit the LDS cache come from the L2 behind the K-block in
-        // flight.  With both handicaps (four strips where 2.8 would do, ~100 distinct operands) the streaming kernel is as
-        // fast or faster (256x144: 1.03 vs 1.06 ms, 512x288: 1.77 vs 1.63); with either one alone the matrix pipe wins by 20-28 %.
-        if (ok && !plan.ops_in_lds && (uint64_t)hp.strips.size() * kMfmaStripBytes * 10u > (uint64_t)ha.in_size * cs * 11u) ok = false;
+        // (Round 2 kept geometries with BOTH handicaps -- four strips where 2.8 would do, ~100 distinct operands read from the L2
+        // instead of LDS -- on the streaming kernel, which was as fast there.  With the tile stage requesting its operands two
+        // units ahead the matrix-pipe kernel wins on every one of them: 1080p -> 256x144 1.88 vs 1.99 ms, 512x288 2.33 vs 2.95,
+        // 640x360 3.15 vs 4.82 (tools/experiments/sweep_mfma_always.py, profiles/r03_resample_sweep.txt); the rule is gone.)
     }
     if (ok) { // all or nothing: whether a geometry gets this kernel must not depend on how full the arena happens to be
         size_t need = sizeof(MfmaVPlan) / 4 + hp.vmeta.size() + hp.vw.size() + 64;
