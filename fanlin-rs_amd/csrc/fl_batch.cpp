@@ -15,7 +15,7 @@ namespace {
 
 // ---- batch execution -------------------------------------------------------
 
-enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3, S1_NEAREST = 4, S1_MFMA = 5 };
+enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3, S1_NEAREST = 4, S1_MFMA = 5, S1_TILE = 6 };
 
 struct Work {
     flgpu_plan plan;
@@ -37,6 +37,7 @@ struct Work {
     uint32_t jpeg_tab = 0;
     uint32_t orient = 0, raw_w = 0, raw_h = 0; // EXIF orientation pre-pass (2..8), source size before it
     size_t orient_off = 0;
+    uint32_t tile_w = 0;        // S1_TILE: output columns per tile (power of two)
     size_t align_off = 0;       // misaligned device source of a matrix-pipe geometry: offset of its aligned copy in d_tmp_al
     bool align_copy = false;
     const uint8_t *raw_src = nullptr;
@@ -79,6 +80,7 @@ void fill_job(const Work &w, Job &j)
     j.ox = pl.place_x; j.oy = pl.place_y;
     j.fill = (uint32_t)w.p->fill_r | ((uint32_t)w.p->fill_g << 8) | ((uint32_t)w.p->fill_b << 16) | (255u << 24);
     j.vtab = w.vtab; j.htab = w.htab;
+    j.pad1 = w.tile_w;
     if (w.s1 == S1_NEAREST) {
         // sample.rs: ratio = in as f32 / out as f32, carried as bits where the Lanczos3 jobs carry table offsets
         const float ry = (float)w.sh / (float)pl.resized_h, rx = (float)w.sw / (float)pl.resized_w;
@@ -86,6 +88,24 @@ void fill_job(const Work &w, Job &j)
     }
 }
 
+
+// Tile width of the tiled two-pass kernel for output columns [cx, cx + cw) of axis h: the largest power of two (128 .. 16) whose
+// tiles all have a source column window that fits the kernel's LDS tile (kTileLdsFloats / (8 rows x channels)); 0 = none does
+// (ratios beyond ~7 with four channels: those geometries belong to the other kernels anyway).
+uint32_t tile_width_for(const HostAxis &h, uint32_t cx, uint32_t cw, uint32_t mc)
+{
+    const uint32_t nc_max = kTileLdsFloats / (8u * mc); // (8 = the kernel's rows per tile)
+    for (uint32_t tw = 128; tw >= 16; tw >>= 1) {
+        bool fits = true;
+        for (uint32_t x0 = cx; x0 < cx + cw && fits; x0 += tw) {
+            const uint32_t x1 = std::min(x0 + tw, cx + cw);
+            if (h.left[x1 - 1] + h.count[x1 - 1] - h.left[x0] > nc_max) fits = false;
+            if (h.woff[x1 - 1] + h.count[x1 - 1] - h.woff[x0] > kTileWeightFloats) fits = false;
+        }
+        if (fits) return tw;
+    }
+    return 0;
+}
 
 // XCD-aware numbering: workgroups are dealt to the 8 XCDs round-robin in launch order and each XCD has its own L2.
 // The strips of one picture re-read each other's halo columns, so inside every run of equally long workgroups the
@@ -326,6 +346,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     const bool force_generic = env_generic && env_generic[0] == '1';
     const char *env_no_mfma = getenv("FLGPU_NO_MFMA"); // tests / A-B runs: keep the streaming kernel (read per batch, so a test can flip it)
     const bool no_mfma = env_no_mfma && env_no_mfma[0] == '1';
+    const char *env_no_tile = getenv("FLGPU_NO_TILE");
+    const bool no_tile = env_no_tile && env_no_tile[0] == '1';
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool full = false;
         size_t n_resample = 0;
@@ -365,6 +387,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 const StreamPlan *sp = get_stream_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, nbands, w.cs, w.pre);
                 if (c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
                 if (sp->ok) { w.s1 = S1_STREAM; w.splan = sp; }
+            }
+            // what neither fused kernel takes (up-scales, mild down-scales, odd pitches, forced generic): the two passes through an
+            // LDS tile instead of an f32 intermediate in HBM, if a tile width fits (FLGPU_NO_TILE=1 keeps the HBM form: tests, A/B)
+            if (w.s1 == S1_GENERIC && !no_tile) {
+                Job jtmp; fill_job(w, jtmp);
+                const uint32_t tw = tile_width_for(*w.ha, jtmp.cx, jtmp.cw, mid_channels(w.cs, w.pre));
+                if (tw) { w.s1 = S1_TILE; w.tile_w = tw; }
             }
         }
         for (auto &w : work) {
@@ -474,6 +503,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             L.g.max_sw = std::max(L.g.max_sw, j.sw); L.g.max_rh = std::max(L.g.max_rh, j.rh);
             L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
             L.g.max_dw = std::max(L.g.max_dw, j.dw); L.g.max_dh = std::max(L.g.max_dh, j.dh);
+            if ((k.kind & 255u) == S1_TILE) {
+                L.g.tile_w_min = L.g.tile_w_min ? std::min(L.g.tile_w_min, w.tile_w) : w.tile_w;
+                c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
+                c->stats.resample_dst_bytes += w.plan.pixel_bytes;
+            }
             if ((k.kind & 255u) == S1_MFMA) {
                 for (MfmaItem it2 : *w.mitems) { it2.job = (uint32_t)jobs.size(); mitems.push_back(it2); }
                 L.nitems += (uint32_t)w.mitems->size();
@@ -646,6 +680,15 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             FL_HIP(c, launch_place(L.g, false, st), "nearest kernel");
         } else if ((L.k.kind & 255u) == S1_PLACE) {
             FL_HIP(c, launch_place(L.g, false, st), "place kernel");
+        } else if ((L.k.kind & 255u) == S1_TILE) {
+            if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
+            L.g.grouped = 1;
+            {
+                ProfileScope ps(c, st, 0);
+                FL_HIP(c, launch_tile_resample(L.g, st), "tiled two-pass resample kernel");
+            }
+            c->stats.resample_launches++;
+            c->stats.generic_launches++; // (the two-pass generic resample, LDS form)
         } else if ((L.k.kind & 255u) == S1_GENERIC) {
             if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
             FL_HIP(c, launch_vpass_generic(L.g, st), "generic vertical pass");

@@ -51,6 +51,7 @@ struct LaunchGeneric {
     uint32_t max_dw, max_dh;  // placement grid
     uint32_t nearest;         // place kernel: FilterType::Nearest gather (jobs carry the f32 ratios in vtab/htab)
     uint32_t blur_lanes;      // blur kernel: lanes per workgroup of this group (blur_lanes() of its pictures)
+    uint32_t tile_w_min;      // tiled two-pass kernel: the narrowest tile width (Job::pad1) among the group's pictures
 };
 
 struct LaunchStream {
@@ -66,6 +67,9 @@ struct LaunchStream {
 
 hipError_t launch_vpass_generic(const LaunchGeneric &g, hipStream_t st);
 hipError_t launch_hpass_generic(const LaunchGeneric &g, hipStream_t st);
+hipError_t launch_tile_resample(const LaunchGeneric &g, hipStream_t st); // the same two passes through an LDS tile (no f32 intermediate in HBM)
+constexpr uint32_t kTileLdsFloats = 6144;    // LDS of the tiled two-pass kernel: 24 KB = 8 rows x 768 (source columns x channels) f32 ...
+constexpr uint32_t kTileWeightFloats = 2048;  // ... + the horizontal weights of a tile's columns (the host checks both when it picks the tile width)
 hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st);
 
 // fused LDS-tiled Gaussian blur (g.cs = channels of the blurred image; g.jobs[i].vtab/htab = Gaussian tables)

@@ -15,6 +15,8 @@
 // v_pk_fma_f32), hands finished f32 rows to the horizontal pass through LDS,
 // and writes rounded u8 pixels straight into the (letterboxed) destination.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -193,6 +195,173 @@ __global__ __launch_bounds__(256) void hpass_generic_kernel(const Job *__restric
 #pragma unroll
     for (int k = 0; k < MC; ++k) c[k] = round_u8(acc[k]);
     store_pixel<MC, LB>(jb.dst, (jb.oy + yy) * jb.dw + jb.ox + xx, c, jb.fill);
+}
+
+// ---------------------------------------------------------------------------
+// Tiled two-pass resample (round 3): the generic path without its f32 intermediate in HBM.  One workgroup = one picture x
+// one tile of kTileRows output rows x jb.pad1 output columns (a power of two the host chose so that the tile's source
+// column window fits the LDS budget).  Vertical pass: wave w takes output rows w, w + 4, ...; lanes walk the window's
+// source columns (coalesced byte loads, weights wave-uniform) and leave the unrounded f32 sums in LDS.  Horizontal pass:
+// one thread per output pixel reads its taps from that LDS tile.  The arithmetic is the generic kernels' -- one fused
+// multiply-add per tap in tap order vertically; horizontally Lanczos3 taps grouped by aligned blocks of 4 source pixels with
+// the block sums added in ascending order (GROUPED, also the oracle's ARITH_FMA mode), Gaussian taps in tap order -- so the
+// results are bit-identical to them.  Serves what neither the matrix-pipe nor the streaming kernel takes: up-scales, mild
+// down-scales, odd pitches (image 0.25.6 imageops/sample.rs vertical_sample + horizontal_sample).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kTileRows = 8; // (16 rows and 64 KB of LDS per workgroup left two workgroups per CU, and the kernel waited on its own loads)
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned; // (gfx950 loads a dword from any byte address: one global_load_dword)
+
+template <int CS, int PRE, bool LB, bool GROUPED>
+__global__ __launch_bounds__(256) void resample_tile_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ arena, uint32_t job_base,
+                                                            uint32_t nbands)
+{
+    extern __shared__ float tile_mid[]; // [rows of the tile][source columns of its window][MC], then the horizontal weights of the tile's columns
+    constexpr int MC = mid_channels(CS, PRE);
+    const Job jb = jobs[job_base + blockIdx.y];
+    const uint32_t tw = jb.pad1, tw_log = 31u - (uint32_t)__clz(tw);
+    const uint32_t tiles_x = (jb.cw + tw - 1u) >> tw_log;
+    if (blockIdx.x >= tiles_x * nbands) return;
+    // One workgroup = one COLUMN of tiles (x range) of one band of rows: everything the horizontal pass needs -- the window's
+    // first source column, its weights (staged in LDS), every thread's own (left, count, weight offset) -- is fetched once and
+    // serves all tiles of the column; what is left per tile are the row tables of the vertical pass.  (A workgroup per tile spent
+    // most of its 23 us in these chains of dependent table loads.)
+    const uint32_t band = blockIdx.x / tiles_x, tx = blockIdx.x - band * tiles_x;
+    const uint32_t band_rows = ((jb.ch + nbands - 1u) / nbands + kTileRows - 1u) / kTileRows * kTileRows;
+    const uint32_t yb0 = jb.cy + band * band_rows, yb1 = min(yb0 + band_rows, jb.cy + jb.ch);
+    if (yb0 >= yb1) return;
+    const uint32_t x0 = jb.cx + (tx << tw_log), x1 = min(x0 + tw, jb.cx + jb.cw);
+    const AxisTable *vt = reinterpret_cast<const AxisTable *>(arena + jb.vtab);
+    const AxisTable *ht = reinterpret_cast<const AxisTable *>(arena + jb.htab);
+    // the windows of an axis table move right monotonically: the column's window is [left of its first column, right end of its last)
+    const uint32_t c0 = arena[ht->left_off + x0];
+    const uint32_t ncols = arena[ht->left_off + x1 - 1u] + arena[ht->count_off + x1 - 1u] - c0;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const size_t pitch = (size_t)jb.sw * CS;
+    // the horizontal weights of the columns lie back to back in the table: staged in LDS behind the f32 tile, coalesced
+    // (read by output column in the horizontal pass they would be one cache line per lane)
+    const uint32_t hw0 = arena[ht->woff_off + x0], hw1 = arena[ht->woff_off + x1 - 1u] + arena[ht->count_off + x1 - 1u];
+    float *tile_w = tile_mid + kTileLdsFloats;
+    const float *hweights = reinterpret_cast<const float *>(arena + ht->weights_off);
+    for (uint32_t k = tid; k < hw1 - hw0; k += 256u) tile_w[k] = hweights[hw0 + k];
+    // this thread's output column and the rows it takes in every tile (256 >> tw_log of them at a time)
+    const uint32_t xx = tid & (tw - 1u), ysub = tid >> tw_log, ystep = 256u >> tw_log, ow = x1 - x0;
+    const bool has_col = xx < ow;
+    const uint32_t hx = x0 + min(xx, ow - 1u);
+    const uint32_t hleft = arena[ht->left_off + hx], hn = arena[ht->count_off + hx];
+    const float *hwp = tile_w + (arena[ht->woff_off + hx] - hw0);
+    for (uint32_t y0 = yb0; y0 < yb1; y0 += kTileRows) {
+        const uint32_t y1 = min(y0 + kTileRows, yb1);
+        if (PRE != PRE_GRAY) {
+            // Vertical pass by BYTE columns: without a pre-op that mixes channels a byte column is filtered like any other, so a lane
+            // takes four consecutive bytes of the window -- one dword load per tap instead of one byte load per channel.
+            const uint32_t nbytes = ncols * (uint32_t)CS;
+            for (uint32_t ry = wave; ry < y1 - y0; ry += 4u) {
+                const uint32_t oy = y0 + ry;
+                const uint32_t left = arena[vt->left_off + oy], n = arena[vt->count_off + oy];
+                const float *w = reinterpret_cast<const float *>(arena + vt->weights_off + arena[vt->woff_off + oy]);
+                for (uint32_t b4 = lane * 4u; b4 < nbytes; b4 += 256u) {
+                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    size_t goff = (size_t)left * pitch + (size_t)c0 * CS + b4;
+                    // Invert (color.rs Invert: 255 - c on the colour channels, alpha untouched) as an XOR mask of the four bytes
+                    uint32_t inv = 0u;
+                    if (PRE == PRE_INVERT) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            const uint32_t chn = (uint32_t)(((size_t)c0 * CS + b4 + j) % (uint32_t)CS);
+                            if (!((CS == 2 || CS == 4) && chn == (uint32_t)CS - 1u)) inv |= 0xffu << (8u * j);
+                        }
+                    }
+                    // (only the window's last taps in the picture's last row can reach past the source: decided once per column group, so
+                    // that the common loop has no branch in it)
+                    if (goff + (size_t)(n - 1u) * pitch + 4u <= (size_t)jb.src_bytes) {
+                        // eight taps' loads go out before the first of them is used (taps past the window's end repeat its last row with
+                        // weight 0 ... by not being used: the loop below stops at n)
+                        for (uint32_t i0 = 0; i0 < n; i0 += 8u) {
+                            uint32_t d[8];
+#pragma unroll
+                            for (uint32_t j = 0; j < 8; ++j) d[j] = *reinterpret_cast<const u32_unaligned *>(jb.src + goff + (size_t)min(i0 + j, n - 1u) * pitch) ^ inv;
+#pragma unroll
+                            for (uint32_t j = 0; j < 8; ++j) {
+                                if (i0 + j >= n) break;
+                                const float wi = w[i0 + j];
+                                acc[0] = __builtin_fmaf((float)(d[j] & 255u), wi, acc[0]);
+                                acc[1] = __builtin_fmaf((float)((d[j] >> 8) & 255u), wi, acc[1]);
+                                acc[2] = __builtin_fmaf((float)((d[j] >> 16) & 255u), wi, acc[2]);
+                                acc[3] = __builtin_fmaf((float)(d[j] >> 24), wi, acc[3]);
+                            }
+                        }
+                    } else {
+                        for (uint32_t i = 0; i < n; ++i) {
+                            uint32_t d = 0u;
+                            for (uint32_t j = 0; j < 4u && goff + j < (size_t)jb.src_bytes; ++j) d |= (uint32_t)jb.src[goff + j] << (8u * j);
+                            d ^= inv;
+                            const float wi = w[i];
+                            acc[0] = __builtin_fmaf((float)(d & 255u), wi, acc[0]);
+                            acc[1] = __builtin_fmaf((float)((d >> 8) & 255u), wi, acc[1]);
+                            acc[2] = __builtin_fmaf((float)((d >> 16) & 255u), wi, acc[2]);
+                            acc[3] = __builtin_fmaf((float)(d >> 24), wi, acc[3]);
+                            goff += pitch;
+                        }
+                    }
+                    float *o = tile_mid + (size_t)ry * nbytes + b4;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) if (b4 + j < nbytes) o[j] = acc[j];
+                }
+            }
+        } else {
+            for (uint32_t ry = wave; ry < y1 - y0; ry += 4u) {
+                const uint32_t oy = y0 + ry;
+                const uint32_t left = arena[vt->left_off + oy], n = arena[vt->count_off + oy];
+                const float *w = reinterpret_cast<const float *>(arena + vt->weights_off + arena[vt->woff_off + oy]);
+                for (uint32_t col = lane; col < ncols; col += 64u) {
+                    float acc[MC];
+#pragma unroll
+                    for (int k = 0; k < MC; ++k) acc[k] = 0.0f;
+                    const uint8_t *p = jb.src + ((size_t)left * jb.sw + c0 + col) * CS;
+                    for (uint32_t i = 0; i < n; ++i) {
+                        uint32_t s[CS];
+#pragma unroll
+                        for (int k = 0; k < CS; ++k) s[k] = p[k];
+                        float v[MC > CS ? MC : CS];
+                        preop_pixel<CS, PRE>(s, v);
+                        const float wi = w[i];
+#pragma unroll
+                        for (int k = 0; k < MC; ++k) acc[k] = __builtin_fmaf(v[k], wi, acc[k]);
+                        p += pitch;
+                    }
+                    float *o = tile_mid + ((size_t)ry * ncols + col) * MC;
+#pragma unroll
+                    for (int k = 0; k < MC; ++k) o[k] = acc[k];
+                }
+            }
+        }
+        __syncthreads();
+        if (has_col) {
+            for (uint32_t yy = ysub; yy < y1 - y0; yy += ystep) {
+                const float *p = tile_mid + ((size_t)yy * ncols + (hleft - c0)) * MC;
+                float acc[MC], part[MC];
+#pragma unroll
+                for (int k = 0; k < MC; ++k) { acc[k] = 0.0f; part[k] = 0.0f; }
+                for (uint32_t i = 0; i < hn; ++i) {
+                    if (GROUPED && i != 0 && ((hleft + i) & 3u) == 0u) {
+#pragma unroll
+                        for (int k = 0; k < MC; ++k) { acc[k] = acc[k] + part[k]; part[k] = 0.0f; }
+                    }
+                    const float wi = hwp[i];
+#pragma unroll
+                    for (int k = 0; k < MC; ++k) part[k] = __builtin_fmaf(p[k], wi, part[k]);
+                    p += MC;
+                }
+#pragma unroll
+                for (int k = 0; k < MC; ++k) acc[k] = acc[k] + part[k];
+                uint32_t cc[MC];
+#pragma unroll
+                for (int k = 0; k < MC; ++k) cc[k] = round_u8(acc[k]);
+                store_pixel<MC, LB>(jb.dst, (jb.oy + (y0 - jb.cy) + yy) * jb.dw + jb.ox + (x0 - jb.cx) + xx, cc, jb.fill);
+            }
+        }
+        __syncthreads(); // the next tile's vertical pass overwrites the LDS tile
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1162,6 +1331,40 @@ static hipError_t launch_hpass_t(const LaunchGeneric &g, hipStream_t st)
     else hipLaunchKernelGGL((hpass_generic_kernel<MC, LB, false>), grid, dim3(256), 0, st, g.jobs, g.arena, g.mid, g.job_base);
     FL_LAUNCH_CHECK();
     return hipSuccess;
+}
+
+template <int CS, int PRE>
+static hipError_t launch_tile_t(const LaunchGeneric &g, hipStream_t st)
+{
+    // grid.x: (tile columns of the widest kept window at the narrowest tile width) x bands of rows -- enough bands that the chip sees
+    // a few thousand workgroups also when the batch is one picture
+    const uint32_t cols = (g.max_cw + g.tile_w_min - 1u) / g.tile_w_min;
+    const uint32_t max_bands = (g.max_ch + kTileRows - 1u) / kTileRows;
+    const uint32_t nbands = std::max(1u, std::min(max_bands, (4096u + cols * g.njobs - 1u) / (cols * g.njobs)));
+    dim3 grid(cols * nbands, g.njobs);
+    const size_t lds = (size_t)(kTileLdsFloats + kTileWeightFloats) * sizeof(float);
+#define FL_TILE_LAUNCH(LB_, GR_)                                                                                                          \
+    do {                                                                                                                                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_tile_kernel<CS, PRE, LB_, GR_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                                    \
+        hipLaunchKernelGGL((resample_tile_kernel<CS, PRE, LB_, GR_>), grid, dim3(256), lds, st, g.jobs, g.arena, g.job_base, nbands);     \
+    } while (0)
+    if (g.letterbox) { if (g.grouped) FL_TILE_LAUNCH(true, true); else FL_TILE_LAUNCH(true, false); }
+    else { if (g.grouped) FL_TILE_LAUNCH(false, true); else FL_TILE_LAUNCH(false, false); }
+#undef FL_TILE_LAUNCH
+    FL_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_tile_resample(const LaunchGeneric &g, hipStream_t st)
+{
+#define FL_CASE(C_, P_) if (g.cs == C_ && g.pre == P_) return launch_tile_t<C_, P_>(g, st)
+    FL_CASE(1, PRE_NONE); FL_CASE(1, PRE_GRAY); FL_CASE(1, PRE_INVERT);
+    FL_CASE(2, PRE_NONE); FL_CASE(2, PRE_GRAY); FL_CASE(2, PRE_INVERT);
+    FL_CASE(3, PRE_NONE); FL_CASE(3, PRE_GRAY); FL_CASE(3, PRE_INVERT);
+    FL_CASE(4, PRE_NONE); FL_CASE(4, PRE_GRAY); FL_CASE(4, PRE_INVERT);
+#undef FL_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_hpass_generic(const LaunchGeneric &g, hipStream_t st)

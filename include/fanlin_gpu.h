@@ -176,7 +176,7 @@ typedef struct flgpu_stats {
     double resample_ms;           /* summed HIP-event time of those launches (profile = 1) */
     uint64_t resample_src_bytes;  /* algorithmic bytes read by those launches */
     uint64_t resample_dst_bytes;  /* algorithmic bytes written by those launches */
-    uint64_t generic_launches;    /* launches of the two-pass generic resample kernels */
+    uint64_t generic_launches;    /* launches of the two-pass generic resample kernels (through an LDS tile, or through HBM) */
     uint64_t blur_launches;
     double blur_ms;
     uint64_t frontend_launches;

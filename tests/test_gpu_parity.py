@@ -499,3 +499,27 @@ def test_seeded_sweep_as_one_mixed_batch(fl, gpu_state, oracle):
     outs = gpu_state.process_batch(imgs, ps)
     for (i, shape, kw), img, got in zip(cases, imgs, outs):
         both_bars(fl, gpu_state, oracle, got, img, **kw)
+
+
+@pytest.mark.parametrize("shape,kw", [
+    ((1080, 1920, 3), dict(w=1000, h=562)),                      # ratio 1.92: too mild for the fused kernels' row schedules
+    ((1080, 1920, 3), dict(w=2000, h=1000)),                     # the largest target the size gate allows: a slight up-scale
+    ((120, 160, 3), dict(w=300, h=200)),                         # BASELINE config 4's thumbnails, up-scaled and letterboxed
+    ((540, 961, 3), dict(w=300, h=200)),                         # 2883-byte rows
+    ((333, 250, 4), dict(w=120, h=90, crop=True, grayscale=True)),
+    ((200, 320, 1), dict(w=640, h=400)),
+    ((97, 61, 2), dict(w=64, h=64, inverse=True, crop=True)),
+    ((700, 999, 3), dict(w=999, h=700)),                         # identity size: no resampling at all
+])
+def test_two_pass_resample_through_an_lds_tile_equals_the_one_through_hbm(fl, gpu_state, oracle, monkeypatch, shape, kw):
+    """Round 3: requests neither fused kernel takes run their two passes through an LDS tile (resample_tile_kernel) instead of an
+    f32 intermediate in HBM.  Same arithmetic, same order: bit-identical to the HBM form (FLGPU_NO_TILE=1) and to the oracle's
+    fused-order mode, within 1 LSB of the reference arithmetic (parity.check_pixels holds both bars)."""
+    import parity
+    img = synth.uniform(*shape, index=shape[0] + shape[1])
+    got, used = parity.device_pixels(fl, gpu_state, img, **kw)
+    assert not used
+    parity.check_pixels(oracle, got, img, False, **parity.oracle_kwargs(kw))
+    monkeypatch.setenv("FLGPU_NO_TILE", "1")
+    other, _ = parity.device_pixels(fl, gpu_state, img, **kw)
+    assert np.array_equal(got, other)
