@@ -107,13 +107,26 @@ def main():
 {tag}_config1_pmc.txt, traffic.json         rocprofv3 --kernel-trace --pmc <one counter group per pass> --output-format csv -- B --steps 2 --warmup 1
 {tag}_bench_*.json                          python3 bench.py [--frontend none | --crop | --blur 10 --grayscale | --frontend jfif444|webp420] (config1: plain defaults with
                                             verification, extras, the three latency probes and the CPU baseline)
-{tag}_latency_sweep.txt              tools/experiments/latency_sweep.sh + tools/latency/latency_probe <threads> 4096 1920 1080 "w=300&h=200"
-{tag}_microbench_valu_rate.txt       tools/microbench/valu_rate.hip
-{tag}_resample_sweep.txt            tools/experiments/resample_sweep.py 1024 (matrix-pipe vs streaming kernel over target sizes)
-{tag}_mfma_model_rate.txt            tools/experiments/mfma_model_rate.py (device vs the numpy model of the matrix-pipe arithmetic vs the reference arithmetic)
-{tag}_microbench_*_probe.txt         tools/microbench/{mfma,vstage,hfirst,tr8,mfma_pipeline}_probe.hip (the skeletons timed before the kernel was built)
 (only rows of this repository's kernels, fl::*, are kept in the kernel statistics)
 """.replace("{tag}", tag))
+        # files other tools wrote for this round: listed only when they exist, so the list never names a file the round does not have
+        others = [
+            ("latency_sweep.txt", 'tools/experiments/latency_sweep.sh + tools/latency/latency_probe <threads> 4096 1920 1080 "w=300&h=200"'),
+            ("microbench_valu_rate.txt", "tools/microbench/valu_rate.hip"),
+            ("resample_sweep.txt", "tools/experiments/resample_sweep.py 1024 (matrix-pipe vs streaming kernel over target sizes)"),
+            ("generic_sweep.txt", "tools/experiments/generic_sweep.py (requests neither fused kernel takes: tiled two-pass kernel vs the form through HBM)"),
+            ("mfma_model_rate.txt", "tools/experiments/mfma_model_rate.py (device vs the numpy model of the matrix-pipe arithmetic vs the reference arithmetic)"),
+            ("jpeg_pmc_before.txt", "tools/collect_jpeg_pmc.sh + tools/summarize_jpeg_pmc.py, encoder as round 2 left it"),
+            ("jpeg_pmc.txt", "tools/collect_jpeg_pmc.sh + tools/summarize_jpeg_pmc.py, encoder of this round"),
+            ("kernel_experiments.txt", "tools/experiments/ab_inproc.py over the ablation builds of tools/experiments/build_ablate.sh (same buffers, same process)"),
+            ("power_probe.txt", "tools/experiments/power_probe.sh (rocm-smi power / clock samples while one kernel runs back to back)"),
+            ("store_probe.txt", "tools/microbench/store_probe.hip"),
+        ]
+        for name, how in others:
+            if os.path.exists(os.path.join(OUT, f"{tag}_{name}")):
+                f.write(f"{tag}_{name:34s} {how}\n")
+        for p in sorted(glob.glob(os.path.join(OUT, f"{tag}_microbench_*_probe.txt"))):
+            f.write(f"{os.path.basename(p):38s} tools/microbench/{os.path.basename(p)[len(tag) + 12:-4]}.hip\n")
     print("profiles/ updated:", sorted(os.listdir(OUT)))
 
 
