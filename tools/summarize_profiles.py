@@ -118,9 +118,10 @@ def main():
             ("mfma_model_rate.txt", "tools/experiments/mfma_model_rate.py (device vs the numpy model of the matrix-pipe arithmetic vs the reference arithmetic)"),
             ("jpeg_pmc_before.txt", "tools/collect_jpeg_pmc.sh + tools/summarize_jpeg_pmc.py, encoder as round 2 left it"),
             ("jpeg_pmc.txt", "tools/collect_jpeg_pmc.sh + tools/summarize_jpeg_pmc.py, encoder of this round"),
-            ("kernel_experiments.txt", "tools/experiments/ab_inproc.py over the ablation builds of tools/experiments/build_ablate.sh (same buffers, same process)"),
+            ("kernel_experiments.txt", "tools/experiments/ab_inproc.py over the ablation builds of tools/build_ablate.sh (same buffers, same process)"),
             ("power_probe.txt", "tools/experiments/power_probe.sh (rocm-smi power / clock samples while one kernel runs back to back)"),
             ("store_probe.txt", "tools/microbench/store_probe.hip"),
+            ("generic_sweep_notile.txt", "FLGPU_NO_TILE=1 tools/experiments/generic_sweep.py (the two-kernel form through HBM)"),
         ]
         for name, how in others:
             if os.path.exists(os.path.join(OUT, f"{tag}_{name}")):
