@@ -443,7 +443,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (one image per thread)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal: several ranks may share one GPU)")
-    ap.add_argument("--latency-requests", type=int, default=1024,
+    ap.add_argument("--latency-requests", type=int, default=4096,
                     help="requests of the per-image latency probe through flgpu_transform (0 = skip)")
     ap.add_argument("--latency-threads", type=int, default=64, help="concurrent caller threads of the latency probe")
     ap.add_argument("--config0-runs", type=int, default=200, help="runs of BASELINE config 0 (lenna.jpg, CPU oracle and one GPU request at a time); 0 = skip")

@@ -135,15 +135,16 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
     if (it != c->mfma_plans.end()) return &it->second;
     MfmaPlan plan;
     HostMfmaPlan hp;
-    build_mfma_plan(va, ha, cs, cx, cy, cw, ch, hp);
+    choose_mfma_plan(va, ha, cs, cx, cy, cw, ch, hp);
     bool ok = hp.ok;
     if (ok) {
-        plan.ops_in_lds = true;
+        plan.wide = hp.wide;
+        plan.ops_in_lds = !hp.wide;
         for (auto &S : hp.strips) {
             plan.max_nout = std::max(plan.max_nout, S.hdr.nout);
             if (S.hdr.n_ops > kMfmaLdsOperands) plan.ops_in_lds = false;
         }
-        if (mfma_lds_bytes(plan.max_nout, plan.ops_in_lds) > 160 * 1024) ok = false;
+        if (mfma_lds_bytes(plan.max_nout, plan.ops_in_lds, plan.wide) > 160 * 1024) ok = false;
         // (Round 2 kept geometries with BOTH handicaps -- four strips where 2.8 would do, ~100 distinct operands read from the L2
         // instead of LDS -- on the streaming kernel, which was as fast there.  With the tile stage requesting its operands two
         // units ahead the matrix-pipe kernel wins on every one of them: 1080p -> 256x144 1.88 vs 1.99 ms, 512x288 2.33 vs 2.95,
@@ -183,8 +184,8 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
     }
     plan.ok = ok;
     if (getenv("FLGPU_DEBUG_MFMA")) {
-        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d;",
-                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds);
+        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d, wide %d;",
+                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds, (int)plan.wide);
         for (auto &S : hp.strips) fprintf(stderr, " strip [%u,%u) byte0 %u hs %u ops %u", S.hdr.x0, S.hdr.x1, S.hdr.byte0, S.hdr.hs, S.hdr.n_ops);
         fprintf(stderr, "\n");
     }

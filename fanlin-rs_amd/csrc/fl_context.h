@@ -91,6 +91,7 @@ struct MfmaPlan {
     const std::vector<MfmaItem> &items_for(uint32_t nbands);
     uint32_t max_nout = 0;
     bool ops_in_lds = false;
+    bool wide = false;       // wide layout (fl_mfma.h): more outputs per strip, operands from the L2
     bool arena_full = false; // the tables did not fit what is left of the arena: not cached, the caller resets the arena and plans again
 };
 

@@ -15,6 +15,7 @@ namespace {
 
 inline uint32_t be16(const uint8_t *p) { return ((uint32_t)p[0] << 8) | p[1]; }
 
+constexpr int kAcBits = 10;  // lookahead of the single-pass decoder's one-step AC table (4 KB per table; 11 bits measured the same)
 constexpr int kFastBits = 9; // lookahead of the one-step tables (11 bits resolve a few more symbols at once and cost as much again in L1 misses: measured equal)
 
 struct Huff {
@@ -23,8 +24,10 @@ struct Huff {
     int32_t maxcode[18];  // per length, -1 = none; [17] = sentinel
     int32_t valoff[17];   // symbol index of the first code of a length minus that code
     uint8_t vals[256];
-    // AC tables only: code AND magnitude bits inside the lookahead -> (value << 8) | (run << 4) | total bits, 0 = slow path
-    int16_t fastac[1 << kFastBits];
+    // AC tables only, the single-pass decoder's table: kAcBits of lookahead resolve code + magnitude (or the end-of-block and
+    // ZRL codes) in one step: bits 0-4 = bits to drop, 5-8 = zero run, 12 = no value (13 = end of block, else ZRL),
+    // 16-31 = value; 0 = slow path
+    uint32_t fastx[1 << kAcBits];
     bool present = false;
 };
 
@@ -47,17 +50,28 @@ bool build_huff(Huff &h, const uint8_t *bits /*[16] counts of lengths 1..16*/, c
         code <<= 1;
     }
     h.maxcode[17] = 0x7fffffff;
-    // short code + short magnitude in one lookup (the common case of AC coefficients: small values after short runs)
-    for (int i = 0; i < (1 << kFastBits); ++i) {
-        h.fastac[i] = 0;
-        const uint32_t f = h.fast[i];
-        if (!f) continue;
-        const int len = (int)(f >> 8), rs = (int)(f & 255u), run = rs >> 4, mag = rs & 15;
-        if (mag == 0 || len + mag > kFastBits) continue;
-        int v = ((i << len) & ((1 << kFastBits) - 1)) >> (kFastBits - mag);           // the magnitude bits that follow the code
-        if (v < (1 << (mag - 1))) v += (int)(~0u << mag) + 1; // F.2.2.1 EXTEND
-        if (v >= -128 && v <= 127) h.fastac[i] = (int16_t)((v * 256) | (run << 4) | (len + mag));
+    // code + magnitude (or end-of-block / ZRL) in one lookup: the common case of AC coefficients is a small value after a short run
+    for (int i = 0; i < (1 << kAcBits); ++i) {
+        h.fastx[i] = 0;
+        // the code at the top of the kAcBits: canonical search (table construction only)
+        int len = 0, sym = -1;
+        for (int l = 1; l <= kAcBits; ++l) {
+            const int c = i >> (kAcBits - l);
+            if (h.maxcode[l] >= 0 && c <= h.maxcode[l] && c + h.valoff[l] >= 0 && c + h.valoff[l] < total) { len = l; sym = h.vals[c + h.valoff[l]]; break; }
+        }
+        if (sym < 0) continue;
+        const int run = sym >> 4, mag = sym & 15;
+        if (mag == 0) {
+            if (run == 0) h.fastx[i] = (uint32_t)len | (3u << 12);
+            else if (run == 15) h.fastx[i] = (uint32_t)len | (1u << 12);
+            continue; // (other run / 0 symbols are not baseline codes: the slow path treats them as it always did)
+        }
+        if (len + mag > kAcBits) continue;
+        int v = ((i << len) & ((1 << kAcBits) - 1)) >> (kAcBits - mag);
+        if (v < (1 << (mag - 1))) v += (int)(~0u << mag) + 1;
+        h.fastx[i] = (uint32_t)(len + mag) | ((uint32_t)run << 5) | ((uint32_t)(uint16_t)(int16_t)v << 16);
     }
+    h.present = true;
     h.present = true;
     return true;
 }
@@ -575,7 +589,6 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
     int pred[4] = {0, 0, 0, 0};
     const uint32_t mcux = H.comp[0].bw / H.comp[0].h, mcuy = H.comp[0].bh / H.comp[0].v;
     uint32_t rst_left = P.info.restart_interval;
-    int16_t blk[64];
     for (uint32_t my = 0; my < mcuy; ++my)
         for (uint32_t mx = 0; mx < mcux; ++mx) {
             if (P.info.restart_interval && rst_left == 0) {
@@ -598,28 +611,94 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                 for (uint32_t v = 0; v < c.v; ++v)
                     for (uint32_t h = 0; h < c.h; ++h) {
                         const uint32_t bx = mx * c.h + h, by = my * c.v + v;
+                        if (nhalf >= ((size_t)1 << 25)) return -2; // block words carry 25 offset bits
+                        // The block is written in its blob form as it is decoded (fl_jpegdec.h: the first kJpegWideHead
+                        // coefficients as i16, the rest as i8 up to the last non-zero one): the 72 bytes it can take are cleared
+                        // and only the coded coefficients are stored.  A coefficient past the head that does not fit a byte
+                        // makes the block "wide" (all i16): rare, and handled by decoding the block again the plain way.
+                        uint8_t *o = coef + nhalf * 2;
+                        memset(o, 0, 72);
+                        const BitReader at_block = br;
+                        const int pred_before = pred[i];
                         const int t = decode_sym(br, hd);
                         if (t < 0 || t > 11) return -1;
                         pred[i] += receive_extend(br, t);
                         if (pred[i] < -32768 || pred[i] > 32767) return -1;
-                        // (the block starts as zeros and only the coded coefficients are written: one 128-byte clear instead of a
-                        // store per zero of every run)
-                        memset(blk, 0, sizeof(blk));
-                        blk[0] = (int16_t)pred[i];
+                        const int16_t dc = (int16_t)pred[i];
+                        memcpy(o, &dc, 2);
                         int last = 0;
-                        uint32_t wide = 0; // becomes non-zero when a coefficient from kJpegWideHead on does not fit a byte
+                        uint32_t wide = 0;
+                        // The bit buffer lives in registers for the length of the block (br is visible to the out-of-line refill,
+                        // so its members are memory to the compiler).
+                        uint64_t buf = br.buf;
+                        int bc = br.cnt;
                         for (int k = 1; k < 64;) {
-                            if (br.cnt < 32) br.fill();
-                            const int fa = ha.fastac[br.peek(kFastBits)];
-                            if (fa) { // code + magnitude in one step (the value fits a byte by construction)
-                                k += (fa >> 4) & 15;
-                                if (k > 63) return -1;
-                                br.drop(fa & 15);
-                                blk[k] = (int16_t)(fa >> 8);
-                                last = k;
-                                ++k;
-                                continue;
+                            if (bc < 32) {
+                                uint64_t raw;
+                                bool done = false;
+                                if (!br.marker && br.pos + 8 <= n) {
+                                    memcpy(&raw, data + br.pos, 8);
+                                    const uint64_t inv = ~raw;
+                                    if (!((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull)) { // no 0xFF among them
+                                        // whole bytes that fit are counted; the bits of the next byte that also land in the
+                                        // buffer are the ones the next refill ORs onto themselves
+                                        buf |= __builtin_bswap64(raw) >> bc;
+                                        br.pos += (size_t)((63 - bc) >> 3);
+                                        bc |= 56;
+                                        done = true;
+                                    }
+                                }
+                                if (!done) { br.buf = buf; br.cnt = bc; br.fill(); buf = br.buf; bc = br.cnt; }
                             }
+                            int val;
+                            const uint32_t e = ha.fastx[buf >> (64 - kAcBits)];
+                            if (e) {
+                                const int nb = (int)(e & 31u);
+                                buf <<= nb; bc -= nb;
+                                if (e & (1u << 12)) {
+                                    if (e & (1u << 13)) break; // end of block
+                                    k += 16;                   // ZRL
+                                    continue;
+                                }
+                                k += (int)((e >> 5) & 15u);
+                                val = (int16_t)(e >> 16);
+                            } else {
+                                br.buf = buf; br.cnt = bc;
+                                const int rs = decode_sym(br, ha);
+                                if (rs < 0) return -1;
+                                const int r = rs >> 4, s = rs & 15;
+                                if (s == 0) {
+                                    buf = br.buf; bc = br.cnt;
+                                    if (r == 15) { k += 16; continue; }
+                                    break;
+                                }
+                                k += r;
+                                val = receive_extend(br, s);
+                                buf = br.buf; bc = br.cnt;
+                            }
+                            if (k > 63) return -1;
+                            if (k < (int)kJpegWideHead) { const int16_t v16 = (int16_t)val; memcpy(o + 2 * k, &v16, 2); }
+                            else { o[kJpegWideHead + k] = (uint8_t)(int8_t)val; wide |= (uint32_t)(val + 128) >> 8; }
+                            last = k;
+                            ++k;
+                        }
+                        br.buf = buf; br.cnt = bc;
+                        uint32_t *word = &words[c.block_base + by * c.bw + bx];
+                        if (!wide) {
+                            const size_t bytes = last < (int)kJpegWideHead ? 2u * ((size_t)last + 1u) : (size_t)last + kJpegWideHead + 1u;
+                            *word = ((uint32_t)nhalf << 7) | ((uint32_t)last << 1);
+                            nhalf += (bytes + 1u) / 2u;
+                            continue;
+                        }
+                        // wide block: once more, into 64 halfwords
+                        br = at_block;
+                        pred[i] = pred_before;
+                        int16_t blk[64];
+                        memset(blk, 0, sizeof(blk));
+                        pred[i] += receive_extend(br, decode_sym(br, hd)); // (checked above)
+                        blk[0] = (int16_t)pred[i];
+                        last = 0;
+                        for (int k = 1; k < 64;) {
                             const int rs = decode_sym(br, ha);
                             if (rs < 0) return -1;
                             const int r = rs >> 4, s = rs & 15;
@@ -629,23 +708,13 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                             }
                             k += r;
                             if (k > 63) return -1;
-                            const int val = receive_extend(br, s);
-                            blk[k] = (int16_t)val;
-                            wide |= (k >= (int)kJpegWideHead) ? ((uint32_t)(val + 128) >> 8) : 0u;
+                            blk[k] = (int16_t)receive_extend(br, s);
                             last = k;
                             ++k;
                         }
-                        const bool narrow = wide == 0;
-                        const uint32_t cnt = (uint32_t)last + 1;
-                        if (nhalf >= ((size_t)1 << 25)) return -2; // block words carry 25 offset bits
-                        words[c.block_base + by * c.bw + bx] = ((uint32_t)nhalf << 7) | ((cnt - 1u) << 1) | (narrow ? 0u : 1u);
-                        uint8_t *o = coef + nhalf * 2;
-                        const uint32_t head = narrow ? (cnt < kJpegWideHead ? cnt : kJpegWideHead) : cnt;
-                        memcpy(o, blk, head * 2);
-                        size_t bytes = head * 2;
-                        for (uint32_t k = head; k < cnt; ++k) o[bytes++] = (uint8_t)(int8_t)blk[k];
-                        if (bytes & 1u) o[bytes++] = 0;
-                        nhalf += bytes / 2;
+                        *word = ((uint32_t)nhalf << 7) | ((uint32_t)last << 1) | 1u;
+                        memcpy(o, blk, 2u * ((size_t)last + 1u));
+                        nhalf += (size_t)last + 1u;
                     }
             }
             if (P.info.restart_interval) rst_left--;

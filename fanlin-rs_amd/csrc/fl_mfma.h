@@ -41,6 +41,11 @@ constexpr uint32_t kMfmaMaxStripOutputs = 408; // outputs (pixels x channels) pe
 // (pitch 409 put them 4 banks apart: 12 of 16 banks hit twice).
 constexpr uint32_t kMfmaOutPitch = 428;
 static_assert(kMfmaOutPitch >= kMfmaMaxStripOutputs + 16 && (4 * kMfmaOutPitch) % 32 == 16, "LDS output tile pitch");
+// The wide layout: no horizontal operands in LDS (they come from the L2), their 40 KB go to the output tiles instead:
+// 2 x 16 x 748 words = 93.5 KB, 242 Rgb8 pixels per strip.
+constexpr uint32_t kMfmaMaxStripOutputsWide = 728;
+constexpr uint32_t kMfmaOutPitchWide = 748;
+static_assert(kMfmaOutPitchWide >= kMfmaMaxStripOutputsWide + 16 && (4 * kMfmaOutPitchWide) % 32 == 16, "LDS output tile pitch (wide)");
 constexpr uint32_t kMfmaDefaultSpinLimit = 1u << 22; // polls of an LDS counter before a wave gives up and reports FLGPU_DEVERR_MFMA_WAIT
 constexpr uint32_t FLGPU_DEVERR_MFMA_WAIT = 1u;      // bit of the batch's device error word
 constexpr uint32_t kMfmaVScaleLog2 = 8;     // vertical weights are stored times 2^8 (keeps the low f16 term normal)
@@ -85,6 +90,7 @@ struct MfmaStrip {
 
 struct HostMfmaPlan {
     bool ok = false;
+    bool wide = false;                   // strips of up to kMfmaMaxStripOutputsWide outputs (choose_mfma_plan)
     std::vector<uint32_t> vmeta, vw;     // MfmaVPlan tables
     uint32_t ntiles = 0, nkb = 0, y0 = 0, rows = 0, tail = 0;
     struct Tile { uint32_t kb_first, kb_last; };
@@ -96,7 +102,10 @@ struct HostMfmaPlan {
 // Builds the tables for output rows [cy, cy+ch) x columns [cx, cx+cw) of a picture with cs interleaved 8-bit channels.
 // ok = false when the geometry does not fit the kernel (more than two tiles alive in a K-block, horizontal windows
 // that touch more than three 16-output tiles per 64-byte chunk, weights too large for the digit planes).
-void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out);
+void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out,
+                     uint32_t max_outputs = kMfmaMaxStripOutputs);
+// The plan the library uses for the geometry: the narrow layout, or the wide one where that saves strips.
+void choose_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out);
 
 struct LaunchMfma {
     const Job *jobs;
@@ -106,11 +115,12 @@ struct LaunchMfma {
     uint32_t cs;           // channels of the source (1..4)
     uint32_t letterbox;
     uint32_t ops_in_lds;   // every strip of the launch has <= kMfmaLdsOperands distinct operands
+    uint32_t wide;         // the launch's plans use the wide layout (never together with ops_in_lds)
     uint32_t max_nout;
     uint32_t spin_limit;   // bound of the kernel's LDS counter waits (kMfmaDefaultSpinLimit; tests force 0 = every wait expires)
     uint32_t *err_word;    // device word of the batch: the kernel ORs FLGPU_DEVERR_MFMA_WAIT into it when a wait expired
 };
-size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds);
+size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds, bool wide = false);
 hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st);
 
 } // namespace fl

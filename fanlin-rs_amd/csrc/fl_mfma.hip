@@ -55,7 +55,8 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f
 // CS: interleaved 8-bit channels of the source (the vertical pass does not care; the horizontal tables carry the channel
 // structure; only the last step, bytes -> destination pixel, is written per channel count).
 // LB: the destination is Rgba8 with the picture placed on a fill frame.  HLDS: the strip's horizontal operands sit in LDS.
-template <int CS, bool LB, bool HLDS>
+// WIDE (never with HLDS): the LDS the operands would take goes to wider output tiles (fl_mfma.h).
+template <int CS, bool LB, bool HLDS, bool WIDE>
 __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
                                                                    const uint32_t *__restrict__ arena, uint32_t ot_words, uint32_t spin_limit,
                                                                    uint32_t *__restrict__ err_word
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const Job jb = jobs[it.job];
     const MfmaVPlan vp = *reinterpret_cast<const MfmaVPlan *>(arena + it.vplan_off);
     const MfmaStrip sp = *reinterpret_cast<const MfmaStrip *>(arena + it.strip_off);
-    constexpr uint32_t np = kMfmaOutPitch; // words per output-tile row (compile-time: the row offsets of the LDS adds become immediates); column sp.nout is a dummy
+    constexpr uint32_t np = WIDE ? kMfmaOutPitchWide : kMfmaOutPitch; // words per output-tile row (compile-time: the row offsets of the LDS adds become immediates); column sp.nout is a dummy
 
     uint32_t *otile = reinterpret_cast<uint32_t *>(mfma_lds);
     uint32_t *add_cnt = reinterpret_cast<uint32_t *>(mfma_lds + 2u * ot_words * 4u);
@@ -186,14 +187,9 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
     const uint32_t npx = sp.x1 - sp.x0;
 
-    // One wave's share (2 of the 16 rows) of a finished output tile: i32 sums -> bytes -> destination.  A strip row has at most
-    // kMfmaMaxStripOutputs / CS pixels = CONV_G groups of 64 lanes.  All LDS reads of the share are issued before the first of
-    // them is used; lanes past the row's end repeat its last pixel (same words read, same value stored to the same address), so
-    // nothing here switches lanes off; rows past the picture's end (short last tile) are skipped as a whole -- their LDS words
-    // are not cleared, the workgroup does not use the buffer again.
-    constexpr uint32_t CONV_G = (kMfmaMaxStripOutputs / (uint32_t)CS + 63u) / 64u;
+    constexpr uint32_t CONV_G = ((WIDE ? kMfmaMaxStripOutputsWide : kMfmaMaxStripOutputs) / (uint32_t)CS + 63u) / 64u;
     // One wave's share (2 of the 16 rows) of a finished output tile: i32 sums -> bytes -> destination.  A strip row has
-    // at most kMfmaMaxStripOutputs / CS pixels = CONV_G groups of 64 lanes.  All LDS reads of the share are issued before the first of
+    // at most kMfmaMaxStripOutputs[Wide] / CS pixels = CONV_G groups of 64 lanes.  All LDS reads of the share are issued before the first of
     // them is used; lanes past the row's end repeat its last pixel (same words read, same value stored to the same address), so
     // nothing here switches lanes off; rows past the picture's end (short last tile) are skipped as a whole -- their LDS words
     // are not cleared, the workgroup does not use the buffer again.
@@ -445,22 +441,22 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 
 } // namespace
 
-size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds)
+size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds, bool wide)
 {
-    return (size_t)2 * 16 * kMfmaOutPitch * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u); // dynamic part; the rows' 64 KB are static
+    return (size_t)2 * 16 * (wide ? kMfmaOutPitchWide : kMfmaOutPitch) * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u); // dynamic part; the rows' 64 KB are static
 }
 
-template <int CS, bool LB, bool HLDS>
+template <int CS, bool LB, bool HLDS, bool WIDE>
 static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 {
-    const size_t lds = mfma_lds_bytes(m.max_nout, HLDS);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = mfma_lds_bytes(m.max_nout, HLDS, WIDE);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
 #ifdef FL_MFMA_TIMING
     static unsigned long long *dbg = nullptr;
     static int launches = 0;
     if (!dbg) { (void)hipMalloc(&dbg, 3 * 64 * 8); (void)hipMemset(dbg, 0, 3 * 64 * 8); }
-    resample_mfma_kernel<CS, LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch, m.spin_limit, m.err_word, dbg);
+    resample_mfma_kernel<CS, LB, HLDS, WIDE><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word, dbg);
     if ((++launches == 5 || launches == 100) && m.nitems > 2900) {
         unsigned long long h[3 * 64];
         (void)hipDeviceSynchronize();
@@ -473,7 +469,7 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
             }
     }
 #else
-    resample_mfma_kernel<CS, LB, HLDS><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * kMfmaOutPitch, m.spin_limit, m.err_word);
+    resample_mfma_kernel<CS, LB, HLDS, WIDE><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word);
 #endif
     return hipGetLastError();
 }
@@ -481,8 +477,9 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 template <int CS>
 static hipError_t launch_mfma_c(const LaunchMfma &m, hipStream_t st)
 {
-    if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<CS, true, true>(m, st) : launch_mfma_t<CS, true, false>(m, st);
-    return m.ops_in_lds ? launch_mfma_t<CS, false, true>(m, st) : launch_mfma_t<CS, false, false>(m, st);
+    if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, true>(m, st) : launch_mfma_t<CS, false, false, true>(m, st);
+    if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<CS, true, true, false>(m, st) : launch_mfma_t<CS, true, false, false>(m, st);
+    return m.ops_in_lds ? launch_mfma_t<CS, false, true, false>(m, st) : launch_mfma_t<CS, false, false, false>(m, st);
 }
 
 hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st)

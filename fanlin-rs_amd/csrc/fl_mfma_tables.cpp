@@ -50,7 +50,7 @@ double f16_value(uint16_t h)
 
 } // namespace
 
-void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out)
+void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out, uint32_t max_outputs)
 {
     out = HostMfmaPlan();
     if (cs < 1 || cs > 4) return;
@@ -119,23 +119,36 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
     int hs = 17;
     while (hs >= 14 && ldexp((double)maxw, hs) > 32000.0) --hs;
     if (hs < 14) return;
-    // fewest equal strips that fit
-    uint32_t per = 0;
-    const uint32_t max_px = kMfmaMaxStripOutputs / cs;
-    for (uint32_t ns = std::max(1u, (cw + max_px - 1u) / max_px); ns <= cw; ++ns) {
-        per = (cw + ns - 1u) / ns;
-        bool fits = true;
-        for (uint32_t x0 = cx; x0 < cx + cw && fits; x0 += per) {
-            const uint32_t x1 = std::min(x0 + per, cx + cw);
-            uint32_t L = 0xffffffffu, R = 0;
-            for (uint32_t x = x0; x < x1; ++x) { L = std::min(L, h.left[x]); R = std::max(R, h.left[x] + h.count[x]); }
-            const uint32_t byte0 = (cs * L) / 16u * 16u;
-            if (cs * R - byte0 > kMfmaStripBytes) fits = false;
+    // Fewest strips that fit (each <= kMfmaStripBytes of source per row incl. its 16-byte alignment, <= max_outputs outputs), taken
+    // greedily from the left under a cap on the pixels per strip; the smallest cap that still gives that count evens them out.
+    // (Equal strips, round 2's rule, needed a fourth strip for 1080p -> 256 columns: the edge strips have one halo, the inner ones
+    // two, so 88 + 80 + 88 fits where 86 + 85 + 85 does not.  The result does not depend on the split: the horizontal sums are
+    // exact integers.)
+    const uint32_t max_px = max_outputs / cs;
+    std::vector<uint32_t> bounds; // x0 of every strip, then cx + cw
+    auto split = [&](uint32_t cap, std::vector<uint32_t> *b) -> uint32_t {
+        uint32_t n = 0;
+        if (b) b->clear();
+        for (uint32_t x0 = cx; x0 < cx + cw; ++n) {
+            uint32_t L = h.left[x0], R = h.left[x0] + h.count[x0], x1 = x0;
+            while (x1 < cx + cw && x1 - x0 < cap) {
+                const uint32_t L2 = std::min(L, h.left[x1]), R2 = std::max(R, h.left[x1] + h.count[x1]);
+                if (cs * R2 - (cs * L2) / 16u * 16u > kMfmaStripBytes) break;
+                L = L2; R = R2; ++x1;
+            }
+            if (x1 == x0) return 0; // one output column alone does not fit
+            if (b) b->push_back(x0);
+            x0 = x1;
         }
-        if (fits) break;
-        per = 0;
-    }
-    if (!per) return;
+        if (b) b->push_back(cx + cw);
+        return n;
+    };
+    if (!max_px) return;
+    const uint32_t ns = split(max_px, nullptr);
+    if (!ns) return;
+    uint32_t cap = (cw + ns - 1u) / ns;
+    while (cap < max_px && split(cap, nullptr) != ns) ++cap;
+    if (split(cap, &bounds) != ns) return;
     // quantised weights, one vector per output column; the largest tap absorbs the rounding so that the sum is exactly 2^hs
     std::vector<std::vector<int32_t>> hq(cw);
     for (uint32_t x = cx; x < cx + cw; ++x) {
@@ -151,9 +164,9 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
         q[big] += (int32_t)(((int64_t)1 << hs) - sum);
         if (abs(q[big]) > 32639) return;
     }
-    for (uint32_t x0 = cx; x0 < cx + cw; x0 += per) {
+    for (size_t si = 0; si + 1 < bounds.size(); ++si) {
         HostMfmaPlan::Strip S;
-        const uint32_t x1 = std::min(x0 + per, cx + cw);
+        const uint32_t x0 = bounds[si], x1 = bounds[si + 1];
         uint32_t L = 0xffffffffu;
         for (uint32_t x = x0; x < x1; ++x) L = std::min(L, h.left[x]);
         S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (cs * L) / 16u * 16u; S.hdr.nout = (x1 - x0) * cs; S.hdr.hs = (uint32_t)hs;
@@ -213,6 +226,25 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
         out.strips.push_back(std::move(S));
     }
     out.ok = true;
+}
+
+// The plan a geometry runs with.  Strips of up to kMfmaMaxStripOutputs outputs leave LDS room for the horizontal operands; where
+// that bound -- not the 2048 source bytes -- is what cuts the picture into strips (ratios below ~4.7 for Rgb8: 1080p -> 480, 512,
+// 640 columns), the wide layout (kMfmaMaxStripOutputsWide outputs per strip, operands read from the L2) needs fewer strips, and a
+// strip is a whole walk over the picture's rows by one workgroup, whatever its width.
+void choose_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out)
+{
+    build_mfma_plan(v, h, cs, cx, cy, cw, ch, out, kMfmaMaxStripOutputs);
+    out.wide = false;
+    // (1- and 2-channel sources keep the narrow layout: a wide row is up to 728 pixels there, and the conversion's 24 sums per
+    // lane pushed hipcc into scratch -- whose reloads wait on vmcnt, i.e. for the K-block in flight)
+    if (!out.ok || out.strips.size() < 2 || cw * cs <= kMfmaMaxStripOutputs || cs < 3) return;
+    HostMfmaPlan w;
+    build_mfma_plan(v, h, cs, cx, cy, cw, ch, w, kMfmaMaxStripOutputsWide);
+    if (w.ok && w.strips.size() < out.strips.size()) {
+        out = std::move(w);
+        out.wide = true;
+    }
 }
 
 } // namespace fl

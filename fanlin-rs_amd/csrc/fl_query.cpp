@@ -519,7 +519,7 @@ int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t 
     build_axis(sh, rh, FILTER_LANCZOS3, 0.0f, v);
     build_axis(sw, rw, FILTER_LANCZOS3, 0.0f, h);
     HostMfmaPlan p;
-    build_mfma_plan(v, h, channels, cx, cy, cw, ch, p);
+    choose_mfma_plan(v, h, channels, cx, cy, cw, ch, p);
     for (int k = 0; k < 8; ++k) info[k] = 0;
     err[0] = err[1] = 0.0;
     if (!p.ok) return 0;

@@ -70,6 +70,19 @@ def test_host_huffman_decoder_reads_the_same_coefficients_as_the_oracle(fl, orac
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+def test_blocks_whose_coefficients_do_not_fit_a_byte(fl, oracle):
+    """The single-pass decoder writes a block in its blob form while decoding it (i16 head, i8 tail) and decodes it a second time, into
+    halfwords, when a tail coefficient turns out not to fit a byte: noise at quality 100 makes a third of the blocks such blocks."""
+    rng = np.random.default_rng(5)
+    for q, sub in ((100, 0), (100, 2), (98, 2), (90, 1)):
+        b = io.BytesIO()
+        Image.fromarray(rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)).save(b, "JPEG", quality=q, subsampling=sub)
+        hdr, got, blob = fl.debug_jpeg_blob(b.getvalue())
+        words = blob[hdr["blocks_off"]: hdr["blocks_off"] + 4 * hdr["nblocks"]].view(np.uint32)
+        assert q < 98 or int((words & 1).sum()) > 50
+        assert np.array_equal(got, oracle.jpeg_file_coefficients(b.getvalue()))
+
+
 def _save(img, **kw):
     b = io.BytesIO()
     Image.fromarray(img[:, :, 0] if img.shape[2] == 1 else img).save(b, "JPEG", **kw)

@@ -27,6 +27,9 @@ GEOMETRIES = [
     (1080, 1920, 317, 200, False),   # 317 x 178: the short last tile ends in the same K-block as the tile before it (one extra pass)
     (1080, 1920, 320, 240, False),   # horizontal operands that do not repeat: read from the L2, not from LDS
     (1080, 1920, 150, 100, False),   # ratio 12.8 on 1080p: four strips
+    (1080, 1920, 256, 144, False),   # three unequal strips: 88 + 80 + 88 columns
+    (1080, 1920, 640, 360, False),   # ratio 3: the wide layout (214 pixels per strip, 93 KB of LDS output tiles, operands from the L2)
+    (1080, 1920, 512, 200, True),    # wide layout with a crop and a letterbox
 ]
 
 # geometries round 2's planner kept on the streaming kernel ("would not pay": four strips where 2.8 would do and horizontal
@@ -57,6 +60,7 @@ def test_geometries_that_round_2_left_to_the_streaming_kernel(fl, gpu_state, ora
     (4, 1080, 1920, 300, 200, False),   # Rgba8 with random alpha: letterboxed -> every pixel is blended onto the fill colour
     (4, 1080, 1920, 300, 169, False),   # Rgba8 -> Rgba8, no letterbox
     (4, 1080, 1920, 300, 200, True),
+    (4, 1080, 1920, 600, 338, False),   # Rgba8 in the wide layout
     (1, 1080, 1920, 300, 200, False),   # Luma8 (grey JPEG sources)
     (1, 2160, 3840, 640, 360, False),
     (2, 1080, 1920, 300, 200, False),   # LumaA8

@@ -27,6 +27,10 @@ GEOMETRIES = [
     (1600, 1200, 2, 250, 188, None),                # LumaA8
     (6000, 4000, 3, 300, 200, None),                # ratio 20
     (1024, 333, 3, 90, 29, None),                   # two tiles
+    (1920, 1080, 3, 256, 144, None),                # three UNEQUAL strips (the inner one has two halos)
+    (1920, 1080, 3, 640, 360, None),                # wide layout: 214 pixels per strip
+    (1920, 1080, 3, 512, 288, None),
+    (1920, 1080, 4, 600, 338, None),                # wide layout, Rgba8
 ]
 
 
@@ -47,6 +51,14 @@ def test_geometries_the_kernel_refuses(fl):
     assert fl.debug_mfma_plan(320, 200, 3, 640, 400) is None          # up-scale
     assert fl.debug_mfma_plan(1920, 1080, 3, 300, 169, (0, 0, 301, 169)) is None   # crop outside the resized picture
     assert fl.debug_mfma_plan(1920, 1080, 5, 300, 169) is None        # not a channel count
+
+
+def test_strips_are_as_few_as_the_source_bytes_allow(fl):
+    """A strip is one workgroup's walk over all rows, whatever its width: equal strips needed a fourth one for 256 columns (the
+    inner strips carry two halos, the outer ones one), and 408 outputs per strip cut 480 / 512 / 640 columns into 4 / 4 / 5."""
+    for rw, rh, strips in ((300, 169, 3), (256, 144, 3), (200, 113, 3), (480, 270, 3), (512, 288, 3), (640, 360, 3), (150, 84, 4)):
+        assert fl.debug_mfma_plan(1920, 1080, 3, rw, rh)["strips"] == strips, (rw, rh)
+    assert fl.debug_mfma_plan(1920, 1080, 1, 640, 360)["strips"] == 2     # (1- and 2-channel sources keep the narrow layout)
 
 
 def test_short_last_tile_is_flagged(fl):
