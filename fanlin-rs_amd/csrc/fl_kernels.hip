@@ -409,6 +409,70 @@ __global__ __launch_bounds__(256) void place_kernel(const Job *__restrict__ jobs
     store_pixel<MC, LB>(jb.dst, y * jb.dw + x, c, jb.fill);
 }
 
+// The same placement, four destination pixels of a row per thread: one thread per pixel with byte loads and stores ran a
+// grayscale-only 1080p request at 0.2 of the HBM peak (tools/experiments/generic_sweep.py).  Where the four pixels lie inside the
+// picture's window the source bytes come as CS dwords (gfx950 loads a dword from any byte address) and the result leaves as
+// dwords; threads that straddle the window's edge fall back to the pixel-wise path above.  No arithmetic differs.
+typedef uint32_t __attribute__((aligned(1))) u32_any; // a dword at any byte address
+template <int CS, int PRE, bool LB>
+__global__ __launch_bounds__(256) void place4_kernel(const Job *__restrict__ jobs, uint32_t job_base)
+{
+    constexpr int MC = mid_channels(CS, PRE);
+    const Job jb = jobs[job_base + blockIdx.z];
+    const uint32_t y = blockIdx.y, x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (y >= jb.dh || x0 >= jb.dw) return;
+    const bool row_in = y >= jb.oy && y < jb.oy + jb.ch;
+    if (row_in && x0 >= jb.ox && x0 + 4u <= jb.ox + jb.cw) {
+        const uint32_t sy = y - jb.oy + jb.cy, sx = x0 - jb.ox + jb.cx;
+        const uint8_t *p = jb.src + ((size_t)sy * jb.sw + sx) * CS;
+        uint32_t d[CS];
+#pragma unroll
+        for (int j = 0; j < CS; ++j) d[j] = *reinterpret_cast<const u32_any *>(p + 4 * j);
+        uint32_t c[4][MC];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            uint32_t s4[CS];
+#pragma unroll
+            for (int k = 0; k < CS; ++k) { const int b = px * CS + k; s4[k] = (d[b >> 2] >> (8 * (b & 3))) & 255u; }
+            float v[MC > CS ? MC : CS];
+            preop_pixel<CS, PRE>(s4, v);
+#pragma unroll
+            for (int k = 0; k < MC; ++k) c[px][k] = (uint32_t)v[k];
+        }
+        if (LB) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) store_pixel<MC, true>(jb.dst, y * jb.dw + x0 + px, c[px], jb.fill);
+        } else {
+            uint8_t *o = jb.dst + ((size_t)y * jb.dw + x0) * MC;
+#pragma unroll
+            for (int j = 0; j < MC; ++j) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int b = 4 * j + q; w |= c[b / MC][b % MC] << (8 * q); }
+                *reinterpret_cast<u32_any *>(o + 4 * j) = w;
+            }
+        }
+        return;
+    }
+    for (uint32_t x = x0; x < min(x0 + 4u, jb.dw); ++x) {
+        const bool inside = row_in && x >= jb.ox && x < jb.ox + jb.cw;
+        if (!inside) {
+            if (LB) reinterpret_cast<uint32_t *>(jb.dst)[y * jb.dw + x] = jb.fill;
+            continue;
+        }
+        const uint8_t *p = jb.src + ((size_t)(y - jb.oy + jb.cy) * jb.sw + (x - jb.ox + jb.cx)) * CS;
+        uint32_t s1[CS];
+#pragma unroll
+        for (int k = 0; k < CS; ++k) s1[k] = p[k];
+        float v[MC > CS ? MC : CS];
+        preop_pixel<CS, PRE>(s1, v);
+        uint32_t c1[MC];
+#pragma unroll
+        for (int k = 0; k < MC; ++k) c1[k] = (uint32_t)v[k];
+        store_pixel<MC, LB>(jb.dst, y * jb.dw + x, c1, jb.fill);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // EXIF orientation (DynamicImage::apply_orientation, image 0.25.6 metadata::Orientation + imageops::rotate90 /
 // rotate180 / rotate270 / flip_horizontal / flip_vertical): a pure pixel permutation, one thread per
@@ -1383,12 +1447,19 @@ static hipError_t launch_place_t(const LaunchGeneric &g, bool border_only, hipSt
     if (g.nearest) {
         if (g.letterbox) hipLaunchKernelGGL((place_kernel<CS, PRE, true, false, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
         else hipLaunchKernelGGL((place_kernel<CS, PRE, false, false, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
-    } else if (g.letterbox) {
-        if (border_only) hipLaunchKernelGGL((place_kernel<CS, PRE, true, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
-        else hipLaunchKernelGGL((place_kernel<CS, PRE, true, false>), grid, dim3(256), 0, st, g.jobs, g.job_base);
+    } else if (border_only) {
+        if (!g.letterbox) return hipSuccess;
+        hipLaunchKernelGGL((place_kernel<CS, PRE, true, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
     } else {
-        if (border_only) return hipSuccess;
-        hipLaunchKernelGGL((place_kernel<CS, PRE, false, false>), grid, dim3(256), 0, st, g.jobs, g.job_base);
+        const bool by_four = g.max_dh <= 65535u && g.njobs <= 65535u && !getenv("FLGPU_NO_PLACE4"); // (grid limits of the y and z dimensions)
+        dim3 grid4(((g.max_dw + 3u) / 4u + 255u) / 256u, g.max_dh, g.njobs);
+        if (g.letterbox) {
+            if (by_four) hipLaunchKernelGGL((place4_kernel<CS, PRE, true>), grid4, dim3(256), 0, st, g.jobs, g.job_base);
+            else hipLaunchKernelGGL((place_kernel<CS, PRE, true, false>), grid, dim3(256), 0, st, g.jobs, g.job_base);
+        } else {
+            if (by_four) hipLaunchKernelGGL((place4_kernel<CS, PRE, false>), grid4, dim3(256), 0, st, g.jobs, g.job_base);
+            else hipLaunchKernelGGL((place_kernel<CS, PRE, false, false>), grid, dim3(256), 0, st, g.jobs, g.job_base);
+        }
     }
     FL_LAUNCH_CHECK();
     return hipSuccess;

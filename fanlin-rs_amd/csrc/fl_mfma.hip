@@ -270,12 +270,6 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // adds zeros to whatever the transposed reads deliver, nothing is requested, and the loop body stays as it is)
     const uint32_t kb_end = it.kb1 + ((vp.tail && it.tile1 == vp.ntiles) ? 1u : 0u);
     for (uint32_t s = it.kb0; s < kb_end; ++s) {
-        if (!HLDS && s != it.kb0) { // (this variant has no registers to spare for the look-ahead: it fetches its weights here, one L2 round trip per pass)
-            const uint32_t sc = s < it.kb1 ? s : vp.nkb;
-            meta_n = arena[vp.meta_off + sc + vzero];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wvn[k] = vw[(sc * 4u + k) * 64u + lane];
-        }
         const bool have_next = s + 1u < it.kb1;
         uint32_t gnext[8];
         if (have_next) request_offsets(s + 1u, gnext);
@@ -297,12 +291,10 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         if (have_next) request(gnext);
         __builtin_amdgcn_s_setprio(0);
         if (s + 1u < kb_end) {
-            if (HLDS) {
-                const uint32_t sn = s + 1u < it.kb1 ? s + 1u : vp.nkb;
-                meta_n = arena[vp.meta_off + sn + vzero];
+            const uint32_t sn = s + 1u < it.kb1 ? s + 1u : vp.nkb;
+            meta_n = arena[vp.meta_off + sn + vzero];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) wvn[k] = vw[(sn * 4u + k) * 64u + lane];
-            }
+            for (int k = 0; k < 4; ++k) wvn[k] = vw[(sn * 4u + k) * 64u + lane];
         }
         TM_B(tm_read);
         // (the meta word says whether the K-block has weights for a second, younger tile (set 1) at all: about a third of the
@@ -477,7 +469,9 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 template <int CS>
 static hipError_t launch_mfma_c(const LaunchMfma &m, hipStream_t st)
 {
-    if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, true>(m, st) : launch_mfma_t<CS, false, false, true>(m, st);
+    if constexpr (CS >= 3) { // (the planner keeps 1- and 2-channel sources on the narrow layout, fl_mfma_tables.cpp choose_mfma_plan)
+        if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, true>(m, st) : launch_mfma_t<CS, false, false, true>(m, st);
+    } else if (m.wide) return hipErrorInvalidValue;
     if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<CS, true, true, false>(m, st) : launch_mfma_t<CS, true, false, false>(m, st);
     return m.ops_in_lds ? launch_mfma_t<CS, false, true, false>(m, st) : launch_mfma_t<CS, false, false, false>(m, st);
 }

@@ -34,6 +34,24 @@ def test_grayscale_bit_exact(fl, gpu_state, oracle, c):
     assert np.array_equal(got, oracle.grayscale(img))
 
 
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+@pytest.mark.parametrize("kw", [dict(grayscale=True), dict(inverse=True), dict(w=53, h=61), dict(w=61, h=37, fill=(7, 130, 250)),
+                                dict(w=59, h=47, inverse=True), dict(w=53, h=37)])
+def test_placement_four_pixels_per_thread_equals_the_pixel_wise_kernel(fl, gpu_state, oracle, c, kw, monkeypatch):
+    """Requests without a resampling pass (pre-op only, letterbox only: 53 x 37 already fits the target) are placed by a kernel that
+    handles four destination pixels per thread wherever they lie inside the picture's window, pixel by pixel at its edges: widths and
+    offsets that are not multiples of four, every channel count, against the one-pixel-per-thread kernel (FLGPU_NO_PLACE4=1)."""
+    img = synth.uniform(37, 53, c, index=40 + c)
+    got = gpu_state.process_pixels(img, fl.make_params(**kw))
+    monkeypatch.setenv("FLGPU_NO_PLACE4", "1")
+    want = gpu_state.process_pixels(img, fl.make_params(**kw))
+    assert got.shape == want.shape and np.array_equal(got, want)
+    if kw == dict(grayscale=True):
+        assert np.array_equal(got, oracle.grayscale(img))
+    if kw == dict(inverse=True):
+        assert np.array_equal(got, oracle.invert(img))
+
+
 def test_grayscale_known_answers(fl, gpu_state):
     # SURVEY 8(a) a6: (255,255,255)->255, (255,0,0)->54, (0,255,0)->182, (0,0,255)->18, (1,1,1)->1
     px = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [1, 1, 1]]], np.uint8)
