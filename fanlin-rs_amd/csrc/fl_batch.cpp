@@ -38,6 +38,7 @@ struct Work {
     uint32_t orient = 0, raw_w = 0, raw_h = 0; // EXIF orientation pre-pass (2..8), source size before it
     size_t orient_off = 0;
     uint32_t tile_w = 0;        // S1_TILE: output columns per tile (power of two)
+    uint32_t tile_vplan = 0;    // S1_TILE: arena offset of the vertical band tables (build_tile_vplan)
     size_t align_off = 0;       // misaligned device source of a matrix-pipe geometry: offset of its aligned copy in d_tmp_al
     bool align_copy = false;
     const uint8_t *raw_src = nullptr;
@@ -81,6 +82,7 @@ void fill_job(const Work &w, Job &j)
     j.fill = (uint32_t)w.p->fill_r | ((uint32_t)w.p->fill_g << 8) | ((uint32_t)w.p->fill_b << 16) | (255u << 24);
     j.vtab = w.vtab; j.htab = w.htab;
     j.pad1 = w.tile_w;
+    j.pad0 = w.tile_vplan;
     if (w.s1 == S1_NEAREST) {
         // sample.rs: ratio = in as f32 / out as f32, carried as bits where the Lanczos3 jobs carry table offsets
         const float ry = (float)w.sh / (float)pl.resized_h, rx = (float)w.sw / (float)pl.resized_w;
@@ -89,13 +91,18 @@ void fill_job(const Work &w, Job &j)
 }
 
 
-// Tile width of the tiled two-pass kernel for output columns [cx, cx + cw) of axis h: the largest power of two (128 .. 16) whose
+// Tile width of the tiled two-pass kernel for output columns [cx, cx + cw) of axis h: the largest power of two (256 .. 16) whose
 // tiles all have a source column window that fits the kernel's LDS tile (kTileLdsFloats / (8 rows x channels)); 0 = none does
-// (ratios beyond ~7 with four channels: those geometries belong to the other kernels anyway).
-uint32_t tile_width_for(const HostAxis &h, uint32_t cx, uint32_t cw, uint32_t mc)
+// (ratios beyond ~7 with four channels: those geometries belong to the other kernels anyway), or a band of 8 output rows [cy + 8 k, ...)
+// of axis v touches more source rows than the kernel's table of vertical weights holds.
+uint32_t tile_width_for(const HostAxis &h, const HostAxis &v, uint32_t cx, uint32_t cw, uint32_t cy, uint32_t ch, uint32_t mc)
 {
+    for (uint32_t y0 = cy; y0 < cy + ch; y0 += 8u) {
+        const uint32_t y1 = std::min(y0 + 8u, cy + ch);
+        if (v.left[y1 - 1] + v.count[y1 - 1] - v.left[y0] > kTileVRows) return 0;
+    }
     const uint32_t nc_max = kTileLdsFloats / (8u * mc); // (8 = the kernel's rows per tile)
-    for (uint32_t tw = 128; tw >= 16; tw >>= 1) {
+    for (uint32_t tw = 256; tw >= 16; tw >>= 1) {
         bool fits = true;
         for (uint32_t x0 = cx; x0 < cx + cw && fits; x0 += tw) {
             const uint32_t x1 = std::min(x0 + tw, cx + cw);
@@ -105,6 +112,31 @@ uint32_t tile_width_for(const HostAxis &h, uint32_t cx, uint32_t cw, uint32_t mc
         if (fits) return tw;
     }
     return 0;
+}
+
+// The tiled two-pass kernel's vertical tables for output rows [cy, cy + ch) of axis v: every band of 8 rows gets its source row
+// range and a dense [source row][output row] weight block, so that the kernel's band loop starts with one coalesced copy instead
+// of three dependent table look-ups per weight.
+void build_tile_vplan(const HostAxis &v, uint32_t cy, uint32_t ch, std::vector<uint32_t> &blk)
+{
+    const uint32_t nb = (ch + 7u) / 8u;
+    uint32_t stride = 1;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t y0 = cy + 8u * b, y1 = std::min(y0 + 8u, cy + ch);
+        stride = std::max(stride, v.left[y1 - 1] + v.count[y1 - 1] - v.left[y0]);
+    }
+    TileVPlanHeader hd{nb, stride, (uint32_t)(sizeof(TileVPlanHeader) / 4), (uint32_t)(sizeof(TileVPlanHeader) / 4) + 2u * nb};
+    blk.assign((size_t)hd.dense_off + (size_t)nb * stride * 8u, 0u);
+    memcpy(blk.data(), &hd, sizeof(hd));
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t y0 = cy + 8u * b, y1 = std::min(y0 + 8u, cy + ch);
+        const uint32_t top = v.left[y0], rv = v.left[y1 - 1] + v.count[y1 - 1] - top;
+        blk[hd.bands_off + 2u * b] = top;
+        blk[hd.bands_off + 2u * b + 1u] = rv;
+        float *dense = reinterpret_cast<float *>(blk.data() + hd.dense_off) + (size_t)b * stride * 8u;
+        for (uint32_t oy = y0; oy < y1; ++oy)
+            for (uint32_t k = 0; k < v.count[oy]; ++k) dense[(size_t)(v.left[oy] + k - top) * 8u + (oy - y0)] = v.weights[v.woff[oy] + k];
+    }
 }
 
 // XCD-aware numbering: workgroups are dealt to the 8 XCDs round-robin in launch order and each XCD has its own L2.
@@ -392,8 +424,19 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             // LDS tile instead of an f32 intermediate in HBM, if a tile width fits (FLGPU_NO_TILE=1 keeps the HBM form: tests, A/B)
             if (w.s1 == S1_GENERIC && !no_tile) {
                 Job jtmp; fill_job(w, jtmp);
-                const uint32_t tw = tile_width_for(*w.ha, jtmp.cx, jtmp.cw, mid_channels(w.cs, w.pre));
-                if (tw) { w.s1 = S1_TILE; w.tile_w = tw; }
+                const uint32_t tw = tile_width_for(*w.ha, *w.va, jtmp.cx, jtmp.cw, jtmp.cy, jtmp.ch, mid_channels(w.cs, w.pre));
+                if (tw) {
+                    const auto key = std::make_tuple(w.vk, jtmp.cy, jtmp.ch);
+                    auto it = c->tile_vplans.find(key);
+                    if (it == c->tile_vplans.end()) {
+                        std::vector<uint32_t> blk;
+                        build_tile_vplan(*w.va, jtmp.cy, jtmp.ch, blk);
+                        const uint32_t off = arena_append(c, blk.data(), blk.size());
+                        if (!off) { full = true; break; }
+                        it = c->tile_vplans.emplace(key, off).first;
+                    }
+                    w.s1 = S1_TILE; w.tile_w = tw; w.tile_vplan = it->second;
+                }
             }
         }
         for (auto &w : work) {

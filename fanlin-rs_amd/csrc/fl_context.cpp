@@ -59,6 +59,7 @@ void arena_reset(flgpu_ctx *c)
     c->stream_plans.clear();
     c->mfma_plans.clear();
     c->blur_plans.clear();
+    c->tile_vplans.clear();
     c->jpeg_tables.clear();
     std::vector<uint32_t> g;
     build_webp_gamma(g);

@@ -142,6 +142,7 @@ struct flgpu_ctx {
     std::map<fl::AxisKey, fl::HostAxis> axis_host;
     std::map<fl::StreamPlanKey, fl::StreamPlan> stream_plans;
     std::map<fl::MfmaPlanKey, fl::MfmaPlan> mfma_plans;
+    std::map<std::tuple<fl::AxisKey, uint32_t, uint32_t>, uint32_t> tile_vplans;     // tiled two-pass kernel: dense vertical weights per band of 8 output rows, per (axis, first kept row, rows)
     std::map<std::tuple<fl::AxisKey, fl::AxisKey, uint32_t>, uint32_t> blur_plans; // blur kernel table blocks per (vertical, horizontal) Gaussian axis
     uint32_t gamma_off = 0;
 

@@ -68,8 +68,12 @@ struct LaunchStream {
 hipError_t launch_vpass_generic(const LaunchGeneric &g, hipStream_t st);
 hipError_t launch_hpass_generic(const LaunchGeneric &g, hipStream_t st);
 hipError_t launch_tile_resample(const LaunchGeneric &g, hipStream_t st); // the same two passes through an LDS tile (no f32 intermediate in HBM)
-constexpr uint32_t kTileLdsFloats = 6144;    // LDS of the tiled two-pass kernel: 24 KB = 8 rows x 768 (source columns x channels) f32 ...
-constexpr uint32_t kTileWeightFloats = 2048;  // ... + the horizontal weights of a tile's columns (the host checks both when it picks the tile width)
+constexpr uint32_t kTileLdsFloats = 8192;    // LDS of the tiled two-pass kernel: 32 KB = 8 rows x 1024 (source columns x channels) f32: four bytes per thread ...
+constexpr uint32_t kTileWeightFloats = 2048;  // ... + the horizontal weights of a tile's columns ...
+constexpr uint32_t kTileVRows = 64;           // ... + the vertical weights of a band: source rows one band of 8 output rows may touch (the host checks all three)
+// Vertical plan of the tiled two-pass kernel (arena block, built by the host per (axis, kept rows)): header, then per band of 8
+// output rows {first source row, source rows touched}, then the dense weights [band][rv_stride][8 output rows] (0 outside a window).
+struct TileVPlanHeader { uint32_t nbands, rv_stride, bands_off, dense_off; }; // offsets in words from the header
 hipError_t launch_place(const LaunchGeneric &g, bool border_only, hipStream_t st);
 
 // fused LDS-tiled Gaussian blur (g.cs = channels of the blurred image; g.jobs[i].vtab/htab = Gaussian tables)

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void hpass_generic_kernel(const Job *__restric
 // down-scales, odd pitches (image 0.25.6 imageops/sample.rs vertical_sample + horizontal_sample).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kTileRows = 8; // (16 rows and 64 KB of LDS per workgroup left two workgroups per CU, and the kernel waited on its own loads)
+constexpr uint32_t kTilePrefetch = 14; // source rows in flight per thread in the vertical pass (ratio 1: a band touches 14 rows)
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned; // (gfx950 loads a dword from any byte address: one global_load_dword)
 
 template <int CS, int PRE, bool LB, bool GROUPED>
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const Job *__restric
     // (read by output column in the horizontal pass they would be one cache line per lane)
     const uint32_t hw0 = arena[ht->woff_off + x0], hw1 = arena[ht->woff_off + x1 - 1u] + arena[ht->count_off + x1 - 1u];
     float *tile_w = tile_mid + kTileLdsFloats;
+    float *tile_v = tile_w + kTileWeightFloats; // [source row of the band's window][output row of the band]: the vertical pass's weights
     const float *hweights = reinterpret_cast<const float *>(arena + ht->weights_off);
     for (uint32_t k = tid; k < hw1 - hw0; k += 256u) tile_w[k] = hweights[hw0 + k];
     // this thread's output column and the rows it takes in every tile (256 >> tw_log of them at a time)
@@ -249,65 +251,112 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const Job *__restric
     const uint32_t hx = x0 + min(xx, ow - 1u);
     const uint32_t hleft = arena[ht->left_off + hx], hn = arena[ht->count_off + hx];
     const float *hwp = tile_w + (arena[ht->woff_off + hx] - hw0);
+    // vertical pass (all but the grayscale pre-op): the picture's band tables (fl_kernels.h TileVPlanHeader), and this thread's four bytes
+    const TileVPlanHeader vp = *reinterpret_cast<const TileVPlanHeader *>(arena + jb.pad0);
+    const uint32_t *vbands = arena + jb.pad0 + vp.bands_off;
+    const float *vdense = reinterpret_cast<const float *>(arena + jb.pad0 + vp.dense_off);
+    const uint32_t nbytes = ncols * (uint32_t)CS, b4 = tid * 4u;
+    const uint32_t npitch = (ncols * (uint32_t)MC + 3u) & ~3u; // floats per row of the LDS tile: rows start 16-byte aligned, so a thread's four sums leave as one ds_write_b128
+    const size_t col_off = (size_t)c0 * CS + b4;
+    uint32_t inv = 0u; // Invert (color.rs Invert: 255 - c on the colour channels, alpha untouched) as an XOR mask of the four bytes
+    if (PRE == PRE_INVERT) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t chn = (uint32_t)((col_off + j) % (uint32_t)CS);
+            if (!((CS == 2 || CS == 4) && chn == (uint32_t)CS - 1u)) inv |= 0xffu << (8u * j);
+        }
+    }
+    // Vertical pass, input-stationary by BYTE columns: without a pre-op that mixes channels a byte column is filtered like any other, so
+    // a thread owns four consecutive bytes of the window, walks down the source rows the band's eight output rows touch -- each dword
+    // loaded ONCE per band, kTilePrefetch of them in flight -- and feeds every row into all eight sums.  The weights are wave-uniform: a
+    // dense [source row][output row] table in LDS, zero where a row lies outside an output row's window.  fma(v, 0, acc) leaves acc as
+    // it is and a sum starts at +0, so each output row still sees exactly its taps, in tap order: the bits of the row-by-row form (one
+    // workgroup-wide round of eight dependent loads per output row and 256 bytes; that form waited for the L2 78 % of the time,
+    // profiles/r03_generic_sweep.txt).  The first rows of a band and its weight table are requested before the horizontal pass of
+    // the band before it, so that their latency is spent under that pass.
+    uint32_t rv = 0;                  // source rows of the band in hand (<= kTileVRows: the host checked)
+    size_t goff = 0;                  // its first row's byte offset for this thread
+    bool whole = false;               // every dword of this thread's column lies inside the source (all but the window's last thread in the picture's last rows)
+    const uint8_t *pl = jb.src;       // the next row to request; it stops at the window's last row (requests past it repeat that row, unused)
+    uint32_t ring[kTilePrefetch];
+    float tvn[(kTileVRows * kTileRows) / 256u];
+#pragma unroll
+    for (uint32_t k = 0; k < kTilePrefetch; ++k) ring[k] = 0u;
+    auto begin_band = [&](uint32_t y0) __attribute__((always_inline)) {
+        const uint32_t bt = (y0 - jb.cy) / kTileRows; // band of the picture (the host's table is per picture, not per workgroup)
+        const uint32_t top = vbands[2u * bt];
+        rv = vbands[2u * bt + 1u];
+        const float *dsrc = vdense + (size_t)bt * vp.rv_stride * kTileRows;
+#pragma unroll
+        for (uint32_t q = 0; q < (kTileVRows * kTileRows) / 256u; ++q) tvn[q] = tid + 256u * q < rv * kTileRows ? dsrc[tid + 256u * q] : 0.0f;
+        goff = (size_t)top * pitch + col_off;
+        whole = b4 < nbytes && goff + (size_t)(rv - 1u) * pitch + 4u <= (size_t)jb.src_bytes;
+        if (whole) {
+            pl = jb.src + goff;
+#pragma unroll
+            for (uint32_t k = 0; k < kTilePrefetch; ++k) {
+                ring[k] = *reinterpret_cast<const u32_unaligned *>(pl);
+                if (k + 1u < rv) pl += pitch;
+            }
+        }
+    };
+    auto publish_weights = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t q = 0; q < (kTileVRows * kTileRows) / 256u; ++q) tile_v[tid + 256u * q] = tvn[q];
+    };
+    if (PRE != PRE_GRAY) {
+        begin_band(yb0);
+        publish_weights();
+        __syncthreads();
+    }
     for (uint32_t y0 = yb0; y0 < yb1; y0 += kTileRows) {
         const uint32_t y1 = min(y0 + kTileRows, yb1);
         if (PRE != PRE_GRAY) {
-            // Vertical pass by BYTE columns: without a pre-op that mixes channels a byte column is filtered like any other, so a lane
-            // takes four consecutive bytes of the window -- one dword load per tap instead of one byte load per channel.
-            const uint32_t nbytes = ncols * (uint32_t)CS;
-            for (uint32_t ry = wave; ry < y1 - y0; ry += 4u) {
-                const uint32_t oy = y0 + ry;
-                const uint32_t left = arena[vt->left_off + oy], n = arena[vt->count_off + oy];
-                const float *w = reinterpret_cast<const float *>(arena + vt->weights_off + arena[vt->woff_off + oy]);
-                for (uint32_t b4 = lane * 4u; b4 < nbytes; b4 += 256u) {
-                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    size_t goff = (size_t)left * pitch + (size_t)c0 * CS + b4;
-                    // Invert (color.rs Invert: 255 - c on the colour channels, alpha untouched) as an XOR mask of the four bytes
-                    uint32_t inv = 0u;
-                    if (PRE == PRE_INVERT) {
+            if (b4 < nbytes) {
+                float acc[kTileRows][4];
 #pragma unroll
-                        for (uint32_t j = 0; j < 4; ++j) {
-                            const uint32_t chn = (uint32_t)(((size_t)c0 * CS + b4 + j) % (uint32_t)CS);
-                            if (!((CS == 2 || CS == 4) && chn == (uint32_t)CS - 1u)) inv |= 0xffu << (8u * j);
-                        }
+                for (uint32_t o = 0; o < kTileRows; ++o)
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) acc[o][j] = 0.0f;
+                auto add_row = [&](uint32_t r, uint32_t d) __attribute__((always_inline)) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(tile_v + r * kTileRows), wb = *reinterpret_cast<const f32x4 *>(tile_v + r * kTileRows + 4u);
+                    const float v0 = (float)(d & 255u), v1 = (float)((d >> 8) & 255u), v2 = (float)((d >> 16) & 255u), v3 = (float)(d >> 24);
+                    const float wr[kTileRows] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                    for (uint32_t o = 0; o < kTileRows; ++o) {
+                        acc[o][0] = __builtin_fmaf(v0, wr[o], acc[o][0]);
+                        acc[o][1] = __builtin_fmaf(v1, wr[o], acc[o][1]);
+                        acc[o][2] = __builtin_fmaf(v2, wr[o], acc[o][2]);
+                        acc[o][3] = __builtin_fmaf(v3, wr[o], acc[o][3]);
                     }
-                    // (only the window's last taps in the picture's last row can reach past the source: decided once per column group, so
-                    // that the common loop has no branch in it)
-                    if (goff + (size_t)(n - 1u) * pitch + 4u <= (size_t)jb.src_bytes) {
-                        // eight taps' loads go out before the first of them is used (taps past the window's end repeat its last row with
-                        // weight 0 ... by not being used: the loop below stops at n)
-                        for (uint32_t i0 = 0; i0 < n; i0 += 8u) {
-                            uint32_t d[8];
+                };
+                // (the choice between dwords and bytes is made once per band, outside the loops: a branch inside them puts every load in a
+                // block of its own, and the compiler drains vmcnt at each join)
+                if (whole) {
+                    for (uint32_t rb = 0; rb < rv; rb += kTilePrefetch) {
 #pragma unroll
-                            for (uint32_t j = 0; j < 8; ++j) d[j] = *reinterpret_cast<const u32_unaligned *>(jb.src + goff + (size_t)min(i0 + j, n - 1u) * pitch) ^ inv;
-#pragma unroll
-                            for (uint32_t j = 0; j < 8; ++j) {
-                                if (i0 + j >= n) break;
-                                const float wi = w[i0 + j];
-                                acc[0] = __builtin_fmaf((float)(d[j] & 255u), wi, acc[0]);
-                                acc[1] = __builtin_fmaf((float)((d[j] >> 8) & 255u), wi, acc[1]);
-                                acc[2] = __builtin_fmaf((float)((d[j] >> 16) & 255u), wi, acc[2]);
-                                acc[3] = __builtin_fmaf((float)(d[j] >> 24), wi, acc[3]);
+                        for (uint32_t k = 0; k < kTilePrefetch; ++k) {
+                            const uint32_t r = rb + k, d = ring[k] ^ inv;
+                            if (rb + kTilePrefetch < rv) { // (wave-uniform: the last round requests nothing, the ring is free for the next band)
+                                ring[k] = *reinterpret_cast<const u32_unaligned *>(pl);
+                                if (r + kTilePrefetch + 1u < rv) pl += pitch;
                             }
-                        }
-                    } else {
-                        for (uint32_t i = 0; i < n; ++i) {
-                            uint32_t d = 0u;
-                            for (uint32_t j = 0; j < 4u && goff + j < (size_t)jb.src_bytes; ++j) d |= (uint32_t)jb.src[goff + j] << (8u * j);
-                            d ^= inv;
-                            const float wi = w[i];
-                            acc[0] = __builtin_fmaf((float)(d & 255u), wi, acc[0]);
-                            acc[1] = __builtin_fmaf((float)((d >> 8) & 255u), wi, acc[1]);
-                            acc[2] = __builtin_fmaf((float)((d >> 16) & 255u), wi, acc[2]);
-                            acc[3] = __builtin_fmaf((float)(d >> 24), wi, acc[3]);
-                            goff += pitch;
+                            if (r < rv) add_row(r, d);
                         }
                     }
-                    float *o = tile_mid + (size_t)ry * nbytes + b4;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) if (b4 + j < nbytes) o[j] = acc[j];
+                } else {
+                    for (uint32_t r = 0; r < rv; ++r) {
+                        const size_t a = goff + (size_t)r * pitch;
+                        uint32_t d = 0u;
+                        for (uint32_t j = 0; j < 4u && a + j < (size_t)jb.src_bytes; ++j) d |= (uint32_t)jb.src[a + j] << (8u * j);
+                        add_row(r, d ^ inv);
+                    }
                 }
+#pragma unroll
+                for (uint32_t o = 0; o < kTileRows; ++o) // (the last thread's sums past the window land in the row's padding)
+                    *reinterpret_cast<f32x4 *>(tile_mid + (size_t)o * npitch + b4) = f32x4{acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
             }
+            if (y0 + kTileRows < yb1) begin_band(y0 + kTileRows); // the next band's first rows and weights: requested now, used after the horizontal pass
         } else {
             for (uint32_t ry = wave; ry < y1 - y0; ry += 4u) {
                 const uint32_t oy = y0 + ry;
@@ -329,36 +378,55 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const Job *__restric
                         for (int k = 0; k < MC; ++k) acc[k] = __builtin_fmaf(v[k], wi, acc[k]);
                         p += pitch;
                     }
-                    float *o = tile_mid + ((size_t)ry * ncols + col) * MC;
+                    float *o = tile_mid + (size_t)ry * npitch + (size_t)col * MC;
 #pragma unroll
                     for (int k = 0; k < MC; ++k) o[k] = acc[k];
                 }
             }
         }
         __syncthreads();
+        if (PRE != PRE_GRAY && y0 + kTileRows < yb1) publish_weights(); // (nobody reads this band's table any more; the barrier at the band's end publishes the next one)
+        // Horizontal pass: a thread owns one output column and NR = tw / 32 of the tile's rows (ysub, ysub + ystep, ...), and takes
+        // them through the taps TOGETHER: the weight, the block boundary of the grouped order and the tap's address are per column,
+        // not per pixel (one pixel at a time spent two thirds of its vector instructions on them).
         if (has_col) {
-            for (uint32_t yy = ysub; yy < y1 - y0; yy += ystep) {
-                const float *p = tile_mid + ((size_t)yy * ncols + (hleft - c0)) * MC;
-                float acc[MC], part[MC];
+            auto hpass = [&](auto nr_tag) __attribute__((always_inline)) {
+                constexpr uint32_t NR = decltype(nr_tag)::value;
+                const float *p = tile_mid + (size_t)ysub * npitch + (size_t)(hleft - c0) * MC;
+                const uint32_t rstep = ystep * npitch;
+                float acc[NR][MC], part[NR][MC];
 #pragma unroll
-                for (int k = 0; k < MC; ++k) { acc[k] = 0.0f; part[k] = 0.0f; }
+                for (uint32_t q = 0; q < NR; ++q)
+#pragma unroll
+                    for (int k = 0; k < MC; ++k) { acc[q][k] = 0.0f; part[q][k] = 0.0f; }
                 for (uint32_t i = 0; i < hn; ++i) {
                     if (GROUPED && i != 0 && ((hleft + i) & 3u) == 0u) {
 #pragma unroll
-                        for (int k = 0; k < MC; ++k) { acc[k] = acc[k] + part[k]; part[k] = 0.0f; }
+                        for (uint32_t q = 0; q < NR; ++q)
+#pragma unroll
+                            for (int k = 0; k < MC; ++k) { acc[q][k] = acc[q][k] + part[q][k]; part[q][k] = 0.0f; }
                     }
                     const float wi = hwp[i];
 #pragma unroll
-                    for (int k = 0; k < MC; ++k) part[k] = __builtin_fmaf(p[k], wi, part[k]);
+                    for (uint32_t q = 0; q < NR; ++q)
+#pragma unroll
+                        for (int k = 0; k < MC; ++k) part[q][k] = __builtin_fmaf(p[q * rstep + k], wi, part[q][k]);
                     p += MC;
                 }
 #pragma unroll
-                for (int k = 0; k < MC; ++k) acc[k] = acc[k] + part[k];
-                uint32_t cc[MC];
+                for (uint32_t q = 0; q < NR; ++q) {
+                    const uint32_t yy = ysub + q * ystep;
+                    if (yy >= y1 - y0) break; // (rows past a short last tile were computed on whatever the LDS held: never stored)
+                    uint32_t cc[MC];
 #pragma unroll
-                for (int k = 0; k < MC; ++k) cc[k] = round_u8(acc[k]);
-                store_pixel<MC, LB>(jb.dst, (jb.oy + (y0 - jb.cy) + yy) * jb.dw + jb.ox + (x0 - jb.cx) + xx, cc, jb.fill);
-            }
+                    for (int k = 0; k < MC; ++k) cc[k] = round_u8(acc[q][k] + part[q][k]);
+                    store_pixel<MC, LB>(jb.dst, (jb.oy + (y0 - jb.cy) + yy) * jb.dw + jb.ox + (x0 - jb.cx) + xx, cc, jb.fill);
+                }
+            };
+            if (tw_log >= 8u) hpass(std::integral_constant<uint32_t, 8>{});
+            else if (tw_log == 7u) hpass(std::integral_constant<uint32_t, 4>{});
+            else if (tw_log == 6u) hpass(std::integral_constant<uint32_t, 2>{});
+            else if (ysub < kTileRows) hpass(std::integral_constant<uint32_t, 1>{});
         }
         __syncthreads(); // the next tile's vertical pass overwrites the LDS tile
     }
@@ -1406,7 +1474,7 @@ static hipError_t launch_tile_t(const LaunchGeneric &g, hipStream_t st)
     const uint32_t max_bands = (g.max_ch + kTileRows - 1u) / kTileRows;
     const uint32_t nbands = std::max(1u, std::min(max_bands, (4096u + cols * g.njobs - 1u) / (cols * g.njobs)));
     dim3 grid(cols * nbands, g.njobs);
-    const size_t lds = (size_t)(kTileLdsFloats + kTileWeightFloats) * sizeof(float);
+    const size_t lds = (size_t)(kTileLdsFloats + kTileWeightFloats + kTileVRows * kTileRows) * sizeof(float);
 #define FL_TILE_LAUNCH(LB_, GR_)                                                                                                          \
     do {                                                                                                                                  \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_tile_kernel<CS, PRE, LB_, GR_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
