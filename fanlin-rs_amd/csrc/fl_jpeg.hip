@@ -355,8 +355,33 @@ __global__ __launch_bounds__(256) void jpeg_dct_quant_kernel(const JpegJob *__re
     for (uint32_t blk = first; blk < last; ++blk) {
         uint32_t smp[3];
         jfif_px(rgb, smp[0], smp[1], smp[2]);
+        // a block of one colour (the fill frame of a letterboxed picture: 75 of the 950 blocks of config 1, 31 % of config 0's)
+        const bool flat = __ballot(rgb != (uint32_t)__builtin_amdgcn_readfirstlane((int)rgb)) == 0ull;
         if (++bcol == jb.bx) { bcol = 0; ++brow; }
         if (blk + 1u < last) rgb = block_pixel(jb, brow, bcol, r, c); // in flight while this block is transformed
+        if (flat) {
+            // Both passes of the transform are linear up to their final shifts and every row of the matrix but the first sums to zero:
+            // a constant block s has pass-1 column 0 = 4 (8 s - 1024) in every row, nothing else, and pass 2 turns that into
+            // d[0] = (32 (8 s - 1024) + 2) >> 2 = 64 (s - 128); all other d are (0 + rounding) >> shift = 0.  The DC term goes through
+            // the quantiser of dct_quant_unit, each component's AC code is its end-of-block code alone.
+            const uint32_t q0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)ql), q0c = (uint32_t)__builtin_amdgcn_readfirstlane((int)qc);
+            const uint32_t m0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)ml), m0c = (uint32_t)__builtin_amdgcn_readfirstlane((int)mc);
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) {
+                const int32_t d = 64 * ((int32_t)smp[comp] - 128);
+                const int32_t sg = d >> 31;
+                const uint32_t an = (uint32_t)((d ^ sg) - sg) >> 3;
+                const uint32_t rq = __umulhi(2u * an + (comp ? q0c : q0l), comp ? m0c : m0l);
+                const int32_t qv = ((int32_t)rq ^ sg) - sg;
+                const uint32_t e = s_ac[comp ? 256u : 0u]; // (run 0, size 0): end of block
+                if (lane == 0u) {
+                    const uint32_t unit = blk * 3u + (uint32_t)comp;
+                    jb.acbits[(size_t)unit * kAcWordsPerUnit] = (e & 0xffffu) << (32u - (e >> 16));
+                    jb.meta[unit] = ((uint32_t)qv & 0xffffu) | ((e >> 16) << 16);
+                }
+            }
+            continue;
+        }
         int32_t zv[3];
 #pragma unroll
         for (int comp = 0; comp < 3; ++comp) zv[comp] = dct_quant_unit(smp[comp], lane, r, c, m1, m2, k1, comp ? qc : ql, comp ? mc : ml, zz, ta16, tb16, ta);
