@@ -121,6 +121,11 @@ def main():
             ("kernel_experiments.txt", "tools/experiments/ab_inproc.py over the ablation builds of tools/build_ablate.sh (same buffers, same process)"),
             ("power_probe.txt", "tools/experiments/power_probe.sh (rocm-smi power / clock samples while one kernel runs back to back)"),
             ("store_probe.txt", "tools/microbench/store_probe.hip"),
+            ("halfblock_probe.txt", "tools/microbench/halfblock_probe.hip"),
+            ("placement_probes.txt", "tools/experiments/placement_probe2.py, placement_probe3.py, placement_probe4.py"),
+            ("tile_kernel_pmc.txt", "tools/experiments/tile_pmc.sh 2000 1000 128"),
+            ("jpeg_decoder_ab.txt", "tools/experiments/jpeg_source_rate.py with the library swapped between runs"),
+            ("config4_mixed.txt", "tools/experiments/config4_mixed.py"),
             ("generic_sweep_notile.txt", "FLGPU_NO_TILE=1 tools/experiments/generic_sweep.py (the two-kernel form through HBM)"),
         ]
         for name, how in others:
