@@ -620,18 +620,30 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                         memset(o, 0, 72);
                         const BitReader at_block = br;
                         const int pred_before = pred[i];
-                        const int t = decode_sym(br, hd);
-                        if (t < 0 || t > 11) return -1;
-                        pred[i] += receive_extend(br, t);
+                        // The bit buffer lives in registers for the length of the block (br is visible to the out-of-line refill,
+                        // so its members are memory to the compiler).
+                        uint64_t buf = br.buf;
+                        int bc = br.cnt;
+                        {   // DC difference: category + magnitude bits in one look-up when they fit the table's reach (as for AC below)
+                            if (bc < 32) { br.buf = buf; br.cnt = bc; br.fill(); buf = br.buf; bc = br.cnt; }
+                            const uint32_t e = hd.fastx[buf >> (64 - kAcBits)];
+                            if (e) {
+                                const int nb = (int)(e & 31u);
+                                buf <<= nb; bc -= nb;
+                                pred[i] += (e & (1u << 12)) ? 0 : (int)(int16_t)(e >> 16);
+                            } else {
+                                br.buf = buf; br.cnt = bc;
+                                const int t = decode_sym(br, hd);
+                                if (t < 0 || t > 11) return -1;
+                                pred[i] += receive_extend(br, t);
+                                buf = br.buf; bc = br.cnt;
+                            }
+                        }
                         if (pred[i] < -32768 || pred[i] > 32767) return -1;
                         const int16_t dc = (int16_t)pred[i];
                         memcpy(o, &dc, 2);
                         int last = 0;
                         uint32_t wide = 0;
-                        // The bit buffer lives in registers for the length of the block (br is visible to the out-of-line refill,
-                        // so its members are memory to the compiler).
-                        uint64_t buf = br.buf;
-                        int bc = br.cnt;
                         for (int k = 1; k < 64;) {
                             if (bc < 32) {
                                 uint64_t raw;
