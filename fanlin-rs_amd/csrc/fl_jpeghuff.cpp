@@ -630,7 +630,11 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                             if (e) {
                                 const int nb = (int)(e & 31u);
                                 buf <<= nb; bc -= nb;
-                                pred[i] += (e & (1u << 12)) ? 0 : (int)(int16_t)(e >> 16);
+                                // (the table is the AC one's shape: a DC symbol is a bare category, so an entry with a run, or the
+                                // ZRL flag, is a symbol no DC table may hold -- what the slow path rejects as t > 11)
+                                if (e & (1u << 12)) { if (!(e & (1u << 13))) return -1; }
+                                else if ((e >> 5) & 15u) return -1;
+                                else pred[i] += (int)(int16_t)(e >> 16);
                             } else {
                                 br.buf = buf; br.cnt = bc;
                                 const int t = decode_sym(br, hd);
@@ -707,7 +711,11 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
                         pred[i] = pred_before;
                         int16_t blk[64];
                         memset(blk, 0, sizeof(blk));
-                        pred[i] += receive_extend(br, decode_sym(br, hd)); // (checked above)
+                        {
+                            const int t = decode_sym(br, hd);
+                            if (t < 0 || t > 11) return -1;
+                            pred[i] += receive_extend(br, t);
+                        }
                         blk[0] = (int16_t)pred[i];
                         last = 0;
                         for (int k = 1; k < 64;) {
