@@ -78,7 +78,7 @@ MAX_DEVICES = 8
 class flgpu_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_batch", C.c_uint32), ("flush_timeout_us", C.c_uint32),
                 ("profile", C.c_uint32), ("queue_lanes", C.c_uint32), ("n_devices", C.c_uint32), ("use_embedded_profile", C.c_uint32),
-                ("reserved", C.c_uint32 * 1),
+                ("decode_threads", C.c_uint32),
                 ("devices", C.c_int32 * MAX_DEVICES)]
 
 

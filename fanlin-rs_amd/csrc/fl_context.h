@@ -215,6 +215,9 @@ struct flgpu_ctx {
     std::mutex adm_mu;
     std::condition_variable adm_cv;
     uint32_t admitted = 0;
+    std::mutex dec_mu;                 // host-side JPEG decoding: at most dec_limit callers at a time (flgpu_config.decode_threads)
+    std::condition_variable dec_cv;
+    uint32_t decoding = 0, dec_limit = 0;
     std::mutex qmu;
     std::condition_variable qcv, qdone;
     std::deque<fl::Request *> queue;

@@ -6,6 +6,7 @@
 // launches; a context that spans several GPUs splits every flushed batch -- and every batch entry point -- into one
 // contiguous shard per device, balanced by algorithmic bytes (W*H*C + output bytes), and returns results in
 // request order.  Images are independent, so no pixel ever crosses between devices.
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -69,6 +70,28 @@ void pin_release(flgpu_ctx *c, PinBlock &b)
 } // namespace fl
 
 namespace {
+
+// CPUs this process may really use: the cgroup's quota where there is one (a container's share of a big host), else the affinity mask.
+uint32_t usable_cpus()
+{
+    uint32_t n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (uint32_t)CPU_COUNT(&set);
+    if (!n) n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota> <period>" or "max <period>"
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (quota + period - 1) / period));
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // cgroup v1
+        long long quota = 0, period = 100000;
+        if (fscanf(g, "%lld", &quota) == 1 && quota > 0) {
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+            n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (quota + period - 1) / period));
+        }
+        fclose(g);
+    }
+    return std::max(1u, n);
+}
 
 uint32_t lanes_per_device(const flgpu_ctx *c) { return std::min<uint32_t>(std::max<uint32_t>(c->cfg.queue_lanes ? c->cfg.queue_lanes : 3u, 1u), 8u); }
 uint32_t batch_per_device(const flgpu_ctx *c) { return c->cfg.max_batch ? c->cfg.max_batch : 32u; } // measured: 3 lanes x 32 keeps the PCIe link busiest
@@ -432,7 +455,19 @@ try {
         // the serial half of the decoder (parsing + Huffman) on the caller's thread, straight into pinned memory:
         // concurrent requests decode in parallel and only the coefficient blob crosses PCIe
         size_t used = 0;
-        const int jrc = jpeg_source_to_blob(c, src, static_cast<uint8_t *>(r.in.p), r.in.cap, &r.jhdr, &used);
+        int jrc;
+        {
+            // no more decoders at once than this process has CPUs: sixty-four runnable decoders on sixteen CPUs all finish late (p99 of
+            // the request 60 ms against 20 ms with 32 callers, profiles/r03_latency_jpeg_sources.txt); waiting in line costs nothing
+            {
+                std::unique_lock<std::mutex> lk(c->dec_mu);
+                if (!c->dec_limit) c->dec_limit = c->cfg.decode_threads ? c->cfg.decode_threads : usable_cpus();
+                c->dec_cv.wait(lk, [&] { return c->decoding < c->dec_limit; });
+                c->decoding++;
+            }
+            struct Turn { flgpu_ctx *c; ~Turn() { { std::lock_guard<std::mutex> lk(c->dec_mu); c->decoding--; } c->dec_cv.notify_one(); } } turn{c};
+            jrc = jpeg_source_to_blob(c, src, static_cast<uint8_t *>(r.in.p), r.in.cap, &r.jhdr, &used);
+        }
         if (jrc) { c->staging.fetch_sub(1, std::memory_order_acq_rel); give_back(); return jrc; }
         r.jpeg = true;
         if (r.jhdr.nc == 4 && c->cfg.use_embedded_profile) r.icc.swap(jinfo.icc);

@@ -163,7 +163,10 @@ typedef struct flgpu_config {
                                   results come back in request order.  An ordinal may repeat (two shards on one GPU). */
     uint32_t use_embedded_profile; /* config `use_embedded_profile` (src/handler.rs:19,446-458): CMYK / YCCK JPEG SOURCES decoded by the
                                       library are converted with their own embedded ICC profile when they carry a usable one */
-    uint32_t reserved[1];
+    uint32_t decode_threads;   /* flgpu_transform with FLGPU_IMG_JPEG_SOURCE: callers that may run the host half of the decoder (Huffman
+                                  decoding, ~2 ms of CPU per 1080p file) at the same time; the others wait their turn.  0 = the CPUs this
+                                  process may use (cgroup quota / affinity mask): more runnable decoders than CPUs only lengthens every
+                                  request's decode -- the reference bounds its in-flight requests the same way (max_clients, src/main.rs:108-110) */
     int32_t devices[FLGPU_MAX_DEVICES];
 } flgpu_config;
 

@@ -18,7 +18,7 @@ pub struct FlPlan { src_w: u32, src_h: u32, mid_c: u32, resampled: u32, resized_
                     plane_w: u32, plane_h: u32, chroma_w: u32, chroma_h: u32, pixel_bytes: u64, out_bytes: u64, max_out_bytes: u64 }
 #[repr(C)] #[derive(Default)]
 pub struct FlConfig { device: i32, max_batch: u32, flush_timeout_us: u32, profile: u32, queue_lanes: u32, n_devices: u32,
-                      use_embedded_profile: u32 /* config `use_embedded_profile`, handler.rs:19 */, reserved: [u32; 1], devices: [i32; 8] }
+                      use_embedded_profile: u32 /* config `use_embedded_profile`, handler.rs:19 */, decode_threads: u32 /* 0 = the CPUs the process may use */, devices: [i32; 8] }
 
 pub const FE_NONE: u8 = 0;
 pub const FE_JFIF444: u8 = 1;
