@@ -37,6 +37,12 @@ EXTRA = {
     "config1_1080p_photo_to_300x200": (1080, 1920, 3, "photo", dict(w=300, h=200)),
     "config1_1080p_photo_crop": (1080, 1920, 3, "photo", dict(w=300, h=200, crop=True)),
     "rgba_1080p_to_300x169": (1080, 1920, 4, "uniform", dict(w=300, h=169)),
+    # round 3's planner: three unequal strips, and the wide LDS layout for ratios below ~4.7
+    "mfma_1080p_to_256x144": (1080, 1920, 3, "photo", dict(w=256, h=144)),
+    "mfma_1080p_to_640x360": (1080, 1920, 3, "photo", dict(w=640, h=360)),
+    # the tiled two-pass kernel (ratios below ~2 and up-scales), whose bytes must be the crate's up to the order of the f32 sums
+    "tile_720p_to_800x450": (720, 1280, 3, "photo", dict(w=800, h=450)),
+    "tile_thumbnail_upscale": (120, 160, 3, "photo", dict(w=300, h=200)),
 }
 EXACT = {"inverse_only", "letterbox_only_rgb", "gray_only_rgba", "orient3_only"}  # no f32 resampling involved
 JPEG_QUALITIES = (75, 85)
