@@ -126,6 +126,7 @@ def main():
             ("tile_kernel_pmc.txt", "tools/experiments/tile_pmc.sh 2000 1000 128"),
             ("jpeg_decoder_ab.txt", "tools/experiments/jpeg_source_rate.py with the library swapped between runs"),
             ("config4_mixed.txt", "tools/experiments/config4_mixed.py"),
+            ("latency_jpeg_sources.txt", "tools/experiments/jpeg_source_rate.py + tools/microbench/jpegdec/decode_bench.cpp"),
             ("generic_sweep_notile.txt", "FLGPU_NO_TILE=1 tools/experiments/generic_sweep.py (the two-kernel form through HBM)"),
         ]
         for name, how in others:
