@@ -485,7 +485,8 @@ class State:
     """
 
     def __init__(self, device: int = -1, max_batch: int = 0, flush_timeout_us: int = 0, profile: bool = False,
-                 queue_lanes: int = 0, devices: Optional[Sequence[int]] = None, use_embedded_profile: bool = False):
+                 queue_lanes: int = 0, devices: Optional[Sequence[int]] = None, use_embedded_profile: bool = False,
+                 decode_threads: int = 0):
         """``devices``: two or more HIP ordinals make ONE context that shards every batch across those GPUs (an ordinal
         may repeat: two shards on one GPU); None / one entry = a single-device context."""
         lib = load_library()
@@ -493,6 +494,7 @@ class State:
         cfg.device, cfg.max_batch, cfg.flush_timeout_us, cfg.profile = device, max_batch, flush_timeout_us, int(profile)
         cfg.queue_lanes = queue_lanes
         cfg.use_embedded_profile = int(use_embedded_profile)
+        cfg.decode_threads = decode_threads  # callers that may run the host half of the JPEG decoder at once (0 = the CPUs the process may use)
         if devices:
             if len(devices) > MAX_DEVICES:
                 raise ValueError("at most 8 devices")

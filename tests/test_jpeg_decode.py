@@ -484,6 +484,27 @@ def test_jpeg_sources_through_the_queue_and_batches(fl, gpu_state, oracle):
 
 
 @pytest.mark.gpu
+def test_one_decoder_at_a_time_serves_every_caller(fl, oracle):
+    """flgpu_config.decode_threads bounds how many callers run the host Huffman decoder at once; with 1 the sixteen callers here take
+    turns -- nobody is dropped, nobody waits for ever, and the results are those of the unbounded context."""
+    import threading
+    files = [make_jpeg(96 + 8 * i, 128 + 8 * i, 3, 75, i % 3, 0, index=500 + i) for i in range(4)]
+    p = fl.make_params(40, 30)
+    with fl.State(device=0, decode_threads=1) as st:
+        want = [st.process_pixels(oracle.jpeg_decode(f), p) for f in files]
+        out = [None] * 64
+        def worker(t):
+            for i in range(t, 64, 16):
+                out[i] = st.process_jpeg_pixels(files[i % 4], p)
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+        [t.start() for t in ts]
+        [t.join(timeout=120) for t in ts]
+        assert not any(t.is_alive() for t in ts)
+        for i in range(64):
+            assert np.array_equal(out[i], want[i % 4])
+
+
+@pytest.mark.gpu
 def test_exif_orientation_is_applied_by_process_jpeg(fl, gpu_state, oracle):
     data = make_jpeg(90, 60, q=92, exif_orientation=6, index=77)
     px = oracle.jpeg_decode(data)
