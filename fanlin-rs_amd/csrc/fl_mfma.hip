@@ -6,6 +6,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <type_traits>
+#include <algorithm>
+#include <map>
+#include <vector>
 
 #include "fl_mfma.h"
 #include "fl_pixel.h"
@@ -425,6 +428,13 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         d[6] = __builtin_amdgcn_s_memrealtime() - tm_rt0;
         d[7] = tm_rt0;
     }
+    if (tid == 0u) { // every workgroup: when it ran and where (XCC_ID: hardware register 20, bits 3:0; HW_ID: register 4, CU 11:8, SH 12, SE 15:13)
+        unsigned long long *d = dbg + 3u * 64u + (size_t)blockIdx.x * 4u;
+        d[0] = tm_rt0;
+        d[1] = __builtin_amdgcn_s_memrealtime();
+        d[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        d[3] = __builtin_readcyclecounter() - tm_t0;
+    }
 #endif
     __syncthreads(); // every wave has added its sums of the last tile
     if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
@@ -447,7 +457,9 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 #ifdef FL_MFMA_TIMING
     static unsigned long long *dbg = nullptr;
     static int launches = 0;
-    if (!dbg) { (void)hipMalloc(&dbg, 3 * 64 * 8); (void)hipMemset(dbg, 0, 3 * 64 * 8); }
+    constexpr size_t kDbgWgs = 16384;
+    if (!dbg) { (void)hipMalloc(&dbg, (3 * 64 + kDbgWgs * 4) * 8); (void)hipMemset(dbg, 0, (3 * 64 + kDbgWgs * 4) * 8); }
+    if (m.nitems > kDbgWgs) return hipErrorInvalidValue;
     resample_mfma_kernel<CS, LB, HLDS, WIDE><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word, dbg);
     if ((++launches == 5 || launches == 100) && m.nitems > 2900) {
         unsigned long long h[3 * 64];
@@ -459,6 +471,29 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
                 fprintf(stderr, "mfma timing launch %d wg %d wave %d: wait %llu, reads+request %llu, vertical mfma %llu, tile stage %llu, total %llu cycles (%llu before the loop) in %.2f us = %.0f MHz, started at %.2f us\n",
                         launches, b, w, d[0], d[1], d[2], d[3], d[4], d[5], d[6] * 0.01, d[6] ? d[4] / (d[6] * 0.01) : 0.0, (d[7] - h[7]) * 0.01);
             }
+    }
+    if (launches == 100 && m.nitems > 2900) { // where and when every workgroup of this launch ran
+        std::vector<unsigned long long> w((size_t)m.nitems * 4);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(w.data(), dbg + 3 * 64, w.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (uint32_t i = 0; i < m.nitems; ++i) { t0 = std::min(t0, w[4 * i]); t1 = std::max(t1, w[4 * i + 1]); }
+        double xend[8] = {0}, xdur[8] = {0}, xcyc[8] = {0}; unsigned xn[8] = {0};
+        std::map<unsigned, unsigned> per_cu;
+        double dmin = 1e30, dmax = 0, dsum = 0;
+        for (uint32_t i = 0; i < m.nitems; ++i) {
+            const unsigned xcc = (unsigned)(w[4 * i + 2] >> 32) & 15u, hw = (unsigned)w[4 * i + 2];
+            const double dur = (double)(w[4 * i + 1] - w[4 * i]) * 0.01, end = (double)(w[4 * i + 1] - t0) * 0.01;
+            xend[xcc & 7] = std::max(xend[xcc & 7], end); xdur[xcc & 7] += dur; xcyc[xcc & 7] += (double)w[4 * i + 3]; xn[xcc & 7]++;
+            per_cu[(xcc << 16) | (hw & 0xff00u)]++;
+            dmin = std::min(dmin, dur); dmax = std::max(dmax, dur); dsum += dur;
+        }
+        unsigned cmin = ~0u, cmax = 0;
+        for (auto &kv : per_cu) { cmin = std::min(cmin, kv.second); cmax = std::max(cmax, kv.second); }
+        fprintf(stderr, "mfma wg times: launch span %.1f us; workgroup duration min %.1f mean %.1f max %.1f us; %zu CUs ran %u .. %u workgroups each\n",
+                (double)(t1 - t0) * 0.01, dmin, dsum / m.nitems, dmax, per_cu.size(), cmin, cmax);
+        for (int x = 0; x < 8; ++x)
+            fprintf(stderr, "  xcc %d: %u workgroups, mean %.1f us (%.0f cycles), last one ends at %.1f us\n", x, xn[x], xn[x] ? xdur[x] / xn[x] : 0.0, xn[x] ? xcyc[x] / xn[x] : 0.0, xend[x]);
     }
 #else
     resample_mfma_kernel<CS, LB, HLDS, WIDE><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word);

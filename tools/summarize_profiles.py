@@ -122,7 +122,9 @@ def main():
             ("power_probe.txt", "tools/experiments/power_probe.sh (rocm-smi power / clock samples while one kernel runs back to back)"),
             ("store_probe.txt", "tools/microbench/store_probe.hip"),
             ("halfblock_probe.txt", "tools/microbench/halfblock_probe.hip"),
-            ("placement_probes.txt", "tools/experiments/placement_probe2.py, placement_probe3.py, placement_probe4.py"),
+            ("placement_probes.txt", "tools/experiments/placement_probe2.py ... placement_probe5.py"),
+            ("xcd_and_placement_counters.txt", "tools/experiments/wgtime_runs.sh (-DFL_MFMA_TIMING build) and tools/experiments/placement_pmc.sh"),
+            ("config2_pmc.txt", "tools/experiments/config2_pmc.sh"),
             ("tile_kernel_pmc.txt", "tools/experiments/tile_pmc.sh 2000 1000 128"),
             ("jpeg_decoder_ab.txt", "tools/experiments/jpeg_source_rate.py with the library swapped between runs"),
             ("config4_mixed.txt", "tools/experiments/config4_mixed.py"),
