@@ -628,10 +628,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     const bool has_results = !fe_groups.empty();
     bool has_err_word = false;
     for (auto &L : s1_launches) has_err_word |= (L.k.kind & 255u) == S1_MFMA;
-    if (has_results || has_err_word) {
-        FL_HIP(c, c->d_status.reserve(n * 8 + 8), "result words");
-        FL_HIP(c, hipMemsetAsync(c->d_status.p, 0, n * 8 + 8, st), "result clear");
-    }
+    // (they live at the end of the batch's descriptor block and arrive zeroed with it: a clear of their own was two fill kernels
+    // and two engine switches between one batch's last kernel and the next one's first)
+    std::vector<size_t> jjob_idx, fjob_idx; // image of every encoder / front-end job: its result words are addressed once the block's place is known
     uint32_t mfma_spin_limit = kMfmaDefaultSpinLimit;
     if (const char *e = getenv("FLGPU_MFMA_SPIN_LIMIT")) mfma_spin_limit = (uint32_t)strtoul(e, nullptr, 10); // tests: 0 = every bounded wait expires
     std::vector<JpegJob> jjobs;
@@ -647,7 +646,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 j.meta = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_coef.p) + w.jpeg_coef_off);
                 j.unit_off = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_off.p) + w.jpeg_off_off);
                 j.acbits = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_jpeg_raw.p) + w.jpeg_raw_off);
-                j.result = static_cast<uint32_t *>(c->d_status.p) + 2 * idx;
+                j.result = nullptr; jjob_idx.push_back(idx);
                 j.w = pl.out_w; j.h = pl.out_h; j.c = pl.out_c;
                 j.bx = pl.plane_w / 8u; j.by = pl.plane_h / 8u;
                 j.tab_off = w.jpeg_tab;
@@ -664,7 +663,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             FrontendJob f; memset(&f, 0, sizeof(f));
             f.src = w.blur_dst ? w.blur_dst : w.s1_dst;
             f.dst = w.final_dst;
-            f.status = static_cast<uint32_t *>(c->d_status.p) + 2 * idx;
+            f.status = nullptr; fjob_idx.push_back(idx);
             f.w = pl.out_w; f.h = pl.out_h; f.c = pl.out_c;
             f.plane_w = pl.plane_w; f.plane_h = pl.plane_h; f.chroma_w = pl.chroma_w; f.chroma_h = pl.chroma_h;
             if (f.c != 4 || ((uintptr_t)f.src & 3u) || ((uintptr_t)f.dst & 3u)) F.rgba = false;
@@ -681,7 +680,9 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     const size_t jobs_b = align_up(jobs.size() * sizeof(Job), 256), items_b = align_up(items.size() * sizeof(StreamItem), 256),
                  fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256), jjobs_b = align_up(jjobs.size() * sizeof(JpegJob), 256),
                  mitems_b = align_up(mitems.size() * sizeof(MfmaItem), 256);
-    const size_t desc_b = jobs_b + items_b + fjobs_b + jjobs_b + mitems_b;
+    const size_t stat_off = jobs_b + items_b + fjobs_b + jjobs_b + mitems_b, stat_b = (has_results || has_err_word) ? align_up(n * 8 + 8, 256) : 0;
+    const size_t desc_b = stat_off + stat_b;
+    uint32_t *status_dev = nullptr;
     const Job *d_jobs = nullptr; const StreamItem *d_items = nullptr; const FrontendJob *d_fjobs = nullptr; const JpegJob *d_jjobs = nullptr;
     const MfmaItem *d_mitems = nullptr;
     DescSlot *slot = nullptr;
@@ -693,12 +694,25 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         FL_HIP(c, slot->host.reserve(desc_b), "pinned descriptors");
         FL_HIP(c, slot->dev.reserve(desc_b), "device descriptors");
         char *hp = static_cast<char *>(slot->host.p);
+        if (stat_b) {
+            status_dev = reinterpret_cast<uint32_t *>(static_cast<char *>(slot->dev.p) + stat_off);
+            memset(hp + stat_off, 0, stat_b);
+            for (size_t k = 0; k < jjobs.size(); ++k) jjobs[k].result = status_dev + 2 * jjob_idx[k];
+            for (size_t k = 0; k < fjobs.size(); ++k) fjobs[k].status = status_dev + 2 * fjob_idx[k];
+        }
         if (!jobs.empty()) memcpy(hp, jobs.data(), jobs.size() * sizeof(Job));
         if (!items.empty()) memcpy(hp + jobs_b, items.data(), items.size() * sizeof(StreamItem));
         if (!fjobs.empty()) memcpy(hp + jobs_b + items_b, fjobs.data(), fjobs.size() * sizeof(FrontendJob));
         if (!jjobs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b, jjobs.data(), jjobs.size() * sizeof(JpegJob));
         if (!mitems.empty()) memcpy(hp + jobs_b + items_b + fjobs_b + jjobs_b, mitems.data(), mitems.size() * sizeof(MfmaItem));
-        FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, st), "descriptor upload");
+        // The block goes up on the context's upload stream and the batch's stream waits for the event: the slot is free (its last
+        // batch has ended, see above), so the copy runs while the PREVIOUS batch's kernels do, and this batch's first kernel follows
+        // that one's last without a copy engine in between.
+        if (!c->up_stream) FL_HIP(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking), "upload stream");
+        if (!slot->uploaded) FL_HIP(c, hipEventCreateWithFlags(&slot->uploaded, hipEventDisableTiming), "event");
+        FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, c->up_stream), "descriptor upload");
+        FL_HIP(c, hipEventRecord(slot->uploaded, c->up_stream), "event record");
+        FL_HIP(c, hipStreamWaitEvent(st, slot->uploaded, 0), "descriptor upload wait");
         char *dp = static_cast<char *>(slot->dev.p);
         d_jobs = reinterpret_cast<const Job *>(dp);
         d_items = reinterpret_cast<const StreamItem *>(dp + jobs_b);
@@ -741,7 +755,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
             m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
             m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.wide = (L.k.kind >> 9) & 1u; m.max_nout = L.max_nout;
-            m.spin_limit = mfma_spin_limit; m.err_word = static_cast<uint32_t *>(c->d_status.p) + 2 * n;
+            m.spin_limit = mfma_spin_limit; m.err_word = status_dev + 2 * n;
             {
                 ProfileScope ps(c, st, 0);
                 FL_HIP(c, launch_mfma(m, st), "matrix-pipe resample kernel");
@@ -805,6 +819,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         dsts[i].bytes = fe == FLGPU_FE_JPEG ? 0 : pl.out_bytes; // an encoded stream's length is a result word: flgpu_batch_results
     }
     c->last_n = n;
+    c->last_status_dev = status_dev;
     c->last_has_results = has_results;
     c->last_has_err_word = has_err_word;
     c->last_fe.resize(n);
@@ -820,8 +835,8 @@ int collect_results(flgpu_ctx *c, size_t n, flgpu_image *dsts, hipStream_t st)
 {
     if ((!c->last_has_results && !c->last_has_err_word) || n != c->last_n) { FL_HIP(c, hipStreamSynchronize(st), "batch sync"); return FLGPU_OK; }
     FL_HIP(c, c->h_results.reserve(n * 8 + 8), "pinned result words");
-    if (c->last_has_results) FL_HIP(c, hipMemcpyAsync(c->h_results.p, c->d_status.p, n * 8 + 8, hipMemcpyDeviceToHost, st), "result words D2H");
-    else FL_HIP(c, hipMemcpyAsync(static_cast<char *>(c->h_results.p) + n * 8, static_cast<char *>(c->d_status.p) + n * 8, 8, hipMemcpyDeviceToHost, st), "error word D2H");
+    if (c->last_has_results) FL_HIP(c, hipMemcpyAsync(c->h_results.p, c->last_status_dev, n * 8 + 8, hipMemcpyDeviceToHost, st), "result words D2H");
+    else FL_HIP(c, hipMemcpyAsync(static_cast<char *>(c->h_results.p) + n * 8, reinterpret_cast<char *>(c->last_status_dev) + n * 8, 8, hipMemcpyDeviceToHost, st), "error word D2H");
     FL_HIP(c, hipStreamSynchronize(st), "batch sync");
     const uint32_t *r = static_cast<const uint32_t *>(c->h_results.p);
     if (c->last_has_err_word && r[2 * n]) {

@@ -404,9 +404,10 @@ void flgpu_destroy(flgpu_ctx *c)
     (void)hipDeviceSynchronize();
     resolve_pending(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (auto &s : c->slots) { s.host.release(); s.dev.release(); if (s.done) (void)hipEventDestroy(s.done); }
+    for (auto &s : c->slots) { s.host.release(); s.dev.release(); if (s.done) (void)hipEventDestroy(s.done); if (s.uploaded) (void)hipEventDestroy(s.uploaded); }
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->last_done) (void)hipEventDestroy(c->last_done);
-    c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_tmp_o.release(); c->d_tmp_al.release(); c->d_status.release(); c->d_in.release(); c->d_out.release();
+    c->d_mid.release(); c->d_tmp_a.release(); c->d_tmp_b.release(); c->d_tmp_o.release(); c->d_tmp_al.release(); c->d_in.release(); c->d_out.release();
     c->d_jpeg_coef.release(); c->d_jpeg_off.release(); c->d_jpeg_raw.release();
     c->d_dec.release(); c->d_decjobs.release(); c->h_decjobs.release();
     release_cmyk(c);

@@ -52,6 +52,7 @@ struct DescSlot {
     PinnedBuf host;
     DeviceBuf dev;
     hipEvent_t done = nullptr;
+    hipEvent_t uploaded = nullptr; // the block has reached the device (recorded on the context's upload stream)
     bool busy = false;
 };
 
@@ -148,7 +149,9 @@ struct flgpu_ctx {
 
     fl::DescSlot slots[4];
     int next_slot = 0;
-    fl::DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_tmp_o, d_tmp_al, d_status;
+    fl::DeviceBuf d_mid, d_tmp_a, d_tmp_b, d_tmp_o, d_tmp_al;
+    uint32_t *last_status_dev = nullptr; // result words + device error word of the batch enqueued last: they live at the end of its descriptor block
+    hipStream_t up_stream = nullptr;     // descriptor blocks travel on a stream of their own, so that batch i + 1's block is on the device before batch i's kernels end
     fl::DeviceBuf d_in, d_out;
     fl::DeviceBuf d_dec, d_decjobs;                    // JPEG decode: planes + decoded pixels of a batch, job descriptors
     fl::PinnedBuf h_decjobs;
