@@ -5,7 +5,7 @@ import sys, os, io
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import oracle_lib, synth
+import oracle_lib, parity, synth
 from bench import load_package
 fl = load_package(); oracle = oracle_lib.load()
 n, seed = int(sys.argv[1]), int(sys.argv[2])
@@ -49,12 +49,20 @@ for i in range(n):
         kw = dict(w=dims[0] if dims else None, h=dims[1] if dims else None, fill=q.fill_color(), crop=q.cropping(), grayscale=q.grayscale(),
                   inverse=q.inverse(), blur_sigma=0.0 if gif else q.blur(), orientation=0 if gif else orient,
                   filter=oracle_lib.FILTER_NEAREST if gif else oracle_lib.FILTER_LANCZOS3)
-        px = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **kw)
+        if gif:
+            px = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **kw)
+        else:
+            # the pixels this request gives when sent alone, after they have cleared the bar of the kernel that served them
+            # (tests/parity.py: bit-exact for the streaming / tiled kernels, <= 1 LSB for the matrix-pipe kernel)
+            try:
+                px = parity.expected_pixels(fl, st, oracle, img, **{k: v for k, v in kw.items() if k != "filter"})
+            except AssertionError as e:
+                print("BAR", str(e)[:200]); px = None
         webp = (not gif) and q.use_webp() and accept.webp_accepted()
         avif = (not gif) and (not webp) and q.use_avif() and accept.avif_accepted()
         qual = min(max(q.quality(), 1), 100)
         want_mime = "image/webp" if webp else "image/avif" if avif else fl.MIME[fmt]
-        if mime != want_mime: ok = False
+        if px is None or mime != want_mime: ok = False
         elif (webp or (fmt == fl.IN_WEBP and not avif)) and qual < 100:
             rgba = px if px.shape[2] == 4 else (np.concatenate([px[:, :, :1]] * 3 + [np.full(px.shape[:2] + (1,), 255, np.uint8)], 2) if px.shape[2] == 1 else
                                                 np.concatenate([px[:, :, :1]] * 3 + [px[:, :, 1:]], 2) if px.shape[2] == 2 else
