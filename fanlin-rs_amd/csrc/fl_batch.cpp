@@ -705,16 +705,21 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (!fjobs.empty()) memcpy(hp + jobs_b + items_b, fjobs.data(), fjobs.size() * sizeof(FrontendJob));
         if (!jjobs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b, jjobs.data(), jjobs.size() * sizeof(JpegJob));
         if (!mitems.empty()) memcpy(hp + jobs_b + items_b + fjobs_b + jjobs_b, mitems.data(), mitems.size() * sizeof(MfmaItem));
-        // The block goes up on the context's upload stream and the batch's stream waits for the event: the slot is free (its last
-        // batch has ended, see above), so the copy runs while the PREVIOUS batch's kernels do, and this batch's first kernel follows
-        // that one's last without a copy engine in between.
-        if (!c->up_stream) FL_HIP(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking), "upload stream");
-        if (!slot->uploaded) FL_HIP(c, hipEventCreateWithFlags(&slot->uploaded, hipEventDisableTiming), "event");
-        FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, c->up_stream), "descriptor upload");
-        FL_HIP(c, hipEventRecord(slot->uploaded, c->up_stream), "event record");
-        // (the HOST waits the ~15 us the 130 KB take: a device-side wait on the event is a barrier packet between the previous
-        // batch's last kernel and this one's first, 7 us of idle chip per batch; the host has the previous batch's 2 ms to spare)
-        FL_HIP(c, hipEventSynchronize(slot->uploaded), "descriptor upload wait");
+        // While a previous batch is still running, the block goes up on the context's upload stream: the slot is free (its last
+        // batch has ended, see above), so the copy runs under that batch's kernels, and this batch's first kernel follows its
+        // last one without a copy engine in between.  A lone request on an idle device sends the block down its own stream (no
+        // second stream, no wait: the 15 us would be 3 % of its latency).
+        if (c->last_done && hipEventQuery(c->last_done) == hipErrorNotReady) {
+            if (!c->up_stream) FL_HIP(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking), "upload stream");
+            if (!slot->uploaded) FL_HIP(c, hipEventCreateWithFlags(&slot->uploaded, hipEventDisableTiming), "event");
+            FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, c->up_stream), "descriptor upload");
+            FL_HIP(c, hipEventRecord(slot->uploaded, c->up_stream), "event record");
+            // (the HOST waits the ~15 us the 130 KB take: a device-side wait on the event is a barrier packet between the previous
+            // batch's last kernel and this one's first, 7 us of idle chip per batch; the host has the previous batch's 2 ms to spare)
+            FL_HIP(c, hipEventSynchronize(slot->uploaded), "descriptor upload wait");
+        } else {
+            FL_HIP(c, hipMemcpyAsync(slot->dev.p, hp, desc_b, hipMemcpyHostToDevice, st), "descriptor upload");
+        }
         char *dp = static_cast<char *>(slot->dev.p);
         d_jobs = reinterpret_cast<const Job *>(dp);
         d_items = reinterpret_cast<const StreamItem *>(dp + jobs_b);
