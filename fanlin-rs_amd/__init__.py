@@ -110,7 +110,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
     "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version", "flgpu_build_info",
-    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob", "flgpu_debug_mfma_plan",
+    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob", "flgpu_debug_mfma_plan", "flgpu_debug_mfma_plan_arith",
 )
 
 _lib = None
@@ -197,6 +197,7 @@ def load_library() -> C.CDLL:
                                            C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_uint64)]
     lib.flgpu_debug_stream_schedulable.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
     lib.flgpu_debug_mfma_plan.argtypes = [C.c_uint32] * 9 + [C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    lib.flgpu_debug_mfma_plan_arith.argtypes = [C.c_uint32] * 10 + [C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -421,14 +422,15 @@ def debug_axis_table(in_size: int, out_size: int, gaussian: bool = False, sigma:
     return (np.array(left, dtype=np.uint32), np.array(count, dtype=np.uint32), np.array(w[: total.value], dtype=np.float32))
 
 
-def debug_mfma_plan(sw: int, sh: int, channels: int, rw: int, rh: int, crop=None) -> Optional[dict]:
-    """Builds and self-checks the matrix-pipe kernel's tables on the host (csrc/fl_query.cpp flgpu_debug_mfma_plan); None if
-    the geometry does not fit the kernel.  crop = (cx, cy, cw, ch) in resized coordinates, default the whole picture."""
+def debug_mfma_plan(sw: int, sh: int, channels: int, rw: int, rh: int, crop=None, packed: bool = False) -> Optional[dict]:
+    """Builds and self-checks the matrix-pipe kernel's tables on the host (csrc/fl_query.cpp flgpu_debug_mfma_plan_arith); None
+    if the geometry does not fit the kernel.  crop = (cx, cy, cw, ch) in resized coordinates, default the whole picture.
+    packed: the tables of rounds 2-3's arithmetic (FLGPU_MFMA_ARITH=packed) instead of the full-width one."""
     lib = load_library()
     cx, cy, cw, ch = crop if crop else (0, 0, rw, rh)
     info = (C.c_uint32 * 8)()
     err = (C.c_double * 2)()
-    if not lib.flgpu_debug_mfma_plan(sw, sh, channels, rw, rh, cx, cy, cw, ch, info, err):
+    if not lib.flgpu_debug_mfma_plan_arith(sw, sh, channels, rw, rh, cx, cy, cw, ch, 0 if packed else 1, info, err):
         return None
     keys = ("tiles", "k_blocks", "strips", "max_operands", "hs", "tail", "bad_horizontal", "bad_vertical")
     d = dict(zip(keys, (int(x) for x in info)))
@@ -644,6 +646,7 @@ class State:
         def run(stream: int = 0):
             _check(lib.flgpu_transform_batch_device(ctx, n, srcs, ps, dsts, C.c_void_p(stream), flags), ctx)
         run._keep = (srcs, dsts, ps)
+        self._keep = run._keep   # (so that batch_results() can collect the last run of a prepared batch too)
         return run
 
     def ycck_to_cmyk(self, raw: np.ndarray) -> np.ndarray:

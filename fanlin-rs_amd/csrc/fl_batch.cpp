@@ -378,6 +378,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     const bool force_generic = env_generic && env_generic[0] == '1';
     const char *env_no_mfma = getenv("FLGPU_NO_MFMA"); // tests / A-B runs: keep the streaming kernel (read per batch, so a test can flip it)
     const bool no_mfma = env_no_mfma && env_no_mfma[0] == '1';
+    // which arithmetic the matrix-pipe kernel computes in (fl_mfma.h): the full-width one unless FLGPU_MFMA_ARITH=packed asks for
+    // rounds 2-3's (A/B runs and the tests that keep the packed kernel's bars; read per batch)
+    const char *env_arith = getenv("FLGPU_MFMA_ARITH");
+    const MfmaArith mfma_arith = (env_arith && env_arith[0] == 'p') ? MFMA_ARITH_PACKED : MFMA_ARITH_FULL;
     const char *env_no_tile = getenv("FLGPU_NO_TILE");
     const bool no_tile = env_no_tile && env_no_tile[0] == '1';
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -402,7 +406,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 uint32_t nbands = 1;
                 if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
                 else if (n_resample < 128) nbands = (uint32_t)std::min<size_t>(16, (256 + n_resample * 3 - 1) / (n_resample * 3));
-                MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
+                MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs, mfma_arith);
                 if (mp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
                 if (mp->ok) { w.s1 = S1_MFMA; w.mplan = mp; w.mitems = &mp->items_for(nbands); continue; }
             }
@@ -484,7 +488,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
-        if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u) | (w.mplan->wide ? 1u << 9 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u) | (w.mplan->wide ? 1u << 9 : 0u) | (w.mplan->full ? 1u << 10 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         else if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         if (w.p->blur_sigma > 0.0f) {
             const uint32_t ce = blur_channels(w);
@@ -761,7 +765,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         } else if ((L.k.kind & 255u) == S1_MFMA) {
             LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
             m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
-            m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.wide = (L.k.kind >> 9) & 1u; m.max_nout = L.max_nout;
+            m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.wide = (L.k.kind >> 9) & 1u; m.full = (L.k.kind >> 10) & 1u; m.max_nout = L.max_nout;
             m.spin_limit = mfma_spin_limit; m.err_word = status_dev + 2 * n;
             {
                 ProfileScope ps(c, st, 0);

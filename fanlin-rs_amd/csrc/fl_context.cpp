@@ -129,15 +129,16 @@ const std::vector<MfmaItem> &MfmaPlan::items_for(uint32_t nbands)
 
 // Tables of the matrix-pipe kernel for one geometry, or ok = false if the kernel cannot or should not take it.
 MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
-                        uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs)
+                        uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs, MfmaArith arith)
 {
-    MfmaPlanKey key{vk, hk, cx, cy, cw, ch, cs};
+    MfmaPlanKey key{vk, hk, cx, cy, cw, ch, cs, (uint32_t)arith};
     auto it = c->mfma_plans.find(key);
     if (it != c->mfma_plans.end()) return &it->second;
     MfmaPlan plan;
     HostMfmaPlan hp;
-    choose_mfma_plan(va, ha, cs, cx, cy, cw, ch, hp);
+    choose_mfma_plan(va, ha, cs, cx, cy, cw, ch, hp, arith);
     bool ok = hp.ok;
+    plan.full = arith == MFMA_ARITH_FULL;
     if (ok) {
         plan.wide = hp.wide;
         plan.ops_in_lds = !hp.wide;
@@ -164,7 +165,7 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
     }
     if (ok) {
         MfmaVPlan vp{};
-        vp.ntiles = hp.ntiles; vp.nkb = hp.nkb; vp.y0 = hp.y0; vp.rows = hp.rows; vp.tail = hp.tail;
+        vp.ntiles = hp.ntiles; vp.nkb = hp.nkb; vp.y0 = hp.y0; vp.rows = hp.rows; vp.tail = hp.tail; vp.nterms = plan.full ? 3u : 2u;
         plan.vplan_off = arena_append(c, nullptr, sizeof(MfmaVPlan) / 4);
         vp.meta_off = arena_append(c, hp.vmeta.data(), hp.vmeta.size());
         vp.w_off = arena_append(c, hp.vw.data(), hp.vw.size());
@@ -185,8 +186,8 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
     }
     plan.ok = ok;
     if (getenv("FLGPU_DEBUG_MFMA")) {
-        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d, wide %d;",
-                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds, (int)plan.wide);
+        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d, wide %d, full-width arithmetic %d;",
+                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds, (int)plan.wide, (int)plan.full);
         for (auto &S : hp.strips) fprintf(stderr, " strip [%u,%u) byte0 %u hs %u ops %u", S.hdr.x0, S.hdr.x1, S.hdr.byte0, S.hdr.hs, S.hdr.n_ops);
         fprintf(stderr, "\n");
     }

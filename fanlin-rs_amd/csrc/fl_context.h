@@ -78,7 +78,8 @@ struct StreamPlan {
 struct MfmaPlanKey {
     AxisKey v, h;
     uint32_t cx, cy, cw, ch, cs;
-    bool operator<(const MfmaPlanKey &o) const { return std::tie(v, h, cx, cy, cw, ch, cs) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.cs); }
+    uint32_t arith; // MfmaArith: the two arithmetics of the kernel have different tables
+    bool operator<(const MfmaPlanKey &o) const { return std::tie(v, h, cx, cy, cw, ch, cs, arith) < std::tie(o.v, o.h, o.cx, o.cy, o.cw, o.ch, o.cs, o.arith); }
 };
 
 // Tables of the matrix-pipe resample kernel for one geometry (fl_mfma.h) and its workgroup lists (job field unset), one per
@@ -93,6 +94,7 @@ struct MfmaPlan {
     uint32_t max_nout = 0;
     bool ops_in_lds = false;
     bool wide = false;       // wide layout (fl_mfma.h): more outputs per strip, operands from the L2
+    bool full = true;        // built for the full-width arithmetic (MFMA_ARITH_FULL)
     bool arena_full = false; // the tables did not fit what is left of the arena: not cached, the caller resets the arena and plans again
 };
 
@@ -251,7 +253,7 @@ void arena_reset(flgpu_ctx *c);
 int arena_flush(flgpu_ctx *c, hipStream_t st);
 uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma, AxisKey *key_out, const HostAxis **host_out);
 MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
-                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs);
+                              uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs, MfmaArith arith = MFMA_ARITH_FULL);
 const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
                                   uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs, uint32_t pre);
 hipEvent_t get_event(flgpu_ctx *c);

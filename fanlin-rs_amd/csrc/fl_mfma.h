@@ -48,9 +48,22 @@ constexpr uint32_t kMfmaOutPitchWide = 748;
 static_assert(kMfmaOutPitchWide >= kMfmaMaxStripOutputsWide + 16 && (4 * kMfmaOutPitchWide) % 32 == 16, "LDS output tile pitch (wide)");
 constexpr uint32_t kMfmaDefaultSpinLimit = 1u << 22; // polls of an LDS counter before a wave gives up and reports FLGPU_DEVERR_MFMA_WAIT
 constexpr uint32_t FLGPU_DEVERR_MFMA_WAIT = 1u;      // bit of the batch's device error word
-constexpr uint32_t kMfmaVScaleLog2 = 8;     // vertical weights are stored times 2^8 (keeps the low f16 term normal)
-constexpr uint32_t kMfmaXFracBits = 6;      // intermediate rows: (value - 128) * 64 as i16
+constexpr uint32_t kMfmaVScaleLog2 = 8;     // packed arithmetic: vertical weights are stored times 2^8 (keeps the low f16 term normal)
+constexpr uint32_t kMfmaXFracBits = 6;      // packed arithmetic: intermediate rows are (value - 128) * 64 as i16
 constexpr uint32_t kMfmaLdsOperands = 40;   // horizontal operands (1 KB each) kept in LDS when a strip has no more distinct ones
+// Full-width arithmetic (the default since round 4; fl_mfma.hip, template parameter FW):
+constexpr uint32_t kMfmaVScaleLog2Full = 15; // vertical weights times 2^15 as three f16 terms; the bytes enter as f16 subnormals (b * 2^-24): sums = value * 2^-9
+constexpr uint32_t kMfmaXFracBitsFull = 14;  // intermediate rows: round((value - 128) * 2^14), 23 bits, as three byte planes
+constexpr uint32_t kMfmaOutFracBitsFull = 20; // the horizontal sums reach the LDS output tile in units of 2^-20 of a pixel step
+
+// The two arithmetics of the kernel (which one a context uses: flgpu_config / FLGPU_MFMA_ARITH, fl_batch.cpp).
+//   PACKED (rounds 2-3): u8 as f16 (1024 + b) x weights as two f16 terms -> f32; intermediate 1/64 steps (i16) x 14..17-bit
+//                        fixed-point weights -> exact i32.  Within 1 LSB of the reference on every byte, ~0.1 % of them off by one.
+//   FULL   (round 4):    no operand narrower than the reference's f32: u8 (exact, f16 subnormal) x the f32 weight itself (three f16
+//                        terms) -> f32 sums in the matrix unit; intermediate rounded to 2^-14 of a pixel step (23 bits + sign,
+//                        three byte planes) x weights rounded to 2^-24 (three byte digits, sums forced to exactly 1) -> all nine
+//                        digit products, exact in i32, recombined to 2^-20 of a pixel step.
+enum MfmaArith : uint32_t { MFMA_ARITH_PACKED = 0, MFMA_ARITH_FULL = 1 };
 
 // One workgroup.
 struct alignas(16) MfmaItem {
@@ -65,19 +78,19 @@ struct alignas(16) MfmaItem {
 // Vertical plan of one (axis, kept rows) pair.  All offsets are arena word offsets.
 //   kb_meta[nkb + 1] per K-block: bits 0-15 = tile that is complete after it (0xffff: none), bit 16/17 = set 0/1 has weights in it;
 //                  entry nkb = the all-zero K-block the kernel appends when `tail` is set (it completes the last tile)
-//   kb_w[nkb][2 sets][2 terms][64 lanes] x 16 bytes: B operand of v_mfma_f32_16x16x32_f16: lane 16g + n holds the
-//                  weights of source rows 32 s + 8 g .. + 7 towards output row 16 tile + n as 8 f16
+//   kb_w[nkb][2 sets][nterms][64 lanes] x 16 bytes: B operand of v_mfma_f32_16x16x32_f16: lane 16g + n holds the
+//                  weights of source rows 32 s + 8 g .. + 7 towards output row 16 tile + n as 8 f16 (nterms = 2: packed, 3: full arithmetic)
 struct MfmaVPlan {
     uint32_t ntiles, nkb;
     uint32_t y0, rows;     // first kept output row (resized coordinates) and how many
     uint32_t meta_off, w_off;
     uint32_t tail;         // the last tile ends in the same K-block as the one before it: one more pass, on the all-zero K-block, completes it
-    uint32_t pad1;
+    uint32_t nterms;       // f16 terms per weight (2 or 3)
 };
 
 // Horizontal plan of one strip.
-//   ctab[8 waves][4 chunks][3]: { first output index of the tile (may be negative or past nout: lanes outside go to the
-//                  dummy column), operand index of the high weight digit, of the low digit }; unused tile slots: operand 0 (all zeros), first output 2^30
+//   ctab[8 waves][4 chunks][3 tile slots][1 + digits]: { first output index of the tile (may be negative or past nout: lanes outside go to the
+//                  dummy column), operand index of each weight digit, high digit first (2 digits: packed, 3: full arithmetic) }; unused tile slots: operand 0 (all zeros), first output 2^30
 //   ops[n_ops][64 lanes] x 16 bytes: B operands of v_mfma_i32_16x16x64_i8, deduplicated
 struct MfmaStrip {
     uint32_t x0, x1;       // output columns [x0, x1) in resized coordinates
@@ -91,6 +104,7 @@ struct MfmaStrip {
 struct HostMfmaPlan {
     bool ok = false;
     bool wide = false;                   // strips of up to kMfmaMaxStripOutputsWide outputs (choose_mfma_plan)
+    MfmaArith arith = MFMA_ARITH_FULL;
     std::vector<uint32_t> vmeta, vw;     // MfmaVPlan tables
     uint32_t ntiles = 0, nkb = 0, y0 = 0, rows = 0, tail = 0;
     struct Tile { uint32_t kb_first, kb_last; };
@@ -103,9 +117,10 @@ struct HostMfmaPlan {
 // ok = false when the geometry does not fit the kernel (more than two tiles alive in a K-block, horizontal windows
 // that touch more than three 16-output tiles per 64-byte chunk, weights too large for the digit planes).
 void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out,
-                     uint32_t max_outputs = kMfmaMaxStripOutputs);
+                     uint32_t max_outputs = kMfmaMaxStripOutputs, MfmaArith arith = MFMA_ARITH_FULL);
 // The plan the library uses for the geometry: the narrow layout, or the wide one where that saves strips.
-void choose_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out);
+void choose_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out,
+                      MfmaArith arith = MFMA_ARITH_FULL);
 
 struct LaunchMfma {
     const Job *jobs;
@@ -116,6 +131,7 @@ struct LaunchMfma {
     uint32_t letterbox;
     uint32_t ops_in_lds;   // every strip of the launch has <= kMfmaLdsOperands distinct operands
     uint32_t wide;         // the launch's plans use the wide layout (never together with ops_in_lds)
+    uint32_t full;         // the launch's plans were built for the full-width arithmetic (MFMA_ARITH_FULL)
     uint32_t max_nout;
     uint32_t spin_limit;   // bound of the kernel's LDS counter waits (kMfmaDefaultSpinLimit; tests force 0 = every wait expires)
     uint32_t *err_word;    // device word of the batch: the kernel ORs FLGPU_DEVERR_MFMA_WAIT into it when a wait expired

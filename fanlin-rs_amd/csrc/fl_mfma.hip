@@ -59,7 +59,9 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f
 // structure; only the last step, bytes -> destination pixel, is written per channel count).
 // LB: the destination is Rgba8 with the picture placed on a fill frame.  HLDS: the strip's horizontal operands sit in LDS.
 // WIDE (never with HLDS): the LDS the operands would take goes to wider output tiles (fl_mfma.h).
-template <int CS, bool LB, bool HLDS, bool WIDE>
+// FW: full-width arithmetic (fl_mfma.h MFMA_ARITH_FULL) -- bytes as f16 subnormals x three-term weights, a 23-bit intermediate in
+// three byte planes x three weight digits; otherwise the packed arithmetic of rounds 2-3.
+template <int CS, bool LB, bool HLDS, bool WIDE, bool FW>
 __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
                                                                    const uint32_t *__restrict__ arena, uint32_t ot_words, uint32_t spin_limit,
                                                                    uint32_t *__restrict__ err_word
@@ -178,15 +180,20 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 
     const uint32_t traddr = (i >> 1) * 16u + (i & 1u) * 8u;
     const u32x4 *vw = reinterpret_cast<const u32x4 *>(arena + vp.w_off);
-    // this wave's 4 chunks x 3 tiles x { first output, operand of the high digit, of the low digit }, kept in SGPRs
-    int32_t ctab[36];
+    // this wave's 4 chunks x 3 tiles x { first output, operand of each weight digit, high digit first }, kept in SGPRs
+    constexpr int CE = FW ? 4 : 3, NT = FW ? 3 : 2; // words per tile slot; f16 terms per vertical weight
+    int32_t ctab[12 * CE];
     {
-        const int32_t *cp = reinterpret_cast<const int32_t *>(arena + sp.ctab_off) + wave * 36u;
+        const int32_t *cp = reinterpret_cast<const int32_t *>(arena + sp.ctab_off) + wave * (12u * CE);
 #pragma unroll
-        for (int k = 0; k < 36; ++k) ctab[k] = __builtin_amdgcn_readfirstlane(cp[k]);
+        for (int k = 0; k < 12 * CE; ++k) ctab[k] = __builtin_amdgcn_readfirstlane(cp[k]);
     }
     const uint32_t hs = sp.hs;
-    const int32_t round_add = (int32_t)((128u << hs) + (1u << (hs + kMfmaXFracBits - 1u)));
+    // packed: sums are (value - 128) * 2^(hs + 6) with the low plane offset by 128; full: value * 2^20 + (2^22 - 0x8080) * 2^6 - 2^27
+    // (the byte planes carry 2^22 + x - 0x8080 for x = (value - 128) * 2^14, the weights of an output sum to exactly 2^hs, and every
+    // wave shifts its part of the sum down to 2^-20 steps before it adds it to the tile, see the stage)
+    const int32_t round_add = FW ? (int32_t)(-132112384 + (1 << (kMfmaOutFracBitsFull - 1u))) : (int32_t)((128u << hs) + (1u << (hs + kMfmaXFracBits - 1u)));
+    const uint32_t out_shift = hs + kMfmaXFracBits; // (packed arithmetic)
     const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
     const uint32_t npx = sp.x1 - sp.x0;
 
@@ -221,8 +228,15 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 uint32_t c8[CS];
 #pragma unroll
                 for (int c = 0; c < CS; ++c) {
-                    const int32_t q = ((int32_t)sums[rr][k][c] + round_add) >> (hs + kMfmaXFracBits);
-                    c8[c] = (uint32_t)min(max(q + 128, 0), 255);
+                    if constexpr (FW) {
+                        // clamp-then-shift: clamp(x >> 20, 0, 255) is the pattern hipcc (ROCm 7.2) fuses into gfx950's v_ashr_pk_u8_i32,
+                        // whose destination keeps stale bits above bit 15 (fl_jpegdec.hip sat17 met the same bug)
+                        const int32_t x = (int32_t)sums[rr][k][c] + round_add;
+                        c8[c] = (uint32_t)min(max(x, 0), (256 << kMfmaOutFracBitsFull) - 1) >> kMfmaOutFracBitsFull;
+                    } else {
+                        const int32_t q = ((int32_t)sums[rr][k][c] + round_add) >> out_shift;
+                        c8[c] = (uint32_t)min(max(q + 128, 0), 255);
+                    }
                     o[c] = 0u;
                 }
                 uint32_t v;
@@ -259,10 +273,10 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // order every LDS wait of the stage then becomes lgkmcnt(0) -- behind all the LDS adds issued so far)
     uint32_t vzero = 0u;
     asm("" : "+v"(vzero));
-    u32x4 wvn[4];
+    u32x4 wvn[2 * NT];
     uint32_t meta_n = arena[vp.meta_off + it.kb0 + vzero];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wvn[k] = vw[(it.kb0 * 4u + k) * 64u + lane];
+    for (int k = 0; k < 2 * NT; ++k) wvn[k] = vw[(it.kb0 * (2u * NT) + k) * 64u + lane];
     {
         uint32_t g0[8];
         request_offsets(it.kb0, g0);
@@ -281,9 +295,9 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         wait_vm0();
         TM_B(tm_wait);
         const uint32_t meta = __builtin_amdgcn_readfirstlane(meta_n);
-        u32x4 wv[4];
+        u32x4 wv[2 * NT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wv[k] = wvn[k];
+        for (int k = 0; k < 2 * NT; ++k) wv[k] = wvn[k];
         v2i raw[16];
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             const uint32_t sn = s + 1u < it.kb1 ? s + 1u : vp.nkb;
             meta_n = arena[vp.meta_off + sn + vzero];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wvn[k] = vw[(sn * 4u + k) * 64u + lane];
+            for (int k = 0; k < 2 * NT; ++k) wvn[k] = vw[(sn * (2u * NT) + k) * 64u + lane];
         }
         TM_B(tm_read);
         // (the meta word says whether the K-block has weights for a second, younger tile (set 1) at all: about a third of the
@@ -306,18 +320,22 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         const bool both_sets = ((meta >> 17) & 1u) != 0u;
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
+            // bytes -> f16 pairs.  Packed arithmetic: 0x6400 | byte = 1024 + byte.  Full width: the byte zero-extended IS the f16
+            // subnormal byte * 2^-24, which gfx950's matrix unit multiplies exactly (tools/microbench/f16_denorm_probe.hip) -- no
+            // bias in the f32 sums, which are then value * 2^-9 (weights are stored times 2^15)
+            constexpr uint32_t fill = FW ? 0u : 0x64646464u, sel_lo = FW ? 0x0c010c00u : 0x04010400u, sel_hi = FW ? 0x0c030c02u : 0x04030402u;
             u32x4 a;
-            a[0] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][0], 0x04010400u); // f16 pairs: 0x6400 | byte = 1024 + byte
-            a[1] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][0], 0x04030402u);
-            a[2] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][1], 0x04010400u);
-            a[3] = __builtin_amdgcn_perm(0x64646464u, (uint32_t)raw[ct][1], 0x04030402u);
+            a[0] = __builtin_amdgcn_perm(fill, (uint32_t)raw[ct][0], sel_lo);
+            a[1] = __builtin_amdgcn_perm(fill, (uint32_t)raw[ct][0], sel_hi);
+            a[2] = __builtin_amdgcn_perm(fill, (uint32_t)raw[ct][1], sel_lo);
+            a[3] = __builtin_amdgcn_perm(fill, (uint32_t)raw[ct][1], sel_hi);
             const f16x8 av = __builtin_bit_cast(f16x8, a);
             if (ablate & 8u) { acc[0][ct][0] += (float)a[0]; acc[1][ct][1] += (float)a[1]; acc[0][ct][2] += (float)a[2]; acc[1][ct][3] += (float)a[3]; continue; }
-            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[0]), acc[0][ct], 0, 0, 0);
-            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[1]), acc[0][ct], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[t]), acc[0][ct], 0, 0, 0);
             if (both_sets) {
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[2]), acc[1][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[3]), acc[1][ct], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[NT + t]), acc[1][ct], 0, 0, 0);
             }
         }
         TM_B(tm_mfma);
@@ -336,42 +354,9 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 // ahead, in front of the LDS adds of the chunk before (LDS executes a wave's instructions in order: behind 12 adds
                 // they would return ~12 adds late), (3) both counters are read in ONE round trip at the top, (4) the previous tile's
                 // rows are read before this tile's adds are issued and converted while its matrix instructions run.
-                u32x4 ahi[4], alo[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const f32x4 v = acc[0][4 * c + a]; // (the older of the two live tiles always sits in set 0, see below)
-                        // acc = 256 * (1024 + value); 1.5 * 2^23 - 64 * (1024 + 128) = 12509184: the sum's low 16 bits are
-                        // round((value - 128) * 64) in two's complement
-                        const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[0], 0.25f, 12509184.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[1], 0.25f, 12509184.0f)),
-                                       x2 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[2], 0.25f, 12509184.0f)), x3 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[3], 0.25f, 12509184.0f));
-                        const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x3, x2, 0x05010400u); // (x0.b0, x1.b0, x0.b1, x1.b1)
-                        alo[c][a] = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u; // low bytes, as signed value - 128
-                        ahi[c][a] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);               // high bytes (signed)
-                    }
-                // units u = 3 c + t (chunk c, tile slot t): operands of unit u + 2 are requested, and the matrix instructions of
-                // unit u + 1 issued, in front of the digit sums and LDS adds of unit u
-                u32x4 h1[3], h0[3];
-                i32x4 t2[2], t1[2], t0[2];
-                auto load_ops = [&](int u) __attribute__((always_inline)) {
-                    uint32_t i1 = (uint32_t)ctab[u * 3 + 1], i0 = (uint32_t)ctab[u * 3 + 2];
-                    asm volatile("" : "+s"(i1), "+s"(i0)); // (keeps hipcc from hoisting the 24 operand addresses out of the row loop into 24 VGPRs)
-                    h1[u % 3] = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
-                    h0[u % 3] = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
-                };
-                auto unit_mfma = [&](int u) __attribute__((always_inline)) {
-                    const i32x4 bh = __builtin_bit_cast(i32x4, h1[u % 3]), bl = __builtin_bit_cast(i32x4, h0[u % 3]);
-                    const i32x4 ah = __builtin_bit_cast(i32x4, ahi[u / 3]), al = __builtin_bit_cast(i32x4, alo[u / 3]);
-                    t2[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah, bh, i32x4{0, 0, 0, 0}, 0, 0, 0);
-                    t1[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah, bl, i32x4{0, 0, 0, 0}, 0, 0, 0);
-                    t0[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, bl, i32x4{0, 0, 0, 0}, 0, 0, 0);
-                    t1[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, bh, t1[u & 1], 0, 0, 0);
-                };
-                if (!(ablate & 1u)) { load_ops(0); load_ops(1); }
                 // the tile that used this buffer two tiles ago must have been converted by every wave, and every wave must have added
                 // its sums of the previous tile (both long since true in practice: the slowest wave never waits)
-                {
+                auto wait_for_the_tiles = [&]() __attribute__((always_inline)) {
                     const uint32_t need_conv = kMfmaWaves * (li >> 1), need_add = li ? kMfmaWaves * (((li - 1u) >> 1) + 1u) : 0u;
                     uint32_t spin = 0;
                     for (;;) {
@@ -382,23 +367,133 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                         __builtin_amdgcn_s_sleep(2);
                     }
                     if (spin >= spin_limit) wg_error = 1u;
-                }
-                if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u); // this wave's two rows of the previous tile
-                if (!(ablate & 1u)) {
-                    unit_mfma(0);
+                };
+                if constexpr (FW) {
+                    // ---- full-width arithmetic ------------------------------------------------------------------------------------
+                    // sums = value * 2^-9.  One fused multiply-add with the magic constant 1.5 * 2^23 - 2^21 leaves
+                    // 2^22 + round((value - 128) * 2^14) in the 23 mantissa bits (|value - 128| < 256: Lanczos overshoot stays far
+                    // inside); its three bytes are the planes: the top one (7 bits) as it is, the lower two offset by 128 so that they are
+                    // signed (the offsets and the 2^22 come out again as constants, round_add above).
+                    u32x4 p2[4], p1[4], p0[4];
 #pragma unroll
-                    for (int u = 0; u < 12; ++u) {
-                        if (u + 2 < 12) load_ops(u + 2);
-                        if (u + 1 < 12) unit_mfma(u + 1);
-                        // lanes outside the strip's outputs (and every lane of a slot not in use: operand 0, first output 2^30) add
-                        // into dummy columns of their own, nout + i: no lane is switched off, no two lanes share an address
-                        const uint32_t o = (uint32_t)(ctab[u * 3] + (int32_t)i);
-                        const uint32_t col = o < sp.nout ? o : sp.nout + i;
+                    for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const uint32_t p = shl8_add(shl8_add((uint32_t)t2[u & 1][r], (uint32_t)t1[u & 1][r]), (uint32_t)t0[u & 1][r]);
-                            if (ablate & 128u) { asm volatile("" : : "v"(p), "v"(col)); continue; }
-                            __hip_atomic_fetch_add(&ot[(4u * g + r) * np + col], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        for (int a = 0; a < 4; ++a) {
+                            const f32x4 v = acc[0][4 * c + a];
+                            const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[0], 8388608.0f, 10485760.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[1], 8388608.0f, 10485760.0f)),
+                                           x2 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[2], 8388608.0f, 10485760.0f)), x3 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[3], 8388608.0f, 10485760.0f));
+                            const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x3, x2, 0x05010400u); // (x0.b0, x1.b0, x0.b1, x1.b1)
+                            p0[c][a] = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u;
+                            p1[c][a] = __builtin_amdgcn_perm(t1, t0, 0x07060302u) ^ 0x80808080u;
+                            p2[c][a] = __builtin_amdgcn_perm(x1, x0, 0x0c0c0602u) | __builtin_amdgcn_perm(x3, x2, 0x06020c0cu);       // (x0.b2, x1.b2, x2.b2, x3.b2)
+                        }
+                    // units u = 3 c + t as in the packed form; per unit three operands (weight digits 2, 1, 0) and all nine digit
+                    // products, summed by the matrix unit into five scales: L[k] = sum over i + j = k of plane i x digit j, exact in i32
+                    // (|L| < 2^22: 64 products of at most 2^14, three of them per term at most)
+                    u32x4 hb[2][3];
+                    i32x4 L[2][5];
+                    auto load_ops = [&](int u) __attribute__((always_inline)) {
+                        uint32_t i2 = (uint32_t)ctab[u * 4 + 1], i1 = (uint32_t)ctab[u * 4 + 2], i0 = (uint32_t)ctab[u * 4 + 3];
+                        asm volatile("" : "+s"(i2), "+s"(i1), "+s"(i0)); // (see the packed form)
+                        hb[u & 1][0] = HLDS ? ops_lds[i2 * 64u + lane] : ops_glb[i2 * 64u + lane];
+                        hb[u & 1][1] = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
+                        hb[u & 1][2] = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
+                    };
+                    auto unit_mfma = [&](int u) __attribute__((always_inline)) {
+                        const i32x4 b2 = __builtin_bit_cast(i32x4, hb[u & 1][0]), b1 = __builtin_bit_cast(i32x4, hb[u & 1][1]), b0 = __builtin_bit_cast(i32x4, hb[u & 1][2]);
+                        const i32x4 a2 = __builtin_bit_cast(i32x4, p2[u / 3]), a1 = __builtin_bit_cast(i32x4, p1[u / 3]), a0 = __builtin_bit_cast(i32x4, p0[u / 3]);
+                        const i32x4 z = {0, 0, 0, 0};
+                        i32x4 *l = L[u & 1]; // (five independent chains, interleaved: no instruction waits for the one before it)
+                        l[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, z, 0, 0, 0);
+                        l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, z, 0, 0, 0);
+                        l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, z, 0, 0, 0);
+                        l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, z, 0, 0, 0);
+                        l[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, z, 0, 0, 0);
+                        l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, l[3], 0, 0, 0);
+                        l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, l[2], 0, 0, 0);
+                        l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, l[1], 0, 0, 0);
+                        l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, l[2], 0, 0, 0);
+                    };
+                    // sum of the unit = L4 2^32 + L3 2^24 + L2 2^16 + L1 2^8 + L0 in units of 2^-(14 + hs) of a pixel step; the LDS tile
+                    // takes it in units of 2^-20 (a wave's part of an output rounded once, to a millionth of a step)
+                    const uint32_t sh = hs + kMfmaXFracBitsFull - kMfmaOutFracBitsFull; // 16..18
+                    const uint32_t s4 = 32u - sh, s3 = 24u - sh, slo = sh - 8u;
+                    const int32_t rnd = 1 << (slo - 1u);
+                    if (!(ablate & 1u)) load_ops(0);
+                    wait_for_the_tiles();
+                    if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u); // this wave's two rows of the previous tile
+                    if (!(ablate & 1u)) {
+                        unit_mfma(0);
+                        load_ops(1);
+#pragma unroll
+                        for (int u = 0; u < 12; ++u) {
+                            if (u + 1 < 12) unit_mfma(u + 1);
+                            if (u + 2 < 12) load_ops(u + 2); // (into the registers unit u's matrix instructions have just read)
+                            const uint32_t o = (uint32_t)(ctab[u * 4] + (int32_t)i);
+                            const uint32_t col = o < sp.nout ? o : sp.nout + i;
+                            const i32x4 *l = L[u & 1];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int32_t low = (((l[2][r] << 8) + l[1][r]) + (l[0][r] >> 8) + rnd) >> slo;
+                                const uint32_t p = ((uint32_t)l[4][r] << s4) + ((uint32_t)l[3][r] << s3) + (uint32_t)low;
+                                if (ablate & 128u) { asm volatile("" : : "v"(p), "v"(col)); continue; }
+                                __hip_atomic_fetch_add(&ot[(4u * g + r) * np + col], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                } else {
+                    // ---- packed arithmetic (rounds 2-3) ---------------------------------------------------------------------------
+                    u32x4 ahi[4], alo[4];
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c)
+    #pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const f32x4 v = acc[0][4 * c + a]; // (the older of the two live tiles always sits in set 0, see below)
+                            // acc = 256 * (1024 + value); 1.5 * 2^23 - 64 * (1024 + 128) = 12509184: the sum's low 16 bits are
+                            // round((value - 128) * 64) in two's complement
+                            const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[0], 0.25f, 12509184.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[1], 0.25f, 12509184.0f)),
+                                           x2 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[2], 0.25f, 12509184.0f)), x3 = __builtin_bit_cast(uint32_t, __builtin_fmaf(v[3], 0.25f, 12509184.0f));
+                            const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x3, x2, 0x05010400u); // (x0.b0, x1.b0, x0.b1, x1.b1)
+                            alo[c][a] = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u; // low bytes, as signed value - 128
+                            ahi[c][a] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);               // high bytes (signed)
+                        }
+                    // units u = 3 c + t (chunk c, tile slot t): operands of unit u + 2 are requested, and the matrix instructions of
+                    // unit u + 1 issued, in front of the digit sums and LDS adds of unit u
+                    u32x4 h1[3], h0[3];
+                    i32x4 t2[2], t1[2], t0[2];
+                    auto load_ops = [&](int u) __attribute__((always_inline)) {
+                        uint32_t i1 = (uint32_t)ctab[u * 3 + 1], i0 = (uint32_t)ctab[u * 3 + 2];
+                        asm volatile("" : "+s"(i1), "+s"(i0)); // (keeps hipcc from hoisting the 24 operand addresses out of the row loop into 24 VGPRs)
+                        h1[u % 3] = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
+                        h0[u % 3] = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
+                    };
+                    auto unit_mfma = [&](int u) __attribute__((always_inline)) {
+                        const i32x4 bh = __builtin_bit_cast(i32x4, h1[u % 3]), bl = __builtin_bit_cast(i32x4, h0[u % 3]);
+                        const i32x4 ah = __builtin_bit_cast(i32x4, ahi[u / 3]), al = __builtin_bit_cast(i32x4, alo[u / 3]);
+                        t2[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah, bh, i32x4{0, 0, 0, 0}, 0, 0, 0);
+                        t1[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah, bl, i32x4{0, 0, 0, 0}, 0, 0, 0);
+                        t0[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, bl, i32x4{0, 0, 0, 0}, 0, 0, 0);
+                        t1[u & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, bh, t1[u & 1], 0, 0, 0);
+                    };
+                    if (!(ablate & 1u)) { load_ops(0); load_ops(1); }
+                    wait_for_the_tiles();
+                    if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u); // this wave's two rows of the previous tile
+                    if (!(ablate & 1u)) {
+                        unit_mfma(0);
+    #pragma unroll
+                        for (int u = 0; u < 12; ++u) {
+                            if (u + 2 < 12) load_ops(u + 2);
+                            if (u + 1 < 12) unit_mfma(u + 1);
+                            // lanes outside the strip's outputs (and every lane of a slot not in use: operand 0, first output 2^30) add
+                            // into dummy columns of their own, nout + i: no lane is switched off, no two lanes share an address
+                            const uint32_t o = (uint32_t)(ctab[u * 3] + (int32_t)i);
+                            const uint32_t col = o < sp.nout ? o : sp.nout + i;
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const uint32_t p = shl8_add(shl8_add((uint32_t)t2[u & 1][r], (uint32_t)t1[u & 1][r]), (uint32_t)t0[u & 1][r]);
+                                if (ablate & 128u) { asm volatile("" : : "v"(p), "v"(col)); continue; }
+                                __hip_atomic_fetch_add(&ot[(4u * g + r) * np + col], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                     }
                 }
@@ -448,11 +543,11 @@ size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds, bool wide)
     return (size_t)2 * 16 * (wide ? kMfmaOutPitchWide : kMfmaOutPitch) * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u); // dynamic part; the rows' 64 KB are static
 }
 
-template <int CS, bool LB, bool HLDS, bool WIDE>
+template <int CS, bool LB, bool HLDS, bool WIDE, bool FW>
 static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 {
     const size_t lds = mfma_lds_bytes(m.max_nout, HLDS, WIDE);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS, WIDE, FW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
 #ifdef FL_MFMA_TIMING
     static unsigned long long *dbg = nullptr;
@@ -460,7 +555,7 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
     constexpr size_t kDbgWgs = 16384;
     if (!dbg) { (void)hipMalloc(&dbg, (3 * 64 + kDbgWgs * 4) * 8); (void)hipMemset(dbg, 0, (3 * 64 + kDbgWgs * 4) * 8); }
     if (m.nitems > kDbgWgs) return hipErrorInvalidValue;
-    resample_mfma_kernel<CS, LB, HLDS, WIDE><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word, dbg);
+    resample_mfma_kernel<CS, LB, HLDS, WIDE, FW><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word, dbg);
     if ((++launches == 5 || launches == 100) && m.nitems > 2900) {
         unsigned long long h[3 * 64];
         (void)hipDeviceSynchronize();
@@ -496,29 +591,29 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
             fprintf(stderr, "  xcc %d: %u workgroups, mean %.1f us (%.0f cycles), last one ends at %.1f us\n", x, xn[x], xn[x] ? xdur[x] / xn[x] : 0.0, xn[x] ? xcyc[x] / xn[x] : 0.0, xend[x]);
     }
 #else
-    resample_mfma_kernel<CS, LB, HLDS, WIDE><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word);
+    resample_mfma_kernel<CS, LB, HLDS, WIDE, FW><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word);
 #endif
     return hipGetLastError();
 }
 
-template <int CS>
+template <int CS, bool FW>
 static hipError_t launch_mfma_c(const LaunchMfma &m, hipStream_t st)
 {
     if constexpr (CS >= 3) { // (the planner keeps 1- and 2-channel sources on the narrow layout, fl_mfma_tables.cpp choose_mfma_plan)
-        if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, true>(m, st) : launch_mfma_t<CS, false, false, true>(m, st);
+        if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, true, FW>(m, st) : launch_mfma_t<CS, false, false, true, FW>(m, st);
     } else if (m.wide) return hipErrorInvalidValue;
-    if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<CS, true, true, false>(m, st) : launch_mfma_t<CS, true, false, false>(m, st);
-    return m.ops_in_lds ? launch_mfma_t<CS, false, true, false>(m, st) : launch_mfma_t<CS, false, false, false>(m, st);
+    if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<CS, true, true, false, FW>(m, st) : launch_mfma_t<CS, true, false, false, FW>(m, st);
+    return m.ops_in_lds ? launch_mfma_t<CS, false, true, false, FW>(m, st) : launch_mfma_t<CS, false, false, false, FW>(m, st);
 }
 
 hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st)
 {
     if (m.nitems == 0) return hipSuccess;
     switch (m.cs) {
-    case 1: return launch_mfma_c<1>(m, st);
-    case 2: return launch_mfma_c<2>(m, st);
-    case 3: return launch_mfma_c<3>(m, st);
-    case 4: return launch_mfma_c<4>(m, st);
+    case 1: return m.full ? launch_mfma_c<1, true>(m, st) : launch_mfma_c<1, false>(m, st);
+    case 2: return m.full ? launch_mfma_c<2, true>(m, st) : launch_mfma_c<2, false>(m, st);
+    case 3: return m.full ? launch_mfma_c<3, true>(m, st) : launch_mfma_c<3, false>(m, st);
+    case 4: return m.full ? launch_mfma_c<4, true>(m, st) : launch_mfma_c<4, false>(m, st);
     default: return hipErrorInvalidValue;
     }
 }

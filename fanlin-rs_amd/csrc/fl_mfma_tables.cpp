@@ -50,9 +50,14 @@ double f16_value(uint16_t h)
 
 } // namespace
 
-void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out, uint32_t max_outputs)
+void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out, uint32_t max_outputs,
+                     MfmaArith arith)
 {
     out = HostMfmaPlan();
+    out.arith = arith;
+    const bool full = arith == MFMA_ARITH_FULL;
+    const uint32_t NTERM = full ? 3u : 2u;  // f16 terms per vertical weight
+    const uint32_t NDIG = full ? 3u : 2u;   // signed byte digits per horizontal weight
     if (cs < 1 || cs > 4) return;
     if (cw == 0 || ch == 0 || cy + ch > v.out_size || cx + cw > h.out_size) return;
     const uint32_t sh = v.in_size, sw = h.in_size;
@@ -83,7 +88,7 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
         if (out.tiles[j + 2].kb_first <= out.tiles[j].kb_last) return; // the accumulator set of tile j is free again before tile j + 2 starts
     // (one K-block more than the picture has: all-zero weights, for the kernel's passes after the last rows)
     out.vmeta.assign(NKB + 1u, 0xffffu);
-    out.vw.assign((size_t)(NKB + 1u) * 2 * 2 * 64 * 4, 0u);
+    out.vw.assign((size_t)(NKB + 1u) * 2 * NTERM * 64 * 4, 0u);
     for (uint32_t j = 0; j < NT; ++j) {
         for (uint32_t s = out.tiles[j].kb_first; s <= out.tiles[j].kb_last; ++s) {
             // accumulator set of tile j during K-block s: 0 if it is the older (lower) of the K-block's live tiles, 1 if the tile
@@ -97,11 +102,17 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
                 for (uint32_t jj = 0; jj < 8; ++jj) {
                     const uint32_t r = kMfmaKRows * s + 8 * g + jj;
                     if (r < v.left[oy] || r >= v.left[oy] + v.count[oy]) continue;
-                    const double w = ldexp((double)v.weights[v.woff[oy] + (r - v.left[oy])], (int)kMfmaVScaleLog2);
-                    const uint16_t wa = f16_bits(w), wb = f16_bits(w - f16_value(wa));
-                    const size_t base = ((((size_t)s * 2 + set) * 2) * 64 + lane) * 4 + jj / 2;
-                    out.vw[base] |= (uint32_t)wa << (16 * (jj & 1u));
-                    out.vw[base + 64 * 4] |= (uint32_t)wb << (16 * (jj & 1u));
+                    // packed: 256 w as two f16 terms (22-23 bits); full: 2^15 w as three (hi + mid + lo is the f32 weight itself
+                    // for every |w| >= 2^-16; smaller ones are exact to 2^-39 absolute: f16 subnormals end at 2^-24)
+                    const double w = ldexp((double)v.weights[v.woff[oy] + (r - v.left[oy])], (int)(full ? kMfmaVScaleLog2Full : kMfmaVScaleLog2));
+                    double rest = w;
+                    const size_t base = ((((size_t)s * 2 + set) * NTERM) * 64 + lane) * 4 + jj / 2;
+                    for (uint32_t t = 0; t < NTERM; ++t) {
+                        const uint16_t wt = f16_bits(rest);
+                        if ((wt & 0x7c00u) == 0x7c00u) { out = HostMfmaPlan(); return; } // (a weight of 2 or more: not a down-scale)
+                        rest -= f16_value(wt);
+                        out.vw[base + (size_t)t * 64 * 4] |= (uint32_t)wt << (16 * (jj & 1u));
+                    }
                 }
             }
         }
@@ -116,9 +127,13 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
     float maxw = 0.0f;
     for (uint32_t x = cx; x < cx + cw; ++x)
         for (uint32_t k = 0; k < h.count[x]; ++k) maxw = std::max(maxw, fabsf(h.weights[h.woff[x] + k]));
-    int hs = 17;
-    while (hs >= 14 && ldexp((double)maxw, hs) > 32000.0) --hs;
-    if (hs < 14) return;
+    // fixed-point scale of the horizontal weights: the largest that keeps every weight inside NDIG balanced byte digits
+    // (packed: 14..17 bits, full: 22..24 -- 24 whenever no weight reaches 1/2, i.e. for every ratio the kernel takes)
+    const int hs_max = full ? 24 : 17, hs_min = full ? 22 : 14;
+    const double qlimit = full ? 8355711.0 : 32639.0; // 127 * 256^(NDIG-1) + ... + 127
+    int hs = hs_max;
+    while (hs >= hs_min && ldexp((double)maxw, hs) > qlimit - 640.0) --hs;
+    if (hs < hs_min) return;
     // Fewest strips that fit (each <= kMfmaStripBytes of source per row incl. its 16-byte alignment, <= max_outputs outputs), taken
     // greedily from the left under a cap on the pixels per strip; the smallest cap that still gives that count evens them out.
     // (Equal strips, round 2's rule, needed a fourth strip for 1080p -> 256 columns: the edge strips have one halo, the inner ones
@@ -162,7 +177,7 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
             if (abs(q[k]) > abs(q[big])) big = k;
         }
         q[big] += (int32_t)(((int64_t)1 << hs) - sum);
-        if (abs(q[big]) > 32639) return;
+        if ((double)abs(q[big]) > qlimit) return;
     }
     for (size_t si = 0; si + 1 < bounds.size(); ++si) {
         HostMfmaPlan::Strip S;
@@ -173,8 +188,9 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
         const int32_t nout = (int32_t)S.hdr.nout;
         // operand 0 is all zeros: the tile slots a chunk does not need multiply by it and add into the dummy column, which keeps
         // the kernel's horizontal stage free of branches (12 matrix instructions back to back per chunk instead of 4 + a wait)
-        S.ctab.assign(kMfmaWaves * 4 * 3 * 3, 0);
-        for (size_t k = 0; k < S.ctab.size(); k += 3) S.ctab[k] = 0x40000000;
+        const uint32_t CE = 1u + NDIG; // words per tile slot: first output, then one operand index per digit (high digit first)
+        S.ctab.assign(kMfmaWaves * 4 * 3 * CE, 0);
+        for (size_t k = 0; k < S.ctab.size(); k += CE) S.ctab[k] = 0x40000000;
         std::map<std::string, uint32_t> seen;
         seen.emplace(std::string(1024, '\0'), 0u);
         S.ops.assign(256, 0u);
@@ -198,20 +214,23 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
                 if (nt > 3) return;
                 for (uint32_t t = 0; t < nt; ++t) {
                     const int32_t base = omin + 16 * (int32_t)t;
-                    std::string op[2] = {std::string(1024, '\0'), std::string(1024, '\0')};
+                    std::string op[3] = {std::string(1024, '\0'), std::string(1024, '\0'), std::string(1024, '\0')};
                     for (uint32_t lane = 0; lane < 64; ++lane) {
                         const uint32_t g = lane >> 4, n = lane & 15u;
                         for (uint32_t a = 0; a < 4; ++a)
                             for (uint32_t r = 0; r < 4; ++r) {
-                                const int32_t q = weight_of(base + (int32_t)n, col0 + 16u * a + 4u * g + r);
-                                const int32_t lo = ((q + 128) & 255) - 128, hi = (q - lo) / 256;
-                                op[0][lane * 16 + 4 * a + r] = (char)(int8_t)hi;
-                                op[1][lane * 16 + 4 * a + r] = (char)(int8_t)lo;
+                                // balanced digits, low to high: q = sum d_k 256^k with every d_k in [-128, 127]
+                                int32_t q = weight_of(base + (int32_t)n, col0 + 16u * a + 4u * g + r);
+                                for (uint32_t d = NDIG; d-- > 0;) {
+                                    const int32_t lo = d ? ((q + 128) & 255) - 128 : q;
+                                    op[d][lane * 16 + 4 * a + r] = (char)(int8_t)lo;
+                                    q = (q - lo) / 256;
+                                }
                             }
                     }
-                    int32_t *e = &S.ctab[((w * 4 + c) * 3 + t) * 3];
+                    int32_t *e = &S.ctab[((w * 4 + c) * 3 + t) * CE];
                     e[0] = base;
-                    for (int d = 0; d < 2; ++d) {
+                    for (uint32_t d = 0; d < NDIG; ++d) {
                         auto it = seen.find(op[d]);
                         if (it == seen.end()) {
                             it = seen.emplace(op[d], (uint32_t)seen.size()).first;
@@ -232,15 +251,15 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
 // that bound -- not the 2048 source bytes -- is what cuts the picture into strips (ratios below ~4.7 for Rgb8: 1080p -> 480, 512,
 // 640 columns), the wide layout (kMfmaMaxStripOutputsWide outputs per strip, operands read from the L2) needs fewer strips, and a
 // strip is a whole walk over the picture's rows by one workgroup, whatever its width.
-void choose_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out)
+void choose_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostMfmaPlan &out, MfmaArith arith)
 {
-    build_mfma_plan(v, h, cs, cx, cy, cw, ch, out, kMfmaMaxStripOutputs);
+    build_mfma_plan(v, h, cs, cx, cy, cw, ch, out, kMfmaMaxStripOutputs, arith);
     out.wide = false;
     // (1- and 2-channel sources keep the narrow layout: a wide row is up to 728 pixels there, and the conversion's 24 sums per
     // lane pushed hipcc into scratch -- whose reloads wait on vmcnt, i.e. for the K-block in flight)
     if (!out.ok || out.strips.size() < 2 || cw * cs <= kMfmaMaxStripOutputs || cs < 3) return;
     HostMfmaPlan w;
-    build_mfma_plan(v, h, cs, cx, cy, cw, ch, w, kMfmaMaxStripOutputsWide);
+    build_mfma_plan(v, h, cs, cx, cy, cw, ch, w, kMfmaMaxStripOutputsWide, arith);
     if (w.ok && w.strips.size() < out.strips.size()) {
         out = std::move(w);
         out.wide = true;

@@ -513,13 +513,21 @@ uint32_t flgpu_abi_version(void) { return FLGPU_ABI_VERSION; }
 int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
                           uint32_t cw, uint32_t ch, uint32_t info[8], double err[2])
 {
+    return flgpu_debug_mfma_plan_arith(sw, sh, channels, rw, rh, cx, cy, cw, ch, 1u, info, err);
+}
+
+int flgpu_debug_mfma_plan_arith(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
+                                uint32_t cw, uint32_t ch, uint32_t arith, uint32_t info[8], double err[2])
+{
     using namespace fl;
-    if (!sw || !sh || !rw || !rh || !info || !err) return 0;
+    if (!sw || !sh || !rw || !rh || !info || !err || arith > 1u) return 0;
+    const uint32_t NTERM = arith ? 3u : 2u, NDIG = arith ? 3u : 2u, CE = 1u + NDIG;
+    const double vscale = ldexp(1.0, (int)(arith ? kMfmaVScaleLog2Full : kMfmaVScaleLog2));
     HostAxis v, h;
     build_axis(sh, rh, FILTER_LANCZOS3, 0.0f, v);
     build_axis(sw, rw, FILTER_LANCZOS3, 0.0f, h);
     HostMfmaPlan p;
-    choose_mfma_plan(v, h, channels, cx, cy, cw, ch, p);
+    choose_mfma_plan(v, h, channels, cx, cy, cw, ch, p, arith ? MFMA_ARITH_FULL : MFMA_ARITH_PACKED);
     for (int k = 0; k < 8; ++k) info[k] = 0;
     err[0] = err[1] = 0.0;
     if (!p.ok) return 0;
@@ -538,13 +546,15 @@ int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t 
             if (s == p.nkb && !p.tail) break;
             for (int set = 0; set < 2; ++set) {
                 bool any = false;
-                for (uint32_t k = 0; k < 2u * 64u * 4u && !any; ++k) any = p.vw[(((size_t)s * 2 + set) * 2) * 64 * 4 + k] != 0u;
+                for (uint32_t k = 0; k < NTERM * 64u * 4u && !any; ++k) any = p.vw[(((size_t)s * 2 + set) * NTERM) * 64 * 4 + k] != 0u;
                 if (!any) continue;
                 if (cur[set] < 0) { cur[set] = (int)next_tile++; }
                 for (uint32_t lane = 0; lane < 64; ++lane)
                     for (uint32_t jj = 0; jj < 8; ++jj) {
-                        const size_t base = ((((size_t)s * 2 + set) * 2) * 64 + lane) * 4 + jj / 2;
-                        const double w = (f16((p.vw[base] >> (16 * (jj & 1))) & 0xffffu) + f16((p.vw[base + 256] >> (16 * (jj & 1))) & 0xffffu)) / 256.0;
+                        const size_t base = ((((size_t)s * 2 + set) * NTERM) * 64 + lane) * 4 + jj / 2;
+                        double w = 0.0;
+                        for (uint32_t t = NTERM; t-- > 0;) w += f16((p.vw[base + (size_t)t * 256] >> (16 * (jj & 1))) & 0xffffu); // (small terms first: exact in double either way)
+                        w /= vscale;
                         const uint32_t r = kMfmaKRows * s + 8 * (lane >> 4) + jj, row = 16u * (uint32_t)cur[set] + (lane & 15u);
                         if (w != 0.0) { if (row >= p.rows || r >= sh) ++bad_rows; else got[row][r] += w; }
                     }
@@ -573,11 +583,11 @@ int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t 
         for (uint32_t w = 0; w < kMfmaWaves; ++w)
             for (uint32_t c = 0; c < 4; ++c)
                 for (uint32_t t = 0; t < 3; ++t) {
-                    const int32_t *e = &S.ctab[((w * 4 + c) * 3 + t) * 3];
-                    const int8_t *o1 = reinterpret_cast<const int8_t *>(S.ops.data() + (size_t)e[1] * 256), *o0 = reinterpret_cast<const int8_t *>(S.ops.data() + (size_t)e[2] * 256);
+                    const int32_t *e = &S.ctab[((w * 4 + c) * 3 + t) * CE];
                     for (uint32_t lane = 0; lane < 64; ++lane)
                         for (uint32_t b = 0; b < 16; ++b) {
-                            const int32_t q = 256 * (int32_t)o1[lane * 16 + b] + (int32_t)o0[lane * 16 + b];
+                            int32_t q = 0; // digits, high one first
+                            for (uint32_t d = 0; d < NDIG; ++d) q = 256 * q + (int32_t)reinterpret_cast<const int8_t *>(S.ops.data() + (size_t)e[1 + d] * 256)[lane * 16 + b];
                             if (q == 0) continue;
                             const int64_t o = (int64_t)e[0] + (lane & 15u);
                             const uint32_t col = kMfmaWaveCols * w + 64u * c + 16u * (b >> 2) + 4u * (lane >> 4) + (b & 3u);

@@ -402,6 +402,10 @@ int flgpu_debug_stream_schedulable(uint32_t in_size, uint32_t out_size, uint32_t
  * |weight - fixed-point weight| of the horizontal ones.  Needs no device. */
 int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
                           uint32_t cw, uint32_t ch, uint32_t info[8], double err[2]);
+/* The same for one of the kernel's two arithmetics (csrc/fl_mfma.h): arith 1 = full width (what the library uses: weights as
+ * three f16 terms / three byte digits; flgpu_debug_mfma_plan is this one), 0 = packed (rounds 2-3: two terms / two digits). */
+int flgpu_debug_mfma_plan_arith(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
+                                uint32_t cw, uint32_t ch, uint32_t arith, uint32_t info[8], double err[2]);
 
 const char *flgpu_strerror(int status);
 const char *flgpu_last_error(flgpu_ctx *ctx); /* detail of the last FLGPU_ERR_DEVICE on this context */

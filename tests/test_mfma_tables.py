@@ -2,9 +2,12 @@
 builds the tables for a geometry and decodes them again the way the kernel reads them -- K-block by K-block with the
 accumulator sets moving as tiles complete, operand by operand through the tile tables -- and compares the result with the
 plain per-axis weight tables (image 0.25.6 imageops/sample.rs index and weight maths, tests/test_tables.py):
-  * every vertical tap lands in the right output row exactly once, as two f16 terms that give back the f32 weight to 2^-24;
+  * every vertical tap lands in the right output row exactly once -- full-width arithmetic (the default): as three f16 terms whose
+    sum IS the f32 weight (exact for every |w| >= 2^-16, to 2^-39 below); packed arithmetic (rounds 2-3, FLGPU_MFMA_ARITH=packed):
+    as two f16 terms that give it back to 2^-24;
   * every horizontal tap lands on the right (output, source byte) pair exactly once, channel structure included, as a
-    fixed-point weight within one rounding of the f32 weight, and each output's weights sum to exactly 1;
+    fixed-point weight (full: three byte digits, 2^-24 steps; packed: two digits, 2^-14..2^-17) within one rounding of the f32
+    weight, and each output's weights sum to exactly 1;
   * nothing else is non-zero (rows and columns outside a window, outputs outside a strip, lanes of unused tile slots)."""
 import pytest
 
@@ -34,14 +37,20 @@ GEOMETRIES = [
 ]
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["full", "packed"])
 @pytest.mark.parametrize("sw,sh,c,rw,rh,crop", GEOMETRIES)
-def test_tables_decode_back_to_the_axis_weights(fl, sw, sh, c, rw, rh, crop):
-    d = fl.debug_mfma_plan(sw, sh, c, rw, rh, crop)
+def test_tables_decode_back_to_the_axis_weights(fl, sw, sh, c, rw, rh, crop, packed):
+    d = fl.debug_mfma_plan(sw, sh, c, rw, rh, crop, packed=packed)
     assert d is not None, "this geometry is meant to fit the kernel"
     assert d["bad_vertical"] == 0 and d["bad_horizontal"] == 0, d
-    assert d["vertical_weight_error"] < 2.0 ** -24, d           # two f16 terms carry 22 bits of a weight < 1/2
+    if packed:
+        assert d["vertical_weight_error"] < 2.0 ** -24, d       # two f16 terms carry 22 bits of a weight < 1/2
+        assert 14 <= d["hs"] <= 17, d
+    else:
+        assert d["vertical_weight_error"] < 2.0 ** -39, d       # three f16 terms ARE the f32 weight (f16 subnormals end at 2^-24 / 2^15)
+        assert 22 <= d["hs"] <= 24, d
     # fixed point with 2^-hs steps; the largest tap of an output absorbs the rounding of the others (so the sum is exactly 1)
-    assert 14 <= d["hs"] <= 17 and d["horizontal_weight_error"] < 64 * 2.0 ** -(d["hs"] + 1), d
+    assert d["horizontal_weight_error"] < 64 * 2.0 ** -(d["hs"] + 1), d
     rows = crop[3] if crop else rh
     assert d["tiles"] == (rows + 15) // 16 and d["k_blocks"] == (sh + 31) // 32 and d["strips"] >= 1
 
@@ -53,12 +62,13 @@ def test_geometries_the_kernel_refuses(fl):
     assert fl.debug_mfma_plan(1920, 1080, 5, 300, 169) is None        # not a channel count
 
 
-def test_strips_are_as_few_as_the_source_bytes_allow(fl):
+@pytest.mark.parametrize("packed", [False, True], ids=["full", "packed"])
+def test_strips_are_as_few_as_the_source_bytes_allow(fl, packed):
     """A strip is one workgroup's walk over all rows, whatever its width: equal strips needed a fourth one for 256 columns (the
     inner strips carry two halos, the outer ones one), and 408 outputs per strip cut 480 / 512 / 640 columns into 4 / 4 / 5."""
     for rw, rh, strips in ((300, 169, 3), (256, 144, 3), (200, 113, 3), (480, 270, 3), (512, 288, 3), (640, 360, 3), (150, 84, 4)):
-        assert fl.debug_mfma_plan(1920, 1080, 3, rw, rh)["strips"] == strips, (rw, rh)
-    assert fl.debug_mfma_plan(1920, 1080, 1, 640, 360)["strips"] == 2     # (1- and 2-channel sources keep the narrow layout)
+        assert fl.debug_mfma_plan(1920, 1080, 3, rw, rh, packed=packed)["strips"] == strips, (rw, rh)
+    assert fl.debug_mfma_plan(1920, 1080, 1, 640, 360, packed=packed)["strips"] == 2     # (1- and 2-channel sources keep the narrow layout)
 
 
 def test_short_last_tile_is_flagged(fl):
