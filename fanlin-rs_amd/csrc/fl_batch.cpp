@@ -488,7 +488,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
-        if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u) | (w.mplan->wide ? 1u << 9 : 0u) | (w.mplan->full ? 1u << 10 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u) | (w.mplan->wide ? 1u << 9 : 0u) | (w.mplan->full ? 1u << 10 : 0u) | (w.mplan->compact ? 1u << 11 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         else if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         if (w.p->blur_sigma > 0.0f) {
             const uint32_t ce = blur_channels(w);
@@ -765,7 +765,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         } else if ((L.k.kind & 255u) == S1_MFMA) {
             LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
             m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
-            m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.wide = (L.k.kind >> 9) & 1u; m.full = (L.k.kind >> 10) & 1u; m.max_nout = L.max_nout;
+            m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.wide = (L.k.kind >> 9) & 1u; m.full = (L.k.kind >> 10) & 1u; m.compact = (L.k.kind >> 11) & 1u; m.max_nout = L.max_nout;
             m.spin_limit = mfma_spin_limit; m.err_word = status_dev + 2 * n;
             {
                 ProfileScope ps(c, st, 0);

@@ -141,12 +141,22 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
     plan.full = arith == MFMA_ARITH_FULL;
     if (ok) {
         plan.wide = hp.wide;
-        plan.ops_in_lds = !hp.wide;
-        for (auto &S : hp.strips) {
-            plan.max_nout = std::max(plan.max_nout, S.hdr.nout);
-            if (S.hdr.n_ops > kMfmaLdsOperands) plan.ops_in_lds = false;
+        for (auto &S : hp.strips) plan.max_nout = std::max(plan.max_nout, S.hdr.nout);
+        if (plan.full) {
+            // full-width arithmetic: the LDS operand area is whatever the layout's output tiles leave (42 operands, 56 in the compact
+            // layout for strips of at most 300 outputs), and each strip whose distinct operands fit reads them from there -- the
+            // others from the L2.  (With 24-bit weights the low digit's operands repeat only where the f32 sample positions have
+            // run out of fraction bits: the right-hand strips of 1080p -> 300 columns have 33 and 49 operands, the leftmost 69.)
+            plan.compact = !plan.wide && plan.max_nout <= kMfmaMaxStripOutputsCompact;
+            const uint32_t cap = mfma_lds_operand_capacity(plan.wide ? 1 : plan.compact ? 2 : 0);
+            for (auto &S : hp.strips) S.hdr.lds_ops = S.hdr.n_ops <= cap ? 1u : 0u;
+            plan.ops_in_lds = false;
+        } else {
+            plan.ops_in_lds = !hp.wide;
+            for (auto &S : hp.strips)
+                if (S.hdr.n_ops > kMfmaLdsOperands) plan.ops_in_lds = false;
+            if (mfma_lds_bytes(plan.max_nout, plan.ops_in_lds, plan.wide) > 160 * 1024) ok = false;
         }
-        if (mfma_lds_bytes(plan.max_nout, plan.ops_in_lds, plan.wide) > 160 * 1024) ok = false;
         // (Round 2 kept geometries with BOTH handicaps -- four strips where 2.8 would do, ~100 distinct operands read from the L2
         // instead of LDS -- on the streaming kernel, which was as fast there.  With the tile stage requesting its operands two
         // units ahead the matrix-pipe kernel wins on every one of them: 1080p -> 256x144 1.88 vs 1.99 ms, 512x288 2.33 vs 2.95,
@@ -186,9 +196,9 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
     }
     plan.ok = ok;
     if (getenv("FLGPU_DEBUG_MFMA")) {
-        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d, wide %d, full-width arithmetic %d;",
-                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds, (int)plan.wide, (int)plan.full);
-        for (auto &S : hp.strips) fprintf(stderr, " strip [%u,%u) byte0 %u hs %u ops %u", S.hdr.x0, S.hdr.x1, S.hdr.byte0, S.hdr.hs, S.hdr.n_ops);
+        fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d, wide %d, compact %d, full-width arithmetic %d;",
+                ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds, (int)plan.wide, (int)plan.compact, (int)plan.full);
+        for (auto &S : hp.strips) fprintf(stderr, " strip [%u,%u) byte0 %u hs %u ops %u%s slots %u", S.hdr.x0, S.hdr.x1, S.hdr.byte0, S.hdr.hs, S.hdr.n_ops, S.hdr.lds_ops ? " (LDS)" : "", S.hdr.slots);
         fprintf(stderr, "\n");
     }
     auto res = c->mfma_plans.emplace(key, std::move(plan));

@@ -95,6 +95,7 @@ struct MfmaPlan {
     bool ops_in_lds = false;
     bool wide = false;       // wide layout (fl_mfma.h): more outputs per strip, operands from the L2
     bool full = true;        // built for the full-width arithmetic (MFMA_ARITH_FULL)
+    bool compact = false;    // full-width arithmetic: strips of at most 300 outputs, the compact LDS layout (56 operands fit)
     bool arena_full = false; // the tables did not fit what is left of the arena: not cached, the caller resets the arena and plans again
 };
 

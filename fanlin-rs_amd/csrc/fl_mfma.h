@@ -46,6 +46,15 @@ static_assert(kMfmaOutPitch >= kMfmaMaxStripOutputs + 16 && (4 * kMfmaOutPitch) 
 constexpr uint32_t kMfmaMaxStripOutputsWide = 728;
 constexpr uint32_t kMfmaOutPitchWide = 748;
 static_assert(kMfmaOutPitchWide >= kMfmaMaxStripOutputsWide + 16 && (4 * kMfmaOutPitchWide) % 32 == 16, "LDS output tile pitch (wide)");
+// The three LDS layouts of the kernel (template parameter LAYOUT): words per output-tile row / outputs per strip / operands
+// (1 KB each) that fit next to the two output tiles and the rows' 64 KB.
+constexpr uint32_t kMfmaMaxStripOutputsCompact = 300;
+constexpr uint32_t kMfmaOutPitchCompact = 316;
+static_assert(kMfmaOutPitchCompact >= kMfmaMaxStripOutputsCompact + 16 && (4 * kMfmaOutPitchCompact) % 32 == 16, "LDS output tile pitch (compact)");
+constexpr uint32_t mfma_out_pitch(int layout) { return layout == 1 ? kMfmaOutPitchWide : layout == 2 ? kMfmaOutPitchCompact : kMfmaOutPitch; }
+constexpr uint32_t mfma_max_outputs(int layout) { return layout == 1 ? kMfmaMaxStripOutputsWide : layout == 2 ? kMfmaMaxStripOutputsCompact : kMfmaMaxStripOutputs; }
+// full-width arithmetic: operands the LDS operand area of a layout holds (160 KB - the rows' 64 KB - two output tiles - counters)
+constexpr uint32_t mfma_lds_operand_capacity(int layout) { return layout == 1 ? 0u : (160u * 1024u - 64u * 1024u - 2u * 16u * mfma_out_pitch(layout) * 4u - 16u) / 1024u; }
 constexpr uint32_t kMfmaDefaultSpinLimit = 1u << 22; // polls of an LDS counter before a wave gives up and reports FLGPU_DEVERR_MFMA_WAIT
 constexpr uint32_t FLGPU_DEVERR_MFMA_WAIT = 1u;      // bit of the batch's device error word
 constexpr uint32_t kMfmaVScaleLog2 = 8;     // packed arithmetic: vertical weights are stored times 2^8 (keeps the low f16 term normal)
@@ -99,6 +108,8 @@ struct MfmaStrip {
     uint32_t hs;           // horizontal weights are scaled by 2^hs
     uint32_t n_ops;
     uint32_t ctab_off, ops_off;
+    uint32_t lds_ops;      // full-width arithmetic: the strip's operands fit the launch's LDS operand area and are read from there (else from the L2)
+    uint32_t slots;        // tile slots a 64-byte chunk of this strip uses at most (2 or 3)
 };
 
 struct HostMfmaPlan {
@@ -109,7 +120,7 @@ struct HostMfmaPlan {
     uint32_t ntiles = 0, nkb = 0, y0 = 0, rows = 0, tail = 0;
     struct Tile { uint32_t kb_first, kb_last; };
     std::vector<Tile> tiles;
-    struct Strip { MfmaStrip hdr; std::vector<int32_t> ctab; std::vector<uint32_t> ops; };
+    struct Strip { MfmaStrip hdr{}; std::vector<int32_t> ctab; std::vector<uint32_t> ops; };
     std::vector<Strip> strips;
 };
 
@@ -131,12 +142,14 @@ struct LaunchMfma {
     uint32_t letterbox;
     uint32_t ops_in_lds;   // every strip of the launch has <= kMfmaLdsOperands distinct operands
     uint32_t wide;         // the launch's plans use the wide layout (never together with ops_in_lds)
+    uint32_t compact;      // ... the compact layout (full-width arithmetic only)
     uint32_t full;         // the launch's plans were built for the full-width arithmetic (MFMA_ARITH_FULL)
     uint32_t max_nout;
     uint32_t spin_limit;   // bound of the kernel's LDS counter waits (kMfmaDefaultSpinLimit; tests force 0 = every wait expires)
     uint32_t *err_word;    // device word of the batch: the kernel ORs FLGPU_DEVERR_MFMA_WAIT into it when a wait expired
 };
-size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds, bool wide = false);
+size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds, bool wide = false); // packed arithmetic
+size_t mfma_lds_bytes_full(int layout);                                       // full-width arithmetic: the operand area takes what is left
 hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st);
 
 } // namespace fl

@@ -58,10 +58,12 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f
 // CS: interleaved 8-bit channels of the source (the vertical pass does not care; the horizontal tables carry the channel
 // structure; only the last step, bytes -> destination pixel, is written per channel count).
 // LB: the destination is Rgba8 with the picture placed on a fill frame.  HLDS: the strip's horizontal operands sit in LDS.
-// WIDE (never with HLDS): the LDS the operands would take goes to wider output tiles (fl_mfma.h).
+// LAYOUT: 0 = output tiles of up to 408 outputs per row, 1 (never with HLDS) = wide: the LDS the operands would take goes to
+// output tiles of up to 728 outputs, 2 = compact: up to 300 outputs, which leaves room for 56 operands (fl_mfma.h).
 // FW: full-width arithmetic (fl_mfma.h MFMA_ARITH_FULL) -- bytes as f16 subnormals x three-term weights, a 23-bit intermediate in
-// three byte planes x three weight digits; otherwise the packed arithmetic of rounds 2-3.
-template <int CS, bool LB, bool HLDS, bool WIDE, bool FW>
+// three byte planes x three weight digits; otherwise the packed arithmetic of rounds 2-3.  With FW, HLDS only says that the
+// launch's LDS has an operand area: whether a strip's operands live there is the strip's own flag (MfmaStrip::lds_ops).
+template <int CS, bool LB, bool HLDS, int LAYOUT, bool FW>
 __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
                                                                    const uint32_t *__restrict__ arena, uint32_t ot_words, uint32_t spin_limit,
                                                                    uint32_t *__restrict__ err_word
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const Job jb = jobs[it.job];
     const MfmaVPlan vp = *reinterpret_cast<const MfmaVPlan *>(arena + it.vplan_off);
     const MfmaStrip sp = *reinterpret_cast<const MfmaStrip *>(arena + it.strip_off);
-    constexpr uint32_t np = WIDE ? kMfmaOutPitchWide : kMfmaOutPitch; // words per output-tile row (compile-time: the row offsets of the LDS adds become immediates); column sp.nout is a dummy
+    constexpr bool WIDE = LAYOUT == 1;
+    constexpr uint32_t np = mfma_out_pitch(LAYOUT); // words per output-tile row (compile-time: the row offsets of the LDS adds become immediates); column sp.nout is a dummy
 
     uint32_t *otile = reinterpret_cast<uint32_t *>(mfma_lds);
     uint32_t *add_cnt = reinterpret_cast<uint32_t *>(mfma_lds + 2u * ot_words * 4u);
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const u32x4 *ops_glb = reinterpret_cast<const u32x4 *>(arena + sp.ops_off);
 
     for (uint32_t k = tid; k < 2u * ot_words + CNT_BYTES / 4u; k += THREADS) otile[k] = 0u;
-    if (HLDS)
+    if (HLDS && (!FW || sp.lds_ops))
         for (uint32_t k = tid; k < sp.n_ops * 64u; k += THREADS) reinterpret_cast<u32x4 *>(mfma_lds + 2u * ot_words * 4u + CNT_BYTES)[k] = ops_glb[k];
 
     // Letterbox frame: every workgroup paints the part next to its own band and strip (same split as the streaming kernel).
@@ -138,37 +141,43 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // the two 16-lane groups of a transposed read hit different banks.
     const uint32_t pitch = jb.sw * (uint32_t)CS;
     const uint32_t lq = lane & 7u, lt = lane >> 3;
-    uint32_t coff[2][2]; // [column half][octet parity]: byte offset inside the row, clamped so that 16 bytes stay inside it
+    // Addresses: an SGPR base per row octet of the K-block + a 32-bit byte offset per lane that never changes (the lane's row of
+    // the octet times the pitch + its 16-byte column tile; descriptors promise < 4 GiB per picture): the eight requests of a
+    // K-block cost scalar adds only.  (Round 3 computed eight per-lane offsets per K-block: ~30 vector instructions and eight
+    // registers in every pass.)  The picture's last K-block, whose rows past the end are clamped to the last row -- their
+    // weights are zero, the bytes must merely be readable --, computes its offsets per lane.
+    uint32_t voff[2][2]; // [column half][octet parity]
 #pragma unroll
     for (uint32_t hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (uint32_t par = 0; par < 2; ++par)
-            coff[hh][par] = min(sp.byte0 + wave * kMfmaWaveCols + hh * 128u + ((lt ^ par) * 16u), pitch - 16u);
+            voff[hh][par] = lq * pitch + min(sp.byte0 + wave * kMfmaWaveCols + hh * 128u + ((lt ^ par) * 16u), pitch - 16u); // (clamped so that 16 bytes stay inside the row)
     const uint32_t last_row = jb.sh - 1u;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring);
-    // (addresses: the picture's base pointer in SGPRs + a 32-bit byte offset per lane -- descriptors promise < 4 GiB per picture.
-    // The offsets of a K-block are computed ahead of time (request_offsets, in front of the wait for the rows in flight), and the
-    // requests go out the moment the transposed reads have returned: between "the rows have landed" and "the next rows are
+    // (the requests go out the moment the transposed reads have returned: between "the rows have landed" and "the next rows are
     // requested" the wave's 8 KB of LDS are not in flight, and with one K-block in flight per wave every such cycle is missing
     // bandwidth.)
-    auto request_offsets = [&](uint32_t s, uint32_t (&goff)[8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            const uint32_t ro = u >> 1, hh = u & 1u;
-            const uint32_t row = min(s * kMfmaKRows + ro * 8u + lq, last_row);
-            goff[u] = row * pitch + coff[hh][ro & 1u];
-        }
-    };
-    auto request = [&](const uint32_t (&goff)[8]) __attribute__((always_inline)) {
+    auto request = [&](uint32_t s) __attribute__((always_inline)) {
         // (in slot order: slots 2 ro and 2 ro + 1 are the two 128-byte halves of the same eight 256-byte row pieces, and memory
         // serves them best back to back -- requesting the even slots as soon as "their" transposed reads had returned and the odd
         // ones later measured 6 % SLOWER)
+        const uint8_t *kb_base = static_cast<const uint8_t *>(jb.src) + (size_t)(s * kMfmaKRows) * pitch;
+        if (s * kMfmaKRows + kMfmaKRows - 1u <= last_row) {
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            // (inline asm: hipcc orders EVERY later LDS access behind a global_load_lds it knows about -- s_waitcnt vmcnt(0) in
-            // front of the first counter or operand read -- which would park the whole horizontal stage behind the K-block just
-            // requested.  The transfers are waited for by hand, wait_vm0() in front of the transposed reads.)
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(goff[u]), "s"(jb.src), "s"(ring_lds + u * 1024u) : "memory");
+            for (uint32_t u = 0; u < 8; ++u) {
+                // (inline asm: hipcc orders EVERY later LDS access behind a global_load_lds it knows about -- s_waitcnt vmcnt(0) in
+                // front of the first counter or operand read -- which would park the whole horizontal stage behind the K-block just
+                // requested.  The transfers are waited for by hand, wait_vm0() in front of the transposed reads.)
+                const uint8_t *ob = kb_base + (size_t)((u >> 1) * 8u) * pitch;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[u & 1u][(u >> 1) & 1u]), "s"(ob), "s"(ring_lds + u * 1024u) : "memory");
+            }
+        } else {
+            const uint32_t rows_left = last_row - s * kMfmaKRows; // < 31
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t o = voff[u & 1u][(u >> 1) & 1u] + (min((u >> 1) * 8u + lq, rows_left) - lq) * pitch;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(o), "s"(kb_base), "s"(ring_lds + u * 1024u) : "memory");
+            }
         }
     };
 
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
     const uint32_t npx = sp.x1 - sp.x0;
 
-    constexpr uint32_t CONV_G = ((WIDE ? kMfmaMaxStripOutputsWide : kMfmaMaxStripOutputs) / (uint32_t)CS + 63u) / 64u;
+    constexpr uint32_t CONV_G = (mfma_max_outputs(LAYOUT) / (uint32_t)CS + 63u) / 64u;
     // One wave's share (2 of the 16 rows) of a finished output tile: i32 sums -> bytes -> destination.  A strip row has
     // at most kMfmaMaxStripOutputs[Wide] / CS pixels = CONV_G groups of 64 lanes.  All LDS reads of the share are issued before the first of
     // them is used; lanes past the row's end repeat its last pixel (same words read, same value stored to the same address), so
@@ -265,39 +274,32 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #ifdef FL_MFMA_TIMING
     const unsigned long long tm_loop0 = __builtin_readcyclecounter();
 #endif
-    // A K-block's weights (64 bytes per lane, served by the L2) and its meta word are fetched one K-block ahead, in front
-    // of the request for the rows: the vmcnt(0) in front of the transposed reads covers them for free, while fetched at
-    // the top of their own K-block they would add one L2 round trip to every pass of the loop.
+    // A K-block's weights (64 or 96 bytes per lane, served by the L2) and its meta word are fetched one K-block ahead: the vmcnt(0)
+    // in front of the transposed reads covers them for free, while fetched at the top of their own K-block they would add one L2
+    // round trip to every pass of the loop.  They are requested right BEHIND the pass's vertical matrix instructions, into the
+    // registers those have just read (round 3 requested them in front, into a second set: 16-24 registers more at the kernel's
+    // tightest point and a register-to-register copy of the set in every pass).
     // (the meta word comes through the VECTOR memory path like the weights, its index made opaque to the compiler: a scalar load
     // left in flight across the tile stage shares lgkmcnt with the stage's LDS traffic, and since scalar loads return out of
     // order every LDS wait of the stage then becomes lgkmcnt(0) -- behind all the LDS adds issued so far)
     uint32_t vzero = 0u;
     asm("" : "+v"(vzero));
-    u32x4 wvn[2 * NT];
+    u32x4 wv[2 * NT];
     uint32_t meta_n = arena[vp.meta_off + it.kb0 + vzero];
 #pragma unroll
-    for (int k = 0; k < 2 * NT; ++k) wvn[k] = vw[(it.kb0 * (2u * NT) + k) * 64u + lane];
-    {
-        uint32_t g0[8];
-        request_offsets(it.kb0, g0);
-        request(g0);
-    }
+    for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(it.kb0 * (2u * NT) + k) * 64u + lane];
+    request(it.kb0);
     // (kb_end: one pass more than the band has K-blocks when the picture's short last tile ends together with the tile before
     // it -- that pass runs on the table's all-zero K-block, index vp.nkb, whose meta word names the last tile: the matrix unit
     // adds zeros to whatever the transposed reads deliver, nothing is requested, and the loop body stays as it is)
     const uint32_t kb_end = it.kb1 + ((vp.tail && it.tile1 == vp.ntiles) ? 1u : 0u);
     for (uint32_t s = it.kb0; s < kb_end; ++s) {
         const bool have_next = s + 1u < it.kb1;
-        uint32_t gnext[8];
-        if (have_next) request_offsets(s + 1u, gnext);
         TM_A();
         __builtin_amdgcn_s_setprio(3); // (from here to the next request this wave's instructions go first on its SIMD: its LDS is not in flight)
         wait_vm0();
         TM_B(tm_wait);
         const uint32_t meta = __builtin_amdgcn_readfirstlane(meta_n);
-        u32x4 wv[2 * NT];
-#pragma unroll
-        for (int k = 0; k < 2 * NT; ++k) wv[k] = wvn[k];
         v2i raw[16];
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
@@ -305,19 +307,17 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             raw[ct] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + off));
         }
         wait_lgkm0();
-        if (have_next) request(gnext);
+        if (have_next) request(s + 1u);
         __builtin_amdgcn_s_setprio(0);
-        if (s + 1u < kb_end) {
-            const uint32_t sn = s + 1u < it.kb1 ? s + 1u : vp.nkb;
-            meta_n = arena[vp.meta_off + sn + vzero];
-#pragma unroll
-            for (int k = 0; k < 2 * NT; ++k) wvn[k] = vw[(sn * (2u * NT) + k) * 64u + lane];
-        }
         TM_B(tm_read);
         // (the meta word says whether the K-block has weights for a second, younger tile (set 1) at all: about a third of the
         // K-blocks touch one tile only, and a matrix instruction on zeros costs the same time and nearly the same power --
         // this kernel runs at the socket's power limit, so what it does not compute is what makes it faster)
         const bool both_sets = ((meta >> 17) & 1u) != 0u;
+        // (the test stays INSIDE the loop over the column tiles: hipcc keeps it as sixteen branches, i.e. sixteen small basic blocks, and
+        // that is what holds the register pressure down -- hoisted out, as two straight-line copies of the loop, the scheduler converts
+        // all sixteen column tiles up front and spills ~300 registers (measured, round 4).  Nothing is lost: the conversions of tile
+        // ct + 1 issue while the last matrix instruction of tile ct executes.)
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             // bytes -> f16 pairs.  Packed arithmetic: 0x6400 | byte = 1024 + byte.  Full width: the byte zero-extended IS the f16
@@ -337,6 +337,12 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[NT + t]), acc[1][ct], 0, 0, 0);
             }
+        }
+        if (s + 1u < kb_end) {
+            const uint32_t sn = s + 1u < it.kb1 ? s + 1u : vp.nkb;
+            meta_n = arena[vp.meta_off + sn + vzero];
+#pragma unroll
+            for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(sn * (2u * NT) + k) * 64u + lane];
         }
         TM_B(tm_mfma);
         const uint32_t ft = meta & 0xffffu;
@@ -387,60 +393,91 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                             p1[c][a] = __builtin_amdgcn_perm(t1, t0, 0x07060302u) ^ 0x80808080u;
                             p2[c][a] = __builtin_amdgcn_perm(x1, x0, 0x0c0c0602u) | __builtin_amdgcn_perm(x3, x2, 0x06020c0cu);       // (x0.b2, x1.b2, x2.b2, x3.b2)
                         }
-                    // units u = 3 c + t as in the packed form; per unit three operands (weight digits 2, 1, 0) and all nine digit
-                    // products, summed by the matrix unit into five scales: L[k] = sum over i + j = k of plane i x digit j, exact in i32
-                    // (|L| < 2^22: 64 products of at most 2^14, three of them per term at most)
+                    // Units (chunk c of 64 byte columns, tile slot t of 16 outputs) as in the packed form; per unit three operands (weight
+                    // digits 2, 1, 0) and all nine digit products, summed by the matrix unit into five scales: L[k] = sum over i + j = k of
+                    // plane i x digit j, exact in i32 (|L| < 2^22: 64 products of at most 2^14, three of them per term at most).
+                    // The units of slots 0 and 1 of every chunk run first, as one software pipeline (operands of the unit after next
+                    // requested, the next unit's matrix instructions issued, in front of this unit's recombination and LDS adds); slot 2
+                    // is rare -- a 64-byte chunk reaches a third tile only for ratios below ~4.5 -- and runs behind them if the strip has one.
                     u32x4 hb[2][3];
                     i32x4 L[2][5];
-                    auto load_ops = [&](int u) __attribute__((always_inline)) {
-                        uint32_t i2 = (uint32_t)ctab[u * 4 + 1], i1 = (uint32_t)ctab[u * 4 + 2], i0 = (uint32_t)ctab[u * 4 + 3];
-                        asm volatile("" : "+s"(i2), "+s"(i1), "+s"(i0)); // (see the packed form)
-                        hb[u & 1][0] = HLDS ? ops_lds[i2 * 64u + lane] : ops_glb[i2 * 64u + lane];
-                        hb[u & 1][1] = HLDS ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
-                        hb[u & 1][2] = HLDS ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
-                    };
-                    auto unit_mfma = [&](int u) __attribute__((always_inline)) {
-                        const i32x4 b2 = __builtin_bit_cast(i32x4, hb[u & 1][0]), b1 = __builtin_bit_cast(i32x4, hb[u & 1][1]), b0 = __builtin_bit_cast(i32x4, hb[u & 1][2]);
-                        const i32x4 a2 = __builtin_bit_cast(i32x4, p2[u / 3]), a1 = __builtin_bit_cast(i32x4, p1[u / 3]), a0 = __builtin_bit_cast(i32x4, p0[u / 3]);
-                        const i32x4 z = {0, 0, 0, 0};
-                        i32x4 *l = L[u & 1]; // (five independent chains, interleaved: no instruction waits for the one before it)
-                        l[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, z, 0, 0, 0);
-                        l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, z, 0, 0, 0);
-                        l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, z, 0, 0, 0);
-                        l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, z, 0, 0, 0);
-                        l[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, z, 0, 0, 0);
-                        l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, l[3], 0, 0, 0);
-                        l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, l[2], 0, 0, 0);
-                        l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, l[1], 0, 0, 0);
-                        l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, l[2], 0, 0, 0);
-                    };
                     // sum of the unit = L4 2^32 + L3 2^24 + L2 2^16 + L1 2^8 + L0 in units of 2^-(14 + hs) of a pixel step; the LDS tile
                     // takes it in units of 2^-20 (a wave's part of an output rounded once, to a millionth of a step)
-                    const uint32_t sh = hs + kMfmaXFracBitsFull - kMfmaOutFracBitsFull; // 16..18
-                    const uint32_t s4 = 32u - sh, s3 = 24u - sh, slo = sh - 8u;
-                    const int32_t rnd = 1 << (slo - 1u);
-                    if (!(ablate & 1u)) load_ops(0);
-                    wait_for_the_tiles();
-                    if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u); // this wave's two rows of the previous tile
-                    if (!(ablate & 1u)) {
-                        unit_mfma(0);
-                        load_ops(1);
-#pragma unroll
-                        for (int u = 0; u < 12; ++u) {
-                            if (u + 1 < 12) unit_mfma(u + 1);
-                            if (u + 2 < 12) load_ops(u + 2); // (into the registers unit u's matrix instructions have just read)
+                    // (hs = 24 for every geometry the planner lets through: the shifts are immediates, and the rounding constant of the one
+                    // right shift enters as the C operand of the first L1 product)
+                    constexpr uint32_t sh = 24u + kMfmaXFracBitsFull - kMfmaOutFracBitsFull; // 18
+                    constexpr uint32_t s4 = 32u - sh, s3 = 24u - sh, slo = sh - 8u;
+                    constexpr int32_t rnd = 1 << (slo - 1u);
+                    auto stage = [&](auto in_lds) __attribute__((always_inline)) {
+                        constexpr bool OL = decltype(in_lds)::value;
+                        auto load_ops = [&](int k, int u) __attribute__((always_inline)) { // operands of unit u = 3 c + t into buffer k & 1
+                            uint32_t i2 = (uint32_t)ctab[u * 4 + 1], i1 = (uint32_t)ctab[u * 4 + 2], i0 = (uint32_t)ctab[u * 4 + 3];
+                            asm volatile("" : "+s"(i2), "+s"(i1), "+s"(i0)); // (see the packed form)
+                            hb[k & 1][0] = OL ? ops_lds[i2 * 64u + lane] : ops_glb[i2 * 64u + lane];
+                            hb[k & 1][1] = OL ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
+                            hb[k & 1][2] = OL ? ops_lds[i0 * 64u + lane] : ops_glb[i0 * 64u + lane];
+                        };
+                        auto unit_mfma = [&](int k, int u) __attribute__((always_inline)) {
+                            const i32x4 b2 = __builtin_bit_cast(i32x4, hb[k & 1][0]), b1 = __builtin_bit_cast(i32x4, hb[k & 1][1]), b0 = __builtin_bit_cast(i32x4, hb[k & 1][2]);
+                            const i32x4 a2 = __builtin_bit_cast(i32x4, p2[u / 3]), a1 = __builtin_bit_cast(i32x4, p1[u / 3]), a0 = __builtin_bit_cast(i32x4, p0[u / 3]);
+                            const i32x4 z = {0, 0, 0, 0};
+                            i32x4 *l = L[k & 1]; // (five independent chains, interleaved: no instruction waits for the one before it)
+                            l[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, z, 0, 0, 0);
+                            l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, z, 0, 0, 0);
+                            l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, z, 0, 0, 0);
+                            l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, i32x4{rnd, rnd, rnd, rnd}, 0, 0, 0);
+                            l[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, z, 0, 0, 0);
+                            l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, l[3], 0, 0, 0);
+                            l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, l[2], 0, 0, 0);
+                            l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, l[1], 0, 0, 0);
+                            l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, l[2], 0, 0, 0);
+                        };
+                        auto recombine = [&](int k, int u) __attribute__((always_inline)) {
+                            // lanes outside the strip's outputs (and every lane of a slot not in use: operand 0, first output 2^30) add
+                            // into dummy columns of their own, nout + i: no lane is switched off, no two lanes share an address
                             const uint32_t o = (uint32_t)(ctab[u * 4] + (int32_t)i);
                             const uint32_t col = o < sp.nout ? o : sp.nout + i;
-                            const i32x4 *l = L[u & 1];
+                            const i32x4 *l = L[k & 1];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int32_t low = (((l[2][r] << 8) + l[1][r]) + (l[0][r] >> 8) + rnd) >> slo;
+                                const int32_t low = (((l[2][r] << 8) + l[1][r]) + (l[0][r] >> 8)) >> slo;
                                 const uint32_t p = ((uint32_t)l[4][r] << s4) + ((uint32_t)l[3][r] << s3) + (uint32_t)low;
                                 if (ablate & 128u) { asm volatile("" : : "v"(p), "v"(col)); continue; }
                                 __hip_atomic_fetch_add(&ot[(4u * g + r) * np + col], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
+                        };
+                        // the k-th unit of the first pipeline is (chunk k / 2, slot k % 2), of the second (chunk k, slot 2)
+#define FL_U01(k_) (3 * ((k_) / 2) + (k_) % 2)
+#define FL_U2(k_) (3 * (k_) + 2)
+                        if (!(ablate & 1u)) load_ops(0, FL_U01(0));
+                        wait_for_the_tiles();
+                        if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u); // this wave's two rows of the previous tile
+                        if (!(ablate & 1u)) {
+                            unit_mfma(0, FL_U01(0));
+                            load_ops(1, FL_U01(1));
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                if (k + 1 < 8) unit_mfma(k + 1, FL_U01(k + 1));
+                                if (k + 2 < 8) load_ops(k + 2, FL_U01(k + 2)); // (into the registers unit k's matrix instructions have just read)
+                                recombine(k, FL_U01(k));
+                            }
+                            if (sp.slots > 2u) {
+                                load_ops(0, FL_U2(0));
+                                unit_mfma(0, FL_U2(0));
+                                load_ops(1, FL_U2(1));
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    if (k + 1 < 4) unit_mfma(k + 1, FL_U2(k + 1));
+                                    if (k + 2 < 4) load_ops(k + 2, FL_U2(k + 2));
+                                    recombine(k, FL_U2(k));
+                                }
+                            }
                         }
-                    }
+#undef FL_U01
+#undef FL_U2
+                    };
+                    if (HLDS && sp.lds_ops) stage(std::true_type{});
+                    else stage(std::false_type{});
                 } else {
                     // ---- packed arithmetic (rounds 2-3) ---------------------------------------------------------------------------
                     u32x4 ahi[4], alo[4];
@@ -543,11 +580,17 @@ size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds, bool wide)
     return (size_t)2 * 16 * (wide ? kMfmaOutPitchWide : kMfmaOutPitch) * 4 + CNT_BYTES + (ops_in_lds ? kMfmaLdsOperands * 1024u : 0u); // dynamic part; the rows' 64 KB are static
 }
 
-template <int CS, bool LB, bool HLDS, bool WIDE, bool FW>
+size_t mfma_lds_bytes_full(int layout)
+{
+    return (size_t)2 * 16 * mfma_out_pitch(layout) * 4 + CNT_BYTES + (size_t)mfma_lds_operand_capacity(layout) * 1024u;
+}
+
+template <int CS, bool LB, bool HLDS, int LAYOUT, bool FW>
 static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 {
-    const size_t lds = mfma_lds_bytes(m.max_nout, HLDS, WIDE);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS, WIDE, FW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    constexpr bool WIDE = LAYOUT == 1;
+    const size_t lds = FW ? mfma_lds_bytes_full(LAYOUT) : mfma_lds_bytes(m.max_nout, HLDS, WIDE);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
 #ifdef FL_MFMA_TIMING
     static unsigned long long *dbg = nullptr;
@@ -555,7 +598,7 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
     constexpr size_t kDbgWgs = 16384;
     if (!dbg) { (void)hipMalloc(&dbg, (3 * 64 + kDbgWgs * 4) * 8); (void)hipMemset(dbg, 0, (3 * 64 + kDbgWgs * 4) * 8); }
     if (m.nitems > kDbgWgs) return hipErrorInvalidValue;
-    resample_mfma_kernel<CS, LB, HLDS, WIDE, FW><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word, dbg);
+    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word, dbg);
     if ((++launches == 5 || launches == 100) && m.nitems > 2900) {
         unsigned long long h[3 * 64];
         (void)hipDeviceSynchronize();
@@ -591,7 +634,7 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
             fprintf(stderr, "  xcc %d: %u workgroups, mean %.1f us (%.0f cycles), last one ends at %.1f us\n", x, xn[x], xn[x] ? xdur[x] / xn[x] : 0.0, xn[x] ? xcyc[x] / xn[x] : 0.0, xend[x]);
     }
 #else
-    resample_mfma_kernel<CS, LB, HLDS, WIDE, FW><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * (WIDE ? kMfmaOutPitchWide : kMfmaOutPitch), m.spin_limit, m.err_word);
+    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word);
 #endif
     return hipGetLastError();
 }
@@ -599,11 +642,19 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 template <int CS, bool FW>
 static hipError_t launch_mfma_c(const LaunchMfma &m, hipStream_t st)
 {
-    if constexpr (CS >= 3) { // (the planner keeps 1- and 2-channel sources on the narrow layout, fl_mfma_tables.cpp choose_mfma_plan)
-        if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, true, FW>(m, st) : launch_mfma_t<CS, false, false, true, FW>(m, st);
-    } else if (m.wide) return hipErrorInvalidValue;
-    if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<CS, true, true, false, FW>(m, st) : launch_mfma_t<CS, true, false, false, FW>(m, st);
-    return m.ops_in_lds ? launch_mfma_t<CS, false, true, false, FW>(m, st) : launch_mfma_t<CS, false, false, false, FW>(m, st);
+    if constexpr (FW) { // the operand area takes whatever LDS the layout leaves; each strip says whether it uses it
+        if constexpr (CS >= 3) {
+            if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, 1, true>(m, st) : launch_mfma_t<CS, false, false, 1, true>(m, st);
+        } else if (m.wide) return hipErrorInvalidValue;
+        if (m.compact) return m.letterbox ? launch_mfma_t<CS, true, true, 2, true>(m, st) : launch_mfma_t<CS, false, true, 2, true>(m, st);
+        return m.letterbox ? launch_mfma_t<CS, true, true, 0, true>(m, st) : launch_mfma_t<CS, false, true, 0, true>(m, st);
+    } else {
+        if constexpr (CS >= 3) { // (the planner keeps 1- and 2-channel sources on the narrow layout, fl_mfma_tables.cpp choose_mfma_plan)
+            if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, 1, false>(m, st) : launch_mfma_t<CS, false, false, 1, false>(m, st);
+        } else if (m.wide) return hipErrorInvalidValue;
+        if (m.letterbox) return m.ops_in_lds ? launch_mfma_t<CS, true, true, 0, false>(m, st) : launch_mfma_t<CS, true, false, 0, false>(m, st);
+        return m.ops_in_lds ? launch_mfma_t<CS, false, true, 0, false>(m, st) : launch_mfma_t<CS, false, false, 0, false>(m, st);
+    }
 }
 
 hipError_t launch_mfma(const LaunchMfma &m, hipStream_t st)

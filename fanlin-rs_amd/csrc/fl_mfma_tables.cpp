@@ -128,8 +128,9 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
     for (uint32_t x = cx; x < cx + cw; ++x)
         for (uint32_t k = 0; k < h.count[x]; ++k) maxw = std::max(maxw, fabsf(h.weights[h.woff[x] + k]));
     // fixed-point scale of the horizontal weights: the largest that keeps every weight inside NDIG balanced byte digits
-    // (packed: 14..17 bits, full: 22..24 -- 24 whenever no weight reaches 1/2, i.e. for every ratio the kernel takes)
-    const int hs_max = full ? 24 : 17, hs_min = full ? 22 : 14;
+    // (packed: 14..17 bits; full: 24 or not at all -- no weight reaches 1/2 for any ratio the kernel takes, and the kernel's shifts are
+    // compile-time constants)
+    const int hs_max = full ? 24 : 17, hs_min = full ? 24 : 14;
     const double qlimit = full ? 8355711.0 : 32639.0; // 127 * 256^(NDIG-1) + ... + 127
     int hs = hs_max;
     while (hs >= hs_min && ldexp((double)maxw, hs) > qlimit - 640.0) --hs;
@@ -184,7 +185,7 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
         const uint32_t x0 = bounds[si], x1 = bounds[si + 1];
         uint32_t L = 0xffffffffu;
         for (uint32_t x = x0; x < x1; ++x) L = std::min(L, h.left[x]);
-        S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (cs * L) / 16u * 16u; S.hdr.nout = (x1 - x0) * cs; S.hdr.hs = (uint32_t)hs;
+        S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (cs * L) / 16u * 16u; S.hdr.nout = (x1 - x0) * cs; S.hdr.hs = (uint32_t)hs; S.hdr.slots = 2;
         const int32_t nout = (int32_t)S.hdr.nout;
         // operand 0 is all zeros: the tile slots a chunk does not need multiply by it and add into the dummy column, which keeps
         // the kernel's horizontal stage free of branches (12 matrix instructions back to back per chunk instead of 4 + a wait)
@@ -212,6 +213,7 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
                 if (omax < 0) continue;
                 const uint32_t nt = (uint32_t)(omax - omin) / 16u + 1u;
                 if (nt > 3) return;
+                S.hdr.slots = std::max(S.hdr.slots, std::max(nt, 2u));
                 for (uint32_t t = 0; t < nt; ++t) {
                     const int32_t base = omin + 16 * (int32_t)t;
                     std::string op[3] = {std::string(1024, '\0'), std::string(1024, '\0'), std::string(1024, '\0')};

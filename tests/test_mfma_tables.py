@@ -48,7 +48,7 @@ def test_tables_decode_back_to_the_axis_weights(fl, sw, sh, c, rw, rh, crop, pac
         assert 14 <= d["hs"] <= 17, d
     else:
         assert d["vertical_weight_error"] < 2.0 ** -39, d       # three f16 terms ARE the f32 weight (f16 subnormals end at 2^-24 / 2^15)
-        assert 22 <= d["hs"] <= 24, d
+        assert d["hs"] == 24, d
     # fixed point with 2^-hs steps; the largest tap of an output absorbs the rounding of the others (so the sum is exactly 1)
     assert d["horizontal_weight_error"] < 64 * 2.0 ** -(d["hs"] + 1), d
     rows = crop[3] if crop else rh
