@@ -48,6 +48,22 @@ def shard_batches(global_images: int, world: int):
     return [(r * per, (r + 1) * per) for r in range(world)]
 
 
+KERNEL_DTYPE_FULL = ("u8 (exact, as f16 subnormals) x the reference's f32 weights as three f16 terms -> f32 sums (vertical, v_mfma_f32_16x16x32_f16); "
+                     "24-bit fixed-point intermediate (2^-14 steps, three i8 planes) x 24-bit fixed-point weights (2^-24 steps, three i8 digits), "
+                     "all nine digit products -> exact i32 (horizontal, v_mfma_i32_16x16x64_i8): no operand narrower than f32's 24 bits")
+KERNEL_DTYPE_PACKED = ("u8 x f16-pair weights (22 bit) -> f32 acc (vertical, MFMA); i16 (1/64 steps) x 17-bit fixed weights -> i32 exact (horizontal, MFMA) "
+                       "[FLGPU_MFMA_ARITH=packed: rounds 2-3's arithmetic, narrower than the reference's]")
+KERNEL_DTYPE_STREAM = "f32 (one fused multiply-add per tap, vertical then horizontal)"
+
+
+def kernel_dtype(stats) -> str:
+    """The arithmetic the dominant kernel really computes in (not a precision claim: every byte is checked to lie within 1 LSB of
+    the reference's f32 arithmetic, see verified_against)."""
+    if not stats.get("mfma_launches"):
+        return KERNEL_DTYPE_STREAM
+    return KERNEL_DTYPE_PACKED if os.environ.get("FLGPU_MFMA_ARITH", "")[:1] == "p" else KERNEL_DTYPE_FULL
+
+
 def cpu_baseline(n_images: int, workload: dict, max_threads: int = 16):
     """Times the CPU oracle (reference arithmetic, one image per thread, like one request per
     tokio worker) on a bounded sample of the same workload.  Reported, never a target."""
@@ -395,26 +411,33 @@ def main_one_context(args):
     elapsed = time.perf_counter() - t0
     stats = st.stats()
     ok, err = 1, None
-    if fe == fl.FE_JPEG:
-        srcs_c, dsts_c, _ = run._keep
-        fl._check(st._lib.flgpu_batch_results(st._ctx, n, dsts_c), st._ctx)
-        if any(d.bytes == 0 for d in dsts_c):
-            ok, err = 0, "an encoded stream did not fit its destination"
+    srcs_c, dsts_c, _ = run._keep   # (collected whatever the front end: a device-side failure of the batch comes back here)
+    fl._check(st._lib.flgpu_batch_results(st._ctx, n, dsts_c), st._ctx)
+    if fe == fl.FE_JPEG and any(d.bytes == 0 for d in dsts_c):
+        ok, err = 0, "an encoded stream did not fit its destination"
     launches = max(int(stats["resample_launches"]), 1)
     k_ms = stats["resample_ms"] / launches
     alg_bytes = (stats["resample_src_bytes"] + stats["resample_dst_bytes"]) / launches
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     line = {"metric": baseline_metric(), "value": n * args.steps / elapsed, "unit": "images/s", "n_gpus": N, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 x f16-pair weights -> f32 acc; i16 x 17-bit fixed weights -> i32" if stats.get("mfma_launches") else "f32", "data": "synthetic",
+            "dtype": kernel_dtype(stats), "data": "synthetic",
             "config": {"workload": f"{n} x {SRC_W}x{SRC_H} RGB8 (uniform bytes, HBM-resident, shard k on device k) -> w={REQ_W}&h={REQ_H} Lanczos3 + letterbox RGBA8"
                                    + (f" + baseline JPEG encode (q {args.quality}) on the device" if fe == fl.FE_JPEG else ""),
                        "mode": "one process, one context over the node's GPUs (flgpu_config.devices[]), shards by flgpu_plan_shards",
                        "devices": devices, "shard_images": [int((shard_of == k).sum()) for k in range(N)], "images_per_gpu_per_step": args.batch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "resample_mfma_kernel" if stats.get("mfma_launches") else "resample_stream_kernel", "kernel_ms": k_ms,
-                         "note": "per launch and device: average over the shards' launches"},
+                         "algorithmic_bytes_per_launch": alg_bytes, "note": "per launch and device: average over the shards' launches"},
+            "stage_ms_per_step": {"resample": stats["resample_ms"] / args.steps, "blur": stats["blur_ms"] / args.steps, "frontend": stats["frontend_ms"] / args.steps},
             "cpu_baseline": None}
+    # the same two objects as the per-rank mode: committed PMC traffic of the per-GPU workload, and the CPU port on a bounded sample
+    line["roofline"]["traffic"] = measured_traffic(f"{args.batch} x {SRC_W}x{SRC_H} RGB8 (uniform bytes, HBM-resident) -> w={REQ_W}&h={REQ_H} Lanczos3"
+                                                   + (" crop" if args.crop else " + letterbox RGBA8")
+                                                   + (f" + baseline JPEG encode (q {args.quality}) on the device" if fe == fl.FE_JPEG else ""))
+    if args.cpu_images > 0 and ok:
+        line["cpu_baseline"] = cpu_baseline(args.cpu_images, {"blur_sigma": args.blur, "grayscale": args.grayscale, "crop": args.crop,
+                                                              "jpeg": fe == fl.FE_JPEG, "quality": args.quality}, args.cpu_threads)
     if err:
         line["error"] = err
     print(json.dumps(line), flush=True)
@@ -535,9 +558,11 @@ def main():
     # ---- check what the timed region produced ----
     verified, verr, off_by_one = 0, None, 0.0
     results = None
+    # (collected whatever the front end: flgpu_batch_results is also where a device-side failure of the batch -- the matrix-pipe
+    # kernel's bounded LDS waits -- comes back as FLGPU_ERR_DEVICE)
+    srcs_c, dsts_c, _ = run._keep
+    fl._check(st._lib.flgpu_batch_results(st._ctx, n, dsts_c), st._ctx)
     if fe == fl.FE_JPEG:
-        srcs_c, dsts_c, _ = run._keep
-        fl._check(st._lib.flgpu_batch_results(st._ctx, n, dsts_c), st._ctx)
         results = [(d.flags, d.bytes) for d in dsts_c]
         if any(b == 0 for _, b in results):
             verr = "an encoded stream did not fit its destination"
@@ -574,7 +599,21 @@ def main():
         f32m["roofline"] = {"bound": "hbm", "kernel": "resample_stream_kernel", "kernel_ms": f32m["stage_ms_per_step"]["resample"],
                             "achieved": alg / (f32m["stage_ms_per_step"]["resample"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": alg / (f32m["stage_ms_per_step"]["resample"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        extra["f32 arithmetic (FLGPU_NO_MFMA=1), resize only"] = f32m
+        extra["f32 streaming kernel (FLGPU_NO_MFMA=1), resize only"] = f32m
+        # rounds 2-3's packed arithmetic (22-bit vertical weights, 1/64-step intermediate, 17-bit horizontal weights): narrower than
+        # the reference's f32, kept selectable; the whole metric (resize + letterbox + encode) and the resize alone
+        os.environ["FLGPU_MFMA_ARITH"] = "packed"
+        try:
+            pk = measure(params)
+            pk_r = measure(fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fl.FE_NONE))
+        finally:
+            del os.environ["FLGPU_MFMA_ARITH"]
+        pk["dtype"] = KERNEL_DTYPE_PACKED
+        pk["resize_only"] = pk_r
+        pk["roofline"] = {"bound": "hbm", "kernel": "resample_mfma_kernel<packed>", "kernel_ms": pk["stage_ms_per_step"]["resample"],
+                          "achieved": alg / (pk["stage_ms_per_step"]["resample"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": alg / (pk["stage_ms_per_step"]["resample"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        extra["packed arithmetic (FLGPU_MFMA_ARITH=packed), same workload as `value`"] = pk
         if not (args.grayscale and args.blur):
             extra["config2 (grayscale + blur sigma 10, pixels out)"] = measure(
                 fl.make_params(REQ_W, REQ_H, blur_sigma=10.0, grayscale=True, front_end=fl.FE_NONE))
@@ -591,15 +630,11 @@ def main():
         alg_bytes = (stats["resample_src_bytes"] + stats["resample_dst_bytes"]) / launches
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         workload = {"blur_sigma": args.blur, "grayscale": args.grayscale, "crop": args.crop, "jpeg": fe == fl.FE_JPEG, "quality": args.quality}
-        # the arithmetic the dominant kernel really computes in (not a precision claim: every byte is checked to lie within
-        # 1 LSB of the reference's f32 arithmetic, see verified_against)
-        kernel_dtype = ("u8 x f16-pair weights (22 bit) -> f32 acc (vertical, MFMA); i16 (1/64 steps) x 17-bit fixed weights -> i32 exact (horizontal, MFMA)"
-                        if stats.get("mfma_launches") else "f32 (one fused multiply-add per tap, vertical then horizontal)")
         line = {
             "metric": baseline_metric(),
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": kernel_dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": kernel_dtype(stats), "data": "synthetic",
             "config": {"workload": f"{n} x {SRC_W}x{SRC_H} RGB8 (uniform bytes, HBM-resident) -> w={REQ_W}&h={REQ_H} Lanczos3"
                                    + (" crop" if args.crop else " + letterbox RGBA8")
                                    + (" + grayscale" if args.grayscale else "") + (f" + blur sigma {args.blur:g}" if args.blur else "")
@@ -646,6 +681,13 @@ def main():
             line["config0"] = config0(fl, st, args.config0_runs)
         if args.cpu_images > 0 and world == 1 and ok_flag:
             line["cpu_baseline"] = cpu_baseline(args.cpu_images, workload, args.cpu_threads)
+            # "all host cores of the GPU box (core count stated)": the same sample once more on every core of the
+            # affinity mask (on a 1-GPU share that is the same 16; on a whole host, all of them)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if avail > line["cpu_baseline"]["cores"]:
+                line["cpu_baseline_all_cores"] = cpu_baseline(max(args.cpu_images, 8 * avail), workload, avail)
+            else:
+                line["cpu_baseline_all_cores"] = dict(line["cpu_baseline"], note="the affinity mask has no more cores than the 16-thread figure used")
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

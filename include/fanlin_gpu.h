@@ -341,7 +341,11 @@ int flgpu_transform_batch_device(flgpu_ctx *ctx, size_t n, const flgpu_image *sr
 /* What only the device knows when flgpu_transform_batch_device returns -- the length of an encoded stream
  * (FLGPU_FE_JPEG: dsts[i].bytes, 0 + FLGPU_ERR_BUFFER_TOO_SMALL if it did not fit dsts[i].capacity) and
  * FLGPU_IMG_HAS_ALPHA of the WebP front end: waits for the most recent device batch of this context and completes
- * the same dsts[] array.  The host-memory entry points do this themselves. */
+ * the same dsts[] array.  The host-memory entry points do this themselves.
+ * It is ALSO where a device-side failure of the batch surfaces: the matrix-pipe resample kernel bounds its waits on LDS
+ * hand-offs, and a wait that expired sets the batch's device error word, which this call returns as FLGPU_ERR_DEVICE
+ * (the pixels of that batch are then not valid).  Call it once per device batch before using the results, whatever the
+ * front end. */
 int flgpu_batch_results(flgpu_ctx *ctx, size_t n, flgpu_image *dsts);
 
 /* How a context of n_shards devices splits a batch (pure function, no device needed): shard_of[i] = the shard, hence the
