@@ -197,11 +197,21 @@ int jpeg_source_precheck(flgpu_ctx *c, const flgpu_image *src, const JpegInfo &i
         return FLGPU_ERR_UNSUPPORTED;
     }
     const uint64_t blocks = ((uint64_t)(info.width + 7u) / 8u) * ((info.height + 7u) / 8u) * std::max<uint32_t>(info.components, 1u);
-    if (blocks > 4ull * src->capacity + 64ull) { // (chroma sub-sampling only lowers the count)
-        if (((uint64_t)(info.width + 15u) / 16u) * ((info.height + 15u) / 16u) * 3u > 4ull * src->capacity + 64ull) {
-            c->set_error("malformed JPEG stream: shorter than its header's picture needs");
-            return FLGPU_ERR_INVALID_ARG;
-        }
+    // How short can a file be for that many blocks?  Sequential coding spends at least a DC and an end-of-block code on a block
+    // (two bits); a progressive file needs only its first DC scan (one bit per block), every later scan may end 32767 blocks
+    // with one end-of-band run.  Below that the header lies about the picture.  (Chroma sub-sampling only lowers the count:
+    // the test is repeated on the smallest count the frame could mean.)
+    const uint64_t bits_per_block = info.progressive ? 1u : 2u;
+    const uint64_t fewest = ((uint64_t)(info.width + 15u) / 16u) * ((info.height + 15u) / 16u) * 3u;
+    if (std::min(blocks, std::max<uint64_t>(fewest, 1u)) * bits_per_block > 8ull * src->capacity + 512ull) {
+        c->set_error("malformed JPEG stream: shorter than its header's picture needs");
+        return FLGPU_ERR_INVALID_ARG;
+    }
+    // multi-scan files are assembled in a full coefficient array first (128 bytes per block, fl_jpeghuff.cpp): it counts
+    // against the same 512 MiB
+    if (info.progressive && blocks * 128ull > (512ull << 20)) {
+        c->set_error("JPEG source: the coefficient array of this progressive picture exceeds 512 MiB");
+        return FLGPU_ERR_UNSUPPORTED;
     }
     return FLGPU_OK;
 }

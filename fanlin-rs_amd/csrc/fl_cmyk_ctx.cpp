@@ -104,13 +104,14 @@ bool rccl_load(Rccl *r)
 Rccl *rccl_for(flgpu_ctx *c)
 {
     if (c->rccl) return static_cast<Rccl *>(c->rccl);
+    if (c->rccl_failed) return nullptr; // (a failed dlopen / ncclCommInitAll is remembered: not retried on every table change)
     const size_t n = c->shard_ctx.size();
     std::set<int> distinct(c->devices.begin(), c->devices.end());
     if (n < 2 || distinct.size() != n) return nullptr; // RCCL wants one rank per physical GPU
     Rccl *r = new Rccl();
-    if (!rccl_load(r)) { delete r; return nullptr; }
+    if (!rccl_load(r)) { delete r; c->rccl_failed = true; return nullptr; }
     r->comms.assign(n, nullptr);
-    if (r->CommInitAll(r->comms.data(), (int)n, c->devices.data()) != 0) { delete r; return nullptr; } // (the library stays loaded)
+    if (r->CommInitAll(r->comms.data(), (int)n, c->devices.data()) != 0) { delete r; c->rccl_failed = true; return nullptr; } // (the library stays loaded)
     c->rccl = r;
     return r;
 }
@@ -342,15 +343,24 @@ try {
     Rccl r;
     if (!rccl_load(&r)) return FLGPU_ERR_UNSUPPORTED; // no RCCL on this host: the distribution falls back to copies
     if (auto ver = reinterpret_cast<int (*)(int *)>(dlsym(r.lib, "ncclGetVersion"))) { int v = 0; if (ver(&v) == 0 && info) info[0] = (uint32_t)v; }
-    if (hipSetDevice(device) != hipSuccess) return FLGPU_ERR_NO_DEVICE;
+    // one way out: whatever was created below is released there (the library handle, the communicator, buffers, stream)
     void *comm = nullptr;
+    uint8_t *src = nullptr, *dst = nullptr;
+    hipStream_t st = nullptr;
+    auto leave = [&](int code) {
+        if (st) (void)hipStreamDestroy(st);
+        if (src) (void)hipFree(src);
+        if (dst) (void)hipFree(dst);
+        if (comm) { if (r.CommDestroy(comm) != 0 && code == FLGPU_OK) code = FLGPU_ERR_DEVICE; if (info) info[3] = 1; } // created and destroyed
+        if (r.lib) { dlclose(r.lib); r.lib = nullptr; }
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) return leave(FLGPU_ERR_NO_DEVICE);
     const int devs[1] = {device};
-    if (r.CommInitAll(&comm, 1, devs) != 0 || !comm) return FLGPU_ERR_DEVICE;
+    if (r.CommInitAll(&comm, 1, devs) != 0 || !comm) { comm = nullptr; return leave(FLGPU_ERR_DEVICE); }
     const size_t n = 250563, pad = 4096; // 17^4 x 3 bytes: an odd count, so a wider element type cannot pass by accident
     std::vector<uint8_t> h(n + pad), back(n + pad, 0);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (uint8_t)(i * 2654435761u >> 24);
-    uint8_t *src = nullptr, *dst = nullptr;
-    hipStream_t st = nullptr;
     int rc = FLGPU_ERR_DEVICE;
     if (hipMalloc(&src, n + pad) == hipSuccess && hipMalloc(&dst, n + pad) == hipSuccess && hipStreamCreate(&st) == hipSuccess &&
         hipMemcpy(src, h.data(), n + pad, hipMemcpyHostToDevice) == hipSuccess && hipMemset(dst, 0xA5, n + pad) == hipSuccess) {
@@ -367,12 +377,7 @@ try {
             rc = (good == n && tail_untouched) ? FLGPU_OK : FLGPU_ERR_DEVICE;
         }
     }
-    if (st) (void)hipStreamDestroy(st);
-    if (src) (void)hipFree(src);
-    if (dst) (void)hipFree(dst);
-    if (r.CommDestroy(comm) != 0 && rc == FLGPU_OK) rc = FLGPU_ERR_DEVICE;
-    if (info) info[3] = 1; // the communicator was created and destroyed
-    return rc;
+    return leave(rc);
 } FL_ABI_CATCH
 
 } // extern "C"

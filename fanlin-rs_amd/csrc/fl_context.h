@@ -202,6 +202,7 @@ struct flgpu_ctx {
     std::vector<flgpu_ctx *> shard_ctx;
     std::vector<std::pair<size_t, size_t>> last_shards; // [first, last) image range of each shard in the last device batch
     void *rccl = nullptr;                               // fl_cmyk_ctx.cpp: RCCL communicators of the node (lazy)
+    bool rccl_failed = false;                           // ... or the fact that librccl could not be loaded / initialised (not retried)
     int cmyk_how = 0;                                   // how the default CMYK table last reached the shards: 2 = RCCL broadcast, 1 = copies
 
     // ---- request queue ------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ struct Huff {
     int32_t maxcode[18];  // per length, -1 = none; [17] = sentinel
     int32_t valoff[17];   // symbol index of the first code of a length minus that code
     uint8_t vals[256];
-    // AC tables only, the single-pass decoder's table: kAcBits of lookahead resolve code + magnitude (or the end-of-block and
+    // The single-pass decoder's table (AC and DC tables alike): kAcBits of lookahead resolve code + magnitude (or the end-of-block and
     // ZRL codes) in one step: bits 0-4 = bits to drop, 5-8 = zero run, 12 = no value (13 = end of block, else ZRL),
     // 16-31 = value; 0 = slow path
     uint32_t fastx[1 << kAcBits];
@@ -71,7 +71,6 @@ bool build_huff(Huff &h, const uint8_t *bits /*[16] counts of lengths 1..16*/, c
         if (v < (1 << (mag - 1))) v += (int)(~0u << mag) + 1;
         h.fastx[i] = (uint32_t)(len + mag) | ((uint32_t)run << 5) | ((uint32_t)(uint16_t)(int16_t)v << 16);
     }
-    h.present = true;
     h.present = true;
     return true;
 }
@@ -470,6 +469,7 @@ int decode_scans(const uint8_t *d, size_t n, Parsed &P, const JpegBlobHeader &H,
     const bool progressive = P.info.sof == 0xC2;
     size_t pos = P.sos_marker;
     uint32_t scans = 0;
+    uint64_t work_blocks = 0; // blocks visited by the scans so far
     for (;;) {
         if (pos + 2 > n) return scans ? 0 : -1; // (no EOI: what has been decoded stands, as decoders in the field do)
         if (d[pos] != 0xFF) return -1;
@@ -508,10 +508,20 @@ int decode_scans(const uint8_t *d, size_t n, Parsed &P, const JpegBlobHeader &H,
             for (uint32_t i = 0; i < S.ns; ++i) nb += H.comp[S.ci[i]].h * H.comp[S.ci[i]].v;
             if (nb > 10) return -1;
         }
+        // A bound on the WORK a file may ask for, not only on its scan count: every scan walks all blocks of its components (an
+        // end-of-band run still touches each of them), so a few hundred bytes per scan can cost 10^7 block visits.  Real encoders
+        // write ~10 scans, i.e. each block is visited ~6 times; beyond 32 visits per block of the frame on average the file goes to
+        // the caller's own decoder (-2 = unsupported), before the scan is decoded.
+        {
+            uint64_t visit = 0;
+            for (uint32_t i = 0; i < S.ns; ++i) visit += (uint64_t)H.comp[S.ci[i]].bw * H.comp[S.ci[i]].bh;
+            work_blocks += visit;
+            if (work_blocks > 32ull * H.nblocks + 4096ull) return -2;
+        }
         BitReader br{d, n, pos + len};
         if (decode_scan(br, P, H, S, progressive, coef) != 0) return -1;
         ++scans;
-        if (scans > 1000) return -1;
+        if (scans > 1000) return -2;
         // the next marker: either the reader ran into it, or it lies in the bytes not yet read
         if (br.marker) { pos = br.pos - 2; continue; }
         size_t q = br.pos;

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const Job jb = jobs[it.job];
     const MfmaVPlan vp = *reinterpret_cast<const MfmaVPlan *>(arena + it.vplan_off);
     const MfmaStrip sp = *reinterpret_cast<const MfmaStrip *>(arena + it.strip_off);
-    constexpr bool WIDE = LAYOUT == 1;
     constexpr uint32_t np = mfma_out_pitch(LAYOUT); // words per output-tile row (compile-time: the row offsets of the LDS adds become immediates); column sp.nout is a dummy
 
     uint32_t *otile = reinterpret_cast<uint32_t *>(mfma_lds);

@@ -462,7 +462,9 @@ try {
             {
                 std::unique_lock<std::mutex> lk(c->dec_mu);
                 if (!c->dec_limit) c->dec_limit = c->cfg.decode_threads ? c->cfg.decode_threads : usable_cpus();
-                c->dec_cv.wait(lk, [&] { return c->decoding < c->dec_limit; });
+                // (bounded: a file that keeps its decoder busy for long -- a huge progressive picture -- must not park every other
+                // JPEG request behind it; after the deadline the caller decodes anyway, one runnable thread more than CPUs)
+                (void)c->dec_cv.wait_for(lk, std::chrono::milliseconds(250), [&] { return c->decoding < c->dec_limit; });
                 c->decoding++;
             }
             struct Turn { flgpu_ctx *c; ~Turn() { { std::lock_guard<std::mutex> lk(c->dec_mu); c->decoding--; } c->dec_cv.notify_one(); } } turn{c};

@@ -20,12 +20,26 @@ pub struct FlPlan { src_w: u32, src_h: u32, mid_c: u32, resampled: u32, resized_
 pub struct FlConfig { device: i32, max_batch: u32, flush_timeout_us: u32, profile: u32, queue_lanes: u32, n_devices: u32,
                       use_embedded_profile: u32 /* config `use_embedded_profile`, handler.rs:19 */, decode_threads: u32 /* 0 = the CPUs the process may use */, devices: [i32; 8] }
 
+/// flgpu_jpeg_info: what `ImageReader::with_guessed_format` + `JpegDecoder::new` + `decoder.orientation()` learn from the
+/// header (src/handler.rs:192-206), for the decision "file bytes to the device, or the reference's own decoder".
+#[repr(C)] #[derive(Default, Clone, Copy)]
+pub struct FlJpegInfo { width: u32, height: u32, components: u32, channels: u32, progressive: u32, restart_interval: u32,
+                        h_max: u32, v_max: u32, exif_orientation: u32, supported: u32, adobe_transform: u32, has_icc_profile: u32 }
+
 pub const FE_NONE: u8 = 0;
 pub const FE_JFIF444: u8 = 1;
 pub const FE_WEBP420: u8 = 2;
 pub const FE_JPEG: u8 = 3;
 pub const FILTER_NEAREST: u8 = 1;
 const IMG_HAS_ALPHA: u32 = 2;
+const IMG_JPEG_SOURCE: u32 = 16; // FlImage.flags of a SOURCE: `data` holds the JPEG FILE (capacity = its length), not pixels
+pub const ACCEPT_WEBP: u32 = 1;   // content::Format bits (src/content.rs:12-48)
+pub const ACCEPT_AVIF: u32 = 2;
+pub const RESULT_AS_IS: c_int = 0;        // flgpu_result_kind
+pub const RESULT_JPEG_STREAM: c_int = 1;
+pub const RESULT_WEBP_PLANES: c_int = 2;
+pub const RESULT_PIXELS: c_int = 3;
+const ERR_UNSUPPORTED: c_int = 2; // FLGPU_ERR_UNSUPPORTED: a stream the device decoder does not cover
 const CMYK_INPUT_YCCK: u32 = 1;
 
 extern "C" {
@@ -36,6 +50,11 @@ extern "C" {
     fn flgpu_set_cmyk_profile(ctx: *mut c_void, icc: *const u8, n: u64) -> c_int;
     fn flgpu_cmyk_to_rgb(ctx: *mut c_void, cmyk: *const u8, n_pixels: u64, rgb: *mut u8,
                          embedded_icc: *const u8, icc_len: u64, flags: u32) -> c_int;
+    fn flgpu_jpeg_info_of(jpeg: *const u8, n: u64, info: *mut FlJpegInfo) -> c_int;
+    fn flgpu_process_jpeg_plan(jpeg: *const u8, n: u64, query: *const c_char, accept: u32, plan: *mut FlPlan, kind: *mut c_int) -> c_int;
+    fn flgpu_process_jpeg(ctx: *mut c_void, jpeg: *const u8, n: u64, query: *const c_char, accept: u32,
+                          dst: *mut FlImage, plan: *mut FlPlan, kind: *mut c_int, out_format: *mut c_int) -> c_int;
+    fn flgpu_transform_batch(ctx: *mut c_void, n: usize, srcs: *const FlImage, ps: *const FlParams, dsts: *mut FlImage) -> c_int;
     fn flgpu_strerror(status: c_int) -> *const c_char;
     fn flgpu_abi_version() -> u32;
 }
@@ -116,6 +135,81 @@ impl Gpu {
         Ok(Outcome::Device { plan, bytes: out, has_alpha: dst.flags & IMG_HAS_ALPHA != 0 })
     }
 
+    /// Header of a JPEG file, or None if the bytes are no JPEG (then `with_guessed_format` decides as before, handler.rs:192-204).
+    pub fn jpeg_info(original: &[u8]) -> Option<FlJpegInfo> {
+        let mut info = FlJpegInfo::default();
+        if unsafe { flgpu_jpeg_info_of(original.as_ptr(), original.len() as u64, &mut info) } == 0 { Some(info) } else { None }
+    }
+
+    /// `process_image` for a JPEG input FROM THE FILE BYTES ON (src/handler.rs:192-308 in one call): header, EXIF orientation,
+    /// the raw query string, size gate, `as_is`, container negotiation, then Huffman decoding on this thread and IDCT + colour
+    /// + CMYK fix + pixel pipeline + encode in one device pass.  `query`: the URL's query string as axum received it.
+    /// Ok(None): a stream the device decoder does not cover (arithmetic coding, 12-bit, lossless, hierarchical) -- decode with
+    /// the reference's own decoder and use `transform`.  Ok(Some((kind, out_format, plan, bytes))): `kind` says what `bytes` is --
+    /// RESULT_AS_IS (return `original` untouched, handler.rs:198-201), RESULT_JPEG_STREAM (the finished image/jpeg body),
+    /// RESULT_WEBP_PLANES (Y | U | V for WebPEncode, handler.rs:295-297), RESULT_PIXELS (pixels for the crate's PNG / AVIF /
+    /// lossless-WebP encoder; `out_format` = the negotiated container).
+    pub fn process_jpeg(&self, original: &[u8], query: &str, accept: u32)
+        -> Result<Option<(c_int, c_int, FlPlan, Vec<u8>)>, Box<dyn std::error::Error>>
+    {
+        let q = std::ffi::CString::new(query)?;
+        let (mut plan, mut kind, mut fmt) = (FlPlan::default(), 0 as c_int, 0 as c_int);
+        let rc = unsafe { flgpu_process_jpeg_plan(original.as_ptr(), original.len() as u64, q.as_ptr(), accept, &mut plan, &mut kind) };
+        if rc == ERR_UNSUPPORTED { return Ok(None); }
+        check(rc)?;
+        if kind == RESULT_AS_IS { return Ok(Some((kind, 0, plan, Vec::new()))); }
+        let mut out = vec![0u8; plan.max_out_bytes as usize];
+        let mut dst = FlImage { data: out.as_mut_ptr(), capacity: out.len() as u64, width: 0, height: 0, channels: 0, flags: 0, bytes: 0 };
+        let rc = unsafe { flgpu_process_jpeg(self.0, original.as_ptr(), original.len() as u64, q.as_ptr(), accept, &mut dst, &mut plan, &mut kind, &mut fmt) };
+        if rc == ERR_UNSUPPORTED { return Ok(None); }
+        check(rc)?;
+        out.truncate(dst.bytes as usize);
+        Ok(Some((kind, fmt, plan, out)))
+    }
+
+    /// The same decode + pipeline with parameters already taken from a `Query` (no query string at hand): the SOURCE of `transform`
+    /// is the file -- `FlImage.flags = IMG_JPEG_SOURCE`, `width / height / channels` from `jpeg_info`.  The EXIF orientation is
+    /// read from the file by the library when `orientation` is 0.
+    pub fn transform_jpeg_file(&self, original: &[u8], info: &FlJpegInfo, q: &crate::query::Query, front_end: u8)
+        -> Result<Outcome, Box<dyn std::error::Error>>
+    {
+        if info.supported == 0 { return Ok(Outcome::KeepCpuPath); }
+        let (r, g, b) = q.fill_color();
+        let mut p = FlParams { fill_r: r, fill_g: g, fill_b: b, crop: q.cropping() as u8, blur_sigma: q.blur(),
+                               grayscale: q.grayscale() as u8, inverse: q.inverse() as u8, quality: q.quality(),
+                               front_end, orientation: info.exif_orientation as u8, ..Default::default() };
+        if let Some((w, h)) = q.dimensions() { p.has_dims = 1; p.w = w; p.h = h; }
+        let mut plan = FlPlan::default();
+        check(unsafe { flgpu_plan_output(&p, info.width, info.height, info.channels, &mut plan) })?;
+        let mut out = vec![0u8; plan.max_out_bytes as usize];
+        let src = FlImage { data: original.as_ptr() as *mut u8, capacity: original.len() as u64,
+                            width: info.width, height: info.height, channels: info.channels, flags: IMG_JPEG_SOURCE, bytes: 0 };
+        let mut dst = FlImage { data: out.as_mut_ptr(), capacity: out.len() as u64, width: 0, height: 0, channels: 0, flags: 0, bytes: 0 };
+        check(unsafe { flgpu_transform(self.0, &src, &p, &mut dst) })?;
+        out.truncate(dst.bytes as usize);
+        Ok(Outcome::Device { plan, bytes: out, has_alpha: dst.flags & IMG_HAS_ALPHA != 0 })
+    }
+
+    /// `process_gif` (src/handler.rs:311-366): all frames of an animation in ONE batch -- per frame grayscale / invert, Nearest
+    /// resize and letterbox (lines 327-353), `filter = FILTER_NEAREST`.  Frames are Rgba8 buffers of one size; the results come
+    /// back in frame order for the GIF encoder (lines 355-363).
+    pub fn transform_gif_frames(&self, frames: &[image::RgbaImage], q: &crate::query::Query) -> Result<(FlPlan, Vec<Vec<u8>>), Box<dyn std::error::Error>> {
+        let (r, g, b) = q.fill_color();
+        let mut p = FlParams { fill_r: r, fill_g: g, fill_b: b, crop: q.cropping() as u8, grayscale: q.grayscale() as u8,
+                               inverse: q.inverse() as u8, filter: FILTER_NEAREST, ..Default::default() };
+        if let Some((w, h)) = q.dimensions() { p.has_dims = 1; p.w = w; p.h = h; }
+        let mut plan = FlPlan::default();
+        let (fw, fh) = frames.first().map_or((0, 0), |f| (f.width(), f.height()));
+        check(unsafe { flgpu_plan_output(&p, fw, fh, 4, &mut plan) })?;
+        let mut outs: Vec<Vec<u8>> = frames.iter().map(|_| vec![0u8; plan.out_bytes as usize]).collect();
+        let srcs: Vec<FlImage> = frames.iter().map(|f| FlImage { data: f.as_raw().as_ptr() as *mut u8, capacity: f.as_raw().len() as u64,
+                                                                  width: f.width(), height: f.height(), channels: 4, flags: 0, bytes: 0 }).collect();
+        let mut dsts: Vec<FlImage> = outs.iter_mut().map(|o| FlImage { data: o.as_mut_ptr(), capacity: o.len() as u64, width: 0, height: 0, channels: 0, flags: 0, bytes: 0 }).collect();
+        let ps: Vec<FlParams> = frames.iter().map(|_| FlParams { ..p_clone(&p) }).collect();
+        check(unsafe { flgpu_transform_batch(self.0, frames.len(), srcs.as_ptr(), ps.as_ptr(), dsts.as_mut_ptr()) })?;
+        Ok((plan, outs))
+    }
+
     /// The pixels of `Outcome::Device` (front_end 0) as the `DynamicImage` the rest of process_image expects.
     pub fn into_dynamic(plan: &FlPlan, pixels: Vec<u8>) -> image::DynamicImage {
         use image::{DynamicImage, ImageBuffer};
@@ -129,10 +223,32 @@ impl Gpu {
 }
 impl Drop for Gpu { fn drop(&mut self) { unsafe { flgpu_destroy(self.0) } } }
 
+fn p_clone(p: &FlParams) -> FlParams {
+    FlParams { has_dims: p.has_dims, w: p.w, h: p.h, fill_r: p.fill_r, fill_g: p.fill_g, fill_b: p.fill_b, crop: p.crop, blur_sigma: p.blur_sigma,
+               grayscale: p.grayscale, inverse: p.inverse, quality: p.quality, front_end: p.front_end, orientation: p.orientation, filter: p.filter, reserved: [0; 2] }
+}
 fn err(st: c_int) -> String { unsafe { std::ffi::CStr::from_ptr(flgpu_strerror(st)) }.to_string_lossy().into_owned() }
 fn check(st: c_int) -> Result<(), Box<dyn std::error::Error>> { if st == 0 { Ok(()) } else { Err(err(st).into()) } }
 
-// ---- how process_image uses it (src/handler.rs:221-255 become) -------------------------------------------------------
+// ---- how process_image uses it ---------------------------------------------------------------------------------------------
+// JPEG inputs (src/handler.rs:192-220 + everything below them): hand the FILE over when the header says the device decoder
+// covers it -- entropy decoding on this worker thread, everything else on the device, one call:
+//
+//     if let Some(info) = gpu::Gpu::jpeg_info(original) {                            // instead of with_guessed_format for JPEGs
+//         if info.supported == 1 {
+//             let accept = (content.webp_accepted() as u32) * gpu::ACCEPT_WEBP | (content.avif_accepted() as u32) * gpu::ACCEPT_AVIF;
+//             if let Some((kind, out_format, plan, bytes)) = self.gpu.process_jpeg(original, raw_query, accept)? {
+//                 match kind {
+//                     gpu::RESULT_AS_IS => return Ok((ImageFormat::Jpeg.to_mime_type(), original.to_vec())),      // lines 198-201
+//                     gpu::RESULT_JPEG_STREAM => return Ok((ImageFormat::Jpeg.to_mime_type(), bytes)),            // lines 274-278
+//                     gpu::RESULT_WEBP_PLANES => { /* WebPEncode on the Y | U | V planes, lines 295-297 */ }
+//                     _ => { let img = gpu::Gpu::into_dynamic(&plan, bytes); /* PNG / AVIF / lossless WebP arm for `out_format` */ }
+//                 }
+//             }                                                                       // None: fall through to the decoder below
+//         }
+//     }
+//
+// Every other input, and JPEGs the device decoder does not cover (src/handler.rs:221-255 become):
 //
 //     let orientation = decoder.orientation()?;                                     // line 206, kept
 //     let mut img = DynamicImage::from_decoder(decoder)?;                            // line 220, kept

@@ -94,12 +94,31 @@ def test_rust_shim_mirrors_the_structs(fl):
     import re
     text = open(os.path.join(ROOT, "shim", "handler_gpu.rs")).read()
     assert "flgpu_abi_version() }, 3" in text
-    for rust, cls in (("FlImage", fl.flgpu_image), ("FlParams", fl.flgpu_params), ("FlPlan", fl.flgpu_plan), ("FlConfig", fl.flgpu_config)):
+    mirrors = {"FlImage": fl.flgpu_image, "FlParams": fl.flgpu_params, "FlPlan": fl.flgpu_plan, "FlConfig": fl.flgpu_config, "FlJpegInfo": fl.flgpu_jpeg_info}
+    declared = set(re.findall(r"#\[repr\(C\)\](?:\s*#\[derive\([^)]*\)\])?\s*pub struct (\w+)", text))
+    assert declared == set(mirrors), declared                      # every #[repr(C)] struct of the shim is checked
+    for rust, cls in mirrors.items():
         m = re.search(r"pub struct %s \{(.*?)\}" % rust, text, re.S)
         assert m, rust
         body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
         names = [f.split(":")[0].strip() for f in body.split(",") if ":" in f]
         assert names == [n for n, _ in cls._fields_], (rust, names)
+    # every entry point the shim binds exists in the header (and so in the library: test_library_exports_every_declared_symbol)
+    header = open(os.path.join(ROOT, "include", "fanlin_gpu.h")).read()
+    block = re.search(r'extern "C" \{(.*?)\n\}', text, re.S).group(1)
+    bound = re.findall(r"fn (flgpu_\w+)\(", block)
+    assert {"flgpu_transform", "flgpu_process_jpeg", "flgpu_process_jpeg_plan", "flgpu_jpeg_info_of", "flgpu_transform_batch", "flgpu_cmyk_to_rgb"} <= set(bound)
+    for name in bound:
+        assert re.search(r"\b%s\(" % name, header), name
+    # constants the shim restates
+    for rust_name, c_name in (("IMG_JPEG_SOURCE", "FLGPU_IMG_JPEG_SOURCE"), ("ACCEPT_WEBP", "FLGPU_ACCEPT_WEBP"), ("ACCEPT_AVIF", "FLGPU_ACCEPT_AVIF")):
+        rv = int(re.search(r"const %s: u32 = (\d+);" % rust_name, text).group(1))
+        cv = int(re.search(r"#define %s\s+(\d+)u" % c_name, header).group(1))
+        assert rv == cv, rust_name
+    assert int(re.search(r"const ERR_UNSUPPORTED: c_int = (\d+);", text).group(1)) == fl.ERR_UNSUPPORTED
+    kinds = dict(re.findall(r"FLGPU_(RESULT_\w+) = (\d+)", header))
+    for k, v in kinds.items():
+        assert int(re.search(r"pub const %s: c_int = (\d+);" % k, text).group(1)) == int(v), k
 
 
 def test_loaded_library_was_built_from_the_sources_beside_it(fl):

@@ -151,6 +151,27 @@ def test_mutated_progressive_streams_never_crash(fl):
             pass
 
 
+def test_a_file_cannot_buy_unbounded_decoder_time_with_scans(fl):
+    """A multi-scan file pays per scan for every block of the scan's components, so the decoder bounds the WORK a file may ask
+    for (csrc/fl_jpeghuff.cpp decode_scans: 32 visits per block of the frame on average), not only its scan count: a real
+    progressive file repeated-scan-stuffed far beyond anything an encoder writes comes back as an error at once -- unsupported, so
+    that the reference's own decoder can have it (handler.rs:205-220) -- instead of keeping a decoder slot busy for minutes."""
+    import time
+    data = _save(synth.photo(256, 256, 1, index=3), progressive=True, quality=85)
+    # the file's last scan (SOS marker ... up to EOI), repeated: every copy walks all 1024 blocks again
+    last_sos = data.rfind(b"\xff\xda")
+    eoi = data.rfind(b"\xff\xd9")
+    scan = data[last_sos:eoi]
+    stuffed = data[:eoi] + scan * 400 + b"\xff\xd9"
+    t0 = time.perf_counter()
+    with pytest.raises(fl.FanlinError) as e:
+        fl.debug_jpeg_blob(stuffed)
+    assert time.perf_counter() - t0 < 2.0
+    assert e.value.status in (fl.ERR_UNSUPPORTED, fl.ERR_INVALID_ARG)
+    hdr, coef, _ = fl.debug_jpeg_blob(data)      # the file itself is fine
+    assert hdr["nblocks"] == 1024
+
+
 def test_host_decoder_on_the_reference_picture(fl, oracle):
     data = lenna_bytes()
     info = fl.jpeg_info(data)
