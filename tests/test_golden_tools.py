@@ -35,3 +35,18 @@ def test_golden_dump_source_covers_every_operation_of_process_image():
     for call in ("apply_orientation", ".grayscale()", ".invert()", "resize_to_fill", ".resize(", "from_pixel", "overlay", ".blur(",
                  "JpegEncoder::new_with_quality"):
         assert call in src, call
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_device_mode_measures_the_shipped_kernels(tmp_path):
+    """`compare_golden.py device DIR`: the kernels that ship (the matrix-pipe kernel in its default full-width arithmetic) against
+    the exported oracle files -- and against the crate's, wherever a cargo environment has put them next to these."""
+    d = str(tmp_path / "cases")
+    subprocess.run([sys.executable, TOOL, "export", d], check=True)
+    r = subprocess.run([sys.executable, TOOL, "device", d], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "config1_1080p_uniform_to_300x200" in r.stdout and "(matrix-pipe kernel)" in r.stdout
+    assert "config2_1080p_gray_blur10" in r.stdout and os.path.exists(os.path.join(d, "mfma_4k_to_300x200.device.raw"))

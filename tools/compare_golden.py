@@ -6,6 +6,9 @@
   compare DIR   after `cargo run` in tools/golden_dump: diffs NAME.crate.raw / NAME.crate.jpg against the oracle's
                 files; exit code 0 only if every resample / blur case is within 1 LSB, every exact case and every
                 JPEG stream byte-identical
+  device DIR    (needs a GPU) runs every pixel case through libfanlin_gpu.so -- the kernels that actually ship, the
+                matrix-pipe kernel in its default full-width arithmetic -- writes NAME.device.raw and reports the distance to
+                the oracle and, where NAME.crate.raw exists, to the crate itself (max |diff| and differing bytes)
 
 `export` needs the oracle library (oracle/libfanlin_oracle.so); `compare` needs only numpy.  The case list is
 tests/tools/gen_oracle_golden.py::CASES plus cases for the operations that table does not hold (orientation, Luma /
@@ -31,8 +34,9 @@ EXTRA = {
     "orient6_resize": (60, 90, 3, "photo", dict(w=30, h=30, orientation=6)),
     "orient3_only": (17, 23, 3, "uniform", dict(orientation=3)),
     "lenna_like_512_to_300x200": (512, 512, 3, "photo", dict(w=300, h=200)),
-    # the shapes the matrix-pipe kernel serves (fl_mfma.hip: 22-bit vertical weights, 1/64 intermediate, 17-bit horizontal
-    # weights): the first environment with cargo measures THAT kernel's distance to the crate too, not only the oracle's
+    # the shapes the matrix-pipe kernel serves (fl_mfma.hip; since round 4 in full-width arithmetic: u8 x the f32 weight as three
+    # f16 terms -> f32, a 23-bit intermediate x 24-bit weights -> exact i32): the first environment with cargo measures THAT
+    # kernel's distance to the crate too (`device DIR` below), not only the oracle's
     "config1_1080p_uniform_to_300x200": (1080, 1920, 3, "uniform", dict(w=300, h=200)),
     "config1_1080p_photo_to_300x200": (1080, 1920, 3, "photo", dict(w=300, h=200)),
     "config1_1080p_photo_crop": (1080, 1920, 3, "photo", dict(w=300, h=200, crop=True)),
@@ -40,6 +44,11 @@ EXTRA = {
     # round 3's planner: three unequal strips, and the wide LDS layout for ratios below ~4.7
     "mfma_1080p_to_256x144": (1080, 1920, 3, "photo", dict(w=256, h=144)),
     "mfma_1080p_to_640x360": (1080, 1920, 3, "photo", dict(w=640, h=360)),
+    # round 4: a 4K source (68 K-blocks, 7 strips), a Luma8 source (dense one-channel form), LumaA8, and BASELINE config 2's request
+    "mfma_4k_to_300x200": (2160, 3840, 3, "photo", dict(w=300, h=200)),
+    "mfma_luma_1080p_to_300x200": (1080, 1920, 1, "photo", dict(w=300, h=200)),
+    "mfma_lumaa_1080p_to_300x169": (1080, 1920, 2, "uniform", dict(w=300, h=169)),
+    "config2_1080p_gray_blur10": (1080, 1920, 3, "uniform", dict(w=300, h=200, grayscale=True, blur_sigma=10.0)),
     # the tiled two-pass kernel (ratios below ~2 and up-scales), whose bytes must be the crate's up to the order of the f32 sums
     "tile_720p_to_800x450": (720, 1280, 3, "photo", dict(w=800, h=450)),
     "tile_thumbnail_upscale": (120, 160, 3, "photo", dict(w=300, h=200)),
@@ -131,7 +140,37 @@ def compare(d):
     return 1 if bad else 0
 
 
+def device(d):
+    import importlib
+    import synth
+    sys.path.insert(0, ROOT)
+    fl = importlib.import_module("fanlin-rs_amd")
+    bad = 0
+    with fl.State() as st:
+        for i, (name, (h, w, c, dist, kw)) in enumerate(all_cases().items()):
+            img = getattr(synth, dist)(h, w, c, index=700 + i)
+            before = st.stats()["mfma_launches"]
+            got = st.process_pixels(img, fl.make_params(**kw))
+            used = st.stats()["mfma_launches"] > before
+            got.tofile(os.path.join(d, name + ".device.raw"))
+            line = "%-40s device%s" % (name, " (matrix-pipe kernel)" if used else "")
+            for other in ("oracle", "crate"):
+                try:
+                    want = np.fromfile(os.path.join(d, name + "." + other + ".raw"), np.uint8)
+                except OSError:
+                    continue
+                if want.size != got.size:
+                    line += "  vs %s: SHAPE" % other; bad += 1; continue
+                diff = np.abs(got.reshape(-1).astype(int) - want.astype(int))
+                mx = int(diff.max(initial=0))
+                line += "  vs %s: max |diff| %d, differing %.4f%%" % (other, mx, 100 * float((diff != 0).mean()))
+                bad += 0 if mx <= (0 if name in EXACT else 1) else 1
+            print(line)
+    print("%d case(s) outside their bar" % bad)
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
-    if len(sys.argv) != 3 or sys.argv[1] not in ("export", "compare"):
+    if len(sys.argv) != 3 or sys.argv[1] not in ("export", "compare", "device"):
         sys.exit(__doc__)
-    sys.exit(export(sys.argv[2]) if sys.argv[1] == "export" else compare(sys.argv[2]))
+    sys.exit({"export": export, "compare": compare, "device": device}[sys.argv[1]](sys.argv[2]))
