@@ -90,7 +90,7 @@ class flgpu_stats(C.Structure):
                 ("frontend_launches", C.c_uint64), ("frontend_ms", C.c_double),
                 ("cmyk_pixels", C.c_uint64), ("cmyk_tables_baked", C.c_uint64),
                 ("jpeg_sources", C.c_uint64), ("jpeg_file_bytes", C.c_uint64), ("jpeg_upload_bytes", C.c_uint64),
-                ("mfma_launches", C.c_uint64)]
+                ("mfma_launches", C.c_uint64), ("jpeg_device_huffman", C.c_uint64), ("jpeg_device_huffman_retries", C.c_uint64)]
 
 
 class flgpu_jpeg_info(C.Structure):

@@ -216,9 +216,31 @@ int jpeg_source_precheck(flgpu_ctx *c, const flgpu_image *src, const JpegInfo &i
     return FLGPU_OK;
 }
 
-int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used)
+thread_local bool tl_force_host_huffman = false;
+
+// Whether JPEG sources are entropy-decoded on the device where the file allows it (FLGPU_HOST_HUFFMAN=1: always on the host;
+// tests and A/B runs -- read per call).
+// 0 = this file is Huffman-decoded on the host, 1 = on the device if the caller has no idle CPU for it, 2 = on the device in any case.
+// FLGPU_HOST_HUFFMAN=1: never on the device; FLGPU_DEVICE_HUFFMAN_ALWAYS=1: always (tests, A/B runs); read per call.
+int device_huffman_policy(uint64_t file_bytes)
 {
-    const int rc = jpeg_entropy_decode(src->data, (size_t)src->capacity, blob, cap, used);
+    const char *e = getenv("FLGPU_HOST_HUFFMAN");
+    if (tl_force_host_huffman || (e && e[0] == '1')) return 0;
+    // small files are decoded faster by the thread that holds them than by six kernel launches (tests lower the bound to 0)
+    uint64_t min_bytes = 16384;
+    if (const char *m = getenv("FLGPU_DEVICE_HUFFMAN_MIN_BYTES")) min_bytes = strtoull(m, nullptr, 10);
+    if (file_bytes < min_bytes) return 0;
+    const char *a = getenv("FLGPU_DEVICE_HUFFMAN_ALWAYS");
+    return (a && a[0] == '1') ? 2 : 1;
+}
+
+int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used, bool host_huffman)
+{
+    int rc = -2;
+    // files the device entropy decoder takes (sequential, one interleaved scan, no restart interval) are only STAGED here: header,
+    // code tables, the segment without its stuffing -- tens of microseconds instead of ~2 ms of Huffman decoding on this thread
+    if (!host_huffman && device_huffman_policy(src->capacity) != 0) rc = jpeg_entropy_stage(src->data, (size_t)src->capacity, blob, cap, used);
+    if (rc == -2) rc = jpeg_entropy_decode(src->data, (size_t)src->capacity, blob, cap, used);
     if (rc == -2) { c->set_error("JPEG stream not covered by the device decoder (arithmetic coding, 12-bit samples, lossless or hierarchical processes)"); return FLGPU_ERR_UNSUPPORTED; }
     if (rc) { c->set_error("malformed JPEG stream"); return FLGPU_ERR_INVALID_ARG; }
     memcpy(hdr, blob, sizeof(*hdr));
@@ -240,8 +262,70 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
         scratch += align_up(H->plane_bytes, 256) + align_up(px * H->nc + 64, 256);
         if (H->nc == 4) scratch += align_up((px + 3) / 4 * 12, 256); // the Rgb8 picture after the CMYK table
     }
+    c->last_jh_slot.assign(n, -1);
+    c->last_jh_n = 0;
     if (!nj) return FLGPU_OK;
     { const int brc = clut_batch_begin(c); if (brc) return brc; } // tables selected below stay resident until the batch's kernels are launched
+    // ---- staged sources (kJhMagic): the entropy-coded segment is decoded on the device first, into a blob of its own ----
+    {
+        size_t njh = 0, bytes = 0, nitems = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const JpegBlobHeader *H = srcs[i].hdr;
+            if (!H || H->magic != kJhMagic) continue;
+            ++njh;
+        }
+        if (njh) {
+            // per picture: the blob, states (nsub + 1 x 8), counts and prefix (nsub x 16 each)
+            std::vector<JhJob> jobs;
+            std::vector<JhItem> items;
+            std::vector<size_t> blob_off, scratch_off;
+            uint32_t max_blocks = 0;
+            for (size_t i = 0; i < n; ++i) {
+                const JpegBlobHeader *H = srcs[i].hdr;
+                if (!H || H->magic != kJhMagic) continue;
+                const JpegHuffStage &S = srcs[i].stage;
+                const uint32_t nsub = jh_subsequences(S);
+                blob_off.push_back(bytes); bytes += align_up(jh_blob_bytes(*H), 256);
+                scratch_off.push_back(bytes); bytes += align_up((size_t)(nsub + 2) * 8 + (size_t)nsub * 8 + (size_t)nsub * 32 + 32, 256);
+                JhJob j{};
+                j.stage = static_cast<const uint8_t *>(dsrc[i].data);
+                j.nsub = nsub;
+                for (uint32_t f = 0; f < nsub; f += 256) items.push_back({(uint32_t)jobs.size(), f});
+                c->last_jh_slot[i] = (int32_t)jobs.size();
+                jobs.push_back(j);
+                max_blocks = std::max(max_blocks, H->nblocks);
+            }
+            nitems = items.size();
+            FL_HIP(c, c->d_jh.reserve(bytes), "device entropy decode scratch");
+            FL_HIP(c, c->d_jherr.reserve(njh * 4), "device entropy decode error words");
+            FL_HIP(c, c->h_jherr.reserve(njh * 4), "device entropy decode error words");
+            const size_t jobs_b = align_up(njh * sizeof(JhJob), 256);
+            FL_HIP(c, c->h_jhjobs.reserve(jobs_b + nitems * sizeof(JhItem)), "device entropy decode descriptors");
+            FL_HIP(c, c->d_jhjobs.reserve(jobs_b + nitems * sizeof(JhItem)), "device entropy decode descriptors");
+            size_t k = 0;
+            for (size_t i = 0; i < n; ++i) {
+                if (c->last_jh_slot[i] < 0) continue;
+                JhJob &j = jobs[k];
+                uint8_t *base = static_cast<uint8_t *>(c->d_jh.p);
+                j.blob = base + blob_off[k];
+                j.states = reinterpret_cast<uint64_t *>(base + scratch_off[k]);
+                j.used = j.states + (j.nsub + 2u);
+                j.counts = reinterpret_cast<int32_t *>(base + scratch_off[k] + align_up((size_t)(2u * j.nsub + 2u) * 8, 16));
+                j.prefix = j.counts + (size_t)j.nsub * 4;
+                j.err = static_cast<uint32_t *>(c->d_jherr.p) + k;
+                dsrc[i].data = j.blob; // what the IDCT kernel reads from here on
+                c->stats.jpeg_device_huffman++;
+                ++k;
+            }
+            memcpy(c->h_jhjobs.p, jobs.data(), njh * sizeof(JhJob));
+            memcpy(static_cast<char *>(c->h_jhjobs.p) + jobs_b, items.data(), nitems * sizeof(JhItem));
+            FL_HIP(c, hipMemcpyAsync(c->d_jhjobs.p, c->h_jhjobs.p, jobs_b + nitems * sizeof(JhItem), hipMemcpyHostToDevice, st), "device entropy decode descriptors");
+            FL_HIP(c, launch_jpeg_huff(static_cast<const JhJob *>(c->d_jhjobs.p), jobs.data(), (uint32_t)njh,
+                                       reinterpret_cast<const JhItem *>(static_cast<const char *>(c->d_jhjobs.p) + jobs_b), (uint32_t)nitems, max_blocks, st),
+                   "device entropy decode kernels");
+            c->last_jh_n = (uint32_t)njh;
+        }
+    }
     FL_HIP(c, c->d_dec.reserve(scratch), "JPEG decode scratch");
     FL_HIP(c, c->h_decjobs.reserve(nj * sizeof(JpegDecJob)), "JPEG decode descriptors");
     FL_HIP(c, c->d_decjobs.reserve(nj * sizeof(JpegDecJob)), "JPEG decode descriptors");
@@ -286,6 +370,23 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
     }
     for (const Cmyk &m : cmyk) FL_HIP(c, launch_cmyk_clut(m.raw, m.rgb, m.clut, kCmykGrid, m.px, m.ycck, st), "CMYK kernel");
     return FLGPU_OK;
+}
+
+int entropy_failures(flgpu_ctx *c, size_t n, std::vector<uint8_t> &bad, hipStream_t st)
+{
+    bad.assign(n, 0);
+    if (!c->last_jh_n || c->last_jh_slot.size() != n) return 0;
+    if (hipMemcpyAsync(c->h_jherr.p, c->d_jherr.p, (size_t)c->last_jh_n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        c->set_error("device entropy decode: error words D2H");
+        return -FLGPU_ERR_DEVICE;
+    }
+    int nbad = 0;
+    const uint32_t *e = static_cast<const uint32_t *>(c->h_jherr.p);
+    if (getenv("FLGPU_DEBUG_JH")) for (uint32_t k = 0; k < c->last_jh_n; ++k) fprintf(stderr, "device entropy decode: picture %u error word %u\n", k, e[k]);
+    for (size_t i = 0; i < n; ++i)
+        if (c->last_jh_slot[i] >= 0 && e[c->last_jh_slot[i]]) { bad[i] = 1; ++nbad; }
+    c->stats.jpeg_device_huffman_retries += (uint64_t)nbad;
+    return nbad;
 }
 
 uint64_t staged_out_bytes(const flgpu_params &p, const flgpu_plan &plan, uint64_t)
@@ -906,6 +1007,7 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
             size_t used = 0;
             rc = jpeg_source_to_blob(c, &srcs[i], blobs[i].data(), blobs[i].size(), &jh[i], &used);
             if (rc) return rc;
+            stage_of(blobs[i].data(), jh[i], jhp[i].stage);
             blobs[i].resize(used);
             jhp[i].hdr = &jh[i];
             if (jh[i].nc == 4 && c->cfg.use_embedded_profile && !info.icc.empty()) { iccs[i].swap(info.icc); jhp[i].icc = iccs[i].data(); jhp[i].icc_len = iccs[i].size(); }
@@ -936,6 +1038,16 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
     if (rc) return rc;
     FL_HIP(c, hipMemcpyAsync(c->h_stage_out.p, c->d_out.p, out_b, hipMemcpyDeviceToHost, st), "D2H");
     rc = collect_results(c, n, ddst.data(), st);
+    {   // pictures the device entropy decoder gave up on (states that did not settle, an invalid code word): the whole batch once
+        // more with the host decoder -- which either decodes them or says what is wrong with the file
+        std::vector<uint8_t> bad;
+        const int nbad = entropy_failures(c, n, bad, st);
+        if (nbad < 0) return -nbad;
+        if (nbad > 0 && !tl_force_host_huffman) {
+            struct Force { Force() { tl_force_host_huffman = true; } ~Force() { tl_force_host_huffman = false; } } force;
+            return run_batch_host(c, n, srcs, ps, dsts);
+        }
+    }
     for (size_t i = 0; i < n; ++i) {
         const size_t off = static_cast<uint8_t *>(ddst[i].data) - static_cast<uint8_t *>(c->d_out.p);
         if (ddst[i].bytes > dsts[i].capacity) { // only now is the length of an encoded stream known

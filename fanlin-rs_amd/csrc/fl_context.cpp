@@ -504,6 +504,7 @@ static void add_stats(flgpu_stats *out, const flgpu_stats &ls)
     out->cmyk_pixels += ls.cmyk_pixels; out->cmyk_tables_baked += ls.cmyk_tables_baked;
     out->jpeg_sources += ls.jpeg_sources; out->jpeg_file_bytes += ls.jpeg_file_bytes; out->jpeg_upload_bytes += ls.jpeg_upload_bytes;
     out->mfma_launches += ls.mfma_launches;
+    out->jpeg_device_huffman += ls.jpeg_device_huffman; out->jpeg_device_huffman_retries += ls.jpeg_device_huffman_retries;
 }
 
 int flgpu_get_stats(flgpu_ctx *c, flgpu_stats *out)

@@ -114,6 +114,7 @@ struct Request {
     uint64_t weight = 0;   // algorithmic bytes: W*H*C + out_bytes (shard balancing)
     bool jpeg = false;     // FLGPU_IMG_JPEG_SOURCE: `in` holds the coefficient blob the caller's thread decoded, jhdr its header
     JpegBlobHeader jhdr;
+    JpegHuffStage jstage{}; // jhdr.magic == kJhMagic: `in` holds the staged entropy-coded segment, decoded on the device
     std::vector<uint8_t> icc; // four-component source + use_embedded_profile: the file's own ICC profile
     uint64_t file_bytes = 0;
     int status = 0;
@@ -158,6 +159,11 @@ struct flgpu_ctx {
     fl::DeviceBuf d_in, d_out;
     fl::DeviceBuf d_dec, d_decjobs;                    // JPEG decode: planes + decoded pixels of a batch, job descriptors
     fl::PinnedBuf h_decjobs;
+    // entropy decoding on the device (fl_jpeghuff_dev.hip): blobs + per-subsequence scratch of a batch, descriptors, per-picture error words
+    fl::DeviceBuf d_jh, d_jhjobs, d_jherr;
+    fl::PinnedBuf h_jhjobs, h_jherr;
+    std::vector<int32_t> last_jh_slot; // per image of the batch decoded last: index of its error word, -1 = not entropy-decoded on the device
+    uint32_t last_jh_n = 0;
     fl::DeviceBuf d_jpeg_coef, d_jpeg_off, d_jpeg_raw; // JPEG encode scratch (fl_jpeg.hip): block meta words, bit offsets, AC bits
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> jpeg_tables; // (w, h, quality) -> arena offset of header + q tables
     // per-image result words of the most recent device batch: [2i] flags (bit 0: non-opaque alpha seen by the WebP front
@@ -285,10 +291,28 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
 uint64_t staged_out_bytes(const flgpu_params &p, const flgpu_plan &plan, uint64_t dst_capacity);
 // JPEG sources of a batch: dsrc[i].data = DEVICE copy of the coefficient blob whose header (host copy) is hdrs[i], or
 // hdrs[i] == nullptr for ordinary pixel sources.  Runs the decode kernels into scratch and points dsrc[i] at the pixels.
-struct JpegSrc { const JpegBlobHeader *hdr = nullptr; const uint8_t *icc = nullptr; size_t icc_len = 0; };
+struct JpegSrc {
+    const JpegBlobHeader *hdr = nullptr;
+    const uint8_t *icc = nullptr;
+    size_t icc_len = 0;
+    JpegHuffStage stage{}; // hdr->magic == kJhMagic: the staged segment's description (a host copy: the blob itself is on its way to the device)
+};
 int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc *srcs, hipStream_t st);
+// After the batch decode_jpeg_sources fed has completed on `st`: bad[i] = 1 where the device entropy decoder gave up on picture i
+// (its states did not settle, or the stream holds an invalid code word): the caller decodes that file on the host instead.
+// Returns the number of such pictures, or a negative FLGPU_ERR_* .
+int entropy_failures(flgpu_ctx *c, size_t n, std::vector<uint8_t> &bad, hipStream_t st);
+// internal status of a queued request: run it again with the host entropy decoder
+constexpr int FL_STATUS_RETRY_HOST_HUFFMAN = 1000;
 // Host half for one source: parses + Huffman-decodes `src` (a JPEG file) into `blob`; validates the declared size.
-int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used);
+int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used, bool host_huffman = false);
+// set while a request is run again after the device entropy decoder gave up on its file (this thread's JPEG sources are then decoded on the host)
+extern thread_local bool tl_force_host_huffman;
+int device_huffman_policy(uint64_t file_bytes); // fl_batch.cpp
+inline void stage_of(const uint8_t *staged_blob, const JpegBlobHeader &hdr, JpegHuffStage &out)
+{
+    if (hdr.magic == kJhMagic) memcpy(&out, staged_blob + sizeof(JpegBlobHeader), sizeof(out));
+}
 // fl_cmyk_ctx.cpp: the device-link table for one conversion on context c: the embedded profile's if given and usable
 // (baked once, cached on c), else the configured one (c's own, or its clut_owner's)
 int select_clut(flgpu_ctx *c, const uint8_t *icc, uint64_t icc_len, const void **dev);

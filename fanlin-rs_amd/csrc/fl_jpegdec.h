@@ -73,3 +73,58 @@ struct alignas(16) JpegDecJob {
 hipError_t launch_jpeg_decode(const JpegDecJob *jobs, uint32_t njobs, uint32_t max_blocks, uint32_t max_w, uint32_t max_h, hipStream_t st);
 
 } // namespace fl
+
+// ---- entropy decoding on the device (round 4; fl_jpeghuff_dev.hip) -------------------------------------------------------------
+// For sequential Huffman files in one interleaved scan without restart intervals the host no longer decodes anything: it parses
+// the header, copies the entropy-coded segment with the 0xFF00 stuffing removed, and hands over the four code tables.  The
+// device then decodes the segment in parallel -- subsequences of kJhSubBits bits decoded speculatively, then re-decoded from
+// their predecessor's end state until the states stop changing (a Huffman decoder that starts at a wrong bit re-synchronises
+// after a few code words), a prefix sum over the subsequences' block counts and DC sums, and a last pass that writes the
+// coefficients -- into the SAME blob the host decoder writes (every block "wide", 64 coefficients), so the IDCT / colour
+// kernels do not know the difference.
+namespace fl {
+
+constexpr uint32_t kJhSubBits = 1024;          // bits per subsequence
+constexpr uint32_t kJhLookBits = 10;           // the one-step table's lookahead (= the host decoder's kAcBits)
+constexpr uint32_t kJhTableWords = 1408;       // per code table: fastx[1024], look9[512 x u16], maxcode[18], valoff[17], vals[256 x u8]
+constexpr uint32_t kJhSyncRounds = 2;          // launches of the re-synchronisation kernel after the speculative one (each iterates inside its workgroups)
+constexpr uint32_t kJhMagic = 0x32444a46u;     // "FJD2": a staged entropy-coded segment instead of coefficients
+
+// Behind the JpegBlobHeader of a staged source (magic kJhMagic; the header's blocks_off / coef_off describe the blob the DEVICE builds).
+struct alignas(16) JpegHuffStage {
+    uint32_t stream_off;      // byte offset (from the start of the staged blob) of the unstuffed segment, 16-byte aligned, padded with 16 bytes
+    uint32_t stream_bits;     // its length in bits (whole bytes)
+    uint32_t tables_off;      // byte offset of 4 tables x kJhTableWords words: DC 0, DC 1, AC 0, AC 1
+    uint32_t bpm;             // blocks per MCU (1..10)
+    uint32_t mcux, mcuy;      // MCUs per row / column
+    uint32_t total_blocks;    // = header.nblocks
+    uint32_t staged_bytes;    // size of the staged blob
+    uint8_t blk_comp[12];     // per block of an MCU: component, and its position inside the MCU's h x v group
+    uint8_t blk_h[12], blk_v[12];
+    uint8_t dc_tab[4], ac_tab[4]; // per component: table index 0..3 into the four tables above (AC: 2..3)
+};
+
+// One staged picture of a device entropy-decode launch.
+struct alignas(16) JhJob {
+    const uint8_t *stage;  // device copy of the staged blob (JpegBlobHeader, JpegHuffStage, tables, segment)
+    uint8_t *blob;         // device blob to build: header, block words, 64 x i16 per block
+    uint64_t *used;        // [nsub]: the start state every subsequence was last decoded from
+    uint64_t *states;      // [nsub + 1]: end state of every subsequence (bit position | block of the MCU << 32 | coefficient index << 40); [0] = the start
+    int32_t *counts;       // [nsub][4]: blocks completed, DC difference sums of components 0..2
+    int32_t *prefix;       // [nsub][4]: exclusive prefix sums of the same
+    uint32_t *err;         // device error word of the picture (1: the state chain did not settle, 2: invalid code / DC out of range)
+    uint32_t nsub;
+    uint32_t pad;
+};
+struct JhItem { uint32_t job, first_sub; }; // one workgroup of the per-subsequence kernels: 256 consecutive subsequences of one picture
+
+// Host half: parses `data`, and if the file is one the device entropy decoder takes (sequential, one interleaved scan, no restart
+// interval, 1 or 3 components) writes the staged blob to `out`: 0 ok (*used = its size), -1 malformed, -2 not for this path.
+int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, size_t *used);
+size_t jpeg_stage_bound(size_t file_bytes);
+// Bytes of the device blob / per-subsequence scratch a staged picture needs.
+size_t jh_blob_bytes(const JpegBlobHeader &H);
+uint32_t jh_subsequences(const JpegHuffStage &S);
+hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, hipStream_t st);
+
+} // namespace fl

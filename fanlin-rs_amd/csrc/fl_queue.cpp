@@ -127,7 +127,7 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
         ddst[i].data = static_cast<uint8_t *>(c->d_out.p) + reinterpret_cast<size_t>(ddst[i].data);
         FL_HIP(c, hipMemcpyAsync(dsrc[i].data, batch[i]->in.p, batch[i]->src_bytes, hipMemcpyHostToDevice, st), "H2D");
         if (batch[i]->jpeg) {
-            jhp[i].hdr = &batch[i]->jhdr; jhp[i].icc = batch[i]->icc.empty() ? nullptr : batch[i]->icc.data(); jhp[i].icc_len = batch[i]->icc.size();
+            jhp[i].hdr = &batch[i]->jhdr; jhp[i].stage = batch[i]->jstage; jhp[i].icc = batch[i]->icc.empty() ? nullptr : batch[i]->icc.data(); jhp[i].icc_len = batch[i]->icc.size();
             c->stats.jpeg_file_bytes += batch[i]->file_bytes;
         }
     }
@@ -155,6 +155,12 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
         if (ps[i].front_end == FLGPU_FE_JPEG && !ddst[i].bytes && batch[i]->status == FLGPU_OK) batch[i]->status = FLGPU_ERR_BUFFER_TOO_SMALL;
     }
     if (rrc == FLGPU_ERR_DEVICE) return rrc; // the device error word: no result of this batch is valid
+    {   // requests whose file the device entropy decoder gave up on go back to their callers, who decode on the host and queue again
+        std::vector<uint8_t> bad;
+        const int nbad = entropy_failures(c, n, bad, st);
+        if (nbad < 0) return -nbad;
+        for (size_t i = 0; i < n && nbad; ++i) if (bad[i]) batch[i]->status = FL_STATUS_RETRY_HOST_HUFFMAN;
+    }
     return FLGPU_OK; // otherwise the per-request status above: one oversized stream must not fail its batch mates
 }
 
@@ -457,18 +463,28 @@ try {
         size_t used = 0;
         int jrc;
         {
-            // no more decoders at once than this process has CPUs: sixty-four runnable decoders on sixteen CPUs all finish late (p99 of
-            // the request 60 ms against 20 ms with 32 callers, profiles/r03_latency_jpeg_sources.txt); waiting in line costs nothing
+            // Who decodes the entropy-coded segment?  A thread with an idle CPU under it does it fastest itself (~1.9 ms, and the
+            // request skips six kernel launches); once half of the CPUs this process may use are decoding, further requests are
+            // only STAGED (header + the unstuffed segment, ~0.05 ms) and the device decodes them (fl_jpeghuff_dev.hip) -- host and
+            // device then work side by side, and a burst of callers no longer queues for CPUs.
+            // No more host decoders at once than the process has CPUs: sixty-four runnable decoders on sixteen CPUs all finish late
+            // (p99 of the request 60 ms against 20 ms with 32 callers, profiles/r03_latency_jpeg_sources.txt).
+            const int policy = device_huffman_policy(src->capacity);
+            bool on_host = policy == 0;
             {
                 std::unique_lock<std::mutex> lk(c->dec_mu);
                 if (!c->dec_limit) c->dec_limit = c->cfg.decode_threads ? c->cfg.decode_threads : usable_cpus();
-                // (bounded: a file that keeps its decoder busy for long -- a huge progressive picture -- must not park every other
-                // JPEG request behind it; after the deadline the caller decodes anyway, one runnable thread more than CPUs)
-                (void)c->dec_cv.wait_for(lk, std::chrono::milliseconds(250), [&] { return c->decoding < c->dec_limit; });
-                c->decoding++;
+                if (policy == 1 && c->decoding < std::max(1u, c->dec_limit / 2u)) on_host = true;
+                if (on_host) {
+                    // (bounded: a file that keeps its decoder busy for long -- a huge progressive picture -- must not park every other
+                    // JPEG request behind it; after the deadline the caller decodes anyway, one runnable thread more than CPUs)
+                    (void)c->dec_cv.wait_for(lk, std::chrono::milliseconds(250), [&] { return c->decoding < c->dec_limit; });
+                    c->decoding++;
+                }
             }
-            struct Turn { flgpu_ctx *c; ~Turn() { { std::lock_guard<std::mutex> lk(c->dec_mu); c->decoding--; } c->dec_cv.notify_one(); } } turn{c};
-            jrc = jpeg_source_to_blob(c, src, static_cast<uint8_t *>(r.in.p), r.in.cap, &r.jhdr, &used);
+            struct Turn { flgpu_ctx *c; bool held; ~Turn() { if (held) { { std::lock_guard<std::mutex> lk(c->dec_mu); c->decoding--; } c->dec_cv.notify_one(); } } } turn{c, on_host};
+            jrc = jpeg_source_to_blob(c, src, static_cast<uint8_t *>(r.in.p), r.in.cap, &r.jhdr, &used, on_host);
+            if (!jrc) stage_of(static_cast<const uint8_t *>(r.in.p), r.jhdr, r.jstage);
         }
         if (jrc) { c->staging.fetch_sub(1, std::memory_order_acq_rel); give_back(); return jrc; }
         r.jpeg = true;
@@ -492,6 +508,13 @@ try {
     }
     if (r.status == FLGPU_OK && !dst_pinned) memcpy(dst->data, r.out.p, std::min<uint64_t>(dst->bytes, r.out_bytes));
     give_back();
+    if (r.status == FL_STATUS_RETRY_HOST_HUFFMAN) {
+        // the device entropy decoder gave up on this file (its subsequence states did not settle within the rounds it runs, or the
+        // stream holds an invalid code word): once more, Huffman-decoded on this thread -- which either works or names the defect
+        if (tl_force_host_huffman) return FLGPU_ERR_DEVICE;
+        struct Force { Force() { tl_force_host_huffman = true; } ~Force() { tl_force_host_huffman = false; } } force;
+        return flgpu_transform(c, src, p, dst);
+    }
     if (dst_pinned) dst->flags |= FLGPU_IMG_PINNED;
     return r.status;
 } FL_ABI_CATCH

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define FLGPU_ABI_VERSION 3
+#define FLGPU_ABI_VERSION 4
 
 typedef enum flgpu_status {
     FLGPU_OK = 0,
@@ -190,6 +190,8 @@ typedef struct flgpu_stats {
     uint64_t jpeg_file_bytes;     /* their file bytes ... */
     uint64_t jpeg_upload_bytes;   /* ... and what crossed PCIe for them (coefficient blobs) */
     uint64_t mfma_launches;       /* of resample_launches: launches of the matrix-pipe kernel (fl_mfma.hip) */
+    uint64_t jpeg_device_huffman; /* of jpeg_sources: files whose entropy-coded segment was decoded on the device too (fl_jpeghuff_dev.hip) */
+    uint64_t jpeg_device_huffman_retries; /* ... of which the device gave up on and the host decoded after all */
 } flgpu_stats;
 
 typedef struct flgpu_ctx flgpu_ctx;

@@ -547,3 +547,89 @@ def test_unsupported_jpeg_sources_are_refused_not_mangled(fl, gpu_state):
         gpu_state.process_jpeg(data, "w=30&h=30")
     assert e.value.status == fl.ERR_UNSUPPORTED
     assert gpu_state.process_jpeg(data, "rgb=1,2,3")[1] == fl.RESULT_AS_IS
+
+
+# ---------------------------------------------------------------------------- entropy decoding on the device (round 4) --
+
+DEVICE_HUFFMAN_FILES = [
+    # h, w, c, quality, subsampling, dist
+    (1080, 1920, 3, 85, 2, "photo"),     # the bench's JPEG sources: 4:2:0, ~300 KB
+    (1080, 1920, 3, 95, 0, "uniform"),   # noise at high quality: long code words, the slow path of every table
+    (720, 1280, 3, 5, 2, "photo"),       # almost nothing but end-of-block codes
+    (1081, 1921, 3, 75, 1, "photo"),     # 4:2:2, sizes that are no multiple of the MCU
+    (1000, 1500, 1, 80, 0, "photo"),     # one component: one block per MCU
+    (64, 96, 3, 85, 2, "photo"), (37, 53, 3, 70, 0, "photo"), (8, 8, 3, 90, 0, "photo"), (1, 1, 3, 90, 2, "photo"), (9, 300, 3, 95, 2, "uniform"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DEVICE_HUFFMAN_FILES)
+def test_device_entropy_decoder_reads_the_host_decoders_coefficients(fl, gpu_state, oracle, monkeypatch, case):
+    """Sequential one-scan files without restart intervals are Huffman-decoded ON THE DEVICE (csrc/fl_jpeghuff_dev.hip: speculative
+    subsequence decoding, re-synchronisation rounds, prefix sums, write pass): the decoded picture must be the oracle decoder's, bit
+    for bit -- i.e. every coefficient the host decoder would have read -- and the statistics must say the device did the decoding."""
+    h, w, c, q, sub, dist = case
+    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_MIN_BYTES", "0")
+    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_ALWAYS", "1")   # (by default a lone request is decoded by its own thread: a CPU is idle)
+    img = getattr(synth, dist)(h, w, c, index=h + q)
+    data = _save(img, quality=q, **({"subsampling": sub} if c == 3 else {}))
+    s0 = gpu_state.stats()
+    got = gpu_state.decode_jpeg(data)
+    s1 = gpu_state.stats()
+    assert s1["jpeg_device_huffman"] == s0["jpeg_device_huffman"] + 1 and s1["jpeg_device_huffman_retries"] == s0["jpeg_device_huffman_retries"]
+    assert np.array_equal(got, oracle.jpeg_decode(data))
+    monkeypatch.setenv("FLGPU_HOST_HUFFMAN", "1")                     # the host decoder stays selectable, and agrees
+    assert np.array_equal(gpu_state.decode_jpeg(data), got)
+    assert gpu_state.stats()["jpeg_device_huffman"] == s1["jpeg_device_huffman"]
+
+
+@pytest.mark.gpu
+def test_device_entropy_decoder_in_batches_and_whole_requests(fl, gpu_state, oracle, monkeypatch):
+    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_MIN_BYTES", "0")
+    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_ALWAYS", "1")   # (by default a lone request is decoded by its own thread: a CPU is idle)
+    files = [make_jpeg(360 + 8 * k, 640 - 16 * k, 3, 60 + 5 * k, k % 3, 0, index=40 + k) for k in range(6)]
+    files.append(make_jpeg(200, 300, 3, 80, 2, 5, index=9))           # a restart interval: this one stays with the host decoder
+    files.append(_save(synth.photo(240, 320, 3, index=3), progressive=True, quality=80))   # progressive: host, too
+    p = fl.make_params(150, 100)
+    before = gpu_state.stats()["jpeg_device_huffman"]
+    outs = gpu_state.process_batch(files, [p] * len(files))            # flgpu_transform_batch: one set of launches for all eight
+    assert gpu_state.stats()["jpeg_device_huffman"] - before == 6
+    monkeypatch.setenv("FLGPU_HOST_HUFFMAN", "1")
+    host = gpu_state.process_batch(files, [p] * len(files))
+    monkeypatch.delenv("FLGPU_HOST_HUFFMAN")
+    for f, o, hh in zip(files, outs, host):
+        assert np.array_equal(o, hh)
+        if not fl.jpeg_info(f)["progressive"]:
+            assert np.array_equal(o, parity.expected_pixels(fl, gpu_state, oracle, oracle.jpeg_decode(f), w=150, h=100))
+    # the whole request of the metric from file bytes: the same stream whichever side decodes the entropy-coded segment
+    big = make_jpeg(1080, 1920, 3, 85, 2, 0, index=5)
+    a = gpu_state.process_jpeg(big, "w=300&h=200")
+    monkeypatch.setenv("FLGPU_HOST_HUFFMAN", "1")
+    b = gpu_state.process_jpeg(big, "w=300&h=200")
+    assert a[1] == fl.RESULT_JPEG_STREAM and a[2] == b[2]
+
+
+@pytest.mark.gpu
+def test_device_entropy_decoder_on_broken_streams(fl, gpu_state, monkeypatch):
+    """Mutated and truncated segments: the device decoder reports an invalid code word (or a chain of states that did not settle)
+    and the request is decoded on the host once more -- which returns an error or a picture, as before; never a crash or a hang."""
+    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_MIN_BYTES", "0")
+    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_ALWAYS", "1")   # (by default a lone request is decoded by its own thread: a CPU is idle)
+    rng = np.random.default_rng(11)
+    data = bytearray(make_jpeg(240, 320, 3, 85, 2, 0, index=21))
+    sos = data.find(b"\xff\xda") + 14
+    for trial in range(40):
+        d = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            d[int(rng.integers(sos, len(d) - 2))] = int(rng.integers(0, 255))    # (255 would start a marker: a different path)
+        try:
+            gpu_state.decode_jpeg(bytes(d))
+        except fl.FanlinError as e:
+            assert e.status in (fl.ERR_INVALID_ARG, fl.ERR_UNSUPPORTED)
+    for cut in (len(data) - 2, len(data) // 2, sos + 40):
+        try:
+            gpu_state.decode_jpeg(bytes(data[:cut]))
+        except fl.FanlinError as e:
+            assert e.status in (fl.ERR_INVALID_ARG, fl.ERR_UNSUPPORTED)
+    good = gpu_state.decode_jpeg(bytes(data))                                   # the context is fine afterwards
+    assert good.shape == (240, 320, 3)

@@ -41,6 +41,10 @@ def main():
     kernel_stats("config1", "c1", f"{tag}_config1_kernel_stats.csv")
     kernel_stats("config2", "c2", f"{tag}_config2_kernel_stats.csv")
     kernel_stats("jpeg", "jp", f"{tag}_config1_resize_only_kernel_stats.csv")
+    try:
+        kernel_stats("config1_packed", "c1p", f"{tag}_config1_packed_arithmetic_kernel_stats.csv")
+    except OSError:
+        pass
     try:  # roctx ranges of the runtime (FLGPU_ROCTX=1) as rocprofv3 --marker-trace reports them
         import shutil
         for f in glob.glob(os.path.join(RAW, "markers", "*marker*stats*.csv")) + glob.glob(os.path.join(RAW, "markers", "*/*marker*stats*.csv")):
