@@ -673,7 +673,17 @@ def main():
             try:
                 jp = latency_probe_c(args, query, fe, 0, synthetic_jpeg_files())
                 if jp:
-                    jp["path"] = "flgpu_transform with FLGPU_IMG_JPEG_SOURCE (1920x1080 q85 4:2:0 files): host Huffman decode + device IDCT/colour + pipeline"
+                    jp["path"] = ("flgpu_transform with FLGPU_IMG_JPEG_SOURCE (1920x1080 q85 4:2:0 files): entropy decoding on the caller's thread while a CPU is "
+                                  "idle, on the device (fl_jpeghuff_dev.hip) beyond that; IDCT + colour + pipeline + encode on the device")
+                    # the same probe with every file Huffman-decoded on the host (round 3's path), for comparison
+                    os.environ["FLGPU_HOST_HUFFMAN"] = "1"
+                    try:
+                        jh = latency_probe_c(args, query, fe, 0, synthetic_jpeg_files())
+                    finally:
+                        del os.environ["FLGPU_HOST_HUFFMAN"]
+                    if jh:
+                        jh["path"] = "the same with FLGPU_HOST_HUFFMAN=1: every file entropy-decoded on its caller's thread"
+                        line["latency_jpeg_sources_host_huffman"] = jh
                     line["latency_jpeg_sources"] = jp
             except Exception as e:  # Pillow missing: the probe is optional
                 line["latency_jpeg_sources"] = {"skipped": repr(e)[:120]}

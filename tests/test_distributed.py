@@ -118,6 +118,7 @@ def _gpu_rank(rank, world, port, out):
     dist.all_reduce(same, op=dist.ReduceOp.MIN)
     payload = blob[:nbytes].cpu()
     table_digest_local = hashlib.sha256(payload.numpy().tobytes()).hexdigest()
+    payload.numpy().tofile(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"fl_tables_rank{rank}.bin"))   # (for the diagnosis below)
     dist.broadcast(payload, src=0)
     blob[:nbytes] = payload.to(dev)
     torch.cuda.synchronize()
@@ -149,6 +150,12 @@ def test_two_ranks_share_rank0_tables_and_clut_on_the_device():
     assert codes == [0, 0]
     r0, r1 = res
     assert r0[1] == 1 and r1[1] == 1 and r0[2] == r1[2] > 4096           # both planned tables of the same size ...
+    if r0[3] != r1[3]:                                                     # say WHERE the two arenas differ before failing
+        import numpy as np
+        d = os.environ.get("TMPDIR", "/tmp")
+        a, b = (np.fromfile(os.path.join(d, f"fl_tables_rank{k}.bin"), np.uint32) for k in (0, 1))
+        w = np.nonzero(a != b)[0]
+        print("table blobs differ in", len(w), "words; first:", [(int(i), hex(int(a[i])), hex(int(b[i]))) for i in w[:24]])
     assert r0[3] == r1[3]                                                  # ... and, built independently, the same bytes
     assert r0[4] == r0[5] == r1[4] == r1[5]                                # common picture: same pixels before and after the import, on both ranks
     assert r0[6] == r1[6]                                                  # conversions through the broadcast CLUT agree
