@@ -98,16 +98,19 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const MfmaStrip sp = *reinterpret_cast<const MfmaStrip *>(arena + it.strip_off);
     constexpr uint32_t np = mfma_out_pitch(LAYOUT); // words per output-tile row (compile-time: the row offsets of the LDS adds become immediates); column sp.nout is a dummy
 
+    // (packed arithmetic: two output tiles that alternate; full width: ONE -- a wave converts its rows of a tile in the pass after
+    // the tile's stage, see try_convert -- and the 20-27 KB go to the operand area, where the flagship's 69 operands then fit)
+    constexpr uint32_t NBUF = FW ? 1u : 2u;
     uint32_t *otile = reinterpret_cast<uint32_t *>(mfma_lds);
-    uint32_t *add_cnt = reinterpret_cast<uint32_t *>(mfma_lds + 2u * ot_words * 4u);
+    uint32_t *add_cnt = reinterpret_cast<uint32_t *>(mfma_lds + NBUF * ot_words * 4u);
     uint32_t *conv_cnt = add_cnt + 2;
-    const u32x4 *ops_lds = reinterpret_cast<const u32x4 *>(mfma_lds + 2u * ot_words * 4u + CNT_BYTES);
+    const u32x4 *ops_lds = reinterpret_cast<const u32x4 *>(mfma_lds + NBUF * ot_words * 4u + CNT_BYTES);
     uint8_t *ring = mfma_ring + wave * RING_BYTES;
     const u32x4 *ops_glb = reinterpret_cast<const u32x4 *>(arena + sp.ops_off);
 
-    for (uint32_t k = tid; k < 2u * ot_words + CNT_BYTES / 4u; k += THREADS) otile[k] = 0u;
+    for (uint32_t k = tid; k < NBUF * ot_words + CNT_BYTES / 4u; k += THREADS) otile[k] = 0u;
     if (HLDS && (!FW || sp.lds_ops))
-        for (uint32_t k = tid; k < sp.n_ops * 64u; k += THREADS) reinterpret_cast<u32x4 *>(mfma_lds + 2u * ot_words * 4u + CNT_BYTES)[k] = ops_glb[k];
+        for (uint32_t k = tid; k < sp.n_ops * 64u; k += THREADS) reinterpret_cast<u32x4 *>(mfma_lds + NBUF * ot_words * 4u + CNT_BYTES)[k] = ops_glb[k];
 
     // Letterbox frame: every workgroup paints the part next to its own band and strip (same split as the streaming kernel).
     const uint32_t y_first = vp.y0 + 16u * it.tile0, y_end = min(vp.y0 + 16u * it.tile1, vp.y0 + vp.rows);
@@ -288,6 +291,29 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #pragma unroll
     for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(it.kb0 * (2u * NT) + k) * 64u + lane];
     request(it.kb0);
+    // Full-width arithmetic, one LDS output tile: a wave converts its two rows of a tile not inside the NEXT tile's stage (the packed
+    // form, two tiles) but as soon as every wave has added its sums -- in the passes right after the tile's own stage, which wait
+    // for rows anyway.  pend_li: the tile (band-local number) this wave has added to but not converted yet.
+    uint32_t pend_li = 0xffffffffu;
+    auto try_convert = [&](bool must) __attribute__((always_inline)) {
+        const uint32_t need = kMfmaWaves * (pend_li + 1u);
+        uint32_t spin = 0;
+        for (;;) {
+            const uint32_t ad = __hip_atomic_load(&add_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            if (ad >= need) break;
+            if (!must) return;          // not every wave has added yet: look again in the next pass
+            if (++spin >= spin_limit) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (spin >= spin_limit) wg_error = 1u; // (as in the packed form's wait: a limit of 0 -- the tests' -- reports every wait)
+        if (!(ablate & 2u)) convert_rows(it.tile0 + pend_li, 0u);
+        pend_li = 0xffffffffu;
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __hip_atomic_fetch_add(&conv_cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
     // (kb_end: one pass more than the band has K-blocks when the picture's short last tile ends together with the tile before
     // it -- that pass runs on the table's all-zero K-block, index vp.nkb, whose meta word names the last tile: the matrix unit
     // adds zeros to whatever the transposed reads deliver, nothing is requested, and the loop body stays as it is)
@@ -308,6 +334,9 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         wait_lgkm0();
         if (have_next) request(s + 1u);
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (FW) {
+            if (pend_li != 0xffffffffu) try_convert(false);
+        }
         TM_B(tm_read);
         // (the meta word says whether the K-block has weights for a second, younger tile (set 1) at all: about a third of the
         // K-blocks touch one tile only, and a matrix instruction on zeros costs the same time and nearly the same power --
@@ -352,7 +381,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 for (int ct = 0; ct < 16; ++ct) asm volatile("" : : "v"(acc[0][ct][0]), "v"(acc[0][ct][1]), "v"(acc[0][ct][2]), "v"(acc[0][ct][3]));
             }
             if (mine) {
-                const uint32_t li = ft - it.tile0, buf = li & 1u;
+                const uint32_t li = ft - it.tile0, buf = FW ? 0u : (li & 1u);
                 uint32_t *ot = otile + buf * ot_words;
                 // The stage is written for instruction-level parallelism -- two waves per SIMD run it at the same time, so nothing else
                 // hides its latencies: (1) all A operands first (vector work only), (2) a chunk's B operands are requested one chunk
@@ -449,8 +478,18 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #define FL_U01(k_) (3 * ((k_) / 2) + (k_) % 2)
 #define FL_U2(k_) (3 * (k_) + 2)
                         if (!(ablate & 1u)) load_ops(0, FL_U01(0));
-                        wait_for_the_tiles();
-                        if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u); // this wave's two rows of the previous tile
+                        // one tile: this wave's rows of the previous tile, if no pass since has found them complete, and then every
+                        // other wave's -- the tile must be all zeros again before the first add
+                        (void)wait_for_the_tiles;
+                        if (pend_li != 0xffffffffu) try_convert(true);
+                        uint32_t spin = 0;
+                        for (;;) {
+                            const uint32_t cv = __hip_atomic_load(&conv_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                            if (cv >= kMfmaWaves * li || ++spin >= spin_limit) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (spin >= spin_limit) wg_error = 1u;
                         if (!(ablate & 1u)) {
                             unit_mfma(0, FL_U01(0));
                             load_ops(1, FL_U01(1));
@@ -536,8 +575,9 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 if (lane == 0) { // one release for both counters
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
                     __hip_atomic_fetch_add(&add_cnt[buf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (li >= 1u) __hip_atomic_fetch_add(&conv_cnt[buf ^ 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!FW && li >= 1u) __hip_atomic_fetch_add(&conv_cnt[buf ^ 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                if constexpr (FW) pend_li = li;
             }
             // The younger tile becomes the older one: set 0 <- set 1, set 1 <- 0, so that the finished tile is always read from
             // compile-time registers (set 0).  Plain moves: at the power limit 128 moves are cheaper than the 32 matrix
@@ -568,7 +608,11 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     }
 #endif
     __syncthreads(); // every wave has added its sums of the last tile
-    if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
+    if constexpr (FW) {
+        if (pend_li != 0xffffffffu && !(ablate & 6u)) convert_rows(it.tile0 + pend_li, 0u);
+    } else {
+        if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
+    }
     if (wg_error && lane == 0) atomicOr(err_word, FLGPU_DEVERR_MFMA_WAIT);
 }
 
@@ -581,7 +625,7 @@ size_t mfma_lds_bytes(uint32_t max_nout, bool ops_in_lds, bool wide)
 
 size_t mfma_lds_bytes_full(int layout)
 {
-    return (size_t)2 * 16 * mfma_out_pitch(layout) * 4 + CNT_BYTES + (size_t)mfma_lds_operand_capacity(layout) * 1024u;
+    return (size_t)16 * mfma_out_pitch(layout) * 4 + CNT_BYTES + (size_t)mfma_lds_operand_capacity(layout) * 1024u; // ONE output tile
 }
 
 template <int CS, bool LB, bool HLDS, int LAYOUT, bool FW>
