@@ -15,7 +15,8 @@ namespace {
 
 // ---- batch execution -------------------------------------------------------
 
-enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3, S1_NEAREST = 4, S1_MFMA = 5, S1_TILE = 6 };
+enum Stage1Kind { S1_NONE = 0, S1_PLACE = 1, S1_GENERIC = 2, S1_STREAM = 3, S1_NEAREST = 4, S1_MFMA = 5, S1_TILE = 6, S1_WTILE = 7 };
+constexpr uint32_t kBlurWtileKind = 0x1000u; // blur group key: the window-tile kernel instead of blur_tile_kernel (| its register split)
 
 struct Work {
     flgpu_plan plan;
@@ -42,6 +43,8 @@ struct Work {
     size_t align_off = 0;       // misaligned device source of a matrix-pipe geometry: offset of its aligned copy in d_tmp_al
     bool align_copy = false;
     const uint8_t *raw_src = nullptr;
+    const WtPlan *wplan = nullptr;   // S1_WTILE: the window-tile matrix-pipe kernel's tables
+    const WtPlan *bwplan = nullptr;  // ... for the blur stage, where that kernel serves it
 };
 
 struct GroupKey {
@@ -59,6 +62,23 @@ uint32_t blur_channels(const Work &w)
         ce = grey ? 1u : 3u;
     }
     return ce;
+}
+
+// Blurs the window-tile matrix-pipe kernel takes: all but the one-channel shortcut (a grey picture on a grey frame: the vector
+// kernel filters one byte column in four there, the matrix kernel would filter all four).
+bool wtile_blur_wanted(const Work &w)
+{
+    static const bool always = [] { const char *e = getenv("FLGPU_WTILE_BLUR_ALWAYS"); return e && e[0] == '1'; }();
+    return always || blur_channels(w) != 1u;
+}
+
+// Row bands per picture for the window-tile kernel: small batches are cut so that the chip still sees a few hundred workgroups
+// (the result does not depend on the cut: every M-tile is computed from the same rows by the same instructions).
+uint32_t wtile_bands(const WtPlan &p, size_t pictures)
+{
+    if (const char *e = getenv("FLGPU_FORCE_BANDS")) return (uint32_t)std::max(1, atoi(e));
+    const size_t wgs = std::max<size_t>(1, pictures * p.n_strips);
+    return (uint32_t)std::min<size_t>(p.n_mt, std::max<size_t>(1, (512 + wgs - 1) / wgs));
 }
 
 void fill_job(const Work &w, Job &j)
@@ -495,6 +515,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     const MfmaArith mfma_arith = (env_arith && env_arith[0] == 'p') ? MFMA_ARITH_PACKED : MFMA_ARITH_FULL;
     const char *env_no_tile = getenv("FLGPU_NO_TILE");
     const bool no_tile = env_no_tile && env_no_tile[0] == '1';
+    // the window-tile matrix-pipe kernel (fl_wtile.h) for mild ratios, up-scales and blurs: full-width arithmetic only; FLGPU_NO_WTILE=1
+    // keeps the f32 vector kernels (tests, A/B)
+    const char *env_no_wtile = getenv("FLGPU_NO_WTILE");
+    const bool use_wtile = !(env_no_wtile && env_no_wtile[0] == '1') && !no_mfma && !force_generic && mfma_arith == MFMA_ARITH_FULL;
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool full = false;
         size_t n_resample = 0;
@@ -535,6 +559,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 if (c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
                 if (sp->ok) { w.s1 = S1_STREAM; w.splan = sp; }
             }
+            // what neither fused kernel takes and no pre-op precedes: the window-tile matrix-pipe kernel (any pitch and alignment)
+            if (w.s1 == S1_GENERIC && use_wtile && w.pre == PRE_NONE && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
+                Job jtmp; fill_job(w, jtmp);
+                WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
+                if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
+                if (wp->ok) { w.s1 = S1_WTILE; w.wplan = wp; }
+            }
             // what neither fused kernel takes (up-scales, mild down-scales, odd pitches, forced generic): the two passes through an
             // LDS tile instead of an f32 intermediate in HBM, if a tile width fits (FLGPU_NO_TILE=1 keeps the HBM form: tests, A/B)
             if (w.s1 == S1_GENERIC && !no_tile) {
@@ -561,7 +592,12 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 AxisKey kv; const HostAxis *hv;
                 if (!get_axis(c, w.plan.out_h, w.plan.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &kv, &hv) ||
                     !get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h)) full = true;
-                else {
+                else if (use_wtile && wtile_blur_wanted(w)) {
+                    WtPlan *wp = get_wtile_plan(c, kv, *hv, k, *h, 0, 0, w.plan.out_w, w.plan.out_h, w.plan.out_c);
+                    if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) full = true;
+                    else if (wp->ok) w.bwplan = wp;
+                }
+                if (!full && !w.bwplan) {
                     const uint32_t ty = blur_band_rows(blur_channels(w));
                     if (blur_tile_supported(h->max_taps) && blur_tile_supported(hv->max_taps) && !c->blur_plans.count(std::make_tuple(kv, k, ty))) {
                         std::vector<uint32_t> blk;
@@ -599,9 +635,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
-        if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u) | (w.mplan->wide ? 1u << 9 : 0u) | (w.mplan->full ? 1u << 10 : 0u) | (w.mplan->compact ? 1u << 11 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        if (w.s1 == S1_WTILE) s1_groups[{(uint32_t)S1_WTILE | (w.wplan->nslot << 8), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
+        else if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u) | (w.mplan->wide ? 1u << 9 : 0u) | (w.mplan->full ? 1u << 10 : 0u) | (w.mplan->compact ? 1u << 11 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
         else if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
-        if (w.p->blur_sigma > 0.0f) {
+        if (w.p->blur_sigma > 0.0f && w.bwplan) blur_groups[{kBlurWtileKind | w.bwplan->nslot, w.plan.out_c, 0, 0}].push_back(i);
+        else if (w.p->blur_sigma > 0.0f) {
             const uint32_t ce = blur_channels(w);
             // pictures of one launch share the workgroup width the kernel is instantiated for
             AxisKey hk2; const HostAxis *hh2 = nullptr;
@@ -640,7 +678,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
 
     auto new_launch = [&](const GroupKey &k) {
         S1Launch L{};
-        L.k = k; L.job_base = (uint32_t)jobs.size(); L.item_base = (uint32_t)((k.kind & 255u) == S1_MFMA ? mitems.size() : items.size());
+        L.k = k; L.job_base = (uint32_t)jobs.size(); L.item_base = (uint32_t)(((k.kind & 255u) == S1_MFMA || (k.kind & 255u) == S1_WTILE || (k.kind & kBlurWtileKind)) ? mitems.size() : items.size());
         L.g.cs = k.cs; L.g.pre = k.pre; L.g.letterbox = k.lb; L.g.grouped = 1;
         return L;
     };
@@ -663,6 +701,14 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             L.g.max_dw = std::max(L.g.max_dw, j.dw); L.g.max_dh = std::max(L.g.max_dh, j.dh);
             if ((k.kind & 255u) == S1_TILE) {
                 L.g.tile_w_min = L.g.tile_w_min ? std::min(L.g.tile_w_min, w.tile_w) : w.tile_w;
+                c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
+                c->stats.resample_dst_bytes += w.plan.pixel_bytes;
+            }
+            if ((k.kind & 255u) == S1_WTILE) {
+                const size_t before = mitems.size();
+                w.wplan->items_for(wtile_bands(*w.wplan, kv.second.size()), (uint32_t)jobs.size(), mitems);
+                L.nitems += (uint32_t)(mitems.size() - before);
+                L.lds = std::max(L.lds, (size_t)w.wplan->lds_bytes);
                 c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
                 c->stats.resample_dst_bytes += w.plan.pixel_bytes;
             }
@@ -715,6 +761,15 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             {
                 auto bt = c->blur_plans.find(std::make_tuple(vkey, hkey, blur_band_rows(k.pre ? k.pre : pl.out_c)));
                 j.pad0 = bt != c->blur_plans.end() ? bt->second : 0u; // table block of the blur kernel
+            }
+            if (k.kind & kBlurWtileKind) {
+                const size_t before = mitems.size();
+                w.bwplan->items_for(wtile_bands(*w.bwplan, kv.second.size()), (uint32_t)jobs.size(), mitems);
+                L.nitems += (uint32_t)(mitems.size() - before);
+                L.lds = std::max(L.lds, (size_t)w.bwplan->lds_bytes);
+                jobs.push_back(j);
+                L.njobs++;
+                continue;
             }
             const size_t mid = (size_t)pl.out_w * pl.out_h * pl.out_c;
             if (L.njobs && L.mid_floats + mid > kMidCapFloats) { blur_launches.push_back(L); L = new_launch(k); }
@@ -868,6 +923,18 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             }
             c->stats.resample_launches++;
             c->stats.generic_launches++; // (the two-pass generic resample, LDS form)
+        } else if ((L.k.kind & 255u) == S1_WTILE) {
+            if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
+            LaunchWtile m{};
+            m.jobs = d_jobs; m.items = reinterpret_cast<const WtItem *>(d_mitems + L.item_base); m.arena = c->d_arena; m.nitems = L.nitems;
+            m.nslot = (L.k.kind >> 8) & 255u; m.nkmax = kWtOperandRegs / m.nslot; m.letterbox = L.k.lb; m.lds_bytes = (uint32_t)L.lds;
+            {
+                ProfileScope ps(c, st, 0);
+                FL_HIP(c, launch_wtile(m, st), "window-tile matrix-pipe kernel");
+            }
+            c->stats.resample_launches++;
+            c->stats.mfma_launches++;
+            c->stats.wtile_launches++;
         } else if ((L.k.kind & 255u) == S1_GENERIC) {
             if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
             FL_HIP(c, launch_vpass_generic(L.g, st), "generic vertical pass");
@@ -900,7 +967,14 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         L.g.job_base = L.job_base; L.g.njobs = L.njobs; L.g.letterbox = 0;
         L.g.grouped = 0;
         ProfileScope ps(c, st, 1);
-        if (L.blur_tiled && !force_generic) {
+        if (L.k.kind & kBlurWtileKind) {
+            LaunchWtile m{};
+            m.jobs = d_jobs; m.items = reinterpret_cast<const WtItem *>(d_mitems + L.item_base); m.arena = c->d_arena; m.nitems = L.nitems;
+            m.nslot = L.k.kind & 255u; m.nkmax = kWtOperandRegs / m.nslot; m.letterbox = 0; m.lds_bytes = (uint32_t)L.lds;
+            FL_HIP(c, launch_wtile(m, st), "window-tile matrix-pipe kernel (blur)");
+            c->stats.mfma_launches++;
+            c->stats.wtile_launches++;
+        } else if (L.blur_tiled && !force_generic) {
             L.g.pre = L.k.pre; // channels to filter (group key), see blur_tile_kernel
             L.g.blur_lanes = L.k.kind;
             FL_HIP(c, launch_blur_tile(L.g, L.blur_grid_x, L.lds, st), "blur kernel");

@@ -58,6 +58,7 @@ void arena_reset(flgpu_ctx *c)
     c->axis_host.clear();
     c->stream_plans.clear();
     c->mfma_plans.clear();
+    c->wtile_plans.clear();
     c->blur_plans.clear();
     c->tile_vplans.clear();
     c->jpeg_tables.clear();
@@ -125,6 +126,54 @@ const std::vector<MfmaItem> &MfmaPlan::items_for(uint32_t nbands)
             items.push_back(mi);
         }
     return items_by_bands.emplace(nb, std::move(items)).first->second;
+}
+
+static_assert(sizeof(WtItem) == sizeof(MfmaItem) && alignof(WtItem) == alignof(MfmaItem), "the two kernels' workgroup records share the batch's item array");
+
+void WtPlan::items_for(uint32_t nbands, uint32_t job, std::vector<MfmaItem> &out) const
+{
+    const uint32_t nb = std::max(1u, std::min(nbands, n_mt));
+    for (uint32_t s = 0; s < n_strips; ++s)
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t t0 = (uint32_t)((uint64_t)n_mt * b / nb), t1 = (uint32_t)((uint64_t)n_mt * (b + 1) / nb);
+            if (t1 <= t0) continue;
+            WtItem wi{};
+            wi.job = job; wi.plan_off = off; wi.strip = s; wi.mt0 = t0; wi.mt1 = t1;
+            MfmaItem mi;
+            memcpy(&mi, &wi, sizeof(mi));
+            out.push_back(mi);
+        }
+}
+
+// Tables of the window-tile kernel for one geometry (resample or blur axes), or ok = false.
+WtPlan *get_wtile_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
+                       uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs)
+{
+    MfmaPlanKey key{vk, hk, cx, cy, cw, ch, cs, 0u};
+    auto it = c->wtile_plans.find(key);
+    if (it != c->wtile_plans.end()) return &it->second;
+    WtPlan plan;
+    HostWtPlan hp;
+    build_wtile_plan(va, ha, cs, cx, cy, cw, ch, hp);
+    if (hp.ok) {
+        if (c->h_arena.size() + hp.blk.size() + 2048 > c->arena_cap_words) {
+            static thread_local WtPlan full_plan;
+            full_plan = WtPlan();
+            full_plan.arena_full = hp.blk.size() + 4096 <= c->arena_cap_words; // (tables larger than the whole arena: never)
+            if (full_plan.arena_full) return &full_plan;
+            hp.ok = false;
+        }
+    }
+    if (hp.ok) {
+        plan.off = arena_append(c, hp.blk.data(), hp.blk.size());
+        plan.ok = plan.off != 0;
+        plan.nslot = hp.nslot; plan.nkmax = hp.nkmax; plan.n_mt = hp.n_mt; plan.n_strips = hp.n_strips; plan.lds_bytes = hp.lds_bytes;
+    }
+    if (getenv("FLGPU_DEBUG_MFMA"))
+        fprintf(stderr, "window-tile plan %ux%u -> rows [%u,+%u) cols [%u,+%u) x %u: ok %d, M-tiles %u, strips %u, registers %u x %u, LDS %u, %zu words\n",
+                ha.in_size, va.in_size, cy, ch, cx, cw, cs, (int)plan.ok, hp.n_mt, hp.n_strips, hp.nslot, hp.nkmax, hp.lds_bytes, hp.blk.size());
+    auto res = c->wtile_plans.emplace(key, plan);
+    return &res.first->second;
 }
 
 // Tables of the matrix-pipe kernel for one geometry, or ok = false if the kernel cannot or should not take it.
@@ -505,6 +554,7 @@ static void add_stats(flgpu_stats *out, const flgpu_stats &ls)
     out->jpeg_sources += ls.jpeg_sources; out->jpeg_file_bytes += ls.jpeg_file_bytes; out->jpeg_upload_bytes += ls.jpeg_upload_bytes;
     out->mfma_launches += ls.mfma_launches;
     out->jpeg_device_huffman += ls.jpeg_device_huffman; out->jpeg_device_huffman_retries += ls.jpeg_device_huffman_retries;
+    out->wtile_launches += ls.wtile_launches;
 }
 
 int flgpu_get_stats(flgpu_ctx *c, flgpu_stats *out)

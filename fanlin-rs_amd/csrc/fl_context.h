@@ -30,6 +30,7 @@
 #include "fl_kernels.h"
 #include "fl_mfma.h"
 #include "fl_tables.h"
+#include "fl_wtile.h"
 
 namespace fl {
 
@@ -99,6 +100,16 @@ struct MfmaPlan {
     bool arena_full = false; // the tables did not fit what is left of the arena: not cached, the caller resets the arena and plans again
 };
 
+// Tables of the window-tile matrix-pipe kernel for one geometry (fl_wtile.h): one block in the arena.  Keyed like the other plans;
+// a Gaussian blur is the same thing with Gaussian axes of equal in and out size.
+struct WtPlan {
+    bool ok = false;
+    bool arena_full = false; // the tables did not fit what is left of the arena: not cached, the caller resets the arena and plans again
+    uint32_t off = 0;        // arena word offset of the WtHeader
+    uint32_t nslot = 0, nkmax = 0, n_mt = 0, n_strips = 0, lds_bytes = 0;
+    void items_for(uint32_t nbands, uint32_t job, std::vector<MfmaItem> &out) const; // (WtItem and MfmaItem share the batch's item array: same size)
+};
+
 struct PinBlock {
     void *p = nullptr;
     size_t cap = 0;
@@ -147,6 +158,7 @@ struct flgpu_ctx {
     std::map<fl::AxisKey, fl::HostAxis> axis_host;
     std::map<fl::StreamPlanKey, fl::StreamPlan> stream_plans;
     std::map<fl::MfmaPlanKey, fl::MfmaPlan> mfma_plans;
+    std::map<fl::MfmaPlanKey, fl::WtPlan> wtile_plans;   // (arith field unused)
     std::map<std::tuple<fl::AxisKey, uint32_t, uint32_t>, uint32_t> tile_vplans;     // tiled two-pass kernel: dense vertical weights per band of 8 output rows, per (axis, first kept row, rows)
     std::map<std::tuple<fl::AxisKey, fl::AxisKey, uint32_t>, uint32_t> blur_plans; // blur kernel table blocks per (vertical, horizontal) Gaussian axis
     uint32_t gamma_off = 0;
@@ -262,6 +274,8 @@ int arena_flush(flgpu_ctx *c, hipStream_t st);
 uint32_t get_axis(flgpu_ctx *c, uint32_t in, uint32_t out, Filter f, float sigma, AxisKey *key_out, const HostAxis **host_out);
 MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
                               uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs, MfmaArith arith = MFMA_ARITH_FULL);
+WtPlan *get_wtile_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
+                       uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t cs);
 const StreamPlan *get_stream_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, const AxisKey &hk, const HostAxis &ha,
                                   uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, uint32_t nbands, uint32_t cs, uint32_t pre);
 hipEvent_t get_event(flgpu_ctx *c);

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "fl_mfma.h"
+#include "fl_wtile.h"
 
 namespace fl {
 
@@ -266,6 +267,198 @@ void choose_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_
         out = std::move(w);
         out.wide = true;
     }
+}
+
+// ---- the window-tile kernel's tables (fl_wtile.h) -------------------------------------------------------------------------------
+void build_wtile_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, HostWtPlan &out)
+{
+    out = HostWtPlan();
+    if (cs < 1 || cs > 4 || cw == 0 || ch == 0 || cy + ch > v.out_size || cx + cw > h.out_size) return;
+    const uint32_t sh = v.in_size, sw = h.in_size, nout = cw * cs;
+    const uint32_t NMT = (ch + 15u) / 16u, NNT = (nout + 15u) / 16u;
+    if (sh >= 65536u || sw * cs >= (1u << 20)) return;
+    std::vector<uint32_t> ops;                 // operand words, deduplicated per tile (a blur's interior tiles all share one block)
+    std::map<std::string, uint32_t> seen;      // block bytes -> word offset inside `ops`
+    auto intern = [&](const std::vector<uint32_t> &b) -> uint32_t {
+        std::string key(reinterpret_cast<const char *>(b.data()), b.size() * 4);
+        auto it = seen.find(key);
+        if (it != seen.end()) return it->second;
+        const uint32_t off = (uint32_t)ops.size();
+        ops.insert(ops.end(), b.begin(), b.end());
+        seen.emplace(std::move(key), off);
+        return off;
+    };
+    // ---- vertical: per M-tile a K window of whole 32-row steps starting at a multiple of 8 rows ----
+    std::vector<WtMTile> mts(NMT);
+    uint32_t nkv_max = 0, prev_kr0 = 0;
+    for (uint32_t j = 0; j < NMT; ++j) {
+        uint32_t a = 0xffffffffu, b = 0;
+        for (uint32_t n = 0; n < 16 && 16 * j + n < ch; ++n) {
+            const uint32_t oy = cy + 16 * j + n;
+            a = std::min(a, v.left[oy]);
+            b = std::max(b, v.left[oy] + v.count[oy]);
+        }
+        const uint32_t kr0 = a & ~7u, nk = (b - kr0 + kMfmaKRows - 1u) / kMfmaKRows;
+        if (nk == 0 || nk > kWtMaxKV) return;
+        if (j && kr0 < prev_kr0) return; // the ring only moves down (a window may END earlier than the one before it -- the picture's last rows: nothing new to load then)
+        prev_kr0 = kr0;
+        std::vector<uint32_t> blk((size_t)nk * 3 * 64 * 4, 0u);
+        for (uint32_t k = 0; k < nk; ++k)
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                const uint32_t g = lane >> 4, n = lane & 15u;
+                if (16 * j + n >= ch) continue;
+                const uint32_t oy = cy + 16 * j + n;
+                for (uint32_t jj = 0; jj < 8; ++jj) {
+                    const uint32_t r = kr0 + kMfmaKRows * k + 8 * g + jj;
+                    if (r < v.left[oy] || r >= v.left[oy] + v.count[oy]) continue;
+                    double rest = ldexp((double)v.weights[v.woff[oy] + (r - v.left[oy])], (int)kMfmaVScaleLog2Full);
+                    for (uint32_t t = 0; t < 3; ++t) {
+                        const uint16_t wt = f16_bits(rest);
+                        if ((wt & 0x7c00u) == 0x7c00u) return; // a weight of 2 or more
+                        rest -= f16_value(wt);
+                        blk[(((size_t)k * 3 + t) * 64 + lane) * 4 + jj / 2] |= (uint32_t)wt << (16 * (jj & 1u));
+                    }
+                }
+            }
+        mts[j] = {kr0, nk, intern(blk), 0u};
+        nkv_max = std::max(nkv_max, nk);
+    }
+    // ---- horizontal weights: fixed point at the finest of 2^-24 / 2^-23 / 2^-22 whose three balanced digits hold the largest ----
+    float maxw = 0.0f;
+    for (uint32_t x = cx; x < cx + cw; ++x)
+        for (uint32_t k = 0; k < h.count[x]; ++k) maxw = std::max(maxw, fabsf(h.weights[h.woff[x] + k]));
+    const double qlimit = 8355711.0; // 127 * 65536 + 127 * 256 + 127
+    int hs = 24;
+    while (hs >= 22 && ldexp((double)maxw, hs) > qlimit - 640.0) --hs;
+    if (hs < 22) return;
+    std::vector<std::vector<int32_t>> hq(cw);
+    for (uint32_t x = cx; x < cx + cw; ++x) {
+        std::vector<int32_t> &q = hq[x - cx];
+        q.resize(h.count[x]);
+        int64_t sum = 0;
+        uint32_t big = 0;
+        for (uint32_t k = 0; k < h.count[x]; ++k) {
+            q[k] = (int32_t)llround(ldexp((double)h.weights[h.woff[x] + k], hs));
+            sum += q[k];
+            if (abs(q[k]) > abs(q[big])) big = k;
+        }
+        q[big] += (int32_t)(((int64_t)1 << hs) - sum);
+        if ((double)abs(q[big]) > qlimit) return;
+    }
+    auto weight_of = [&](uint32_t o, uint32_t col) -> int32_t { // weight of source byte `col` of a row in output byte o
+        if (o >= nout || col >= cs * sw) return 0;
+        const uint32_t px = col / cs, x = cx + o / cs;
+        if (o % cs != col % cs || px < h.left[x] || px >= h.left[x] + h.count[x]) return 0;
+        return hq[x - cx][px - h.left[x]];
+    };
+    std::vector<WtNTile> nts(NNT);
+    uint32_t nkh_max = 0;
+    for (uint32_t j = 0; j < NNT; ++j) {
+        uint32_t a = 0xffffffffu, b = 0;
+        for (uint32_t n = 0; n < 16 && 16 * j + n < nout; ++n) {
+            const uint32_t o = 16 * j + n, x = cx + o / cs;
+            a = std::min(a, cs * h.left[x] + o % cs);
+            b = std::max(b, cs * (h.left[x] + h.count[x] - 1u) + o % cs + 1u);
+        }
+        const uint32_t kc0 = a & ~15u, nk = (b - kc0 + 63u) / 64u;
+        if (nk == 0 || nk > kWtMaxKH) return;
+        if (j && kc0 < nts[j - 1].kc0) return;
+        std::vector<uint32_t> blk((size_t)nk * 3 * 64 * 4, 0u);
+        uint8_t *bytes = reinterpret_cast<uint8_t *>(blk.data());
+        for (uint32_t k = 0; k < nk; ++k)
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                const uint32_t g = lane >> 4, n = lane & 15u;
+                for (uint32_t jj = 0; jj < 16; ++jj) {
+                    int32_t q = weight_of(16 * j + n, kc0 + 64u * k + 16u * g + jj);
+                    for (uint32_t d = 3; d-- > 0;) { // balanced digits, low to high; operand 0 holds the highest
+                        const int32_t lo = d ? ((q + 128) & 255) - 128 : q;
+                        bytes[((((size_t)k * 3 + d) * 64 + lane) * 16) + jj] = (uint8_t)(int8_t)lo;
+                        q = (q - lo) / 256;
+                    }
+                }
+            }
+        nts[j] = {kc0, nk, intern(blk), 0u};
+        nkh_max = std::max(nkh_max, nk);
+    }
+    // ---- strips: as many N-tiles as the LDS and the wave's operand registers allow ----
+    uint32_t ring_rows = 0;
+    for (auto &m : mts) ring_rows = std::max(ring_rows, 32u * m.nk);
+    std::map<uint32_t, uint32_t> freq;
+    for (auto &t : nts) freq[t.ops]++;
+    uint32_t common_n = 0;
+    for (auto &kv : freq) common_n = std::max(common_n, kv.second);
+    const bool uniform = NNT >= 4 && common_n * 2 >= NNT; // most column tiles share their operands: one register set serves them
+    uint32_t nkmax = 1;
+    while (nkmax < nkh_max) nkmax *= 2;
+    if (uniform) nkmax = kWtOperandRegs;
+    const uint32_t nslot = kWtOperandRegs / nkmax;
+    const uint32_t step = cs == 3 ? 3u : 1u;     // a strip starts on a pixel boundary: 16 n0 must be a multiple of cs
+    const uint32_t tn_regs = uniform ? 0xffffu : kWtWaves * nslot;
+    auto strip_of = [&](uint32_t n0, uint32_t n1) {
+        WtStrip S{};
+        S.n0 = n0; S.n1 = n1; S.col0 = nts[n0].kc0;
+        uint32_t end = 0;
+        for (uint32_t j = n0; j < n1; ++j) end = std::max(end, nts[j].kc0 + 64u * nts[j].nk);
+        uint32_t spw = (end - S.col0 + 15u) / 16u;
+        if (!(spw & 1u)) ++spw;
+        S.sp = 16u * spw;
+        S.lds_bytes = ring_rows * S.sp + 3u * 16u * S.sp + nkv_max * 3u * 1024u + 16u * (16u * (n1 - n0) + 16u);
+        return S;
+    };
+    auto split = [&](uint32_t cap, std::vector<WtStrip> *b) -> uint32_t {
+        uint32_t n = 0;
+        if (b) b->clear();
+        for (uint32_t n0 = 0; n0 < NNT; ++n) {
+            uint32_t n1 = n0;
+            while (n1 < NNT) {
+                const uint32_t t = std::min(NNT, n1 + step);
+                if (t - n0 > cap || t - n0 > tn_regs || strip_of(n0, t).lds_bytes > kWtLdsBudget) break;
+                n1 = t;
+            }
+            if (n1 == n0) return 0;
+            if (b) b->push_back(strip_of(n0, n1));
+            n0 = n1;
+        }
+        return n;
+    };
+    const uint32_t ns = split(0xffffu, nullptr);
+    if (!ns) return;
+    uint32_t cap = ((NNT + ns - 1u) / ns + step - 1u) / step * step;
+    while (split(cap, nullptr) != ns) cap += step;
+    std::vector<WtStrip> strips;
+    if (split(cap, &strips) != ns) return;
+    uint32_t lds_max = 0;
+    for (auto &S : strips) {
+        std::map<uint32_t, uint32_t> f;
+        for (uint32_t j = S.n0; j < S.n1; ++j) f[nts[j].ops]++;
+        S.common_ops = 0xffffffffu;
+        uint32_t best = 1;
+        for (auto &kv : f) if (kv.second > best) { best = kv.second; S.common_ops = kv.first; }
+        for (uint32_t j = S.n0; j < S.n1; ++j) if (nts[j].ops == S.common_ops) S.common_nk = nts[j].nk;
+        lds_max = std::max(lds_max, S.lds_bytes);
+    }
+    // ---- the block ----
+    WtHeader hd{};
+    hd.n_mt = NMT; hd.n_nt = NNT; hd.n_strips = (uint32_t)strips.size(); hd.cs = cs;
+    hd.rows = ch; hd.nout = nout; hd.src_rows = sh; hd.src_rowbytes = sw * cs; hd.hs = (uint32_t)hs;
+    hd.ring_rows = ring_rows; hd.ring_magic = (uint32_t)((((uint64_t)1 << 32) + ring_rows - 1u) / ring_rows);
+    hd.nkv_max = nkv_max; hd.nkh_max = nkh_max;
+    const uint32_t hw = sizeof(WtHeader) / 4;
+    hd.mt_off = hw;
+    hd.nt_off = hd.mt_off + NMT * (uint32_t)(sizeof(WtMTile) / 4);
+    hd.strip_off = hd.nt_off + NNT * (uint32_t)(sizeof(WtNTile) / 4);
+    const uint32_t ops_off = (hd.strip_off + hd.n_strips * (uint32_t)(sizeof(WtStrip) / 4) + 3u) & ~3u; // operands are read 16 bytes at a time
+    for (auto &m : mts) m.ops += ops_off;
+    for (auto &t : nts) t.ops += ops_off;
+    for (auto &S : strips) if (S.common_ops != 0xffffffffu) S.common_ops += ops_off;
+    out.blk.assign((size_t)ops_off + ops.size(), 0u);
+    memcpy(out.blk.data(), &hd, sizeof(hd));
+    memcpy(out.blk.data() + hd.mt_off, mts.data(), mts.size() * sizeof(WtMTile));
+    memcpy(out.blk.data() + hd.nt_off, nts.data(), nts.size() * sizeof(WtNTile));
+    memcpy(out.blk.data() + hd.strip_off, strips.data(), strips.size() * sizeof(WtStrip));
+    memcpy(out.blk.data() + ops_off, ops.data(), ops.size() * 4);
+    out.nslot = nslot; out.nkmax = nkmax; out.n_mt = NMT; out.n_strips = hd.n_strips; out.lds_bytes = lds_max;
+    out.ok = true;
 }
 
 } // namespace fl

@@ -1,0 +1,283 @@
+// fl_wtile.hip -- the window-tile matrix-pipe kernel for gfx950 (design, arithmetic and table layout: fl_wtile.h).
+// Reference: image 0.25.6 imageops/sample.rs vertical_sample + horizontal_sample behind resize_exact and blur
+// (src/handler.rs:229-255 of the reference).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "fl_mfma.h"
+#include "fl_pixel.h"
+#include "fl_wtile.h"
+
+namespace fl {
+
+namespace {
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned; // (gfx950 loads 16 bytes from any byte address)
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef __attribute__((address_space(1))) uint32_t *gptr32;
+typedef __attribute__((address_space(1))) uint8_t *gptr8;
+typedef __attribute__((address_space(1))) u32_unaligned *gptr32u;
+
+extern __shared__ __attribute__((aligned(16))) uint8_t wt_lds[];
+
+// NSLOT x NKMAX = kWtOperandRegs: a wave keeps the horizontal operands of NSLOT N-tiles of up to NKMAX K-steps each in registers
+// for its whole walk (<1, 8> also serves strips whose N-tiles mostly share ONE operand block: a blur's interior columns).
+template <int NSLOT, int NKMAX>
+__global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job *__restrict__ jobs, const WtItem *__restrict__ items,
+                                                                       const uint32_t *__restrict__ arena, uint32_t lb)
+{
+    static_assert(NSLOT * NKMAX == (int)kWtOperandRegs, "operand register budget");
+    const WtItem it = items[blockIdx.x];
+    const Job jb = jobs[it.job];
+    const uint32_t *plan = arena + it.plan_off;
+    const WtHeader hd = *reinterpret_cast<const WtHeader *>(plan);
+    const WtStrip sp = reinterpret_cast<const WtStrip *>(plan + hd.strip_off)[it.strip];
+    const WtMTile *mts = reinterpret_cast<const WtMTile *>(plan + hd.mt_off);
+    const WtNTile *nts = reinterpret_cast<const WtNTile *>(plan + hd.nt_off);
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, g = lane >> 4, i = lane & 15u;
+    const uint32_t SP = sp.sp, spw = SP >> 4, RR = hd.ring_rows;
+    const uint32_t tn = sp.n1 - sp.n0, OP = 16u * tn + 16u;
+    // LDS: [ring: RR rows x SP] [planes: 3 x 16 rows x SP] [vertical operands of the M-tile: nkv_max x 3 KB] [output tile: 16 x OP bytes]
+    uint8_t *ring = wt_lds;
+    uint8_t *planes = ring + RR * SP;
+    u32x4 *wv_lds = reinterpret_cast<u32x4 *>(planes + 48u * SP);
+    uint8_t *otile = reinterpret_cast<uint8_t *>(wv_lds) + hd.nkv_max * 3072u;
+    auto rmod = [&](uint32_t r) -> uint32_t { return r - RR * __umulhi(r, hd.ring_magic); }; // r mod RR (r < 65536)
+
+    // ---- source rows -> ring.  A thread owns one 16-byte column of the window and every rpp-th row; up to kWtPrefetch pieces stay in
+    // registers between the request (during the previous M-tile's horizontal pass) and the LDS write (top of the step). ----
+    const uint32_t tcol = tid % spw, trow = tid / spw, rpp = kWtThreads / spw; // (one division per workgroup)
+    const uint32_t pitch = hd.src_rowbytes;
+    auto fetch = [&](uint32_t r) -> u32x4 {
+        const uint32_t row = min(r, hd.src_rows - 1u); // rows past the picture carry zero weights: any finite bytes do
+        const uint32_t off = row * pitch + sp.col0 + 16u * tcol;
+        if (off + 16u <= jb.src_bytes) return *reinterpret_cast<const u32x4_unaligned *>(jb.src + off);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        for (uint32_t b = 0; b < 16u && off + b < jb.src_bytes; ++b) v[b >> 2] |= (uint32_t)jb.src[off + b] << (8u * (b & 3u));
+        return v;
+    };
+    auto put = [&](uint32_t r, u32x4 v) { *reinterpret_cast<u32x4 *>(ring + rmod(r) * SP + 16u * tcol) = v; };
+    u32x4 pre[kWtPrefetch];
+    uint32_t pre_r0 = 0, pre_r1 = 0;      // rows requested for the coming step: [pre_r0, pre_r1)
+    u32x4 wpre[2];                        // ... and its vertical operands (nkv x 192 16-byte pieces over 512 threads)
+    uint32_t wpre_n = 0;
+    auto request = [&](uint32_t r0, uint32_t r1, const WtMTile &m) {
+        pre_r0 = r0; pre_r1 = r1;
+#pragma unroll
+        for (uint32_t k = 0; k < kWtPrefetch; ++k) {
+            const uint32_t r = r0 + trow + k * rpp;
+            if (trow < rpp && r < r1) pre[k] = fetch(r);
+        }
+        wpre_n = m.nk * 192u;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(plan + m.ops);
+#pragma unroll
+        for (uint32_t k = 0; k < 2; ++k)
+            if (tid + k * kWtThreads < wpre_n) wpre[k] = src[tid + k * kWtThreads];
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (uint32_t k = 0; k < kWtPrefetch; ++k) {
+            const uint32_t r = pre_r0 + trow + k * rpp;
+            if (trow < rpp && r < pre_r1) put(r, pre[k]);
+        }
+        // (more new rows than the registers held: the rest now, synchronously -- ratios just below the streaming kernel's range)
+        if (trow < rpp)
+            for (uint32_t r = pre_r0 + trow + kWtPrefetch * rpp; r < pre_r1; r += rpp) put(r, fetch(r));
+#pragma unroll
+        for (uint32_t k = 0; k < 2; ++k)
+            if (tid + k * kWtThreads < wpre_n) wv_lds[tid + k * kWtThreads] = wpre[k];
+    };
+
+    // ---- this wave's horizontal operands: its N-tiles are the same in every M-tile ----
+    u32x4 hb[NSLOT][NKMAX][3];
+    uint32_t cached[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const uint32_t nt = sp.n0 + wave + kWtWaves * (uint32_t)s;
+        cached[s] = 0xffffffffu;
+        uint32_t nk = 0;
+        if (NSLOT == 1 && sp.common_ops != 0xffffffffu) { cached[s] = sp.common_ops; nk = sp.common_nk; }
+        else if (nt < sp.n1) { cached[s] = nts[nt].ops; nk = nts[nt].nk; }
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(plan + (cached[s] != 0xffffffffu ? cached[s] : 0u));
+#pragma unroll
+        for (int k = 0; k < NKMAX; ++k)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) hb[s][k][d] = (uint32_t)k < nk ? src[(k * 3 + d) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    }
+
+    const uint32_t sh = hd.hs - 6u, slo = sh - 8u, s4 = 32u - sh, s3 = 24u - sh;
+    const int32_t rnd = 1 << (slo - 1u);
+    constexpr int32_t round_add = -132112384 + (1 << 19); // the planes' offsets (2^22, 128 * 2^8, 128) times the weight sum, and the rounding half (fl_mfma.hip)
+
+    {   // the band's first window, synchronously
+        const WtMTile m0 = mts[it.mt0];
+        request(m0.kr0, m0.kr0 + 32u * m0.nk, m0);
+    }
+    for (uint32_t mt = it.mt0; mt < it.mt1; ++mt) {
+        const WtMTile m = mts[mt];
+        commit();
+        __syncthreads();
+        // ---- vertical ----
+        {
+            u32x4 wv[kWtMaxKV][3];
+#pragma unroll
+            for (uint32_t k = 0; k < kWtMaxKV; ++k)
+#pragma unroll
+                for (uint32_t t = 0; t < 3; ++t) wv[k][t] = k < m.nk ? wv_lds[(k * 3u + t) * 64u + lane] : u32x4{0u, 0u, 0u, 0u};
+            uint32_t radr[kWtMaxKV]; // lane's address inside a column tile: 8 rows of a lane group, two 8-byte halves per row
+#pragma unroll
+            for (uint32_t k = 0; k < kWtMaxKV; ++k) radr[k] = (rmod(m.kr0 + 32u * k + 8u * g) + (i >> 1)) * SP + 8u * (i & 1u);
+            for (uint32_t ct = wave; ct < spw; ct += kWtWaves) {
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (uint32_t k = 0; k < kWtMaxKV; ++k) {
+                    if (k >= m.nk) break;
+                    const v2i raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + radr[k] + 16u * ct));
+                    u32x4 a;
+                    a[0] = __builtin_amdgcn_perm(0u, (uint32_t)raw[0], 0x0c010c00u);
+                    a[1] = __builtin_amdgcn_perm(0u, (uint32_t)raw[0], 0x0c030c02u);
+                    a[2] = __builtin_amdgcn_perm(0u, (uint32_t)raw[1], 0x0c010c00u);
+                    a[3] = __builtin_amdgcn_perm(0u, (uint32_t)raw[1], 0x0c030c02u);
+                    const f16x8 av = __builtin_bit_cast(f16x8, a);
+#pragma unroll
+                    for (uint32_t t = 0; t < 3; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[k][t]), acc, 0, 0, 0);
+                }
+                // sums = value * 2^-9 -> 2^22 + round((value - 128) * 2^14) in the mantissa -> three byte planes (fl_mfma.hip, full width)
+                const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[0], 8388608.0f, 10485760.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[1], 8388608.0f, 10485760.0f)),
+                               x2 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[2], 8388608.0f, 10485760.0f)), x3 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[3], 8388608.0f, 10485760.0f));
+                const uint32_t t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x3, x2, 0x05010400u);
+                const uint32_t p0 = __builtin_amdgcn_perm(t1, t0, 0x05040100u) ^ 0x80808080u;
+                const uint32_t p1 = __builtin_amdgcn_perm(t1, t0, 0x07060302u) ^ 0x80808080u;
+                const uint32_t p2 = __builtin_amdgcn_perm(x1, x0, 0x0c0c0602u) | __builtin_amdgcn_perm(x3, x2, 0x06020c0cu);
+                uint8_t *pw = planes + i * SP + 16u * ct + 4u * g; // lane (output row i, columns 4 g .. 4 g + 3)
+                *reinterpret_cast<uint32_t *>(pw) = p2;
+                *reinterpret_cast<uint32_t *>(pw + 16u * SP) = p1;
+                *reinterpret_cast<uint32_t *>(pw + 32u * SP) = p0;
+            }
+        }
+        __syncthreads();
+        // ---- the next step's rows and operands: requested now, written at the top of the next step ----
+        if (mt + 1u < it.mt1) {
+            const WtMTile mn = mts[mt + 1u];
+            request(max(m.kr0 + 32u * m.nk, mn.kr0), mn.kr0 + 32u * mn.nk, mn);
+        } else { pre_r0 = pre_r1 = 0; wpre_n = 0; }
+        // ---- horizontal ----
+        auto ntile = [&](auto slot_tag, uint32_t nt) __attribute__((always_inline)) {
+            constexpr int S = decltype(slot_tag)::value;
+            const WtNTile t = nts[nt];
+            const uint8_t *pa = planes + i * SP + (t.kc0 - sp.col0) + 16u * g; // lane (output row i, 16 bytes of K group g)
+            i32x4 L[5];
+            const i32x4 z = {0, 0, 0, 0};
+            L[0] = z; L[2] = z; L[3] = z; L[4] = z; L[1] = i32x4{rnd, rnd, rnd, rnd};
+            auto step = [&](const u32x4 &a2u, const u32x4 &a1u, const u32x4 &a0u, const u32x4 &b2u, const u32x4 &b1u, const u32x4 &b0u) __attribute__((always_inline)) {
+                const i32x4 a2 = __builtin_bit_cast(i32x4, a2u), a1 = __builtin_bit_cast(i32x4, a1u), a0 = __builtin_bit_cast(i32x4, a0u);
+                const i32x4 b2 = __builtin_bit_cast(i32x4, b2u), b1 = __builtin_bit_cast(i32x4, b1u), b0 = __builtin_bit_cast(i32x4, b0u);
+                L[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, L[4], 0, 0, 0);
+                L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, L[3], 0, 0, 0);
+                L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, L[2], 0, 0, 0);
+                L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, L[1], 0, 0, 0);
+                L[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, L[0], 0, 0, 0);
+                L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, L[3], 0, 0, 0);
+                L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, L[2], 0, 0, 0);
+                L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, L[1], 0, 0, 0);
+                L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, L[2], 0, 0, 0);
+            };
+            if (t.ops == cached[S]) {
+#pragma unroll
+                for (int k = 0; k < NKMAX; ++k) {
+                    if ((uint32_t)k >= t.nk) break;
+                    const u32x4 a2 = *reinterpret_cast<const u32x4 *>(pa + 64u * k), a1 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 16u * SP),
+                                a0 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 32u * SP);
+                    step(a2, a1, a0, hb[S][k][0], hb[S][k][1], hb[S][k][2]);
+                }
+            } else { // a tile that shares nothing (a blur's border columns), or more tiles than register sets: operands from the L2
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(plan + t.ops);
+                for (uint32_t k = 0; k < t.nk; ++k) {
+                    const u32x4 b2 = src[(k * 3u + 0u) * 64u + lane], b1 = src[(k * 3u + 1u) * 64u + lane], b0 = src[(k * 3u + 2u) * 64u + lane];
+                    const u32x4 a2 = *reinterpret_cast<const u32x4 *>(pa + 64u * k), a1 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 16u * SP),
+                                a0 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 32u * SP);
+                    step(a2, a1, a0, b2, b1, b0);
+                }
+            }
+            // sum = L4 2^32 + L3 2^24 + L2 2^16 + L1 2^8 + L0 in units of 2^-(14 + hs) of a pixel step -> 2^-20, then the byte
+            uint8_t *ow = otile + 16u * (nt - sp.n0) + i; // lane (output byte i of the tile, rows 4 g .. 4 g + 3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int32_t low = (((L[2][r] << 8) + L[1][r]) + (L[0][r] >> 8)) >> slo;
+                const int32_t p = (int32_t)(((uint32_t)L[4][r] << s4) + ((uint32_t)L[3][r] << s3) + (uint32_t)low);
+                const int32_t x = p + round_add;
+                // (clamp-then-shift: clamp(x >> 20, 0, 255) is the pattern hipcc fuses into gfx950's broken v_ashr_pk_u8_i32)
+                ow[(4u * g + (uint32_t)r) * OP] = (uint8_t)((uint32_t)min(max(x, 0), (256 << 20) - 1) >> 20);
+            }
+        };
+#define FL_WT_SLOT(S_) if constexpr (NSLOT > S_) { const uint32_t nt = sp.n0 + wave + kWtWaves * S_##u; if (nt < sp.n1) ntile(std::integral_constant<int, S_>{}, nt); }
+        FL_WT_SLOT(0) FL_WT_SLOT(1) FL_WT_SLOT(2) FL_WT_SLOT(3) FL_WT_SLOT(4) FL_WT_SLOT(5) FL_WT_SLOT(6) FL_WT_SLOT(7)
+#undef FL_WT_SLOT
+        // (strips wider than 8 NSLOT tiles: uniform strips, whose tiles share slot NSLOT - 1's block -- or take the on-the-fly path)
+        for (uint32_t nt = sp.n0 + wave + kWtWaves * (uint32_t)NSLOT; nt < sp.n1; nt += kWtWaves) ntile(std::integral_constant<int, NSLOT - 1>{}, nt);
+        __syncthreads();
+        // ---- output tile -> destination: 32 threads per row ----
+        {
+            const uint32_t rr = tid >> 5, t32 = tid & 31u, y = 16u * mt + rr;
+            const uint32_t b0 = 16u * sp.n0, b1 = min(16u * sp.n1, hd.nout);
+            if (y < hd.rows) {
+                const uint8_t *orow = otile + rr * OP;
+                const uint32_t cs = hd.cs, px0 = b0 / cs, npx = (b1 - b0) / cs;
+                const size_t drow = (size_t)(jb.oy + y) * jb.dw + jb.ox + px0;
+                if (lb) {
+                    gptr32 d = (gptr32)(reinterpret_cast<uint32_t *>(jb.dst) + drow);
+                    for (uint32_t q = t32; q < npx; q += 32u) {
+                        const uint8_t *p = orow + q * cs;
+                        uint32_t v;
+                        if (cs == 1u) v = p[0] * 0x010101u | 0xff000000u;
+                        else if (cs == 2u) v = blend_over_fill(jb.fill, p[0], p[0], p[0], p[1]);
+                        else if (cs == 3u) v = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
+                        else v = blend_over_fill(jb.fill, p[0], p[1], p[2], p[3]);
+                        d[q] = v;
+                    }
+                } else {
+                    uint8_t *d = jb.dst + drow * cs;
+                    const uint32_t nb = b1 - b0;
+                    for (uint32_t b = 4u * t32; b < nb; b += 128u) {
+                        const uint32_t v = *reinterpret_cast<const uint32_t *>(orow + b);
+                        if (b + 4u <= nb) *(gptr32u)(d + b) = v;
+                        else for (uint32_t k = 0; b + k < nb; ++k) ((gptr8)d)[b + k] = (uint8_t)(v >> (8u * k));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NSLOT, int NKMAX>
+hipError_t launch_wtile_t(const LaunchWtile &m, hipStream_t st)
+{
+    static bool attr_set = false; // (per instantiation; the attribute is per function and device, contexts on other devices set it again harmlessly)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_wtile_kernel<NSLOT, NKMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr_set;
+    if (e != hipSuccess) return e;
+    resample_wtile_kernel<NSLOT, NKMAX><<<m.nitems, kWtThreads, m.lds_bytes, st>>>(m.jobs, m.items, m.arena, m.letterbox);
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_wtile(const LaunchWtile &m, hipStream_t st)
+{
+    if (!m.nitems) return hipSuccess;
+    if (m.lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
+    if (m.nslot == 8 && m.nkmax == 1) return launch_wtile_t<8, 1>(m, st);
+    if (m.nslot == 4 && m.nkmax == 2) return launch_wtile_t<4, 2>(m, st);
+    if (m.nslot == 2 && m.nkmax == 4) return launch_wtile_t<2, 4>(m, st);
+    if (m.nslot == 1 && m.nkmax == 8) return launch_wtile_t<1, 8>(m, st);
+    return hipErrorInvalidValue;
+}
+
+} // namespace fl

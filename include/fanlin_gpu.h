@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define FLGPU_ABI_VERSION 4
+#define FLGPU_ABI_VERSION 5
 
 typedef enum flgpu_status {
     FLGPU_OK = 0,
@@ -189,9 +189,10 @@ typedef struct flgpu_stats {
     uint64_t jpeg_sources;        /* FLGPU_IMG_JPEG_SOURCE pictures decoded on the device */
     uint64_t jpeg_file_bytes;     /* their file bytes ... */
     uint64_t jpeg_upload_bytes;   /* ... and what crossed PCIe for them (coefficient blobs) */
-    uint64_t mfma_launches;       /* of resample_launches: launches of the matrix-pipe kernel (fl_mfma.hip) */
+    uint64_t mfma_launches;       /* launches of the matrix-pipe kernels (fl_mfma.hip, fl_wtile.hip; the latter also for blurs) */
     uint64_t jpeg_device_huffman; /* of jpeg_sources: files whose entropy-coded segment was decoded on the device too (fl_jpeghuff_dev.hip) */
     uint64_t jpeg_device_huffman_retries; /* ... of which the device gave up on and the host decoded after all */
+    uint64_t wtile_launches;      /* of mfma_launches: launches of the window-tile matrix-pipe kernel (fl_wtile.hip: mild ratios, up-scales, blurs) */
 } flgpu_stats;
 
 typedef struct flgpu_ctx flgpu_ctx;
@@ -412,6 +413,14 @@ int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t 
  * three f16 terms / three byte digits; flgpu_debug_mfma_plan is this one), 0 = packed (rounds 2-3: two terms / two digits). */
 int flgpu_debug_mfma_plan_arith(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
                                 uint32_t cw, uint32_t ch, uint32_t arith, uint32_t info[8], double err[2]);
+
+/* The window-tile matrix-pipe kernel's arithmetic (csrc/fl_wtile.h) run on the host from the kernel's own tables: a plain resize_exact
+ * of `src` (sw x sh pixels, cs interleaved bytes) to rw x rh, or -- blur_sigma > 0 -- its Gaussian blur, written to dst (rw x rh x cs,
+ * no letterbox).  Returns 1 if the geometry fits the kernel, 0 if not (or if a table carries a weight on a byte that does not exist).
+ * info[0..7] = M-tiles, N-tiles, strips, log2 of the horizontal weight scale, operand register split (N-tiles x K-steps), LDS bytes,
+ * table words.  src / dst may be null (plan only).  Test infrastructure: nothing in the library calls it.  Needs no device. */
+int flgpu_debug_wtile_model(const uint8_t *src, uint32_t sw, uint32_t sh, uint32_t cs, uint32_t rw, uint32_t rh, float blur_sigma,
+                            uint8_t *dst, uint32_t info[8]);
 
 const char *flgpu_strerror(int status);
 const char *flgpu_last_error(flgpu_ctx *ctx); /* detail of the last FLGPU_ERR_DEVICE on this context */

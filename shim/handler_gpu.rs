@@ -79,7 +79,7 @@ impl Gpu {
     /// `devices`: HIP ordinals of the node's GPUs (`&[0]` for one); all of them serve the one shared State,
     /// as all tokio workers share one `Arc<State>` (src/main.rs:108-112).
     pub fn new(max_clients: u32, devices: &[i32], use_embedded_profile: bool) -> Result<Self, String> {
-        assert_eq!(unsafe { flgpu_abi_version() }, 4, "libfanlin_gpu.so / shim mismatch");
+        assert_eq!(unsafe { flgpu_abi_version() }, 5, "libfanlin_gpu.so / shim mismatch");
         let mut cfg = FlConfig { device: devices.first().copied().unwrap_or(-1), max_batch: max_clients.max(1),
                                  flush_timeout_us: 200, use_embedded_profile: use_embedded_profile as u32, ..Default::default() };
         if devices.len() > 1 {
