@@ -64,12 +64,21 @@ uint32_t blur_channels(const Work &w)
     return ce;
 }
 
+// Resamples the window-tile matrix-pipe kernel takes from the f32 vector kernels: down-scales (of those neither fused kernel takes:
+// ratios below ~3).  For up-scales the two measure the same (profiles/r04_generic_sweep.txt) and the vector kernel reproduces the
+// reference's f32 sums to the order of additions, so it keeps them.  FLGPU_WTILE_ALWAYS=1: every geometry the kernel can take (tests).
+bool wtile_resample_wanted(const Work &w)
+{
+    const char *e = getenv("FLGPU_WTILE_ALWAYS"); // (read per batch: a test can flip it)
+    return (e && e[0] == '1') || 4u * w.sh >= 5u * w.plan.resized_h || 4u * w.sw >= 5u * w.plan.resized_w;
+}
+
 // Blurs the window-tile matrix-pipe kernel takes: all but the one-channel shortcut (a grey picture on a grey frame: the vector
 // kernel filters one byte column in four there, the matrix kernel would filter all four).
 bool wtile_blur_wanted(const Work &w)
 {
-    static const bool always = [] { const char *e = getenv("FLGPU_WTILE_BLUR_ALWAYS"); return e && e[0] == '1'; }();
-    return always || blur_channels(w) != 1u;
+    const char *e = getenv("FLGPU_WTILE_BLUR_ALWAYS");
+    return (e && e[0] == '1') || blur_channels(w) != 1u;
 }
 
 // Row bands per picture for the window-tile kernel: small batches are cut so that the chip still sees a few hundred workgroups
@@ -560,7 +569,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 if (sp->ok) { w.s1 = S1_STREAM; w.splan = sp; }
             }
             // what neither fused kernel takes and no pre-op precedes: the window-tile matrix-pipe kernel (any pitch and alignment)
-            if (w.s1 == S1_GENERIC && use_wtile && w.pre == PRE_NONE && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
+            if (w.s1 == S1_GENERIC && use_wtile && w.pre == PRE_NONE && wtile_resample_wanted(w) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
                 Job jtmp; fill_job(w, jtmp);
                 WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
                 if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }

@@ -388,9 +388,10 @@ void build_wtile_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_
     uint32_t common_n = 0;
     for (auto &kv : freq) common_n = std::max(common_n, kv.second);
     const bool uniform = NNT >= 4 && common_n * 2 >= NNT; // most column tiles share their operands: one register set serves them
-    uint32_t nkmax = 1;
-    while (nkmax < nkh_max) nkmax *= 2;
+    // register split of the kernel instantiation: 6 x 1, 3 x 2, 2 x 3 or 1 x 6 (N-tiles per wave x K-steps)
+    uint32_t nkmax = nkh_max <= 3u ? nkh_max : kWtOperandRegs;
     if (uniform) nkmax = kWtOperandRegs;
+    else if (nkh_max > kWtOperandRegs) return; // (tiles of 7-8 K-steps that share nothing: not a geometry this kernel is for)
     const uint32_t nslot = kWtOperandRegs / nkmax;
     const uint32_t step = cs == 3 ? 3u : 1u;     // a strip starts on a pixel boundary: 16 n0 must be a multiple of cs
     const uint32_t tn_regs = uniform ? 0xffffu : kWtWaves * nslot;
@@ -402,7 +403,7 @@ void build_wtile_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_
         uint32_t spw = (end - S.col0 + 15u) / 16u;
         if (!(spw & 1u)) ++spw;
         S.sp = 16u * spw;
-        S.lds_bytes = ring_rows * S.sp + 3u * 16u * S.sp + nkv_max * 3u * 1024u + 16u * (16u * (n1 - n0) + 16u);
+        S.lds_bytes = wt_lds_bytes(ring_rows, S.sp, nkv_max, n1 - n0);
         return S;
     };
     auto split = [&](uint32_t cap, std::vector<WtStrip> *b) -> uint32_t {

@@ -36,9 +36,16 @@ constexpr uint32_t kWtWaves = 8;
 constexpr uint32_t kWtThreads = kWtWaves * 64;
 constexpr uint32_t kWtMaxKV = 4;          // K-steps of 32 source rows per M-tile (<= 128 rows: sigma 20 needs 96 + alignment)
 constexpr uint32_t kWtMaxKH = 8;          // K-steps of 64 source bytes per N-tile (sigma 20 on Rgba8: 16 + 2 * 160 bytes)
-constexpr uint32_t kWtOperandRegs = 8;    // (N-tile, K-step) operand triples a wave keeps in registers (3 x 4 VGPRs each)
+constexpr uint32_t kWtOperandRegs = 6;    // (N-tile, K-step) operand triples a wave keeps in registers (3 x 4 VGPRs each: 72 of its 256)
 constexpr uint32_t kWtLdsBudget = 150 * 1024;
 constexpr uint32_t kWtPrefetch = 4;       // 16-byte pieces a thread keeps in flight for the next step's rows
+
+// LDS layout of a workgroup: ring | three planes of 16 rows | the M-tile's vertical operands | output tile | the strip's N-tile records
+__host__ __device__ constexpr uint32_t wt_out_pitch(uint32_t tn) { return 16u * tn + 24u; } // (= 8 mod 32: the four row groups of a byte write land on different banks)
+__host__ __device__ constexpr uint32_t wt_lds_bytes(uint32_t ring_rows, uint32_t sp, uint32_t nkv_max, uint32_t tn)
+{
+    return ring_rows * sp + 48u * sp + nkv_max * 3072u + 16u * wt_out_pitch(tn) + 16u * tn;
+}
 
 // Header of a plan block in the arena; all offsets are words relative to the header.
 struct WtHeader {

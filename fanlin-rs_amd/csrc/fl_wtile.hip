@@ -28,7 +28,7 @@ typedef __attribute__((address_space(1))) u32_unaligned *gptr32u;
 extern __shared__ __attribute__((aligned(16))) uint8_t wt_lds[];
 
 // NSLOT x NKMAX = kWtOperandRegs: a wave keeps the horizontal operands of NSLOT N-tiles of up to NKMAX K-steps each in registers
-// for its whole walk (<1, 8> also serves strips whose N-tiles mostly share ONE operand block: a blur's interior columns).
+// for its whole walk (<1, 6> also serves strips whose N-tiles mostly share ONE operand block: a blur's interior columns).
 template <int NSLOT, int NKMAX>
 __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job *__restrict__ jobs, const WtItem *__restrict__ items,
                                                                        const uint32_t *__restrict__ arena, uint32_t lb)
@@ -43,24 +43,27 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     const WtNTile *nts = reinterpret_cast<const WtNTile *>(plan + hd.nt_off);
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, g = lane >> 4, i = lane & 15u;
     const uint32_t SP = sp.sp, spw = SP >> 4, RR = hd.ring_rows;
-    const uint32_t tn = sp.n1 - sp.n0, OP = 16u * tn + 16u;
-    // LDS: [ring: RR rows x SP] [planes: 3 x 16 rows x SP] [vertical operands of the M-tile: nkv_max x 3 KB] [output tile: 16 x OP bytes]
+    const uint32_t tn = sp.n1 - sp.n0, OP = wt_out_pitch(tn);
+    // LDS: [ring: RR rows x SP] [planes: 3 x 16 rows x SP] [vertical operands of the M-tile: nkv_max x 3 KB] [output tile: 16 x OP bytes] [the strip's N-tile records]
     uint8_t *ring = wt_lds;
     uint8_t *planes = ring + RR * SP;
     u32x4 *wv_lds = reinterpret_cast<u32x4 *>(planes + 48u * SP);
     uint8_t *otile = reinterpret_cast<uint8_t *>(wv_lds) + hd.nkv_max * 3072u;
+    u32x4 *ntl = reinterpret_cast<u32x4 *>(otile + 16u * OP);
     auto rmod = [&](uint32_t r) -> uint32_t { return r - RR * __umulhi(r, hd.ring_magic); }; // r mod RR (r < 65536)
+    for (uint32_t k = tid; k < tn; k += kWtThreads) ntl[k] = reinterpret_cast<const u32x4 *>(nts + sp.n0)[k];
 
     // ---- source rows -> ring.  A thread owns one 16-byte column of the window and every rpp-th row; up to kWtPrefetch pieces stay in
-    // registers between the request (during the previous M-tile's horizontal pass) and the LDS write (top of the step). ----
+    // registers between the request (before the horizontal pass) and the LDS write (after it). ----
     const uint32_t tcol = tid % spw, trow = tid / spw, rpp = kWtThreads / spw; // (one division per workgroup)
     const uint32_t pitch = hd.src_rowbytes;
+    const gptr8 gsrc = (gptr8)jb.src;
     auto fetch = [&](uint32_t r) -> u32x4 {
         const uint32_t row = min(r, hd.src_rows - 1u); // rows past the picture carry zero weights: any finite bytes do
         const uint32_t off = row * pitch + sp.col0 + 16u * tcol;
-        if (off + 16u <= jb.src_bytes) return *reinterpret_cast<const u32x4_unaligned *>(jb.src + off);
+        if (off + 16u <= jb.src_bytes) return *(const __attribute__((address_space(1))) u32x4_unaligned *)(gsrc + off);
         u32x4 v = {0u, 0u, 0u, 0u};
-        for (uint32_t b = 0; b < 16u && off + b < jb.src_bytes; ++b) v[b >> 2] |= (uint32_t)jb.src[off + b] << (8u * (b & 3u));
+        for (uint32_t b = 0; b < 16u && off + b < jb.src_bytes; ++b) v[b >> 2] |= (uint32_t)gsrc[off + b] << (8u * (b & 3u));
         return v;
     };
     auto put = [&](uint32_t r, u32x4 v) { *reinterpret_cast<u32x4 *>(ring + rmod(r) * SP + 16u * tcol) = v; };
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     uint32_t pre_r0 = 0, pre_r1 = 0;      // rows requested for the coming step: [pre_r0, pre_r1)
     u32x4 wpre[2];                        // ... and its vertical operands (nkv x 192 16-byte pieces over 512 threads)
     uint32_t wpre_n = 0;
-    auto request = [&](uint32_t r0, uint32_t r1, const WtMTile &m) {
+    auto request = [&](uint32_t r0, uint32_t r1, const WtMTile &m) __attribute__((always_inline)) {
         pre_r0 = r0; pre_r1 = r1;
 #pragma unroll
         for (uint32_t k = 0; k < kWtPrefetch; ++k) {
@@ -81,13 +84,14 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
         for (uint32_t k = 0; k < 2; ++k)
             if (tid + k * kWtThreads < wpre_n) wpre[k] = src[tid + k * kWtThreads];
     };
-    auto commit = [&]() {
+    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (uint32_t k = 0; k < kWtPrefetch; ++k) {
             const uint32_t r = pre_r0 + trow + k * rpp;
             if (trow < rpp && r < pre_r1) put(r, pre[k]);
         }
-        // (more new rows than the registers held: the rest now, synchronously -- ratios just below the streaming kernel's range)
+        // (more new rows than the registers held: the rest now, synchronously -- a band's first window, ratios just below the
+        // streaming kernel's range)
         if (trow < rpp)
             for (uint32_t r = pre_r0 + trow + kWtPrefetch * rpp; r < pre_r1; r += rpp) put(r, fetch(r));
 #pragma unroll
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
         const uint32_t nt = sp.n0 + wave + kWtWaves * (uint32_t)s;
         cached[s] = 0xffffffffu;
         uint32_t nk = 0;
-        if (NSLOT == 1 && sp.common_ops != 0xffffffffu) { cached[s] = sp.common_ops; nk = sp.common_nk; }
+        if (NSLOT == 1 && sp.common_ops != 0xffffffffu && sp.common_nk <= (uint32_t)NKMAX) { cached[s] = sp.common_ops; nk = sp.common_nk; }
         else if (nt < sp.n1) { cached[s] = nts[nt].ops; nk = nts[nt].nk; }
         const u32x4 *src = reinterpret_cast<const u32x4 *>(plan + (cached[s] != 0xffffffffu ? cached[s] : 0u));
 #pragma unroll
@@ -116,39 +120,141 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     const int32_t rnd = 1 << (slo - 1u);
     constexpr int32_t round_add = -132112384 + (1 << 19); // the planes' offsets (2^22, 128 * 2^8, 128) times the weight sum, and the rounding half (fl_mfma.hip)
 
-    {   // the band's first window, synchronously
-        const WtMTile m0 = mts[it.mt0];
-        request(m0.kr0, m0.kr0 + 32u * m0.nk, m0);
-    }
+    // nine products of one K-step of one N-tile: five accumulator chains (the first step starts them from constants: the matrix
+    // instruction takes 0 as an inline operand, and the rounding constant of the recombination's right shift rides in L1)
+    auto step = [&](auto first_tag, i32x4 (&L)[5], const u32x4 &a2u, const u32x4 &a1u, const u32x4 &a0u, const u32x4 &b2u, const u32x4 &b1u, const u32x4 &b0u) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const i32x4 a2 = __builtin_bit_cast(i32x4, a2u), a1 = __builtin_bit_cast(i32x4, a1u), a0 = __builtin_bit_cast(i32x4, a0u);
+        const i32x4 b2 = __builtin_bit_cast(i32x4, b2u), b1 = __builtin_bit_cast(i32x4, b1u), b0 = __builtin_bit_cast(i32x4, b0u);
+        const i32x4 z = {0, 0, 0, 0};
+        L[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, FIRST ? z : L[4], 0, 0, 0);
+        L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, FIRST ? z : L[3], 0, 0, 0);
+        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, FIRST ? z : L[2], 0, 0, 0);
+        L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, FIRST ? i32x4{rnd, rnd, rnd, rnd} : L[1], 0, 0, 0);
+        L[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, FIRST ? z : L[0], 0, 0, 0);
+        L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, L[3], 0, 0, 0);
+        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, L[2], 0, 0, 0);
+        L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, L[1], 0, 0, 0);
+        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, L[2], 0, 0, 0);
+    };
+    // sum = L4 2^32 + L3 2^24 + L2 2^16 + L1 2^8 + L0 in units of 2^-(14 + hs) of a pixel step -> 2^-20, then the byte
+    auto emit = [&](const i32x4 (&L)[5], uint32_t jt) __attribute__((always_inline)) {
+        uint8_t *ow = otile + 16u * jt + i; // lane (output byte i of the tile, rows 4 g .. 4 g + 3)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int32_t low = (((L[2][r] << 8) + L[1][r]) + (L[0][r] >> 8)) >> slo;
+            const int32_t p = (int32_t)(((uint32_t)L[4][r] << s4) + ((uint32_t)L[3][r] << s3) + (uint32_t)low);
+            const int32_t x = p + round_add;
+            // (clamp-then-shift: clamp(x >> 20, 0, 255) is the pattern hipcc fuses into gfx950's broken v_ashr_pk_u8_i32)
+            ow[(4u * g + (uint32_t)r) * OP] = (uint8_t)((uint32_t)min(max(x, 0), (256 << 20) - 1) >> 20);
+        }
+    };
+    // Two N-tiles whose operands sit in registers, side by side: their 2 x 9 matrix instructions per K-step are independent of one another
+    // (two waves per SIMD leave a lone tile's accumulator chains exposed).  K-steps past a tile's own count multiply by zero operands.
+    auto pair = [&](auto sa_tag, auto sb_tag, uint32_t jtA, uint32_t jtB, bool hasB) __attribute__((always_inline)) {
+        constexpr int SA = decltype(sa_tag)::value, SB = decltype(sb_tag)::value;
+        const u32x4 tA = ntl[jtA], tB = ntl[hasB ? jtB : jtA];
+        const uint8_t *pa = planes + i * SP + (tA[0] - sp.col0) + 16u * g, *pb = planes + i * SP + (tB[0] - sp.col0) + 16u * g;
+        const uint32_t nkp = hasB ? max(tA[1], tB[1]) : tA[1];
+        i32x4 LA[5], LB[5];
+#pragma unroll
+        for (int k = 0; k < NKMAX; ++k) {
+            if (k > 0 && (uint32_t)k >= nkp) break; // (every tile has a first K-step)
+            const u32x4 a2 = *reinterpret_cast<const u32x4 *>(pa + 64u * k), a1 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 16u * SP),
+                        a0 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 32u * SP);
+            const u32x4 c2 = *reinterpret_cast<const u32x4 *>(pb + 64u * k), c1 = *reinterpret_cast<const u32x4 *>(pb + 64u * k + 16u * SP),
+                        c0 = *reinterpret_cast<const u32x4 *>(pb + 64u * k + 32u * SP);
+            if (k == 0) {
+                step(std::true_type{}, LA, a2, a1, a0, hb[SA][k][0], hb[SA][k][1], hb[SA][k][2]);
+                if (hasB) step(std::true_type{}, LB, c2, c1, c0, hb[SB][k][0], hb[SB][k][1], hb[SB][k][2]);
+            } else {
+                step(std::false_type{}, LA, a2, a1, a0, hb[SA][k][0], hb[SA][k][1], hb[SA][k][2]);
+                if (hasB) step(std::false_type{}, LB, c2, c1, c0, hb[SB][k][0], hb[SB][k][1], hb[SB][k][2]);
+            }
+        }
+        emit(LA, jtA);
+        if (hasB) emit(LB, jtB);
+    };
+    // a tile that shares nothing (a blur's border columns): operands from the L2
+    auto fly = [&](uint32_t jt) __attribute__((always_inline)) {
+        const u32x4 t = ntl[jt];
+        const uint8_t *pa = planes + i * SP + (t[0] - sp.col0) + 16u * g;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(plan + t[2]);
+        i32x4 L[5];
+        {
+            const u32x4 b2 = src[lane], b1 = src[64u + lane], b0 = src[128u + lane];
+            const u32x4 a2 = *reinterpret_cast<const u32x4 *>(pa), a1 = *reinterpret_cast<const u32x4 *>(pa + 16u * SP), a0 = *reinterpret_cast<const u32x4 *>(pa + 32u * SP);
+            step(std::true_type{}, L, a2, a1, a0, b2, b1, b0);
+        }
+        for (uint32_t k = 1; k < t[1]; ++k) {
+            const u32x4 b2 = src[(k * 3u + 0u) * 64u + lane], b1 = src[(k * 3u + 1u) * 64u + lane], b0 = src[(k * 3u + 2u) * 64u + lane];
+            const u32x4 a2 = *reinterpret_cast<const u32x4 *>(pa + 64u * k), a1 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 16u * SP),
+                        a0 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 32u * SP);
+            step(std::false_type{}, L, a2, a1, a0, b2, b1, b0);
+        }
+        emit(L, jt);
+    };
+    // output tile -> destination: 32 threads per row
+    auto store_tile = [&](uint32_t mt) __attribute__((always_inline)) {
+        const uint32_t rr = tid >> 5, t32 = tid & 31u, y = 16u * mt + rr;
+        const uint32_t b0 = 16u * sp.n0, b1 = min(16u * sp.n1, hd.nout);
+        if (y >= hd.rows) return;
+        const uint8_t *orow = otile + rr * OP;
+        const uint32_t cs = hd.cs, px0 = b0 / cs, npx = (b1 - b0) / cs;
+        const size_t drow = (size_t)(jb.oy + y) * jb.dw + jb.ox + px0;
+        if (lb) {
+            gptr32 d = (gptr32)(reinterpret_cast<uint32_t *>(jb.dst) + drow);
+            if (cs == 3u) { // four pixels = three dwords of the tile
+                for (uint32_t q = 4u * t32; q < npx; q += 128u) {
+                    const uint32_t *p = reinterpret_cast<const uint32_t *>(orow + 3u * q);
+                    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+                    const uint32_t v0 = (w0 & 0xffffffu) | 0xff000000u, v1 = (w0 >> 24) | ((w1 & 0xffffu) << 8) | 0xff000000u,
+                                   v2 = (w1 >> 16) | ((w2 & 0xffu) << 16) | 0xff000000u, v3 = (w2 >> 8) | 0xff000000u;
+                    d[q] = v0;
+                    if (q + 1u < npx) d[q + 1u] = v1;
+                    if (q + 2u < npx) d[q + 2u] = v2;
+                    if (q + 3u < npx) d[q + 3u] = v3;
+                }
+            } else {
+                for (uint32_t q = t32; q < npx; q += 32u) {
+                    const uint8_t *p = orow + q * cs;
+                    uint32_t v;
+                    if (cs == 1u) v = p[0] * 0x010101u | 0xff000000u;
+                    else if (cs == 2u) v = blend_over_fill(jb.fill, p[0], p[0], p[0], p[1]);
+                    else v = blend_over_fill(jb.fill, p[0], p[1], p[2], p[3]);
+                    d[q] = v;
+                }
+            }
+        } else {
+            const gptr8 d = (gptr8)(jb.dst + drow * cs);
+            const uint32_t nb = b1 - b0;
+            for (uint32_t b = 4u * t32; b < nb; b += 128u) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(orow + b);
+                if (b + 4u <= nb) *(gptr32u)(d + b) = v;
+                else for (uint32_t k = 0; b + k < nb; ++k) d[b + k] = (uint8_t)(v >> (8u * k));
+            }
+        }
+    };
+
+    WtMTile m = mts[it.mt0];
+    request(m.kr0, m.kr0 + 32u * m.nk, m); // the band's first window
+    commit();
+    __syncthreads();
     for (uint32_t mt = it.mt0; mt < it.mt1; ++mt) {
-        const WtMTile m = mts[mt];
-        commit();
-        __syncthreads();
-        // ---- vertical ----
+        const bool more = mt + 1u < it.mt1;
+        const WtMTile mn = mts[more ? mt + 1u : mt]; // (a scalar load: back long before the request below needs it)
+        if (mt > it.mt0) store_tile(mt - 1u);
+        // ---- vertical: two column tiles side by side ----
         {
             u32x4 wv[kWtMaxKV][3];
 #pragma unroll
             for (uint32_t k = 0; k < kWtMaxKV; ++k)
 #pragma unroll
-                for (uint32_t t = 0; t < 3; ++t) wv[k][t] = k < m.nk ? wv_lds[(k * 3u + t) * 64u + lane] : u32x4{0u, 0u, 0u, 0u};
+                for (uint32_t t = 0; t < 3; ++t) wv[k][t] = wv_lds[(k * 3u + t) * 64u + lane]; // (K-steps past m.nk: whatever the LDS holds, never used)
             uint32_t radr[kWtMaxKV]; // lane's address inside a column tile: 8 rows of a lane group, two 8-byte halves per row
 #pragma unroll
             for (uint32_t k = 0; k < kWtMaxKV; ++k) radr[k] = (rmod(m.kr0 + 32u * k + 8u * g) + (i >> 1)) * SP + 8u * (i & 1u);
-            for (uint32_t ct = wave; ct < spw; ct += kWtWaves) {
-                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (uint32_t k = 0; k < kWtMaxKV; ++k) {
-                    if (k >= m.nk) break;
-                    const v2i raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + radr[k] + 16u * ct));
-                    u32x4 a;
-                    a[0] = __builtin_amdgcn_perm(0u, (uint32_t)raw[0], 0x0c010c00u);
-                    a[1] = __builtin_amdgcn_perm(0u, (uint32_t)raw[0], 0x0c030c02u);
-                    a[2] = __builtin_amdgcn_perm(0u, (uint32_t)raw[1], 0x0c010c00u);
-                    a[3] = __builtin_amdgcn_perm(0u, (uint32_t)raw[1], 0x0c030c02u);
-                    const f16x8 av = __builtin_bit_cast(f16x8, a);
-#pragma unroll
-                    for (uint32_t t = 0; t < 3; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[k][t]), acc, 0, 0, 0);
-                }
+            auto to_planes = [&](const f32x4 &acc, uint32_t ct) __attribute__((always_inline)) {
                 // sums = value * 2^-9 -> 2^22 + round((value - 128) * 2^14) in the mantissa -> three byte planes (fl_mfma.hip, full width)
                 const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[0], 8388608.0f, 10485760.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[1], 8388608.0f, 10485760.0f)),
                                x2 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[2], 8388608.0f, 10485760.0f)), x3 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[3], 8388608.0f, 10485760.0f));
@@ -160,100 +266,77 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
                 *reinterpret_cast<uint32_t *>(pw) = p2;
                 *reinterpret_cast<uint32_t *>(pw + 16u * SP) = p1;
                 *reinterpret_cast<uint32_t *>(pw + 32u * SP) = p0;
-            }
-        }
-        __syncthreads();
-        // ---- the next step's rows and operands: requested now, written at the top of the next step ----
-        if (mt + 1u < it.mt1) {
-            const WtMTile mn = mts[mt + 1u];
-            request(max(m.kr0 + 32u * m.nk, mn.kr0), mn.kr0 + 32u * mn.nk, mn);
-        } else { pre_r0 = pre_r1 = 0; wpre_n = 0; }
-        // ---- horizontal ----
-        auto ntile = [&](auto slot_tag, uint32_t nt) __attribute__((always_inline)) {
-            constexpr int S = decltype(slot_tag)::value;
-            const WtNTile t = nts[nt];
-            const uint8_t *pa = planes + i * SP + (t.kc0 - sp.col0) + 16u * g; // lane (output row i, 16 bytes of K group g)
-            i32x4 L[5];
-            const i32x4 z = {0, 0, 0, 0};
-            L[0] = z; L[2] = z; L[3] = z; L[4] = z; L[1] = i32x4{rnd, rnd, rnd, rnd};
-            auto step = [&](const u32x4 &a2u, const u32x4 &a1u, const u32x4 &a0u, const u32x4 &b2u, const u32x4 &b1u, const u32x4 &b0u) __attribute__((always_inline)) {
-                const i32x4 a2 = __builtin_bit_cast(i32x4, a2u), a1 = __builtin_bit_cast(i32x4, a1u), a0 = __builtin_bit_cast(i32x4, a0u);
-                const i32x4 b2 = __builtin_bit_cast(i32x4, b2u), b1 = __builtin_bit_cast(i32x4, b1u), b0 = __builtin_bit_cast(i32x4, b0u);
-                L[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, L[4], 0, 0, 0);
-                L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, L[3], 0, 0, 0);
-                L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, L[2], 0, 0, 0);
-                L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, L[1], 0, 0, 0);
-                L[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, L[0], 0, 0, 0);
-                L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, L[3], 0, 0, 0);
-                L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, L[2], 0, 0, 0);
-                L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, L[1], 0, 0, 0);
-                L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, L[2], 0, 0, 0);
             };
-            if (t.ops == cached[S]) {
+            auto to_f16 = [&](const v2i &raw) __attribute__((always_inline)) -> f16x8 {
+                u32x4 a;
+                a[0] = __builtin_amdgcn_perm(0u, (uint32_t)raw[0], 0x0c010c00u);
+                a[1] = __builtin_amdgcn_perm(0u, (uint32_t)raw[0], 0x0c030c02u);
+                a[2] = __builtin_amdgcn_perm(0u, (uint32_t)raw[1], 0x0c010c00u);
+                a[3] = __builtin_amdgcn_perm(0u, (uint32_t)raw[1], 0x0c030c02u);
+                return __builtin_bit_cast(f16x8, a);
+            };
+            for (uint32_t ct = wave; ct < spw; ct += 2u * kWtWaves) {
+                const bool hasB = ct + kWtWaves < spw;
+                const uint32_t ctb = hasB ? ct + kWtWaves : ct;
+                f32x4 accA = {0.0f, 0.0f, 0.0f, 0.0f}, accB = {0.0f, 0.0f, 0.0f, 0.0f};
+                v2i rawA[kWtMaxKV], rawB[kWtMaxKV];
 #pragma unroll
-                for (int k = 0; k < NKMAX; ++k) {
-                    if ((uint32_t)k >= t.nk) break;
-                    const u32x4 a2 = *reinterpret_cast<const u32x4 *>(pa + 64u * k), a1 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 16u * SP),
-                                a0 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 32u * SP);
-                    step(a2, a1, a0, hb[S][k][0], hb[S][k][1], hb[S][k][2]);
+                for (uint32_t k = 0; k < kWtMaxKV; ++k) {
+                    if (k >= m.nk) break;
+                    rawA[k] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + radr[k] + 16u * ct));
+                    rawB[k] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + radr[k] + 16u * ctb));
                 }
-            } else { // a tile that shares nothing (a blur's border columns), or more tiles than register sets: operands from the L2
-                const u32x4 *src = reinterpret_cast<const u32x4 *>(plan + t.ops);
-                for (uint32_t k = 0; k < t.nk; ++k) {
-                    const u32x4 b2 = src[(k * 3u + 0u) * 64u + lane], b1 = src[(k * 3u + 1u) * 64u + lane], b0 = src[(k * 3u + 2u) * 64u + lane];
-                    const u32x4 a2 = *reinterpret_cast<const u32x4 *>(pa + 64u * k), a1 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 16u * SP),
-                                a0 = *reinterpret_cast<const u32x4 *>(pa + 64u * k + 32u * SP);
-                    step(a2, a1, a0, b2, b1, b0);
-                }
-            }
-            // sum = L4 2^32 + L3 2^24 + L2 2^16 + L1 2^8 + L0 in units of 2^-(14 + hs) of a pixel step -> 2^-20, then the byte
-            uint8_t *ow = otile + 16u * (nt - sp.n0) + i; // lane (output byte i of the tile, rows 4 g .. 4 g + 3)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int32_t low = (((L[2][r] << 8) + L[1][r]) + (L[0][r] >> 8)) >> slo;
-                const int32_t p = (int32_t)(((uint32_t)L[4][r] << s4) + ((uint32_t)L[3][r] << s3) + (uint32_t)low);
-                const int32_t x = p + round_add;
-                // (clamp-then-shift: clamp(x >> 20, 0, 255) is the pattern hipcc fuses into gfx950's broken v_ashr_pk_u8_i32)
-                ow[(4u * g + (uint32_t)r) * OP] = (uint8_t)((uint32_t)min(max(x, 0), (256 << 20) - 1) >> 20);
-            }
-        };
-#define FL_WT_SLOT(S_) if constexpr (NSLOT > S_) { const uint32_t nt = sp.n0 + wave + kWtWaves * S_##u; if (nt < sp.n1) ntile(std::integral_constant<int, S_>{}, nt); }
-        FL_WT_SLOT(0) FL_WT_SLOT(1) FL_WT_SLOT(2) FL_WT_SLOT(3) FL_WT_SLOT(4) FL_WT_SLOT(5) FL_WT_SLOT(6) FL_WT_SLOT(7)
-#undef FL_WT_SLOT
-        // (strips wider than 8 NSLOT tiles: uniform strips, whose tiles share slot NSLOT - 1's block -- or take the on-the-fly path)
-        for (uint32_t nt = sp.n0 + wave + kWtWaves * (uint32_t)NSLOT; nt < sp.n1; nt += kWtWaves) ntile(std::integral_constant<int, NSLOT - 1>{}, nt);
-        __syncthreads();
-        // ---- output tile -> destination: 32 threads per row ----
-        {
-            const uint32_t rr = tid >> 5, t32 = tid & 31u, y = 16u * mt + rr;
-            const uint32_t b0 = 16u * sp.n0, b1 = min(16u * sp.n1, hd.nout);
-            if (y < hd.rows) {
-                const uint8_t *orow = otile + rr * OP;
-                const uint32_t cs = hd.cs, px0 = b0 / cs, npx = (b1 - b0) / cs;
-                const size_t drow = (size_t)(jb.oy + y) * jb.dw + jb.ox + px0;
-                if (lb) {
-                    gptr32 d = (gptr32)(reinterpret_cast<uint32_t *>(jb.dst) + drow);
-                    for (uint32_t q = t32; q < npx; q += 32u) {
-                        const uint8_t *p = orow + q * cs;
-                        uint32_t v;
-                        if (cs == 1u) v = p[0] * 0x010101u | 0xff000000u;
-                        else if (cs == 2u) v = blend_over_fill(jb.fill, p[0], p[0], p[0], p[1]);
-                        else if (cs == 3u) v = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
-                        else v = blend_over_fill(jb.fill, p[0], p[1], p[2], p[3]);
-                        d[q] = v;
-                    }
-                } else {
-                    uint8_t *d = jb.dst + drow * cs;
-                    const uint32_t nb = b1 - b0;
-                    for (uint32_t b = 4u * t32; b < nb; b += 128u) {
-                        const uint32_t v = *reinterpret_cast<const uint32_t *>(orow + b);
-                        if (b + 4u <= nb) *(gptr32u)(d + b) = v;
-                        else for (uint32_t k = 0; b + k < nb; ++k) ((gptr8)d)[b + k] = (uint8_t)(v >> (8u * k));
+                for (uint32_t k = 0; k < kWtMaxKV; ++k) {
+                    if (k >= m.nk) break;
+                    const f16x8 av = to_f16(rawA[k]), bv = to_f16(rawB[k]);
+#pragma unroll
+                    for (uint32_t t = 0; t < 3; ++t) {
+                        accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[k][t]), accA, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, __builtin_bit_cast(f16x8, wv[k][t]), accB, 0, 0, 0);
                     }
                 }
+                to_planes(accA, ct);
+                if (hasB) to_planes(accB, ctb);
             }
         }
+        __syncthreads();
+        // ---- the next step's rows and operands: requested now, in flight during the horizontal pass ----
+        if (more) request(max(m.kr0 + 32u * m.nk, mn.kr0), mn.kr0 + 32u * mn.nk, mn);
+        else { pre_r0 = pre_r1 = 0; wpre_n = 0; }
+        // ---- horizontal: this wave's N-tiles w, w + 8, ... in pairs ----
+        {
+            const uint32_t mine = wave < tn ? (tn - wave + kWtWaves - 1u) / kWtWaves : 0u; // tiles of this wave
+#define FL_WT_PAIR(S_) \
+            if constexpr (NSLOT > S_) { \
+                constexpr int SB_ = (S_ + 1 < NSLOT) ? S_ + 1 : S_; \
+                const uint32_t ja = wave + kWtWaves * S_##u, jb2 = ja + kWtWaves; \
+                if (S_##u < mine) { \
+                    const bool okA = ntl[ja][2] == cached[S_], hasB = S_##u + 1u < mine && SB_ != S_ && ntl[jb2][2] == cached[SB_]; \
+                    if (okA) pair(std::integral_constant<int, S_>{}, std::integral_constant<int, SB_>{}, ja, jb2, hasB); else fly(ja); \
+                    if (!hasB && S_##u + 1u < mine && SB_ != S_) fly(jb2); \
+                } \
+                __builtin_amdgcn_sched_barrier(0); /* one pair at a time: hoisting the next pairs' LDS reads up here costs more registers than the file has */ \
+            }
+            if constexpr (NSLOT > 1) {
+                FL_WT_PAIR(0) FL_WT_PAIR(2) FL_WT_PAIR(4)
+                for (uint32_t s = NSLOT; s < mine; ++s) fly(wave + kWtWaves * s); // (never: the planner gives a wave at most NSLOT tiles)
+            } else {
+                // one register set: every tile that shares it (a blur's interior columns) runs from registers, two at a time
+                for (uint32_t s = 0; s < mine; s += 2u) {
+                    const uint32_t ja = wave + kWtWaves * s, jb2 = ja + kWtWaves;
+                    const bool okA = ntl[ja][2] == cached[0], inB = s + 1u < mine, okB = inB && ntl[jb2][2] == cached[0];
+                    if (okA) pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ja, jb2, okB); else fly(ja);
+                    if (inB && !(okA && okB)) fly(jb2);
+                }
+            }
+#undef FL_WT_PAIR
+        }
+        commit();
+        __syncthreads();
+        m = mn;
     }
+    store_tile(it.mt1 - 1u);
 }
 
 template <int NSLOT, int NKMAX>
@@ -273,10 +356,10 @@ hipError_t launch_wtile(const LaunchWtile &m, hipStream_t st)
 {
     if (!m.nitems) return hipSuccess;
     if (m.lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
-    if (m.nslot == 8 && m.nkmax == 1) return launch_wtile_t<8, 1>(m, st);
-    if (m.nslot == 4 && m.nkmax == 2) return launch_wtile_t<4, 2>(m, st);
-    if (m.nslot == 2 && m.nkmax == 4) return launch_wtile_t<2, 4>(m, st);
-    if (m.nslot == 1 && m.nkmax == 8) return launch_wtile_t<1, 8>(m, st);
+    if (m.nslot == 6 && m.nkmax == 1) return launch_wtile_t<6, 1>(m, st);
+    if (m.nslot == 3 && m.nkmax == 2) return launch_wtile_t<3, 2>(m, st);
+    if (m.nslot == 2 && m.nkmax == 3) return launch_wtile_t<2, 3>(m, st);
+    if (m.nslot == 1 && m.nkmax == 6) return launch_wtile_t<1, 6>(m, st);
     return hipErrorInvalidValue;
 }
 

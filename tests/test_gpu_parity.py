@@ -218,7 +218,8 @@ def test_edge_distributions(fl, gpu_state, oracle):
 # ----------------------------------------------------------------------------- blur --
 
 @pytest.mark.parametrize("sigma", [10.0, 20.0])
-def test_blur_only(fl, gpu_state, oracle, sigma):
+def test_blur_only(fl, gpu_state, oracle, sigma, monkeypatch):
+    monkeypatch.setenv("FLGPU_NO_WTILE", "1")   # the f32 vector blur kernel and its bit-exact bar (the matrix-pipe blur: tests/test_wtile.py)
     img = synth.uniform(200, 300, 4, index=20)
     got = gpu_state.process_pixels(img, fl.make_params(blur_sigma=sigma))
     assert np.array_equal(got, oracle.blur(img, sigma, arith=oracle_lib.ARITH_FMA))
@@ -243,7 +244,8 @@ def test_blur_channel_shortcuts_are_exact(fl, gpu_state, oracle, kw):
     check_resample(fl, gpu_state, oracle, img, **kw)
 
 
-def test_blur_wide_image_tiles(fl, gpu_state, oracle):
+def test_blur_wide_image_tiles(fl, gpu_state, oracle, monkeypatch):
+    monkeypatch.setenv("FLGPU_NO_WTILE", "1")   # (as above)
     img = synth.uniform(90, 700, 3, index=23)       # several column tiles, halo across tile borders
     got = gpu_state.process_pixels(img, fl.make_params(blur_sigma=20.0))
     assert np.array_equal(got, oracle.blur(img, 20.0, arith=oracle_lib.ARITH_FMA))
@@ -534,6 +536,7 @@ def test_two_pass_resample_through_an_lds_tile_equals_the_one_through_hbm(fl, gp
     f32 intermediate in HBM.  Same arithmetic, same order: bit-identical to the HBM form (FLGPU_NO_TILE=1) and to the oracle's
     fused-order mode, within 1 LSB of the reference arithmetic (parity.check_pixels holds both bars)."""
     import parity
+    monkeypatch.setenv("FLGPU_NO_WTILE", "1")   # (round 4: down-scales among these go to the window-tile matrix-pipe kernel by default, tests/test_wtile.py)
     img = synth.uniform(*shape, index=shape[0] + shape[1])
     got, used = parity.device_pixels(fl, gpu_state, img, **kw)
     assert not used

@@ -141,8 +141,10 @@ def test_band_splits_and_batches_give_the_same_bytes(fl, gpu_state, oracle, monk
     assert np.array_equal(mixed[0], alone)                                           # next to a streaming-kernel job and another geometry
 
 
-def test_requests_the_kernel_does_not_take(fl, gpu_state, oracle):
-    """Unaligned rows, pre-ops and mild ratios stay with the streaming / generic kernels."""
+def test_requests_the_kernel_does_not_take(fl, gpu_state, oracle, monkeypatch):
+    """Unaligned rows, pre-ops and mild ratios stay with the streaming / generic kernels (the window-tile matrix-pipe kernel, which
+    takes the mild ratios among them since round 4, is switched off here: tests/test_wtile.py)."""
+    monkeypatch.setenv("FLGPU_NO_WTILE", "1")
     cases = [(synth.uniform(540, 961, 3, index=1), dict(w=300, h=200)),            # 2883-byte rows
              (synth.uniform(540, 962, 4, index=2), dict(w=150, h=100)),            # Rgba8, 3848-byte rows: not a multiple of 16
              (synth.uniform(540, 1000, 1, index=3), dict(w=150, h=100)),           # Luma8, 1000-byte rows

@@ -44,9 +44,9 @@ for name, n, (H, W, C), kw in CASES:
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / steps
         s = st.stats()
-        kern = "matrix-pipe" if s["mfma_launches"] else ("generic two-pass" if s["generic_launches"] else ("streaming" if s["resample_launches"] else "place / blur only"))
+        kern = "window-tile matrix" if s.get("wtile_launches") and s["wtile_launches"] == s["mfma_launches"] else "matrix-pipe (+ window-tile blur)" if s.get("wtile_launches") else "matrix-pipe" if s["mfma_launches"] else ("generic two-pass" if s["generic_launches"] else ("streaming" if s["resample_launches"] else "place / blur only"))
         alg = n * (H * W * C + int(plan.pixel_bytes))
-        line = f"{name:72s} n={n:5d}  {kern:18s} {ms:8.3f} ms/step  {n / ms:9.1f} k images/s  algorithmic {alg / 1e9:6.3f} GB -> {alg / (ms * 1e-3) / 1e12:5.2f} TB/s = {alg / (ms * 1e-3) / 8e12:5.3f} of peak" \
+        line = f"{name:72s} n={n:5d}  {kern:32s} {ms:8.3f} ms/step  {n / ms:9.1f} k images/s  algorithmic {alg / 1e9:6.3f} GB -> {alg / (ms * 1e-3) / 1e12:5.2f} TB/s = {alg / (ms * 1e-3) / 8e12:5.3f} of peak" \
                f"  [resample {s['resample_ms'] / steps:.3f} ms, blur {s['blur_ms'] / steps:.3f} ms]"
     print(line, flush=True)
     out.append(line)

@@ -13,8 +13,8 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$O/[ab]/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "resample_tile" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "resample_tile" in r["Kernel_Name"] or "resample_wtile" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc): print(f"{k:28s} {sum(acc[k]) / len(acc[k]):16.0f}  ({len(acc[k])} dispatches)")
 for r in csv.DictReader(open(glob.glob("$O/stats/*kernel_stats.csv")[0])):
-    if "resample_tile" in r["Name"]: print("average ns", r["AverageNs"], "calls", r["Calls"])
+    if "resample_tile" in r["Name"] or "resample_wtile" in r["Name"]: print("average ns", r["AverageNs"], "calls", r["Calls"])
 PY
