@@ -34,6 +34,14 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
                                                                        const uint32_t *__restrict__ arena, uint32_t lb)
 {
     static_assert(NSLOT * NKMAX == (int)kWtOperandRegs, "operand register budget");
+    // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh with ABL_FILE=fl_wtile.hip): 1 = no vertical pass, 2 = no horizontal pass,
+    // 4 = no stores to the destination, 8 = no row / operand traffic after a band's first window, 16 = horizontal MFMAs without the
+    // recombination and the byte writes
+#ifdef FL_ABLATE
+    constexpr uint32_t ablate = FL_ABLATE;
+#else
+    constexpr uint32_t ablate = 0;
+#endif
     const WtItem it = items[blockIdx.x];
     const Job jb = jobs[it.job];
     const uint32_t *plan = arena + it.plan_off;
@@ -118,7 +126,11 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
 
     const uint32_t sh = hd.hs - 6u, slo = sh - 8u, s4 = 32u - sh, s3 = 24u - sh;
     const int32_t rnd = 1 << (slo - 1u);
-    constexpr int32_t round_add = -132112384 + (1 << 19); // the planes' offsets (2^22, 128 * 2^8, 128) times the weight sum, and the rounding half (fl_mfma.hip)
+    // the planes' offsets (2^22, 128 * 2^8, 128) times the weight sum, and the final rounding's half (fl_mfma.hip): a multiple of 2^8,
+    // so it rides in as the first C operand of the L3 chain (which enters the sum shifted left by s3 <= 8) instead of an add per output
+    constexpr int32_t round_add = -132112384 + (1 << 19);
+    static_assert(round_add % 256 == 0, "folded into L3");
+    const int32_t c3 = round_add >> s3;
 
     // nine products of one K-step of one N-tile: five accumulator chains (the first step starts them from constants: the matrix
     // instruction takes 0 as an inline operand, and the rounding constant of the recombination's right shift rides in L1)
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
         const i32x4 b2 = __builtin_bit_cast(i32x4, b2u), b1 = __builtin_bit_cast(i32x4, b1u), b0 = __builtin_bit_cast(i32x4, b0u);
         const i32x4 z = {0, 0, 0, 0};
         L[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, FIRST ? z : L[4], 0, 0, 0);
-        L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, FIRST ? z : L[3], 0, 0, 0);
+        L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, FIRST ? i32x4{c3, c3, c3, c3} : L[3], 0, 0, 0);
         L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, FIRST ? z : L[2], 0, 0, 0);
         L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, FIRST ? i32x4{rnd, rnd, rnd, rnd} : L[1], 0, 0, 0);
         L[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, FIRST ? z : L[0], 0, 0, 0);
@@ -139,12 +151,12 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     };
     // sum = L4 2^32 + L3 2^24 + L2 2^16 + L1 2^8 + L0 in units of 2^-(14 + hs) of a pixel step -> 2^-20, then the byte
     auto emit = [&](const i32x4 (&L)[5], uint32_t jt) __attribute__((always_inline)) {
+        if (ablate & 16u) { asm volatile("" : : "v"(L[0]), "v"(L[1]), "v"(L[2]), "v"(L[3]), "v"(L[4])); return; }
         uint8_t *ow = otile + 16u * jt + i; // lane (output byte i of the tile, rows 4 g .. 4 g + 3)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int32_t low = (((L[2][r] << 8) + L[1][r]) + (L[0][r] >> 8)) >> slo;
-            const int32_t p = (int32_t)(((uint32_t)L[4][r] << s4) + ((uint32_t)L[3][r] << s3) + (uint32_t)low);
-            const int32_t x = p + round_add;
+            const int32_t x = (int32_t)(((uint32_t)L[4][r] << s4) + ((uint32_t)L[3][r] << s3) + (uint32_t)low);
             // (clamp-then-shift: clamp(x >> 20, 0, 255) is the pattern hipcc fuses into gfx950's broken v_ashr_pk_u8_i32)
             ow[(4u * g + (uint32_t)r) * OP] = (uint8_t)((uint32_t)min(max(x, 0), (256 << 20) - 1) >> 20);
         }
@@ -243,17 +255,23 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     for (uint32_t mt = it.mt0; mt < it.mt1; ++mt) {
         const bool more = mt + 1u < it.mt1;
         const WtMTile mn = mts[more ? mt + 1u : mt]; // (a scalar load: back long before the request below needs it)
-        if (mt > it.mt0) store_tile(mt - 1u);
-        // ---- vertical: two column tiles side by side ----
-        {
-            u32x4 wv[kWtMaxKV][3];
+        // the next step's rows and operands: requested first, in flight during both passes (a request behind the vertical pass
+        // came back after the horizontal one had finished: 2 us of HBM latency against 1.5 us of work)
+        if (more && !(ablate & 8u)) request(max(m.kr0 + 32u * m.nk, mn.kr0), mn.kr0 + 32u * mn.nk, mn);
+        else { pre_r0 = pre_r1 = 0; wpre_n = 0; }
+        if (mt > it.mt0 && !(ablate & 4u)) store_tile(mt - 1u);
+        // ---- vertical: two column tiles side by side; one copy of the pass per K-step count (static loops: no partly defined
+        // register arrays, which cost hipcc hundreds of spilled registers here) ----
+        auto vertical = [&](auto nk_tag) __attribute__((always_inline)) {
+            constexpr uint32_t NKV = decltype(nk_tag)::value;
+            u32x4 wv[NKV][3]; // (eight waves read the same 3 KB per K-step: the largest LDS traffic of this pass)
 #pragma unroll
-            for (uint32_t k = 0; k < kWtMaxKV; ++k)
+            for (uint32_t k = 0; k < NKV; ++k)
 #pragma unroll
-                for (uint32_t t = 0; t < 3; ++t) wv[k][t] = wv_lds[(k * 3u + t) * 64u + lane]; // (K-steps past m.nk: whatever the LDS holds, never used)
-            uint32_t radr[kWtMaxKV]; // lane's address inside a column tile: 8 rows of a lane group, two 8-byte halves per row
+                for (uint32_t t = 0; t < 3; ++t) wv[k][t] = wv_lds[(k * 3u + t) * 64u + lane];
+            uint32_t radr[NKV]; // lane's address inside a column tile: 8 rows of a lane group, two 8-byte halves per row
 #pragma unroll
-            for (uint32_t k = 0; k < kWtMaxKV; ++k) radr[k] = (rmod(m.kr0 + 32u * k + 8u * g) + (i >> 1)) * SP + 8u * (i & 1u);
+            for (uint32_t k = 0; k < NKV; ++k) radr[k] = (rmod(m.kr0 + 32u * k + 8u * g) + (i >> 1)) * SP + 8u * (i & 1u);
             auto to_planes = [&](const f32x4 &acc, uint32_t ct) __attribute__((always_inline)) {
                 // sums = value * 2^-9 -> 2^22 + round((value - 128) * 2^14) in the mantissa -> three byte planes (fl_mfma.hip, full width)
                 const uint32_t x0 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[0], 8388608.0f, 10485760.0f)), x1 = __builtin_bit_cast(uint32_t, __builtin_fmaf(acc[1], 8388608.0f, 10485760.0f)),
@@ -275,20 +293,18 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
                 a[3] = __builtin_amdgcn_perm(0u, (uint32_t)raw[1], 0x0c030c02u);
                 return __builtin_bit_cast(f16x8, a);
             };
-            for (uint32_t ct = wave; ct < spw; ct += 2u * kWtWaves) {
-                const bool hasB = ct + kWtWaves < spw;
-                const uint32_t ctb = hasB ? ct + kWtWaves : ct;
+            uint32_t ct = wave;
+            for (; ct + kWtWaves < spw; ct += 2u * kWtWaves) {
+                const uint32_t ctb = ct + kWtWaves;
                 f32x4 accA = {0.0f, 0.0f, 0.0f, 0.0f}, accB = {0.0f, 0.0f, 0.0f, 0.0f};
-                v2i rawA[kWtMaxKV], rawB[kWtMaxKV];
+                v2i rawA[NKV], rawB[NKV];
 #pragma unroll
-                for (uint32_t k = 0; k < kWtMaxKV; ++k) {
-                    if (k >= m.nk) break;
+                for (uint32_t k = 0; k < NKV; ++k) {
                     rawA[k] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + radr[k] + 16u * ct));
                     rawB[k] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + radr[k] + 16u * ctb));
                 }
 #pragma unroll
-                for (uint32_t k = 0; k < kWtMaxKV; ++k) {
-                    if (k >= m.nk) break;
+                for (uint32_t k = 0; k < NKV; ++k) {
                     const f16x8 av = to_f16(rawA[k]), bv = to_f16(rawB[k]);
 #pragma unroll
                     for (uint32_t t = 0; t < 3; ++t) {
@@ -297,15 +313,31 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
                     }
                 }
                 to_planes(accA, ct);
-                if (hasB) to_planes(accB, ctb);
+                to_planes(accB, ctb);
             }
+            if (ct < spw) { // the wave's last, single column tile
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                v2i raw[NKV];
+#pragma unroll
+                for (uint32_t k = 0; k < NKV; ++k) raw[k] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(ring + radr[k] + 16u * ct));
+#pragma unroll
+                for (uint32_t k = 0; k < NKV; ++k) {
+                    const f16x8 av = to_f16(raw[k]);
+#pragma unroll
+                    for (uint32_t t = 0; t < 3; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[k][t]), acc, 0, 0, 0);
+                }
+                to_planes(acc, ct);
+            }
+        };
+        if (!(ablate & 1u)) {
+            if (m.nk == 1u) vertical(std::integral_constant<uint32_t, 1>{});
+            else if (m.nk == 2u) vertical(std::integral_constant<uint32_t, 2>{});
+            else if (m.nk == 3u) vertical(std::integral_constant<uint32_t, 3>{});
+            else vertical(std::integral_constant<uint32_t, 4>{});
         }
         __syncthreads();
-        // ---- the next step's rows and operands: requested now, in flight during the horizontal pass ----
-        if (more) request(max(m.kr0 + 32u * m.nk, mn.kr0), mn.kr0 + 32u * mn.nk, mn);
-        else { pre_r0 = pre_r1 = 0; wpre_n = 0; }
         // ---- horizontal: this wave's N-tiles w, w + 8, ... in pairs ----
-        {
+        if (!(ablate & 2u)) {
             const uint32_t mine = wave < tn ? (tn - wave + kWtWaves - 1u) / kWtWaves : 0u; // tiles of this wave
 #define FL_WT_PAIR(S_) \
             if constexpr (NSLOT > S_) { \
@@ -336,7 +368,7 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
         __syncthreads();
         m = mn;
     }
-    store_tile(it.mt1 - 1u);
+    if (!(ablate & 4u)) store_tile(it.mt1 - 1u);
 }
 
 template <int NSLOT, int NKMAX>

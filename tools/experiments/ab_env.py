@@ -14,8 +14,11 @@ ap.add_argument("--h", type=int, default=200)
 ap.add_argument("--crop", action="store_true")
 ap.add_argument("--gray", action="store_true")
 ap.add_argument("--channels", type=int, default=3)
+ap.add_argument("--srcw", type=int, default=1920)
+ap.add_argument("--srch", type=int, default=1080)
+ap.add_argument("--blur", type=float, default=0.0)
 a = ap.parse_args()
-n, H, W, C = a.n, 1080, 1920, a.channels
+n, H, W, C = a.n, a.srch, a.srcw, a.channels
 src = torch.randint(0, 256, (n, H, W, C), dtype=torch.uint8, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 runs, dst = [], None
@@ -28,14 +31,14 @@ for i, v in enumerate(a.variants):
     spec = importlib.util.spec_from_file_location("fl_%d" % i, os.path.join(pkg, "__init__.py"), submodule_search_locations=[pkg])
     fl = importlib.util.module_from_spec(spec); sys.modules["fl_%d" % i] = fl; spec.loader.exec_module(fl); fl.load_library()
     st = fl.State(device=0, profile=True); st.__enter__()
-    p = fl.make_params(a.w, a.h, crop=a.crop, grayscale=a.gray)
+    p = fl.make_params(a.w, a.h, crop=a.crop, grayscale=a.gray, blur_sigma=a.blur) if a.w else fl.make_params(blur_sigma=a.blur)
     plan = fl.plan_output(p, W, H, C)
     stride = (int(plan.out_bytes) + 255) // 256 * 256
     if dst is None:
         dst = torch.zeros((n, stride), dtype=torch.uint8, device="cuda")
     run = st.prepared_batch([src.data_ptr() + k * H * W * C for k in range(n)], [(H, W, C)] * n, p, [dst.data_ptr() + k * stride for k in range(n)], [stride] * n)
     runs.append((v, st, run, env))
-KEYS = ("FLGPU_MFMA_ARITH", "FLGPU_NO_MFMA", "FLGPU_FORCE_BANDS")
+KEYS = ("FLGPU_MFMA_ARITH", "FLGPU_NO_MFMA", "FLGPU_FORCE_BANDS", "FLGPU_NO_WTILE", "FLGPU_WTILE_ALWAYS")
 def setenv(env):
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(env)
@@ -51,7 +54,7 @@ for r in range(a.rounds):
         for _ in range(a.launches): run(stream)
         torch.cuda.synchronize()
         s = st.stats()
-        times[v].append(s["resample_ms"] / max(s["resample_launches"], 1))
+        times[v].append((s["blur_ms"] / max(s["blur_launches"], 1)) if a.blur > 0 and not a.w else s["resample_ms"] / max(s["resample_launches"], 1))
 for v, _, _, _ in runs:
     t = times[v]
     print(f"{os.path.basename(v):56s} median {statistics.median(t):.4f} ms  min {min(t):.4f}  max {max(t):.4f}   ({' '.join(f'{x:.3f}' for x in t)})", flush=True)
