@@ -544,6 +544,17 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             const bool aligned = (!w.unaligned || w.cs == 3) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
             // The matrix-pipe kernel takes down-scales (any channel count, no pre-op) whose rows are 16-byte aligned (it moves 16-byte pieces of a row
             // straight into LDS).  The choice depends on the request's geometry only, never on the batch around it.
+            const char *env_wt_first = getenv("FLGPU_WTILE_FIRST"); // experiments: the window-tile kernel before the streaming matrix-pipe kernel
+            // Ratios 1.25 .. 3.1 go to the window-tile kernel BEFORE the fused ones: measured against the streaming matrix-pipe kernel
+            // (wide layout, operands from L2 there) 0.79 vs 0.83 ms per 256 at ratio 3, 0.99 vs 1.20 at 2.4, and against the streaming
+            // f32 kernel 1.16 vs 2.10 at 2.13; above ratio 3.4 the fused kernels win (profiles/r04_wtile_experiments.txt).
+            const bool wt_range = 4u * w.sh >= 5u * w.plan.resized_h && 10u * w.sh < 31u * w.plan.resized_h;
+            if (((env_wt_first && env_wt_first[0] == '1') || wt_range) && use_wtile && w.pre == PRE_NONE && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
+                Job jtmp; fill_job(w, jtmp);
+                WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
+                if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
+                if (wp->ok) { w.s1 = S1_WTILE; w.wplan = wp; continue; }
+            }
             if (w.pre == PRE_NONE && !force_generic && !no_mfma && (w.sw * w.cs) % 16u == 0 && (uintptr_t)w.src % 16u == 0 &&
                 (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0) && w.sw * w.cs >= 64u) {
                 Job jtmp; fill_job(w, jtmp);

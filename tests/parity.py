@@ -38,6 +38,13 @@ def maxdiff(a, b):
     return int(np.abs(a.astype(np.int16) - b.astype(np.int16)).max()) if a.size else 0
 
 
+# The off-by-one RATE bar of the matrix-pipe kernels assumes pictures whose exact results do not sit on rounding boundaries.  A 1-pixel
+# checkerboard scaled by ~2 is the opposite: every output is 127.5 +- a few 1e-4, so which side of the boundary a byte lands on
+# is decided by the last bits of ANY arithmetic, the reference's own f32 included -- tests of such inputs switch the rate bar off
+# (monkeypatch.setattr(parity, "RATE_BAR", False)) and keep the 1 LSB bar.
+RATE_BAR = True
+
+
 def oracle_kwargs(kw):
     return dict(w=kw.get("w"), h=kw.get("h"), fill=kw.get("fill", (32, 32, 32)), crop=kw.get("crop", False),
                 blur_sigma=kw.get("blur_sigma", 0.0), grayscale=kw.get("grayscale", False), inverse=kw.get("inverse", False),
@@ -51,7 +58,7 @@ def check_pixels(oracle, got, img, used_mfma, **okw):
     d = np.abs(got.astype(np.int16) - want_ref.astype(np.int16))
     assert int(d.max()) <= TOL_LSB, f"> {TOL_LSB} LSB vs reference arithmetic {okw}"
     if used_mfma:
-        if got.size >= 20000:   # (a rate means little on a handful of pixels)
+        if got.size >= 20000 and RATE_BAR:   # (a rate means little on a handful of pixels)
             assert float((d > 0).mean()) <= mfma_off_by_one_bar(), f"{1e6 * float((d > 0).mean()):.0f} bytes per million differ from the reference arithmetic {okw}"
     else:
         want_fma = oracle.process_pixels(img, arith=oracle_lib.ARITH_FMA, **okw)
