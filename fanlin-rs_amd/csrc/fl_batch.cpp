@@ -466,7 +466,15 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         // but whose base is not 16-byte aligned (only possible through the device-batch entry point; staged and decoded sources
         // are 256-byte aligned) is copied to aligned scratch first.  The two kernels may differ by 1 LSB; an HTTP cache in front of
         // the service must not see that difference come and go with an address.
-        if (pl.resampled && w.s1 == S1_GENERIC && !pre_changes && !w.orient && ((size_t)w.sw * w.cs) % 16u == 0 && (uintptr_t)s.data % 16u != 0) {
+        // (only where that kernel can be the one: its own gate below -- no pre-op, rows of at least 64 bytes, not switched off -- and a
+        // ratio above the window-tile kernel's range, which takes any alignment; everything else is served by kernels that do not care)
+        const bool mfma_candidate = [&] {
+            const char *e1 = getenv("FLGPU_NO_MFMA"), *e2 = getenv("FLGPU_FORCE_GENERIC"), *e3 = getenv("FLGPU_NO_WTILE"), *e4 = getenv("FLGPU_MFMA_ARITH");
+            if ((e1 && e1[0] == '1') || (e2 && e2[0] == '1') || (size_t)w.sw * w.cs < 64u) return false;
+            const bool wtile_on = !(e3 && e3[0] == '1') && !(e4 && e4[0] == 'p');
+            return wtile_on ? 10u * (uint64_t)w.sh >= 31u * (uint64_t)pl.resized_h : (uint64_t)w.sh >= 2u * (uint64_t)pl.resized_h; // (its planner refuses ratios below ~3.4 anyway)
+        }();
+        if (pl.resampled && w.s1 == S1_GENERIC && !pre_changes && !w.orient && mfma_candidate && ((size_t)w.sw * w.cs) % 16u == 0 && (uintptr_t)s.data % 16u != 0) {
             w.align_off = tmp_al_bytes; w.align_copy = true;
             tmp_al_bytes += align_up((size_t)s.width * s.height * s.channels, 256);
         }
