@@ -49,8 +49,15 @@ EXTRA = {
     "mfma_luma_1080p_to_300x200": (1080, 1920, 1, "photo", dict(w=300, h=200)),
     "mfma_lumaa_1080p_to_300x169": (1080, 1920, 2, "uniform", dict(w=300, h=169)),
     "config2_1080p_gray_blur10": (1080, 1920, 3, "uniform", dict(w=300, h=200, grayscale=True, blur_sigma=10.0)),
-    # the tiled two-pass kernel (ratios below ~2 and up-scales), whose bytes must be the crate's up to the order of the f32 sums
+    # round 4: the window-tile matrix-pipe kernel (fl_wtile.hip: ratios 1.25 .. 3.1 and blurs at the full-width arithmetic): a mild
+    # down-scale (this case went through the f32 tile kernel before), ratio 3 with odd rows, a colour blur of a large picture, and a
+    # blur behind the flagship resample
     "tile_720p_to_800x450": (720, 1280, 3, "photo", dict(w=800, h=450)),
+    "wtile_1080p_to_1000x562": (1080, 1920, 3, "photo", dict(w=1000, h=562)),
+    "wtile_odd_pitch_ratio3": (540, 961, 3, "uniform", dict(w=320, h=180)),
+    "wtile_blur20_800x600": (600, 800, 3, "photo", dict(blur_sigma=20.0)),
+    "wtile_1080p_to_300x200_blur8": (1080, 1920, 3, "photo", dict(w=300, h=200, blur_sigma=8.0)),
+    # the tiled two-pass kernel (up-scales), whose bytes must be the crate's up to the order of the f32 sums
     "tile_thumbnail_upscale": (120, 160, 3, "photo", dict(w=300, h=200)),
 }
 EXACT = {"inverse_only", "letterbox_only_rgb", "gray_only_rgba", "orient3_only"}  # no f32 resampling involved
