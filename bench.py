@@ -614,6 +614,29 @@ def main():
                           "achieved": alg / (pk["stage_ms_per_step"]["resample"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": alg / (pk["stage_ms_per_step"]["resample"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         extra["packed arithmetic (FLGPU_MFMA_ARITH=packed), same workload as `value`"] = pk
+        # round 4: the window-tile matrix-pipe kernel (csrc/fl_wtile.h) -- a sigma-20 blur behind the flagship resample, and a mild
+        # down-scale (ratio 1.92) of the first 256 pictures of the same batch
+        if not args.blur:
+            extra["config1 + blur sigma 20 (blur on the window-tile matrix-pipe kernel), pixels out"] = measure(
+                fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=20.0, front_end=fl.FE_NONE))
+        if SRC_W == 1920 and SRC_H == 1080 and n >= 256:
+            pm = fl.make_params(1000, 562, front_end=fl.FE_NONE)
+            plm = fl.plan_output(pm, SRC_W, SRC_H, SRC_C)
+            strm = (int(plm.out_bytes) + 255) // 256 * 256
+            dstm = torch.zeros((256, strm), dtype=torch.uint8, device=dev)
+            rm = st.prepared_batch(srcp[:256], shapes[:256], pm, [dstm.data_ptr() + k * strm for k in range(256)], [strm] * 256)
+            rm(stream)
+            torch.cuda.synchronize()
+            steps_m = max(4, args.extra_steps // 4)
+            el, s2 = timed_loop(rm, stream, steps_m, 2, st, 1, dist, cdev)
+            algm = 256 * (SRC_W * SRC_H * SRC_C + int(plm.pixel_bytes))
+            k_ms = s2["resample_ms"] / steps_m
+            extra["256 x 1080p -> w=1000&h=562 (ratio 1.92, window-tile matrix-pipe kernel), pixels out"] = {
+                "images_per_s": 256 * steps_m / el, "ms_per_step": el / steps_m * 1e3, "stage_ms_per_step": {"resample": k_ms},
+                "wtile_launches": int(s2.get("wtile_launches", 0)),
+                "roofline": {"bound": "hbm", "kernel": "resample_wtile_kernel", "kernel_ms": k_ms, "achieved": algm / (k_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            del rm, dstm
         if not (args.grayscale and args.blur):
             extra["config2 (grayscale + blur sigma 10, pixels out)"] = measure(
                 fl.make_params(REQ_W, REQ_H, blur_sigma=10.0, grayscale=True, front_end=fl.FE_NONE))
