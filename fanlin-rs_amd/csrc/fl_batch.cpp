@@ -557,7 +557,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             // (wide layout, operands from L2 there) 0.79 vs 0.83 ms per 256 at ratio 3, 0.99 vs 1.20 at 2.4, and against the streaming
             // f32 kernel 1.16 vs 2.10 at 2.13; above ratio 3.4 the fused kernels win (profiles/r04_wtile_experiments.txt).
             const bool wt_range = 4u * w.sh >= 5u * w.plan.resized_h && 10u * w.sh < 31u * w.plan.resized_h;
-            if (((env_wt_first && env_wt_first[0] == '1') || wt_range) && use_wtile && w.pre == PRE_NONE && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
+            if (((env_wt_first && env_wt_first[0] == '1') || wt_range) && use_wtile && (w.pre == PRE_NONE || w.pre == PRE_INVERT) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
                 Job jtmp; fill_job(w, jtmp);
                 WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
                 if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
@@ -588,7 +588,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 if (sp->ok) { w.s1 = S1_STREAM; w.splan = sp; }
             }
             // what neither fused kernel takes and no pre-op precedes: the window-tile matrix-pipe kernel (any pitch and alignment)
-            if (w.s1 == S1_GENERIC && use_wtile && w.pre == PRE_NONE && wtile_resample_wanted(w) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
+            if (w.s1 == S1_GENERIC && use_wtile && (w.pre == PRE_NONE || w.pre == PRE_INVERT) && wtile_resample_wanted(w) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
                 Job jtmp; fill_job(w, jtmp);
                 WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
                 if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
@@ -955,7 +955,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if (L.k.lb) FL_HIP(c, launch_place(L.g, true, st), "border fill");
             LaunchWtile m{};
             m.jobs = d_jobs; m.items = reinterpret_cast<const WtItem *>(d_mitems + L.item_base); m.arena = c->d_arena; m.nitems = L.nitems;
-            m.nslot = (L.k.kind >> 8) & 255u; m.nkmax = kWtOperandRegs / m.nslot; m.letterbox = L.k.lb; m.lds_bytes = (uint32_t)L.lds;
+            m.nslot = (L.k.kind >> 8) & 255u; m.nkmax = kWtOperandRegs / m.nslot; m.letterbox = L.k.lb; m.lds_bytes = (uint32_t)L.lds; m.invert = L.k.pre == PRE_INVERT;
             {
                 ProfileScope ps(c, st, 0);
                 FL_HIP(c, launch_wtile(m, st), "window-tile matrix-pipe kernel");

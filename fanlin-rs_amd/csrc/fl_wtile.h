@@ -97,6 +97,7 @@ struct LaunchWtile {
     uint32_t nslot, nkmax;
     uint32_t letterbox;
     uint32_t lds_bytes;
+    uint32_t invert;       // PRE_INVERT: the colour channels enter as 255 - c
 };
 hipError_t launch_wtile(const LaunchWtile &m, hipStream_t st);
 

@@ -31,7 +31,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t wt_lds[];
 // for its whole walk (<1, 6> also serves strips whose N-tiles mostly share ONE operand block: a blur's interior columns).
 template <int NSLOT, int NKMAX>
 __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job *__restrict__ jobs, const WtItem *__restrict__ items,
-                                                                       const uint32_t *__restrict__ arena, uint32_t lb)
+                                                                       const uint32_t *__restrict__ arena, uint32_t lb, uint32_t invert)
 {
     static_assert(NSLOT * NKMAX == (int)kWtOperandRegs, "operand register budget");
     // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh with ABL_FILE=fl_wtile.hip): 1 = no vertical pass, 2 = no horizontal pass,
@@ -66,13 +66,16 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     const uint32_t tcol = tid % spw, trow = tid / spw, rpp = kWtThreads / spw; // (one division per workgroup)
     const uint32_t pitch = hd.src_rowbytes;
     const gptr8 gsrc = (gptr8)jb.src;
+    // Invert (reference src/handler.rs:226-228, color.rs Invert: 255 - c on the colour channels, alpha untouched) as an XOR on the way into
+    // the ring: a 16-byte piece starts on a pixel boundary for 2 and 4 channels, and 1 and 3 channels have no alpha
+    const uint32_t inv = !invert ? 0u : hd.cs == 4u ? 0x00ffffffu : hd.cs == 2u ? 0x00ff00ffu : 0xffffffffu;
     auto fetch = [&](uint32_t r) -> u32x4 {
         const uint32_t row = min(r, hd.src_rows - 1u); // rows past the picture carry zero weights: any finite bytes do
         const uint32_t off = row * pitch + sp.col0 + 16u * tcol;
-        if (off + 16u <= jb.src_bytes) return *(const __attribute__((address_space(1))) u32x4_unaligned *)(gsrc + off);
+        if (off + 16u <= jb.src_bytes) return *(const __attribute__((address_space(1))) u32x4_unaligned *)(gsrc + off) ^ inv;
         u32x4 v = {0u, 0u, 0u, 0u};
         for (uint32_t b = 0; b < 16u && off + b < jb.src_bytes; ++b) v[b >> 2] |= (uint32_t)gsrc[off + b] << (8u * (b & 3u));
-        return v;
+        return v ^ inv;
     };
     auto put = [&](uint32_t r, u32x4 v) { *reinterpret_cast<u32x4 *>(ring + rmod(r) * SP + 16u * tcol) = v; };
     u32x4 pre[kWtPrefetch];
@@ -378,7 +381,7 @@ hipError_t launch_wtile_t(const LaunchWtile &m, hipStream_t st)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_wtile_kernel<NSLOT, NKMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr_set;
     if (e != hipSuccess) return e;
-    resample_wtile_kernel<NSLOT, NKMAX><<<m.nitems, kWtThreads, m.lds_bytes, st>>>(m.jobs, m.items, m.arena, m.letterbox);
+    resample_wtile_kernel<NSLOT, NKMAX><<<m.nitems, kWtThreads, m.lds_bytes, st>>>(m.jobs, m.items, m.arena, m.letterbox, m.invert);
     return hipGetLastError();
 }
 

@@ -67,6 +67,9 @@ DEVICE_CASES = [
     ((250, 330, 4), dict(blur_sigma=3.0)),
     ((256, 384, 3), dict(blur_sigma=20.0)),
     ((1080, 1920, 3), dict(w=300, h=200, blur_sigma=8.0)),  # streaming matrix-pipe resample, then the blur on this kernel
+    ((300, 400, 3), dict(w=250, h=190, inverse=True)),     # inverse: an XOR on the way into the LDS ring
+    ((300, 400, 4), dict(w=240, h=180, inverse=True)),     # ... that leaves alpha alone
+    ((300, 400, 2), dict(w=250, h=190, inverse=True, crop=True)),
     ((540, 513, 3), dict(w=300, h=200)),                   # ratio 2.7 (ahead of the fused kernels since the routing rule), 1539-byte rows
     ((1080, 1920, 3), dict(w=640, h=360)),                 # ratio 3
 ]

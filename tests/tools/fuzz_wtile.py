@@ -27,6 +27,8 @@ for i in range(n):
         ratio = float(rng.uniform(0.6, 3.3))
         kw.update(w=int(min(2000, max(20, sw / ratio + rng.integers(-3, 4)))), h=int(min(1000, max(20, sh / ratio + rng.integers(-3, 4)))),
                   crop=bool(rng.integers(0, 2)), fill=tuple(int(x) for x in rng.integers(0, 256, 3)))
+    if kind != 1 and rng.integers(0, 5) == 0:
+        kw["inverse"] = True
     if kind in (1, 2):                                        # a blur, alone or behind the resize
         kw["blur_sigma"] = float(rng.choice([0.3, 0.8, 1.5, 3.0, 7.0, 10.0, 14.5, 20.0]))
     img = synth.uniform(sh, sw, c, index=i) if i % 3 else synth.photo(sh, sw, c, index=i)
