@@ -54,7 +54,7 @@ static_assert(kMfmaOutPitchCompact >= kMfmaMaxStripOutputsCompact + 16 && (4 * k
 constexpr uint32_t mfma_out_pitch(int layout) { return layout == 1 ? kMfmaOutPitchWide : layout == 2 ? kMfmaOutPitchCompact : kMfmaOutPitch; }
 constexpr uint32_t mfma_max_outputs(int layout) { return layout == 1 ? kMfmaMaxStripOutputsWide : layout == 2 ? kMfmaMaxStripOutputsCompact : kMfmaMaxStripOutputs; }
 // full-width arithmetic: operands the LDS operand area of a layout holds (160 KB - the rows' 64 KB - ONE output tile - counters)
-constexpr uint32_t mfma_lds_operand_capacity(int layout) { return layout == 1 ? 0u : (160u * 1024u - 64u * 1024u - 16u * mfma_out_pitch(layout) * 4u - 16u) / 1024u; }
+constexpr uint32_t mfma_lds_operand_capacity(int layout) { return (160u * 1024u - 64u * 1024u - 16u * mfma_out_pitch(layout) * 4u - 16u) / 1024u; } // 69 / 49 (wide) / 76 (compact)
 constexpr uint32_t kMfmaDefaultSpinLimit = 1u << 22; // polls of an LDS counter before a wave gives up and reports FLGPU_DEVERR_MFMA_WAIT
 constexpr uint32_t FLGPU_DEVERR_MFMA_WAIT = 1u;      // bit of the batch's device error word
 constexpr uint32_t kMfmaVScaleLog2 = 8;     // packed arithmetic: vertical weights are stored times 2^8 (keeps the low f16 term normal)

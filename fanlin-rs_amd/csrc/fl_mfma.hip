@@ -687,7 +687,7 @@ static hipError_t launch_mfma_c(const LaunchMfma &m, hipStream_t st)
 {
     if constexpr (FW) { // the operand area takes whatever LDS the layout leaves; each strip says whether it uses it
         if constexpr (CS >= 3) {
-            if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, false, 1, true>(m, st) : launch_mfma_t<CS, false, false, 1, true>(m, st);
+            if (m.wide) return m.letterbox ? launch_mfma_t<CS, true, true, 1, true>(m, st) : launch_mfma_t<CS, false, true, 1, true>(m, st);
         } else if (m.wide) return hipErrorInvalidValue;
         if (m.compact) return m.letterbox ? launch_mfma_t<CS, true, true, 2, true>(m, st) : launch_mfma_t<CS, false, true, 2, true>(m, st);
         return m.letterbox ? launch_mfma_t<CS, true, true, 0, true>(m, st) : launch_mfma_t<CS, false, true, 0, true>(m, st);
