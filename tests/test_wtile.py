@@ -143,3 +143,32 @@ def test_large_blur_at_the_sweep_size(fl, gpu_state, oracle):
     got, used = parity.device_pixels(fl, gpu_state, img, blur_sigma=20.0)
     assert used
     parity.check_pixels(oracle, got, img, True, **parity.oracle_kwargs(dict(blur_sigma=20.0)))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_geometries_through_the_host_model(fl, oracle, seed):
+    """The table builder on geometries nobody picked by hand: sources of 8 .. 200 pixels a side, 1-4 channels, ratios 0.5 .. 3.2 or
+    blurs of sigma 0.3 .. 12; where the kernel takes the geometry, the host run of its tables is within 1 LSB of the reference arithmetic."""
+    rng = np.random.default_rng(seed)
+    taken = 0
+    for k in range(25):
+        c = int(rng.choice([1, 2, 3, 3, 4]))
+        sh, sw = int(rng.integers(8, 200)), int(rng.integers(8, 200))
+        img = synth.uniform(sh, sw, c, index=1000 * seed + k)
+        if rng.integers(0, 3) == 0:
+            sigma = float(rng.choice([0.3, 0.9, 2.5, 6.0, 12.0]))
+            r, want = fl.debug_wtile_model(img, blur_sigma=sigma), oracle.blur(img, sigma)
+            what = (sh, sw, c, "blur", sigma)
+        else:
+            ratio = float(rng.uniform(0.5, 3.2))
+            rw, rh = max(1, int(sw / ratio)), max(1, int(sh / ratio))
+            r, want = fl.debug_wtile_model(img, rw, rh), oracle.resize_exact(img, rw, rh)
+            what = (sh, sw, c, rw, rh)
+        if r is None:
+            continue
+        taken += 1
+        got = r[0]
+        d = np.abs(got.astype(np.int16) - np.asarray(want).reshape(got.shape).astype(np.int16))
+        assert int(d.max()) <= parity.TOL_LSB, what
+        assert float((d > 0).mean()) <= 0.002, what   # (small pictures: a rate means little, a systematic error would be percents)
+    assert taken >= 20
