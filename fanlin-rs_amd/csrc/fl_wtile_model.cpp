@@ -94,7 +94,7 @@ extern "C" int flgpu_debug_wtile_model(const uint8_t *src, uint32_t sw, uint32_t
                                 L[4] += (int64_t)a2 * d2; L[3] += (int64_t)a2 * d1 + (int64_t)a1 * d2; L[2] += (int64_t)a2 * d0 + (int64_t)a1 * d1 + (int64_t)a0 * d2;
                                 L[1] += (int64_t)a1 * d0 + (int64_t)a0 * d1; L[0] += (int64_t)a0 * d0;
                             }
-                    const int32_t low = (int32_t)((((L[2] << 8) + L[1]) + (L[0] >> 8)) >> slo);
+                    const int32_t low = (int32_t)(((L[2] * 256 + L[1]) + (L[0] >> 8)) >> slo); // (the device shifts; a negative left operand is only UB on paper before C++20)
                     const int32_t pp = (int32_t)(((uint32_t)L[4] << s4) + ((uint32_t)L[3] << s3) + (uint32_t)low);
                     const int32_t xx = pp + round_add;
                     dst[(size_t)y * nout + o] = (uint8_t)((uint32_t)std::min(std::max(xx, 0), (256 << 20) - 1) >> 20);

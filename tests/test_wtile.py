@@ -172,3 +172,24 @@ def test_random_geometries_through_the_host_model(fl, oracle, seed):
         assert int(d.max()) <= parity.TOL_LSB, what
         assert float((d > 0).mean()) <= 0.002, what   # (small pictures: a rate means little, a systematic error would be percents)
     assert taken >= 20
+
+
+def test_table_builder_and_host_model_under_address_sanitizer(tmp_path):
+    """csrc/fl_mfma_tables.cpp build_wtile_plan and csrc/fl_wtile_model.cpp over 150 random geometries (1 x 1 to 300 x 300 sources,
+    1-4 channels, targets up to 400 x 400, blurs of sigma 0.3 .. 20), built with g++ -fsanitize=address,undefined (host-only code,
+    no GPU): windows at picture borders, strips and operand blocks must stay inside their buffers."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs g++ and the HIP headers")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "fanlin-rs_amd", "csrc")
+    exe = str(tmp_path / "asan_wtile_tables")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-D__HIP_PLATFORM_AMD__",
+                    "-I/opt/rocm/include", "-I" + csrc, os.path.join(root, "tests", "tools", "asan_wtile_tables.cpp"),
+                    os.path.join(csrc, "fl_mfma_tables.cpp"), os.path.join(csrc, "fl_tables.cpp"), os.path.join(csrc, "fl_wtile_model.cpp"), "-o", exe],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([exe, "150"], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    plans, rejected = (int(x) for x in r.stdout.split())
+    assert plans > 100 and plans + rejected == 150
