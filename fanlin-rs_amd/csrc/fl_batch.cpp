@@ -764,6 +764,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             std::stable_sort(first, first + L.nitems, [](const MfmaItem &a, const MfmaItem &b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
             xcd_interleave(&*first, L.nitems, [](const MfmaItem &x) { return x.kb1 - x.kb0; });
         }
+        if ((k.kind & 255u) == S1_WTILE && L.nitems > 1) {
+            // strips and bands of a picture on one XCD (their source windows overlap: the halo then comes from that XCD's L2)
+            auto first = mitems.begin() + L.item_base;
+            xcd_interleave(&*first, L.nitems, [](const MfmaItem &) { return 1u; });
+        }
         if ((k.kind & 255u) == S1_STREAM && L.nitems > 1) {
             // longest workgroups first: in a mixed batch a 4K band walks four times the rows of a 1080p one, and the
             // hardware hands out workgroups in index order -- started last, the long ones would be the launch's tail
@@ -817,6 +822,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             L.g.max_cw = std::max(L.g.max_cw, j.cw); L.g.max_ch = std::max(L.g.max_ch, j.ch);
             jobs.push_back(j);
             L.njobs++;
+        }
+        if ((k.kind & kBlurWtileKind) && L.nitems > 1) {
+            auto first = mitems.begin() + L.item_base;
+            xcd_interleave(&*first, L.nitems, [](const MfmaItem &) { return 1u; });
         }
         blur_launches.push_back(L);
     }
