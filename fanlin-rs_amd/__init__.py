@@ -111,7 +111,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
     "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version", "flgpu_build_info",
-    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob", "flgpu_debug_mfma_plan", "flgpu_debug_mfma_plan_arith", "flgpu_debug_wtile_model",
+    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob", "flgpu_debug_mfma_plan", "flgpu_debug_mfma_plan_arith",
 )
 
 _lib = None
@@ -437,33 +437,6 @@ def debug_mfma_plan(sw: int, sh: int, channels: int, rw: int, rh: int, crop=None
     d = dict(zip(keys, (int(x) for x in info)))
     d["vertical_weight_error"], d["horizontal_weight_error"] = float(err[0]), float(err[1])
     return d
-
-
-def debug_wtile_model(img=None, rw: int = 0, rh: int = 0, blur_sigma: float = 0.0, shape=None):
-    """The window-tile matrix-pipe kernel's arithmetic run on the host from the kernel's own tables (csrc/fl_wtile_model.cpp): the
-    resize_exact of `img` (H x W x C uint8) to rw x rh, or its Gaussian blur; returns (pixels, info) or None if the geometry does
-    not fit the kernel.  With img = None and shape = (H, W, C): the plan's info only."""
-    import numpy as np
-    lib = load_library()
-    lib.flgpu_debug_wtile_model.restype = C.c_int
-    lib.flgpu_debug_wtile_model.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.POINTER(C.c_uint32)]
-    info = (C.c_uint32 * 8)()
-    keys = ("m_tiles", "n_tiles", "strips", "hs", "nslot", "nkmax", "lds_bytes", "table_words")
-    if img is None:
-        h, w, c = shape
-        if not lib.flgpu_debug_wtile_model(None, w, h, c, rw, rh, blur_sigma, None, info):
-            return None
-        return None, dict(zip(keys, (int(x) for x in info)))
-    img = np.ascontiguousarray(img, dtype=np.uint8)
-    if img.ndim == 2:
-        img = img[:, :, None]
-    h, w, c = img.shape
-    if blur_sigma > 0.0:
-        rw, rh = w, h
-    out = np.zeros((rh, rw, c), np.uint8)
-    if not lib.flgpu_debug_wtile_model(img.ctypes.data, w, h, c, rw, rh, blur_sigma, out.ctypes.data, info):
-        return None
-    return out, dict(zip(keys, (int(x) for x in info)))
 
 
 def debug_stream_schedulable(in_size: int, out_size: int, y0: int = 0, y1: Optional[int] = None) -> Tuple[bool, int]:

@@ -414,14 +414,6 @@ int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t 
 int flgpu_debug_mfma_plan_arith(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
                                 uint32_t cw, uint32_t ch, uint32_t arith, uint32_t info[8], double err[2]);
 
-/* The window-tile matrix-pipe kernel's arithmetic (csrc/fl_wtile.h) run on the host from the kernel's own tables: a plain resize_exact
- * of `src` (sw x sh pixels, cs interleaved bytes) to rw x rh, or -- blur_sigma > 0 -- its Gaussian blur, written to dst (rw x rh x cs,
- * no letterbox).  Returns 1 if the geometry fits the kernel, 0 if not (or if a table carries a weight on a byte that does not exist).
- * info[0..7] = M-tiles, N-tiles, strips, log2 of the horizontal weight scale, operand register split (N-tiles x K-steps), LDS bytes,
- * table words.  src / dst may be null (plan only).  Test infrastructure: nothing in the library calls it.  Needs no device. */
-int flgpu_debug_wtile_model(const uint8_t *src, uint32_t sw, uint32_t sh, uint32_t cs, uint32_t rw, uint32_t rh, float blur_sigma,
-                            uint8_t *dst, uint32_t info[8]);
-
 const char *flgpu_strerror(int status);
 const char *flgpu_last_error(flgpu_ctx *ctx); /* detail of the last FLGPU_ERR_DEVICE on this context */
 uint32_t flgpu_abi_version(void);

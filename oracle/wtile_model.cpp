@@ -1,17 +1,19 @@
-// fl_wtile_model.cpp -- flgpu_debug_wtile_model: the window-tile kernel's arithmetic (fl_wtile.h) run on the host FROM THE KERNEL'S OWN
-// TABLES, operand for operand: what the tests hold the device's bytes against (tests/test_wtile.py), and -- against the oracle --
-// what checks the table builder without a device.  Not a product path: nothing in the library calls it.
+// wtile_model.cpp -- TEST INFRASTRUCTURE (like the rest of oracle/: only tests/, smoke() and bench's cpu_baseline may use this directory).
+// The window-tile matrix-pipe kernel's arithmetic (fanlin-rs_amd/csrc/fl_wtile.h) run on the host FROM THE KERNEL'S OWN TABLES, operand
+// for operand: built together with the product's table builder (csrc/fl_mfma_tables.cpp, csrc/fl_tables.cpp: host-only code) into
+// oracle/libwtile_model.so.  What the tests hold the device's bytes against (tests/test_wtile.py), and -- against the C oracle -- what
+// checks the table builder without a device.  Reference: image 0.25.6 imageops/sample.rs behind resize_exact and blur
+// (/root/reference/src/handler.rs:229-255).  Nothing in libfanlin_gpu.so contains or calls it.
 #include <math.h>
 #include <string.h>
 
 #include <vector>
 
-#include "../../include/fanlin_gpu.h"
-#include "fl_mfma.h"
-#include "fl_tables.h"
-#include "fl_wtile.h"
+#include "../fanlin-rs_amd/csrc/fl_mfma.h"
+#include "../fanlin-rs_amd/csrc/fl_tables.h"
+#include "../fanlin-rs_amd/csrc/fl_wtile.h"
 
-extern "C" int flgpu_debug_wtile_model(const uint8_t *src, uint32_t sw, uint32_t sh, uint32_t cs, uint32_t rw, uint32_t rh, float blur_sigma,
+extern "C" int wtile_model_run(const uint8_t *src, uint32_t sw, uint32_t sh, uint32_t cs, uint32_t rw, uint32_t rh, float blur_sigma,
                                        uint8_t *dst, uint32_t info[8])
 {
     using namespace fl;

@@ -2,7 +2,7 @@
 Reference: image 0.25.6 imageops/sample.rs vertical_sample + horizontal_sample behind resize_exact and blur
 (/root/reference/src/handler.rs:229-255).
 
-Without a device: the kernel's own tables, run operand for operand on the host (flgpu_debug_wtile_model), against the oracle --
+Without a device: the kernel's own tables, run operand for operand on the host (oracle/wtile_model.cpp), against the oracle --
 that pins the table builder (windows, f16 terms, byte digits, strips) and the arithmetic's error budget.  With a device: the
 kernel's bytes against the oracle's bars for the matrix-pipe kernels (tests/parity.py) AND against that model."""
 import os
@@ -12,6 +12,7 @@ import pytest
 
 import parity
 import synth
+import wtile_model
 
 MODEL_CASES = [  # (source shape, resize target (w, h) or None, blur sigma)
     ((270, 480, 3), (250, 141), 0.0),     # ratio 1.92, three channels: two K-steps per tile on both axes
@@ -31,10 +32,10 @@ MODEL_CASES = [  # (source shape, resize target (w, h) or None, blur sigma)
 def test_host_model_of_the_tables_is_within_one_lsb_of_the_reference_arithmetic(fl, oracle, shape, target, sigma):
     img = synth.uniform(*shape, index=sum(shape))
     if target:
-        r = fl.debug_wtile_model(img, target[0], target[1])
+        r = wtile_model.run(img, target[0], target[1])
         want = oracle.resize_exact(img, target[0], target[1])
     else:
-        r = fl.debug_wtile_model(img, blur_sigma=sigma)
+        r = wtile_model.run(img, blur_sigma=sigma)
         want = oracle.blur(img, sigma)
     assert r is not None, "the geometry is meant to fit the kernel"
     got, info = r
@@ -46,14 +47,14 @@ def test_host_model_of_the_tables_is_within_one_lsb_of_the_reference_arithmetic(
 
 
 def test_plan_choices(fl):
-    _, down = fl.debug_wtile_model(None, 1000, 562, shape=(1080, 1920, 3))
+    _, down = wtile_model.run(None, 1000, 562, shape=(1080, 1920, 3))
     assert down["hs"] == 23 and down["strips"] >= 2 and down["nkmax"] in (2, 3)      # Lanczos3 at ratio 1.92: the centre weight is just above 1/2
-    _, up = fl.debug_wtile_model(None, 300, 200, shape=(120, 160, 3))
+    _, up = wtile_model.run(None, 300, 200, shape=(120, 160, 3))
     assert up["hs"] in (22, 23) and up["nkmax"] == 1                                  # an up-scale's centre tap is near 1
-    _, blur = fl.debug_wtile_model(None, blur_sigma=20.0, shape=(1000, 2000, 3))
+    _, blur = wtile_model.run(None, blur_sigma=20.0, shape=(1000, 2000, 3))
     assert blur["hs"] == 24 and blur["nslot"] == 1 and blur["nkmax"] == 6             # interior column tiles share ONE operand block
     assert blur["table_words"] < 400_000                                              # ... which is why the tables stay small
-    assert fl.debug_wtile_model(None, 100, 100, shape=(1080, 1920, 3)) is None        # ratio 10.8: more rows per tile than the ring holds
+    assert wtile_model.run(None, 100, 100, shape=(1080, 1920, 3)) is None        # ratio 10.8: more rows per tile than the ring holds
 
 
 DEVICE_CASES = [
@@ -106,11 +107,11 @@ def test_device_equals_the_host_model_of_its_tables(fl, gpu_state, shape, target
     monkeypatch.setenv("FLGPU_WTILE_ALWAYS", "1")
     img = synth.uniform(*shape, index=7 + shape[0])
     if target:
-        model, _ = fl.debug_wtile_model(img, target[0], target[1])
+        model, _ = wtile_model.run(img, target[0], target[1])
         got, used = parity.device_pixels(fl, gpu_state, img, w=target[0], h=target[1])   # same aspect: nothing but the picture in the frame
         got = got[:, :, :shape[2]]   # Rgba8 frame of a same-aspect request: (r, g, b, 255) / (l, l, l, 255)
     else:
-        model, _ = fl.debug_wtile_model(img, blur_sigma=sigma)
+        model, _ = wtile_model.run(img, blur_sigma=sigma)
         got, used = parity.device_pixels(fl, gpu_state, img, blur_sigma=sigma)
     assert used
     assert got.shape == model.shape
@@ -157,12 +158,12 @@ def test_random_geometries_through_the_host_model(fl, oracle, seed):
         img = synth.uniform(sh, sw, c, index=1000 * seed + k)
         if rng.integers(0, 3) == 0:
             sigma = float(rng.choice([0.3, 0.9, 2.5, 6.0, 12.0]))
-            r, want = fl.debug_wtile_model(img, blur_sigma=sigma), oracle.blur(img, sigma)
+            r, want = wtile_model.run(img, blur_sigma=sigma), oracle.blur(img, sigma)
             what = (sh, sw, c, "blur", sigma)
         else:
             ratio = float(rng.uniform(0.5, 3.2))
             rw, rh = max(1, int(sw / ratio)), max(1, int(sh / ratio))
-            r, want = fl.debug_wtile_model(img, rw, rh), oracle.resize_exact(img, rw, rh)
+            r, want = wtile_model.run(img, rw, rh), oracle.resize_exact(img, rw, rh)
             what = (sh, sw, c, rw, rh)
         if r is None:
             continue
@@ -175,7 +176,7 @@ def test_random_geometries_through_the_host_model(fl, oracle, seed):
 
 
 def test_table_builder_and_host_model_under_address_sanitizer(tmp_path):
-    """csrc/fl_mfma_tables.cpp build_wtile_plan and csrc/fl_wtile_model.cpp over 150 random geometries (1 x 1 to 300 x 300 sources,
+    """csrc/fl_mfma_tables.cpp build_wtile_plan and oracle/wtile_model.cpp over 150 random geometries (1 x 1 to 300 x 300 sources,
     1-4 channels, targets up to 400 x 400, blurs of sigma 0.3 .. 20), built with g++ -fsanitize=address,undefined (host-only code,
     no GPU): windows at picture borders, strips and operand blocks must stay inside their buffers."""
     import shutil
@@ -187,7 +188,7 @@ def test_table_builder_and_host_model_under_address_sanitizer(tmp_path):
     exe = str(tmp_path / "asan_wtile_tables")
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-D__HIP_PLATFORM_AMD__",
                     "-I/opt/rocm/include", "-I" + csrc, os.path.join(root, "tests", "tools", "asan_wtile_tables.cpp"),
-                    os.path.join(csrc, "fl_mfma_tables.cpp"), os.path.join(csrc, "fl_tables.cpp"), os.path.join(csrc, "fl_wtile_model.cpp"), "-o", exe],
+                    os.path.join(csrc, "fl_mfma_tables.cpp"), os.path.join(csrc, "fl_tables.cpp"), os.path.join(root, "oracle", "wtile_model.cpp"), "-o", exe],
                    check=True, capture_output=True, text=True)
     r = subprocess.run([exe, "150"], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0, r.stderr[-3000:]

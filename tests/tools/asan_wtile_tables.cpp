@@ -1,5 +1,5 @@
 // Host-only harness for tests/test_wtile.py: the window-tile kernel's table builder (csrc/fl_mfma_tables.cpp build_wtile_plan) and the
-// host run of its tables (csrc/fl_wtile_model.cpp) over random geometries, built with -fsanitize=address,undefined: any out-of-bounds
+// host run of its tables (oracle/wtile_model.cpp) over random geometries, built with -fsanitize=address,undefined: any out-of-bounds
 // access in the builders (windows at picture borders, strips, operand blocks) aborts the run.  Prints "<plans> <rejected>".
 #include <stdint.h>
 #include <stdio.h>
@@ -7,7 +7,7 @@
 
 #include <vector>
 
-extern "C" int flgpu_debug_wtile_model(const uint8_t *src, uint32_t sw, uint32_t sh, uint32_t cs, uint32_t rw, uint32_t rh, float blur_sigma,
+extern "C" int wtile_model_run(const uint8_t *src, uint32_t sw, uint32_t sh, uint32_t cs, uint32_t rw, uint32_t rh, float blur_sigma,
                                        uint8_t *dst, uint32_t info[8]);
 
 int main(int argc, char **argv)
@@ -25,11 +25,11 @@ int main(int argc, char **argv)
         if (rnd(0, 2) == 0) {
             static const float sig[] = {0.3f, 1.0f, 4.0f, 10.0f, 20.0f};
             std::vector<uint8_t> dst(src.size());
-            r = flgpu_debug_wtile_model(src.data(), sw, sh, cs, 0, 0, sig[rnd(0, 4)], dst.data(), info);
+            r = wtile_model_run(src.data(), sw, sh, cs, 0, 0, sig[rnd(0, 4)], dst.data(), info);
         } else {
             const uint32_t rw = rnd(1, 400), rh = rnd(1, 400);
             std::vector<uint8_t> dst((size_t)rw * rh * cs);
-            r = flgpu_debug_wtile_model(src.data(), sw, sh, cs, rw, rh, 0.0f, dst.data(), info);
+            r = wtile_model_run(src.data(), sw, sh, cs, rw, rh, 0.0f, dst.data(), info);
         }
         if (r) ++ok; else ++rejected;
     }

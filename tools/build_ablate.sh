@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../fanlin-rs_amd/csrc"
 mkdir -p /tmp/abl
 KFILE=${ABL_FILE:-fl_kernels.hip}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math"
-ALL="fl_kernels.hip fl_mfma.hip fl_wtile.hip fl_wtile_model.cpp fl_mfma_tables.cpp fl_context.cpp fl_batch.cpp fl_queue.cpp fl_cmyk_ctx.cpp fl_tables.cpp fl_query.cpp fl_cmyk.cpp fl_jpeghuff.cpp fl_jpeg.hip fl_jpegdec.hip fl_jpeghuff_dev.hip"
+ALL="fl_kernels.hip fl_mfma.hip fl_wtile.hip fl_mfma_tables.cpp fl_context.cpp fl_batch.cpp fl_queue.cpp fl_cmyk_ctx.cpp fl_tables.cpp fl_query.cpp fl_cmyk.cpp fl_jpeghuff.cpp fl_jpeg.hip fl_jpegdec.hip fl_jpeghuff_dev.hip"
 OTHERS=""; for f in $ALL; do [ "$f" = "$KFILE" ] || OTHERS="$OTHERS $f"; done
 make -s fl_buildinfo.gen.cpp >/dev/null 2>&1 || true
 for f in $OTHERS fl_buildinfo.gen.cpp; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o /tmp/abl/$f.o & done
