@@ -1,5 +1,8 @@
+"""Blur of BASELINE config 2 (grey, one channel filtered) and of its colour twin on the vector blur kernel and on the window-tile
+matrix-pipe kernel (FLGPU_WTILE_BLUR_ALWAYS=1): where the routing rule `all but the one-channel shortcut` comes from.
+   python tools/experiments/config2_blur_ab.py"""
 import importlib, os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 fl = importlib.import_module("fanlin-rs_amd")
 n, H, W, C = 1024, 1080, 1920, 3
 src = torch.randint(0, 256, (n, H, W, C), dtype=torch.uint8, device="cuda")
