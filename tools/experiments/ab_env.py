@@ -38,7 +38,7 @@ for i, v in enumerate(a.variants):
         dst = torch.zeros((n, stride), dtype=torch.uint8, device="cuda")
     run = st.prepared_batch([src.data_ptr() + k * H * W * C for k in range(n)], [(H, W, C)] * n, p, [dst.data_ptr() + k * stride for k in range(n)], [stride] * n)
     runs.append((v, st, run, env))
-KEYS = ("FLGPU_MFMA_ARITH", "FLGPU_NO_MFMA", "FLGPU_FORCE_BANDS", "FLGPU_NO_WTILE", "FLGPU_WTILE_ALWAYS", "FLGPU_WTILE_FIRST", "FLGPU_WTILE_NO_OVERLAP")
+KEYS = ("FLGPU_NO_SMALL", "FLGPU_MFMA_ARITH", "FLGPU_NO_MFMA", "FLGPU_FORCE_BANDS", "FLGPU_NO_WTILE", "FLGPU_WTILE_ALWAYS", "FLGPU_WTILE_FIRST", "FLGPU_WTILE_NO_OVERLAP")
 def setenv(env):
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(env)
