@@ -136,7 +136,9 @@ def test_config3_shape_on_two_shards(fl, gpu_state, two_shards, oracle):
 @pytest.mark.gpu
 def test_host_batches_and_the_request_queue_on_two_shards(fl, gpu_state, two_shards, oracle):
     imgs = [synth.photo(200 + 13 * i, 260 + 7 * i, 3 + (i % 2), index=960 + i) for i in range(24)]
-    ps = [fl.make_params(100 + i, 80, crop=bool(i % 3 == 0), quality=60 + i, front_end=fl.FE_JPEG if i % 4 == 0 else fl.FE_NONE) for i in range(24)]
+    # (ratios 2 .. 5: the window-tile matrix-pipe kernel and the fused ones side by side; every fifth request with a blur behind it)
+    ps = [fl.make_params(100 + i, 80, crop=bool(i % 3 == 0), quality=60 + i, blur_sigma=3.0 if i % 5 == 0 else 0.0,
+                         front_end=fl.FE_JPEG if i % 4 == 0 else fl.FE_NONE) for i in range(24)]
     one = gpu_state.process_batch(imgs, ps)
     two = two_shards.process_batch(imgs, ps)
     for a, b in zip(one, two):
