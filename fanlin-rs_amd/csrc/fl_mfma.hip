@@ -217,24 +217,24 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     auto convert_rows = [&](uint32_t tile, uint32_t buf) __attribute__((always_inline)) {
         uint32_t *ot = otile + buf * ot_words;
         const uint32_t ngrp = (npx + 63u) >> 6; // lane groups in use (wave-uniform)
-        // (both rows' sums are fetched up front where the registers allow it -- Rgb8, the flagship: 12 of them; the Rgba8 and the wide
-        // instantiations fetch row by row: 16-24 registers of sums at this point pushed them into scratch, whose reloads wait on vmcnt,
+        // (both rows' sums are fetched up front where the registers allow it -- Rgb8, the flagship: 12 of them; the other
+        // instantiations fetch one lane group at a time: 16-24 registers of sums at this point pushed them into scratch, whose reloads wait on vmcnt,
         // i.e. for the K-block in flight)
         constexpr bool BOTH = CS == 3 && CONV_G <= 2;
-        uint32_t sums[2][CONV_G][CS];
-        auto fetch_row = [&](uint32_t rr) __attribute__((always_inline)) {
+        uint32_t sums[BOTH ? 2 : 1][BOTH ? CONV_G : 1][CS];
+        if (BOTH) {
 #pragma unroll
-            for (uint32_t k = 0; k < CONV_G; ++k) {
-                const uint32_t xo = min(lane + 64u * k, npx - 1u);
-                const uint32_t *o = ot + (2u * wave + rr) * np + (uint32_t)CS * xo;
+            for (uint32_t rr = 0; rr < 2; ++rr)
 #pragma unroll
-                for (int c = 0; c < CS; ++c) sums[BOTH ? rr : 0u][k][c] = o[c];
-            }
-        };
-        if (BOTH) { fetch_row(0); fetch_row(1); }
+                for (uint32_t k = 0; k < CONV_G; ++k) {
+                    const uint32_t xo = min(lane + 64u * k, npx - 1u);
+                    const uint32_t *o = ot + (2u * wave + rr) * np + (uint32_t)CS * xo;
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) sums[BOTH ? rr : 0u][BOTH ? k : 0u][c] = o[c];
+                }
+        }
 #pragma unroll
         for (uint32_t rr = 0; rr < 2; ++rr) {
-            if (!BOTH) fetch_row(rr);
             const uint32_t row = 2u * wave + rr;
             const bool live = 16u * tile + row < vp.rows;
 #pragma unroll
@@ -242,16 +242,20 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 if (k >= ngrp || !live) continue;
                 const uint32_t xo = min(lane + 64u * k, npx - 1u);
                 uint32_t *o = ot + row * np + (uint32_t)CS * xo;
+                if (!BOTH) { // (one lane group at a time: CS registers of sums)
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) sums[0][0][c] = o[c];
+                }
                 uint32_t c8[CS];
 #pragma unroll
                 for (int c = 0; c < CS; ++c) {
                     if constexpr (FW) {
                         // clamp-then-shift: clamp(x >> 20, 0, 255) is the pattern hipcc (ROCm 7.2) fuses into gfx950's v_ashr_pk_u8_i32,
                         // whose destination keeps stale bits above bit 15 (fl_jpegdec.hip sat17 met the same bug)
-                        const int32_t x = (int32_t)sums[BOTH ? rr : 0u][k][c] + round_add;
+                        const int32_t x = (int32_t)sums[BOTH ? rr : 0u][BOTH ? k : 0u][c] + round_add;
                         c8[c] = (uint32_t)min(max(x, 0), (256 << kMfmaOutFracBitsFull) - 1) >> kMfmaOutFracBitsFull;
                     } else {
-                        const int32_t q = ((int32_t)sums[BOTH ? rr : 0u][k][c] + round_add) >> out_shift;
+                        const int32_t q = ((int32_t)sums[BOTH ? rr : 0u][BOTH ? k : 0u][c] + round_add) >> out_shift;
                         c8[c] = (uint32_t)min(max(q + 128, 0), 255);
                     }
                     o[c] = 0u;
