@@ -359,9 +359,10 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
                 constexpr int SB_ = (S_ + 1 < NSLOT) ? S_ + 1 : S_; \
                 const uint32_t ja = wave + kWtWaves * S_##u, jb2 = ja + kWtWaves; \
                 if (S_##u < mine) { \
-                    const bool okA = ntl[ja][2] == cached[S_], hasB = S_##u + 1u < mine && SB_ != S_ && ntl[jb2][2] == cached[SB_]; \
-                    if (okA) pair(std::integral_constant<int, S_>{}, std::integral_constant<int, SB_>{}, ja, jb2, hasB); else fly(ja); \
-                    if (!hasB && S_##u + 1u < mine && SB_ != S_) fly(jb2); \
+                    const bool inB = S_##u + 1u < mine && SB_ != S_; /* a second tile in this pair of slots */ \
+                    const bool okA = ntl[ja][2] == cached[S_], okB = inB && ntl[jb2][2] == cached[SB_]; \
+                    if (okA) pair(std::integral_constant<int, S_>{}, std::integral_constant<int, SB_>{}, ja, jb2, okB); else fly(ja); \
+                    if (inB && !(okA && okB)) fly(jb2); \
                 } \
                 __builtin_amdgcn_sched_barrier(0); /* one pair at a time: hoisting the next pairs' LDS reads up here costs more registers than the file has */ \
             }
