@@ -472,7 +472,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             const char *e1 = getenv("FLGPU_NO_MFMA"), *e2 = getenv("FLGPU_FORCE_GENERIC"), *e3 = getenv("FLGPU_NO_WTILE"), *e4 = getenv("FLGPU_MFMA_ARITH");
             if ((e1 && e1[0] == '1') || (e2 && e2[0] == '1') || (size_t)w.sw * w.cs < 64u) return false;
             const bool wtile_on = !(e3 && e3[0] == '1') && !(e4 && e4[0] == 'p');
-            return wtile_on ? 10u * (uint64_t)w.sh >= 31u * (uint64_t)pl.resized_h : (uint64_t)w.sh >= 2u * (uint64_t)pl.resized_h; // (its planner refuses ratios below ~3.4 anyway)
+            return wtile_on ? 2u * (uint64_t)w.sh >= 5u * (uint64_t)pl.resized_h : (uint64_t)w.sh >= 2u * (uint64_t)pl.resized_h; // (below: the window-tile kernel, any alignment)
         }();
         if (pl.resampled && w.s1 == S1_GENERIC && !pre_changes && !w.orient && mfma_candidate && ((size_t)w.sw * w.cs) % 16u == 0 && (uintptr_t)s.data % 16u != 0) {
             w.align_off = tmp_al_bytes; w.align_copy = true;
@@ -553,10 +553,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             // The matrix-pipe kernel takes down-scales (any channel count, no pre-op) whose rows are 16-byte aligned (it moves 16-byte pieces of a row
             // straight into LDS).  The choice depends on the request's geometry only, never on the batch around it.
             const char *env_wt_first = getenv("FLGPU_WTILE_FIRST"); // experiments: the window-tile kernel before the streaming matrix-pipe kernel
-            // Ratios 1.25 .. 3.1 go to the window-tile kernel BEFORE the fused ones: measured against the streaming matrix-pipe kernel
-            // (wide layout, operands from L2 there) 0.79 vs 0.83 ms per 256 at ratio 3, 0.99 vs 1.20 at 2.4, and against the streaming
-            // f32 kernel 1.16 vs 2.10 at 2.13; above ratio 3.4 the fused kernels win (profiles/r04_wtile_experiments.txt).
-            const bool wt_range = 4u * w.sh >= 5u * w.plan.resized_h && 10u * w.sh < 31u * w.plan.resized_h;
+            // Ratios 1.25 .. 2.5 go to the window-tile kernel BEFORE the fused ones: measured 1.00 vs 1.03 ms per 256 at ratio 2.4 and -- against the
+            // streaming f32 kernel, which serves what the matrix-pipe planner refuses down there -- 1.16 vs 2.10 at 2.13.  From 2.67 up the
+            // streaming matrix-pipe kernel wins since its wide layout keeps operands in LDS (0.78 vs 0.92 at 2.67, 0.72 vs 0.80 at 3;
+            // profiles/r04_wtile_experiments.txt); where ITS planner refuses a geometry below ratio 3.4, the window-tile kernel is asked again.
+            const bool wt_range = 4u * w.sh >= 5u * w.plan.resized_h && 2u * w.sh < 5u * w.plan.resized_h;
             if (((env_wt_first && env_wt_first[0] == '1') || wt_range) && use_wtile && (w.pre == PRE_NONE || w.pre == PRE_INVERT) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
                 Job jtmp; fill_job(w, jtmp);
                 WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
@@ -572,6 +573,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs, mfma_arith);
                 if (mp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
                 if (mp->ok) { w.s1 = S1_MFMA; w.mplan = mp; w.mitems = &mp->items_for(nbands); continue; }
+            }
+            if (use_wtile && (w.pre == PRE_NONE || w.pre == PRE_INVERT) && 2u * w.sh >= 5u * w.plan.resized_h && 10u * w.sh < 34u * w.plan.resized_h &&
+                (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) { // (ratio 2.5 .. 3.4 and no streaming matrix-pipe plan: unaligned rows, a pre-op, a refused geometry)
+                Job jtmp; fill_job(w, jtmp);
+                WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
+                if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
+                if (wp->ok) { w.s1 = S1_WTILE; w.wplan = wp; continue; }
             }
             if (stream_supported(w.cs, w.pre) && aligned && !force_generic) {
                 Job jtmp; fill_job(w, jtmp);

@@ -327,8 +327,10 @@ def test_request_queue_concurrent_callers(fl, gpu_state, oracle):
     import threading
     imgs = [synth.uniform(360, 640, 3, index=50 + i) for i in range(24)]
     got = [None] * len(imgs)
+    gate = threading.Barrier(len(imgs))   # (all callers enter together: started one after the other, a fast device serves each alone now and then)
 
     def call(i):
+        gate.wait()
         got[i] = gpu_state.process_pixels(imgs[i], fl.make_params(300, 200))
 
     before = gpu_state.stats()

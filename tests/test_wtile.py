@@ -71,8 +71,9 @@ DEVICE_CASES = [
     ((300, 400, 3), dict(w=250, h=190, inverse=True)),     # inverse: an XOR on the way into the LDS ring
     ((300, 400, 4), dict(w=240, h=180, inverse=True)),     # ... that leaves alpha alone
     ((300, 400, 2), dict(w=250, h=190, inverse=True, crop=True)),
-    ((540, 513, 3), dict(w=300, h=200)),                   # ratio 2.7 (ahead of the fused kernels since the routing rule), 1539-byte rows
-    ((1080, 1920, 3), dict(w=640, h=360)),                 # ratio 3
+    ((540, 513, 3), dict(w=300, h=200)),                   # ratio 2.7, 1539-byte rows: the streaming matrix-pipe kernel refuses them, this one is asked next
+    ((1080, 1920, 3), dict(w=800, h=450)),                 # ratio 2.4: the upper end of what goes to this kernel before the fused ones
+    ((1080, 1922, 3), dict(w=640, h=360)),                 # ratio 3 with rows the streaming matrix-pipe kernel cannot take (5766 bytes): asked again
 ]
 
 
