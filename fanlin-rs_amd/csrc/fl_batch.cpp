@@ -64,13 +64,13 @@ uint32_t blur_channels(const Work &w)
     return ce;
 }
 
-// Resamples the window-tile matrix-pipe kernel takes from the f32 vector kernels: down-scales (of those neither fused kernel takes:
-// ratios below ~3).  For up-scales the two measure the same (profiles/r04_generic_sweep.txt) and the vector kernel reproduces the
-// reference's f32 sums to the order of additions, so it keeps them.  FLGPU_WTILE_ALWAYS=1: every geometry the kernel can take (tests).
-bool wtile_resample_wanted(const Work &w)
+// Resamples the window-tile matrix-pipe kernel takes from the f32 vector kernels: every one its planner accepts.  (The first version
+// measured equal to the tiled kernel on up-scales and the rule kept those there; after the kernel's tuning it is ahead on them as
+// well -- 1080p -> 2000x1000 1.23 vs 1.48 ms per 128, 720p -> 1600x900 1.64 vs 1.97 per 256, 1080p -> 1600x900 1.02 vs 1.77 per 128,
+// thumbnails 3.4 vs 3.55 per 8,192; profiles/r04_wtile_experiments.txt.)
+bool wtile_resample_wanted(const Work &)
 {
-    const char *e = getenv("FLGPU_WTILE_ALWAYS"); // (read per batch: a test can flip it)
-    return (e && e[0] == '1') || 4u * w.sh >= 5u * w.plan.resized_h || 4u * w.sw >= 5u * w.plan.resized_w;
+    return true;
 }
 
 // Blurs the window-tile matrix-pipe kernel takes: all but the one-channel shortcut (a grey picture on a grey frame: the vector
@@ -553,11 +553,11 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             // The matrix-pipe kernel takes down-scales (any channel count, no pre-op) whose rows are 16-byte aligned (it moves 16-byte pieces of a row
             // straight into LDS).  The choice depends on the request's geometry only, never on the batch around it.
             const char *env_wt_first = getenv("FLGPU_WTILE_FIRST"); // experiments: the window-tile kernel before the streaming matrix-pipe kernel
-            // Ratios 1.25 .. 2.5 go to the window-tile kernel BEFORE the fused ones: measured 1.00 vs 1.03 ms per 256 at ratio 2.4 and -- against the
+            // Ratios below 2.5 (up-scales included) go to the window-tile kernel BEFORE the fused ones: measured 1.00 vs 1.03 ms per 256 at ratio 2.4 and -- against the
             // streaming f32 kernel, which serves what the matrix-pipe planner refuses down there -- 1.16 vs 2.10 at 2.13.  From 2.67 up the
             // streaming matrix-pipe kernel wins since its wide layout keeps operands in LDS (0.78 vs 0.92 at 2.67, 0.72 vs 0.80 at 3;
             // profiles/r04_wtile_experiments.txt); where ITS planner refuses a geometry below ratio 3.4, the window-tile kernel is asked again.
-            const bool wt_range = 4u * w.sh >= 5u * w.plan.resized_h && 2u * w.sh < 5u * w.plan.resized_h;
+            const bool wt_range = 2u * w.sh < 5u * w.plan.resized_h;
             if (((env_wt_first && env_wt_first[0] == '1') || wt_range) && use_wtile && (w.pre == PRE_NONE || w.pre == PRE_INVERT) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
                 Job jtmp; fill_job(w, jtmp);
                 WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
