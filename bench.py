@@ -52,16 +52,16 @@ KERNEL_DTYPE_FULL = ("u8 (exact, as f16 subnormals) x the reference's f32 weight
                      "24-bit fixed-point intermediate (2^-14 steps, three i8 planes) x 24-bit fixed-point weights (2^-24 steps, three i8 digits), "
                      "all nine digit products -> exact i32 (horizontal, v_mfma_i32_16x16x64_i8): no operand narrower than f32's 24 bits")
 KERNEL_DTYPE_PACKED = ("u8 x f16-pair weights (22 bit) -> f32 acc (vertical, MFMA); i16 (1/64 steps) x 17-bit fixed weights -> i32 exact (horizontal, MFMA) "
-                       "[FLGPU_MFMA_ARITH=packed: rounds 2-3's arithmetic, narrower than the reference's]")
+                       "[switch mfma_arith=1: rounds 2-3's arithmetic, narrower than the reference's]")
 KERNEL_DTYPE_STREAM = "f32 (one fused multiply-add per tap, vertical then horizontal)"
 
 
-def kernel_dtype(stats) -> str:
+def kernel_dtype(stats, st=None) -> str:
     """The arithmetic the dominant kernel really computes in (not a precision claim: every byte is checked to lie within 1 LSB of
     the reference's f32 arithmetic, see verified_against)."""
     if not stats.get("mfma_launches"):
         return KERNEL_DTYPE_STREAM
-    return KERNEL_DTYPE_PACKED if os.environ.get("FLGPU_MFMA_ARITH", "")[:1] == "p" else KERNEL_DTYPE_FULL
+    return KERNEL_DTYPE_PACKED if (st is not None and st.debug_get("mfma_arith") == 1) else KERNEL_DTYPE_FULL
 
 
 def cpu_baseline(n_images: int, workload: dict, max_threads: int = 16):
@@ -421,7 +421,7 @@ def main_one_context(args):
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     line = {"metric": baseline_metric(), "value": n * args.steps / elapsed, "unit": "images/s", "n_gpus": N, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": kernel_dtype(stats), "data": "synthetic",
+            "dtype": kernel_dtype(stats, st), "data": "synthetic",
             "config": {"workload": f"{n} x {SRC_W}x{SRC_H} RGB8 (uniform bytes, HBM-resident, shard k on device k) -> w={REQ_W}&h={REQ_H} Lanczos3 + letterbox RGBA8"
                                    + (f" + baseline JPEG encode (q {args.quality}) on the device" if fe == fl.FE_JPEG else ""),
                        "mode": "one process, one context over the node's GPUs (flgpu_config.devices[]), shards by flgpu_plan_shards",
@@ -590,30 +590,24 @@ def main():
                 fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fl.FE_NONE))
         # the same resize with the reference's own arithmetic width: the streaming kernel (f32 accumulation, bit-exact against the
         # oracle's fused-order mode) serves the request when the matrix-pipe kernel is switched off
-        os.environ["FLGPU_NO_MFMA"] = "1"
-        try:
+        with st.switches(no_mfma=1):
             f32m = measure(fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fl.FE_NONE))
-        finally:
-            del os.environ["FLGPU_NO_MFMA"]
         alg = SRC_W * SRC_H * SRC_C * n + int(fl.plan_output(fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale), SRC_W, SRC_H, SRC_C).pixel_bytes) * n
         f32m["roofline"] = {"bound": "hbm", "kernel": "resample_stream_kernel", "kernel_ms": f32m["stage_ms_per_step"]["resample"],
                             "achieved": alg / (f32m["stage_ms_per_step"]["resample"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": alg / (f32m["stage_ms_per_step"]["resample"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        extra["f32 streaming kernel (FLGPU_NO_MFMA=1), resize only"] = f32m
+        extra["f32 streaming kernel (switch no_mfma), resize only"] = f32m
         # rounds 2-3's packed arithmetic (22-bit vertical weights, 1/64-step intermediate, 17-bit horizontal weights): narrower than
         # the reference's f32, kept selectable; the whole metric (resize + letterbox + encode) and the resize alone
-        os.environ["FLGPU_MFMA_ARITH"] = "packed"
-        try:
+        with st.switches(mfma_arith=1):
             pk = measure(params)
             pk_r = measure(fl.make_params(REQ_W, REQ_H, crop=args.crop, blur_sigma=args.blur, grayscale=args.grayscale, front_end=fl.FE_NONE))
-        finally:
-            del os.environ["FLGPU_MFMA_ARITH"]
         pk["dtype"] = KERNEL_DTYPE_PACKED
         pk["resize_only"] = pk_r
         pk["roofline"] = {"bound": "hbm", "kernel": "resample_mfma_kernel<packed>", "kernel_ms": pk["stage_ms_per_step"]["resample"],
                           "achieved": alg / (pk["stage_ms_per_step"]["resample"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": alg / (pk["stage_ms_per_step"]["resample"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        extra["packed arithmetic (FLGPU_MFMA_ARITH=packed), same workload as `value`"] = pk
+        extra["packed arithmetic (switch mfma_arith=1), same workload as `value`"] = pk
         # round 4: the window-tile matrix-pipe kernel (csrc/fl_wtile.h) -- a sigma-20 blur behind the flagship resample, and a mild
         # down-scale (ratio 1.92) of the first 256 pictures of the same batch
         if not args.blur:
@@ -657,7 +651,7 @@ def main():
             "metric": baseline_metric(),
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": kernel_dtype(stats), "data": "synthetic",
+            "vs_baseline": None, "dtype": kernel_dtype(stats, st), "data": "synthetic",
             "config": {"workload": f"{n} x {SRC_W}x{SRC_H} RGB8 (uniform bytes, HBM-resident) -> w={REQ_W}&h={REQ_H} Lanczos3"
                                    + (" crop" if args.crop else " + letterbox RGBA8")
                                    + (" + grayscale" if args.grayscale else "") + (f" + blur sigma {args.blur:g}" if args.blur else "")

@@ -110,7 +110,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_set_cmyk_profile", "flgpu_cmyk_bake_available", "flgpu_set_cmyk_clut", "flgpu_get_cmyk_clut",
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
-    "flgpu_reset_stats", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version", "flgpu_build_info",
+    "flgpu_reset_stats", "flgpu_debug_set", "flgpu_debug_get", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version", "flgpu_build_info",
     "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob", "flgpu_debug_mfma_plan", "flgpu_debug_mfma_plan_arith",
 )
 
@@ -188,6 +188,9 @@ def load_library() -> C.CDLL:
     lib.flgpu_import_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.flgpu_get_stats.argtypes = [C.c_void_p, C.POINTER(flgpu_stats)]
     lib.flgpu_reset_stats.argtypes = [C.c_void_p]
+    if hasattr(lib, "flgpu_debug_set"):   # (libraries of rounds 1-4, loaded through FLGPU_LIB by the A/B tools, have no such entry point)
+        lib.flgpu_debug_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.flgpu_debug_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     lib.flgpu_strerror.argtypes = [C.c_int]
     lib.flgpu_strerror.restype = C.c_char_p
     lib.flgpu_last_error.argtypes = [C.c_void_p]
@@ -720,3 +723,32 @@ class State:
 
     def reset_stats(self) -> None:
         _check(self._lib.flgpu_reset_stats(self._ctx), self._ctx)
+
+    # -- test / experiment switches (flgpu_debug_set: the library reads the environment only in flgpu_create) ---------------
+    def debug_set(self, key: str, value: int = 1) -> None:
+        """``key``: "no_mfma", "no_wtile", "mfma_arith" (1 = packed), "force_bands", "host_huffman", ... (include/fanlin_gpu.h);
+        "reset" restores every default."""
+        _check(self._lib.flgpu_debug_set(self._ctx, key.encode(), int(value)), self._ctx)
+
+    def debug_get(self, key: str) -> int:
+        v = C.c_int64()
+        _check(self._lib.flgpu_debug_get(self._ctx, key.encode(), C.byref(v)), self._ctx)
+        return int(v.value)
+
+    def switches(self, **kw):
+        """``with state.switches(no_mfma=1, force_bands=3): ...`` -- sets the switches, restores their old values on exit."""
+        state = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.old = {k: state.debug_get(k) for k in kw}
+                for k, v in kw.items():
+                    state.debug_set(k, v)
+                return state
+
+            def __exit__(self_inner, *exc):
+                for k, v in self_inner.old.items():
+                    state.debug_set(k, v)
+                return False
+
+        return _Scope()

@@ -75,17 +75,16 @@ bool wtile_resample_wanted(const Work &)
 
 // Blurs the window-tile matrix-pipe kernel takes: all but the one-channel shortcut (a grey picture on a grey frame: the vector
 // kernel filters one byte column in four there, the matrix kernel would filter all four).
-bool wtile_blur_wanted(const Work &w)
+bool wtile_blur_wanted(const DebugSwitches &dbg, const Work &w)
 {
-    const char *e = getenv("FLGPU_WTILE_BLUR_ALWAYS");
-    return (e && e[0] == '1') || blur_channels(w) != 1u;
+    return dbg.on(DBG_WTILE_BLUR_ALWAYS) || blur_channels(w) != 1u;
 }
 
 // Row bands per picture for the window-tile kernel: small batches are cut so that the chip still sees a few hundred workgroups
 // (the result does not depend on the cut: every M-tile is computed from the same rows by the same instructions).
-uint32_t wtile_bands(const WtPlan &p, size_t pictures)
+uint32_t wtile_bands(const DebugSwitches &dbg, const WtPlan &p, size_t pictures)
 {
-    if (const char *e = getenv("FLGPU_FORCE_BANDS")) return (uint32_t)std::max(1, atoi(e));
+    if (const int64_t b = dbg.get(DBG_FORCE_BANDS)) return (uint32_t)std::max<int64_t>(1, b);
     const size_t wgs = std::max<size_t>(1, pictures * p.n_strips);
     return (uint32_t)std::min<size_t>(p.n_mt, std::max<size_t>(1, (512 + wgs - 1) / wgs));
 }
@@ -175,7 +174,11 @@ void build_tile_vplan(const HostAxis &v, uint32_t cy, uint32_t ch, std::vector<u
 template <class Item, class Len>
 void xcd_interleave(Item *first, uint32_t nitems, Len len_of)
 {
-    static const bool no_xcd_order = [] { const char *e = getenv("FLGPU_NO_XCD_ORDER"); return e && e[0] == '1'; }(); // A/B experiments
+#ifdef FL_EXPERIMENT
+    static const bool no_xcd_order = [] { const char *e = getenv("FLGPU_NO_XCD_ORDER"); return e && e[0] == '1'; }(); // A/B experiments (experiment builds only)
+#else
+    constexpr bool no_xcd_order = false;
+#endif
     std::vector<Item> tmp;
     for (uint32_t a = 0; a < nitems && !no_xcd_order;) {
         uint32_t b = a;
@@ -247,20 +250,16 @@ int jpeg_source_precheck(flgpu_ctx *c, const flgpu_image *src, const JpegInfo &i
 
 thread_local bool tl_force_host_huffman = false;
 
-// Whether JPEG sources are entropy-decoded on the device where the file allows it (FLGPU_HOST_HUFFMAN=1: always on the host;
-// tests and A/B runs -- read per call).
+// Whether JPEG sources are entropy-decoded on the device where the file allows it.
 // 0 = this file is Huffman-decoded on the host, 1 = on the device if the caller has no idle CPU for it, 2 = on the device in any case.
-// FLGPU_HOST_HUFFMAN=1: never on the device; FLGPU_DEVICE_HUFFMAN_ALWAYS=1: always (tests, A/B runs); read per call.
-int device_huffman_policy(uint64_t file_bytes)
+// Switches (flgpu_debug_set; tests and A/B runs): host_huffman = never on the device, device_huffman_always = always,
+// device_huffman_min_bytes = files below it are decoded faster by the thread that holds them than by six kernel launches.
+int device_huffman_policy(const flgpu_ctx *c, uint64_t file_bytes)
 {
-    const char *e = getenv("FLGPU_HOST_HUFFMAN");
-    if (tl_force_host_huffman || (e && e[0] == '1')) return 0;
-    // small files are decoded faster by the thread that holds them than by six kernel launches (tests lower the bound to 0)
-    uint64_t min_bytes = 16384;
-    if (const char *m = getenv("FLGPU_DEVICE_HUFFMAN_MIN_BYTES")) min_bytes = strtoull(m, nullptr, 10);
-    if (file_bytes < min_bytes) return 0;
-    const char *a = getenv("FLGPU_DEVICE_HUFFMAN_ALWAYS");
-    return (a && a[0] == '1') ? 2 : 1;
+    const DebugSwitches &dbg = *c->dbg;
+    if (tl_force_host_huffman || dbg.on(DBG_HOST_HUFFMAN)) return 0;
+    if (file_bytes < (uint64_t)std::max<int64_t>(0, dbg.get(DBG_DEVICE_HUFFMAN_MIN_BYTES))) return 0;
+    return dbg.on(DBG_DEVICE_HUFFMAN_ALWAYS) ? 2 : 1;
 }
 
 int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used, bool host_huffman)
@@ -268,7 +267,7 @@ int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, siz
     int rc = -2;
     // files the device entropy decoder takes (sequential, one interleaved scan, no restart interval) are only STAGED here: header,
     // code tables, the segment without its stuffing -- tens of microseconds instead of ~2 ms of Huffman decoding on this thread
-    if (!host_huffman && device_huffman_policy(src->capacity) != 0) rc = jpeg_entropy_stage(src->data, (size_t)src->capacity, blob, cap, used);
+    if (!host_huffman && device_huffman_policy(c, src->capacity) != 0) rc = jpeg_entropy_stage(src->data, (size_t)src->capacity, blob, cap, used);
     if (rc == -2) rc = jpeg_entropy_decode(src->data, (size_t)src->capacity, blob, cap, used);
     if (rc == -2) { c->set_error("JPEG stream not covered by the device decoder (arithmetic coding, 12-bit samples, lossless or hierarchical processes)"); return FLGPU_ERR_UNSUPPORTED; }
     if (rc) { c->set_error("malformed JPEG stream"); return FLGPU_ERR_INVALID_ARG; }
@@ -411,7 +410,7 @@ int entropy_failures(flgpu_ctx *c, size_t n, std::vector<uint8_t> &bad, hipStrea
     }
     int nbad = 0;
     const uint32_t *e = static_cast<const uint32_t *>(c->h_jherr.p);
-    if (getenv("FLGPU_DEBUG_JH")) for (uint32_t k = 0; k < c->last_jh_n; ++k) fprintf(stderr, "device entropy decode: picture %u error word %u\n", k, e[k]);
+    if (c->dbg->on(DBG_DEBUG_JH)) for (uint32_t k = 0; k < c->last_jh_n; ++k) fprintf(stderr, "device entropy decode: picture %u error word %u\n", k, e[k]);
     for (size_t i = 0; i < n; ++i)
         if (c->last_jh_slot[i] >= 0 && e[c->last_jh_slot[i]]) { bad[i] = 1; ++nbad; }
     c->stats.jpeg_device_huffman_retries += (uint64_t)nbad;
@@ -468,12 +467,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         // the service must not see that difference come and go with an address.
         // (only where that kernel can be the one: its own gate below -- no pre-op, rows of at least 64 bytes, not switched off -- and a
         // ratio above the window-tile kernel's range, which takes any alignment; everything else is served by kernels that do not care)
-        const bool mfma_candidate = [&] {
-            const char *e1 = getenv("FLGPU_NO_MFMA"), *e2 = getenv("FLGPU_FORCE_GENERIC"), *e3 = getenv("FLGPU_NO_WTILE"), *e4 = getenv("FLGPU_MFMA_ARITH");
-            if ((e1 && e1[0] == '1') || (e2 && e2[0] == '1') || (size_t)w.sw * w.cs < 64u) return false;
-            const bool wtile_on = !(e3 && e3[0] == '1') && !(e4 && e4[0] == 'p');
-            return wtile_on ? 2u * (uint64_t)w.sh >= 5u * (uint64_t)pl.resized_h : (uint64_t)w.sh >= 2u * (uint64_t)pl.resized_h; // (below: the window-tile kernel, any alignment)
-        }();
+        // (from ratio 2 up whether or not the window-tile kernel is on: that kernel takes any alignment, but where ITS planner refuses
+        // a geometry below ratio 2.5 the request falls through to the matrix-pipe branch -- which must not then depend on the address)
+        const bool mfma_candidate = !c->dbg->on(DBG_NO_MFMA) && !c->dbg->on(DBG_FORCE_GENERIC) && (size_t)w.sw * w.cs >= 64u &&
+                                    (uint64_t)w.sh >= 2u * (uint64_t)pl.resized_h;
         if (pl.resampled && w.s1 == S1_GENERIC && !pre_changes && !w.orient && mfma_candidate && ((size_t)w.sw * w.cs) % 16u == 0 && (uintptr_t)s.data % 16u != 0) {
             w.align_off = tmp_al_bytes; w.align_copy = true;
             tmp_al_bytes += align_up((size_t)s.width * s.height * s.channels, 256);
@@ -521,21 +518,19 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
 
     // ---- tables ------------------------------------------------------------
     // first pass may overflow the arena: reset once and retry
-    const char *env_generic = getenv("FLGPU_FORCE_GENERIC");
-    const char *env_bands = getenv("FLGPU_FORCE_BANDS");
-    const bool force_generic = env_generic && env_generic[0] == '1';
-    const char *env_no_mfma = getenv("FLGPU_NO_MFMA"); // tests / A-B runs: keep the streaming kernel (read per batch, so a test can flip it)
-    const bool no_mfma = env_no_mfma && env_no_mfma[0] == '1';
-    // which arithmetic the matrix-pipe kernel computes in (fl_mfma.h): the full-width one unless FLGPU_MFMA_ARITH=packed asks for
-    // rounds 2-3's (A/B runs and the tests that keep the packed kernel's bars; read per batch)
-    const char *env_arith = getenv("FLGPU_MFMA_ARITH");
-    const MfmaArith mfma_arith = (env_arith && env_arith[0] == 'p') ? MFMA_ARITH_PACKED : MFMA_ARITH_FULL;
-    const char *env_no_tile = getenv("FLGPU_NO_TILE");
-    const bool no_tile = env_no_tile && env_no_tile[0] == '1';
-    // the window-tile matrix-pipe kernel (fl_wtile.h) for mild ratios, up-scales and blurs: full-width arithmetic only; FLGPU_NO_WTILE=1
-    // keeps the f32 vector kernels (tests, A/B)
-    const char *env_no_wtile = getenv("FLGPU_NO_WTILE");
-    const bool use_wtile = !(env_no_wtile && env_no_wtile[0] == '1') && !no_mfma && !force_generic && mfma_arith == MFMA_ARITH_FULL;
+    // the context's switches (flgpu_debug_set; tests and A/B runs), read once per batch
+    const DebugSwitches &dbg = *c->dbg;
+    const bool force_generic = dbg.on(DBG_FORCE_GENERIC);
+    const uint32_t forced_bands = (uint32_t)std::max<int64_t>(0, dbg.get(DBG_FORCE_BANDS));
+    const bool no_mfma = dbg.on(DBG_NO_MFMA); // keep the streaming kernel
+    // which arithmetic the matrix-pipe kernel computes in (fl_mfma.h): the full-width one unless mfma_arith = 1 asks for
+    // rounds 2-3's (A/B runs and the tests that keep the packed kernel's bars)
+    const MfmaArith mfma_arith = dbg.on(DBG_MFMA_ARITH) ? MFMA_ARITH_PACKED : MFMA_ARITH_FULL;
+    const bool no_tile = dbg.on(DBG_NO_TILE);
+    // the window-tile matrix-pipe kernel (fl_wtile.h) for mild ratios, up-scales and blurs: full-width arithmetic only; no_wtile
+    // keeps the f32 vector kernels
+    const bool use_wtile = !dbg.on(DBG_NO_WTILE) && !no_mfma && !force_generic && mfma_arith == MFMA_ARITH_FULL;
+    const bool wt_first = dbg.on(DBG_WTILE_FIRST); // experiments: the window-tile kernel before the streaming matrix-pipe kernel
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool full = false;
         size_t n_resample = 0;
@@ -552,13 +547,12 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             const bool aligned = (!w.unaligned || w.cs == 3) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0);
             // The matrix-pipe kernel takes down-scales (any channel count, no pre-op) whose rows are 16-byte aligned (it moves 16-byte pieces of a row
             // straight into LDS).  The choice depends on the request's geometry only, never on the batch around it.
-            const char *env_wt_first = getenv("FLGPU_WTILE_FIRST"); // experiments: the window-tile kernel before the streaming matrix-pipe kernel
             // Ratios below 2.5 (up-scales included) go to the window-tile kernel BEFORE the fused ones: measured 1.00 vs 1.03 ms per 256 at ratio 2.4 and -- against the
             // streaming f32 kernel, which serves what the matrix-pipe planner refuses down there -- 1.16 vs 2.10 at 2.13.  From 2.67 up the
             // streaming matrix-pipe kernel wins since its wide layout keeps operands in LDS (0.78 vs 0.92 at 2.67, 0.72 vs 0.80 at 3;
             // profiles/r04_wtile_experiments.txt); where ITS planner refuses a geometry below ratio 3.4, the window-tile kernel is asked again.
             const bool wt_range = 2u * w.sh < 5u * w.plan.resized_h;
-            if (((env_wt_first && env_wt_first[0] == '1') || wt_range) && use_wtile && (w.pre == PRE_NONE || w.pre == PRE_INVERT) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
+            if ((wt_first || wt_range) && use_wtile && (w.pre == PRE_NONE || w.pre == PRE_INVERT) && (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) {
                 Job jtmp; fill_job(w, jtmp);
                 WtPlan *wp = get_wtile_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs);
                 if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
@@ -568,7 +562,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0) && w.sw * w.cs >= 64u) {
                 Job jtmp; fill_job(w, jtmp);
                 uint32_t nbands = 1;
-                if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
+                if (forced_bands) nbands = forced_bands;
                 else if (n_resample < 128) nbands = (uint32_t)std::min<size_t>(16, (256 + n_resample * 3 - 1) / (n_resample * 3));
                 MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs, mfma_arith);
                 if (mp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
@@ -584,7 +578,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if (stream_supported(w.cs, w.pre) && aligned && !force_generic) {
                 Job jtmp; fill_job(w, jtmp);
                 uint32_t nbands = 1;
-                if (env_bands) nbands = (uint32_t)std::max(1, atoi(env_bands));
+                if (forced_bands) nbands = forced_bands;
                 else if (n_resample < 512) {
                     // small batches: split images into row bands so that the chip still gets >= ~1024 workgroups
                     const uint32_t want = (uint32_t)((1024 + n_resample * 2 - 1) / (n_resample * 2));
@@ -628,7 +622,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 AxisKey kv; const HostAxis *hv;
                 if (!get_axis(c, w.plan.out_h, w.plan.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &kv, &hv) ||
                     !get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h)) full = true;
-                else if (use_wtile && wtile_blur_wanted(w)) {
+                else if (use_wtile && wtile_blur_wanted(dbg, w)) {
                     WtPlan *wp = get_wtile_plan(c, kv, *hv, k, *h, 0, 0, w.plan.out_w, w.plan.out_h, w.plan.out_c);
                     if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) full = true;
                     else if (wp->ok) w.bwplan = wp;
@@ -742,7 +736,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             }
             if ((k.kind & 255u) == S1_WTILE) {
                 const size_t before = mitems.size();
-                w.wplan->items_for(wtile_bands(*w.wplan, kv.second.size()), (uint32_t)jobs.size(), mitems);
+                w.wplan->items_for(wtile_bands(dbg, *w.wplan, kv.second.size()), (uint32_t)jobs.size(), mitems);
                 L.nitems += (uint32_t)(mitems.size() - before);
                 L.lds = std::max(L.lds, (size_t)w.wplan->lds_bytes);
                 c->stats.resample_src_bytes += (uint64_t)j.src_bytes;
@@ -805,7 +799,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             }
             if (k.kind & kBlurWtileKind) {
                 const size_t before = mitems.size();
-                w.bwplan->items_for(wtile_bands(*w.bwplan, kv.second.size()), (uint32_t)jobs.size(), mitems);
+                w.bwplan->items_for(wtile_bands(dbg, *w.bwplan, kv.second.size()), (uint32_t)jobs.size(), mitems);
                 L.nitems += (uint32_t)(mitems.size() - before);
                 L.lds = std::max(L.lds, (size_t)w.bwplan->lds_bytes);
                 jobs.push_back(j);
@@ -846,8 +840,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     // (they live at the end of the batch's descriptor block and arrive zeroed with it: a clear of their own was two fill kernels
     // and two engine switches between one batch's last kernel and the next one's first)
     std::vector<size_t> jjob_idx, fjob_idx; // image of every encoder / front-end job: its result words are addressed once the block's place is known
-    uint32_t mfma_spin_limit = kMfmaDefaultSpinLimit;
-    if (const char *e = getenv("FLGPU_MFMA_SPIN_LIMIT")) mfma_spin_limit = (uint32_t)strtoul(e, nullptr, 10); // tests: 0 = every bounded wait expires
+    const uint32_t mfma_spin_limit = (uint32_t)std::max<int64_t>(0, dbg.get(DBG_MFMA_SPIN_LIMIT)); // tests: 0 = every bounded wait expires
     std::vector<JpegJob> jjobs;
     uint32_t jpeg_max_blocks = 0;
     for (auto &kv : fe_groups) {
@@ -891,15 +884,31 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     }
     FL_HIP(c, c->d_mid.reserve(mid_floats_max * 4), "f32 intermediate");
 
-    // one staging slot: [jobs][items][fjobs][jjobs][mitems]
+    // The matrix-pipe kernel's persistent workgroups request the first K-block of their NEXT item in the last pass of the current
+    // one: what that request needs (source, pitch, last row, the strip's first byte, the first K-block), one record per item in item
+    // order, so that it is ONE scalar load at that point and nothing of the next item occupies registers before (fl_mfma.h MfmaReq).
+    std::vector<MfmaReq> mreqs;
+    for (auto &L : s1_launches) {
+        if ((L.k.kind & 255u) != S1_MFMA) continue;
+        mreqs.resize(mitems.size());
+        for (uint32_t k = L.item_base; k < L.item_base + L.nitems; ++k) {
+            const MfmaItem &mi = mitems[k];
+            const Job &j = jobs[mi.job];
+            MfmaReq &r = mreqs[k];
+            r.src = j.src; r.pitch = j.sw * L.k.cs; r.last_row = j.sh - 1u; r.kb0 = mi.kb0;
+            r.byte0 = reinterpret_cast<const MfmaStrip *>(c->h_arena.data() + mi.strip_off)->byte0;
+        }
+    }
+    // one staging slot: [jobs][items][fjobs][jjobs][mitems][mreqs]
     const size_t jobs_b = align_up(jobs.size() * sizeof(Job), 256), items_b = align_up(items.size() * sizeof(StreamItem), 256),
                  fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256), jjobs_b = align_up(jjobs.size() * sizeof(JpegJob), 256),
-                 mitems_b = align_up(mitems.size() * sizeof(MfmaItem), 256);
-    const size_t stat_off = jobs_b + items_b + fjobs_b + jjobs_b + mitems_b, stat_b = (has_results || has_err_word) ? align_up(n * 8 + 8, 256) : 0;
+                 mitems_b = align_up(mitems.size() * sizeof(MfmaItem), 256), mreqs_b = align_up(mreqs.size() * sizeof(MfmaReq), 256);
+    const size_t stat_off = jobs_b + items_b + fjobs_b + jjobs_b + mitems_b + mreqs_b, stat_b = (has_results || has_err_word) ? align_up(n * 8 + 8, 256) : 0;
     const size_t desc_b = stat_off + stat_b;
     uint32_t *status_dev = nullptr;
     const Job *d_jobs = nullptr; const StreamItem *d_items = nullptr; const FrontendJob *d_fjobs = nullptr; const JpegJob *d_jjobs = nullptr;
     const MfmaItem *d_mitems = nullptr;
+    const MfmaReq *d_mreqs = nullptr;
     DescSlot *slot = nullptr;
     if (desc_b) {
         slot = &c->slots[c->next_slot];
@@ -920,6 +929,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (!fjobs.empty()) memcpy(hp + jobs_b + items_b, fjobs.data(), fjobs.size() * sizeof(FrontendJob));
         if (!jjobs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b, jjobs.data(), jjobs.size() * sizeof(JpegJob));
         if (!mitems.empty()) memcpy(hp + jobs_b + items_b + fjobs_b + jjobs_b, mitems.data(), mitems.size() * sizeof(MfmaItem));
+        if (!mreqs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b + jjobs_b + mitems_b, mreqs.data(), mreqs.size() * sizeof(MfmaReq));
         // While a previous batch is still running, the block goes up on the context's upload stream: the slot is free (its last
         // batch has ended, see above), so the copy runs under that batch's kernels, and this batch's first kernel follows its
         // last one without a copy engine in between.  A lone request on an idle device sends the block down its own stream (no
@@ -941,6 +951,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         d_fjobs = reinterpret_cast<const FrontendJob *>(dp + jobs_b + items_b);
         d_jjobs = reinterpret_cast<const JpegJob *>(dp + jobs_b + items_b + fjobs_b);
         d_mitems = reinterpret_cast<const MfmaItem *>(dp + jobs_b + items_b + fjobs_b + jjobs_b);
+        d_mreqs = reinterpret_cast<const MfmaReq *>(dp + jobs_b + items_b + fjobs_b + jjobs_b + mitems_b);
     }
 
     range_plan.reset();
@@ -954,6 +965,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     for (auto &L : s1_launches) {
         L.g.jobs = d_jobs; L.g.arena = c->d_arena; L.g.mid = static_cast<float *>(c->d_mid.p);
         L.g.job_base = L.job_base; L.g.njobs = L.njobs;
+        L.g.no_place4 = dbg.on(DBG_NO_PLACE4) ? 1u : 0u;
         if ((L.k.kind & 255u) == S1_NEAREST) {
             L.g.nearest = 1;
             FL_HIP(c, launch_place(L.g, false, st), "nearest kernel");
@@ -987,7 +999,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             c->stats.generic_launches++;
         } else if ((L.k.kind & 255u) == S1_MFMA) {
             LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
-            m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
+            m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.reqs = d_mreqs + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
             m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.wide = (L.k.kind >> 9) & 1u; m.full = (L.k.kind >> 10) & 1u; m.compact = (L.k.kind >> 11) & 1u; m.max_nout = L.max_nout;
             m.spin_limit = mfma_spin_limit; m.err_word = status_dev + 2 * n;
             {

@@ -169,7 +169,7 @@ WtPlan *get_wtile_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, cons
         plan.ok = plan.off != 0;
         plan.nslot = hp.nslot; plan.nkmax = hp.nkmax; plan.n_mt = hp.n_mt; plan.n_strips = hp.n_strips; plan.lds_bytes = hp.lds_bytes;
     }
-    if (getenv("FLGPU_DEBUG_MFMA"))
+    if (c->dbg->on(DBG_DEBUG_MFMA))
         fprintf(stderr, "window-tile plan %ux%u -> rows [%u,+%u) cols [%u,+%u) x %u: ok %d, M-tiles %u, strips %u, registers %u x %u, LDS %u, %zu words\n",
                 ha.in_size, va.in_size, cy, ch, cx, cw, cs, (int)plan.ok, hp.n_mt, hp.n_strips, hp.nslot, hp.nkmax, hp.lds_bytes, hp.blk.size());
     auto res = c->wtile_plans.emplace(key, plan);
@@ -192,7 +192,7 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
         plan.wide = hp.wide;
         for (auto &S : hp.strips) plan.max_nout = std::max(plan.max_nout, S.hdr.nout);
         if (plan.full) {
-            // full-width arithmetic: the LDS operand area is whatever the layout's output tiles leave (42 operands, 56 in the compact
+            // full-width arithmetic: the LDS operand area is whatever the layout's output tiles leave (69 operands, 49 in the wide and 76 in the compact
             // layout for strips of at most 300 outputs), and each strip whose distinct operands fit reads them from there -- the
             // others from the L2.  (With 24-bit weights the low digit's operands repeat only where the f32 sample positions have
             // run out of fraction bits: the right-hand strips of 1080p -> 300 columns have 33 and 49 operands, the leftmost 69.)
@@ -244,7 +244,7 @@ MfmaPlan *get_mfma_plan(flgpu_ctx *c, const AxisKey &vk, const HostAxis &va, con
         }
     }
     plan.ok = ok;
-    if (getenv("FLGPU_DEBUG_MFMA")) {
+    if (c->dbg->on(DBG_DEBUG_MFMA)) {
         fprintf(stderr, "mfma plan %ux%u rows [%u,+%u) cols [%u,+%u): ok %d, tiles %u, K-blocks %u, max_nout %u, operands in LDS %d, wide %d, compact %d, full-width arithmetic %d;",
                 ha.in_size, va.in_size, cy, ch, cx, cw, (int)ok, hp.ntiles, hp.nkb, plan.max_nout, (int)plan.ops_in_lds, (int)plan.wide, (int)plan.compact, (int)plan.full);
         for (auto &S : hp.strips) fprintf(stderr, " strip [%u,%u) byte0 %u hs %u ops %u%s slots %u", S.hdr.x0, S.hdr.x1, S.hdr.byte0, S.hdr.hs, S.hdr.n_ops, S.hdr.lds_ops ? " (LDS)" : "", S.hdr.slots);
@@ -346,6 +346,19 @@ void resolve_pending(flgpu_ctx *c)
     c->pending.clear();
 }
 
+const char *const kDebugKeyNames[DBG_COUNT] = {
+    "no_mfma", "force_generic", "no_wtile", "wtile_blur_always", "wtile_first", "mfma_arith", "force_bands", "no_tile", "no_place4",
+    "host_huffman", "device_huffman_always", "device_huffman_min_bytes", "mfma_spin_limit", "debug_mfma", "debug_jh",
+};
+
+DebugSwitches::DebugSwitches()
+{
+    for (auto &x : v) x.store(0, std::memory_order_relaxed);
+    v[DBG_DEVICE_HUFFMAN_MIN_BYTES].store(16384, std::memory_order_relaxed); // small files are decoded faster by the thread that holds them than by six kernel launches
+    v[DBG_MFMA_SPIN_LIMIT].store((int64_t)kMfmaDefaultSpinLimit, std::memory_order_relaxed);
+    for (uint32_t k = 0; k < DBG_COUNT; ++k) initial[k] = v[k].load(std::memory_order_relaxed);
+}
+
 namespace {
 struct Roctx {
     int (*push)(const char *) = nullptr;
@@ -382,7 +395,7 @@ ProfileScope::~ProfileScope()
 }
 
 // A context bound to one device with its own stream, arena and scratch: a queue lane or the shard of a device.
-static flgpu_ctx *create_on_device(const flgpu_config &cfg, int dev, int *status)
+static flgpu_ctx *create_on_device(const flgpu_config &cfg, int dev, int *status, const std::shared_ptr<DebugSwitches> &dbg, size_t arena_words)
 {
     auto set = [&](int s) { if (status) *status = s; };
     flgpu_ctx *c = new (std::nothrow) flgpu_ctx();
@@ -394,11 +407,8 @@ static flgpu_ctx *create_on_device(const flgpu_config &cfg, int dev, int *status
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c; set(FLGPU_ERR_NO_DEVICE); return nullptr;
     }
-    c->arena_cap_words = kArenaWords;
-    if (const char *aw = getenv("FLGPU_ARENA_WORDS")) { // tests: a small arena exercises the overflow -> reset path
-        const long v = atol(aw);
-        if (v >= 65536 && (size_t)v <= kArenaWords) c->arena_cap_words = (size_t)v;
-    }
+    c->dbg = dbg;
+    c->arena_cap_words = arena_words;
     if (hipMalloc(reinterpret_cast<void **>(&c->d_arena), kArenaWords * 4) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; set(FLGPU_ERR_OOM); return nullptr;
     }
@@ -413,7 +423,7 @@ flgpu_ctx *create_child(flgpu_ctx *parent, int device)
     flgpu_config lc = parent->cfg;
     lc.queue_lanes = 1;
     int st = 0;
-    return create_on_device(lc, device, &st);
+    return create_on_device(lc, device, &st, parent->dbg, parent->arena_cap_words);
 }
 
 } // namespace fl
@@ -441,7 +451,23 @@ flgpu_ctx *flgpu_create(const flgpu_config *cfg, int *status)
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= ndev) { set(FLGPU_ERR_NO_DEVICE); return nullptr; }
     int st = 0;
-    flgpu_ctx *c = create_on_device(c0, dev, &st);
+    // The one place the library reads the process environment: the switches' start values (fl_context.h DebugSwitches) and the two
+    // creation-time knobs (FLGPU_ARENA_WORDS: a small table arena, tests of the overflow -> reset path; FLGPU_ROCTX, read with the
+    // first range).  Everything later goes through flgpu_debug_set.
+    auto dbg = std::make_shared<DebugSwitches>();
+    for (uint32_t k = 0; k < DBG_COUNT; ++k) {
+        std::string name = "FLGPU_";
+        for (const char *q = kDebugKeyNames[k]; *q; ++q) name.push_back((char)toupper((unsigned char)*q));
+        if (const char *e = getenv(name.c_str())) dbg->v[k].store(k == DBG_MFMA_ARITH ? (e[0] == 'p' || e[0] == '1') : strtoll(e, nullptr, 10), std::memory_order_relaxed);
+        dbg->initial[k] = dbg->get((DebugKey)k);
+    }
+    size_t arena_words = kArenaWords;
+    if (const char *aw = getenv("FLGPU_ARENA_WORDS")) {
+        const long v = atol(aw);
+        if (v >= 65536 && (size_t)v <= kArenaWords) arena_words = (size_t)v;
+    }
+    (void)roctx(); // (FLGPU_ROCTX: read here, once, not with the first batch)
+    flgpu_ctx *c = create_on_device(c0, dev, &st, dbg, arena_words);
     if (!c) { set(st); return nullptr; }
     c->cfg.n_devices = (uint32_t)devs.size();
     c->devices = devs;
@@ -586,6 +612,27 @@ int flgpu_reset_stats(flgpu_ctx *c)
     for (size_t i = 0; i < nl; ++i) (void)flgpu_reset_stats(c->lanes[i]);
     for (flgpu_ctx *s : c->shard_ctx) (void)flgpu_reset_stats(s);
     return FLGPU_OK;
+}
+
+int flgpu_debug_set(flgpu_ctx *c, const char *key, int64_t value)
+{
+    if (!c || !key || !c->dbg) return FLGPU_ERR_INVALID_ARG;
+    if (!strcmp(key, "reset")) {
+        for (uint32_t k = 0; k < fl::DBG_COUNT; ++k) c->dbg->v[k].store(c->dbg->initial[k], std::memory_order_relaxed);
+        return FLGPU_OK;
+    }
+    for (uint32_t k = 0; k < fl::DBG_COUNT; ++k)
+        if (!strcmp(key, fl::kDebugKeyNames[k])) { c->dbg->v[k].store(value, std::memory_order_relaxed); return FLGPU_OK; }
+    c->set_error(std::string("flgpu_debug_set: unknown key ") + key);
+    return FLGPU_ERR_INVALID_ARG;
+}
+
+int flgpu_debug_get(flgpu_ctx *c, const char *key, int64_t *value)
+{
+    if (!c || !key || !value || !c->dbg) return FLGPU_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < fl::DBG_COUNT; ++k)
+        if (!strcmp(key, fl::kDebugKeyNames[k])) { *value = c->dbg->get((fl::DebugKey)k); return FLGPU_OK; }
+    return FLGPU_ERR_INVALID_ARG;
 }
 
 const char *flgpu_last_error(flgpu_ctx *c)

@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -132,6 +133,38 @@ struct Request {
     bool done = false;
 };
 
+// Test and experiment switches of a context (flgpu_debug_set / flgpu_debug_get, include/fanlin_gpu.h).  One block per ROOT context, shared
+// with its queue lanes and device shards; every field is an atomic read with relaxed ordering, so a caller may flip a switch
+// while other threads plan batches (a batch sees the old or the new value, never a torn one).  The process environment is read
+// exactly once, in flgpu_create (FLGPU_<KEY IN CAPITALS> seeds the switch of that name): a server that calls setenv() on another
+// thread cannot race the library, and a stray variable set after start-up cannot change output bytes.
+enum DebugKey : uint32_t {
+    DBG_NO_MFMA = 0,              // the f32 streaming kernel also where the matrix-pipe kernel would run
+    DBG_FORCE_GENERIC,            // the two-pass kernels instead of every fused one
+    DBG_NO_WTILE,                 // mild ratios, up-scales and blurs on the f32 vector kernels
+    DBG_WTILE_BLUR_ALWAYS,        // one-channel blurs on the window-tile kernel too
+    DBG_WTILE_FIRST,              // the window-tile kernel is asked before the streaming matrix-pipe kernel at every ratio
+    DBG_MFMA_ARITH,               // 0 = full-width arithmetic, 1 = the packed arithmetic of rounds 2-3
+    DBG_FORCE_BANDS,              // row bands per picture (0 = the planner's choice)
+    DBG_NO_TILE,                  // the two-pass resample through an f32 picture in HBM instead of the LDS tile
+    DBG_NO_PLACE4,                // placement one pixel per thread
+    DBG_HOST_HUFFMAN,             // JPEG sources are entropy-decoded on the caller's thread
+    DBG_DEVICE_HUFFMAN_ALWAYS,    // ... on the device whenever the file allows it
+    DBG_DEVICE_HUFFMAN_MIN_BYTES, // files below this size are not worth staging (default 16384)
+    DBG_MFMA_SPIN_LIMIT,          // bound of the matrix-pipe kernel's LDS-counter waits (default kMfmaDefaultSpinLimit; 0 = every wait expires)
+    DBG_DEBUG_MFMA,               // print every matrix-pipe plan
+    DBG_DEBUG_JH,                 // print why a staged file went back to the host decoder
+    DBG_COUNT
+};
+struct DebugSwitches {
+    std::atomic<int64_t> v[DBG_COUNT];
+    int64_t initial[DBG_COUNT]; // what flgpu_create left (defaults, or the environment's values): "reset" goes back to these
+    DebugSwitches();
+    int64_t get(DebugKey k) const { return v[k].load(std::memory_order_relaxed); }
+    bool on(DebugKey k) const { return get(k) != 0; }
+};
+extern const char *const kDebugKeyNames[DBG_COUNT];
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline uint32_t float_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
@@ -148,6 +181,7 @@ struct flgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     flgpu_config cfg{};
+    std::shared_ptr<fl::DebugSwitches> dbg; // the root context's switch block, shared with its lanes and shards
     std::mutex mu; // planning + launching on THIS context's stream is serialised (lanes and device shards have their own)
 
     // read-only table arena
@@ -322,7 +356,7 @@ constexpr int FL_STATUS_RETRY_HOST_HUFFMAN = 1000;
 int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used, bool host_huffman = false);
 // set while a request is run again after the device entropy decoder gave up on its file (this thread's JPEG sources are then decoded on the host)
 extern thread_local bool tl_force_host_huffman;
-int device_huffman_policy(uint64_t file_bytes); // fl_batch.cpp
+int device_huffman_policy(const flgpu_ctx *c, uint64_t file_bytes); // fl_batch.cpp
 inline void stage_of(const uint8_t *staged_blob, const JpegBlobHeader &hdr, JpegHuffStage &out)
 {
     if (hdr.magic == kJhMagic) memcpy(&out, staged_blob + sizeof(JpegBlobHeader), sizeof(out));

@@ -184,6 +184,9 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, u
             }
         }
     }
+    // (a block that straddles the subsequence's end: the next walk continues it with a clean flag, so what this part of it saw is
+    // reported here -- the host decoder rejects the same file, and which of the two runs must not decide whether a corrupt file is served)
+    if (MODE == 2 && bad) atomicOr(err, 2u);
     if (MODE >= 1 && cnt4) { cnt4[0] = nblk; cnt4[1] = dcs[0]; cnt4[2] = dcs[1]; cnt4[3] = dcs[2]; }
     return pack_state(p, j, k);
 }
@@ -297,6 +300,12 @@ __global__ __launch_bounds__(256) void jh_scan_kernel(const JhJob *jobs)
         for (int t = 0; t < 256; ++t)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const int32_t v = part[t][k]; part[t][k] = run[k]; run[k] += v; }
+        // The segment must hold every block of the scan.  A truncated file (or one cut by a stray marker) whose last walk stops at the
+        // segment's end before it meets the padding raises no invalid-code error, and its missing blocks would stay zero -- the host
+        // decoder feeds zero bits past the end and carries the DC predictors on, i.e. decodes different pixels: error bit 4, the host
+        // decodes this file.
+        const JpegHuffStage *S = reinterpret_cast<const JpegHuffStage *>(jb.stage + sizeof(JpegBlobHeader));
+        if (run[0] < (int32_t)S->total_blocks) atomicOr(jb.err, 4u);
     }
     __syncthreads();
 #pragma unroll

@@ -52,6 +52,7 @@ struct LaunchGeneric {
     uint32_t nearest;         // place kernel: FilterType::Nearest gather (jobs carry the f32 ratios in vtab/htab)
     uint32_t blur_lanes;      // blur kernel: lanes per workgroup of this group (blur_lanes() of its pictures)
     uint32_t tile_w_min;      // tiled two-pass kernel: the narrowest tile width (Job::pad1) among the group's pictures
+    uint32_t no_place4;       // place kernel: one pixel per thread (the context's no_place4 switch: identical bytes)
 };
 
 struct LaunchStream {

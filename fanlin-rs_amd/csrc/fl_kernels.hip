@@ -1519,7 +1519,7 @@ static hipError_t launch_place_t(const LaunchGeneric &g, bool border_only, hipSt
         if (!g.letterbox) return hipSuccess;
         hipLaunchKernelGGL((place_kernel<CS, PRE, true, true>), grid, dim3(256), 0, st, g.jobs, g.job_base);
     } else {
-        const bool by_four = g.max_dh <= 65535u && g.njobs <= 65535u && !getenv("FLGPU_NO_PLACE4"); // (grid limits of the y and z dimensions)
+        const bool by_four = g.max_dh <= 65535u && g.njobs <= 65535u && !g.no_place4; // (grid limits of the y and z dimensions)
         dim3 grid4(((g.max_dw + 3u) / 4u + 255u) / 256u, g.max_dh, g.njobs);
         if (g.letterbox) {
             if (by_four) hipLaunchKernelGGL((place4_kernel<CS, PRE, true>), grid4, dim3(256), 0, st, g.jobs, g.job_base);

@@ -84,6 +84,17 @@ struct alignas(16) MfmaItem {
     uint32_t flags;        // ITEM_* letterbox duties
 };
 
+// What the request of an item's FIRST K-block needs, one record per item in item order (the persistent workgroups of the full-width
+// kernel issue that request in the last pass of the item before: one scalar load there, nothing of the next item in registers earlier).
+struct alignas(32) MfmaReq {
+    const void *src;       // the job's source picture
+    uint32_t pitch;        // bytes per source row
+    uint32_t last_row;     // source rows - 1
+    uint32_t byte0;        // MfmaStrip::byte0 of the item's strip
+    uint32_t kb0;          // the item's first K-block
+    uint32_t pad[2];
+};
+
 // Vertical plan of one (axis, kept rows) pair.  All offsets are arena word offsets.
 //   kb_meta[nkb + 1] per K-block: bits 0-15 = tile that is complete after it (0xffff: none), bit 16/17 = set 0/1 has weights in it;
 //                  entry nkb = the all-zero K-block the kernel appends when `tail` is set (it completes the last tile)
@@ -136,6 +147,7 @@ void choose_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_
 struct LaunchMfma {
     const Job *jobs;
     const MfmaItem *items;
+    const MfmaReq *reqs;   // one per item (full-width arithmetic)
     const uint32_t *arena;
     uint32_t nitems;
     uint32_t cs;           // channels of the source (1..4)

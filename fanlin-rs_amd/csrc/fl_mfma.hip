@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <type_traits>
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <vector>
 
@@ -63,24 +64,18 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f
 // FW: full-width arithmetic (fl_mfma.h MFMA_ARITH_FULL) -- bytes as f16 subnormals x three-term weights, a 23-bit intermediate in
 // three byte planes x three weight digits; otherwise the packed arithmetic of rounds 2-3.  With FW, HLDS only says that the
 // launch's LDS has an operand area: whether a strip's operands live there is the strip's own flag (MfmaStrip::lds_ops).
+// Persistent workgroups (round 5, full-width arithmetic): the launch has one workgroup per CU and each walks the items
+// blockIdx.x, blockIdx.x + gridDim.x, ... -- with 160 KB of LDS and 512 x 256 registers a CU holds ONE workgroup, so with one item per
+// workgroup every item paid a dispatch, a prologue, the latency of its first K-block and the drain of its last tile with nothing in
+// flight for that CU (15-17 us of ~130).  Now the first K-block of item n + 1 is requested in the LAST pass of item n (the wave's
+// 8 KB of LDS are free once the transposed reads have returned) and flies under the last tile's stage, the conversion of its rows
+// and the next item's set-up.  The LDS counters run on across items (a tile's global number = tiles of earlier items + its number
+// in this one); the packed arithmetic keeps one item per workgroup (its launch has gridDim.x = nitems).
 template <int CS, bool LB, bool HLDS, int LAYOUT, bool FW>
-__global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items,
-                                                                   const uint32_t *__restrict__ arena, uint32_t ot_words, uint32_t spin_limit,
-                                                                   uint32_t *__restrict__ err_word
-#ifdef FL_MFMA_TIMING
-                                                                   , unsigned long long *__restrict__ dbg
-#endif
-)
+__global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items, const MfmaReq *__restrict__ reqs,
+                                                                   const uint32_t *__restrict__ arena, uint32_t nitems, uint32_t ot_words, uint32_t spin_limit,
+                                                                   uint32_t *__restrict__ err_word)
 {
-#ifdef FL_MFMA_TIMING // development aid (tools/build_ablate.sh ... -DFL_MFMA_TIMING): shader-clock cycles per phase of one workgroup's waves
-    unsigned long long tm_wait = 0, tm_read = 0, tm_mfma = 0, tm_flush = 0, tm_t0 = __builtin_readcyclecounter(), tm_a, tm_b;
-    const unsigned long long tm_rt0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
-#define TM_A() tm_a = __builtin_readcyclecounter()
-#define TM_B(acc_) do { tm_b = __builtin_readcyclecounter(); acc_ += tm_b - tm_a; tm_a = tm_b; } while (0)
-#else
-#define TM_A() do { } while (0)
-#define TM_B(acc_) do { } while (0)
-#endif
     // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh): 1 = no horizontal MFMAs / LDS adds, 2 = no conversion of
     // finished tiles, 32 = conversion without its global stores, 4 = no horizontal stage at all, 8 = no vertical MFMAs,
     // 128 = no LDS adds, 8192 (with 4) = the vertical pass alone, its sums kept alive
@@ -89,13 +84,30 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #else
     constexpr uint32_t ablate = 0;
 #endif
+    // experiments (-DFL_VARIANT=mask): 2 = eight digit products per unit (plane 0 x digit 0 dropped) and the four-instruction
+    // recombination, 4 = waves 4-7 start every item a few microseconds late (their stages then run beside the other waves' vertical
+    // passes), 16 = a chunk's planes are made beside the matrix instructions of the chunk before
+#ifdef FL_VARIANT
+    constexpr uint32_t variant = FL_VARIANT;
+#else
+    constexpr uint32_t variant = 0;
+#endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u, g = lane >> 4, i = lane & 15u;
     uint32_t wg_error = 0u; // a bounded wait expired in this lane's wave
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const MfmaItem it = items[blockIdx.x];
-    const Job jb = jobs[it.job];
-    const MfmaVPlan vp = *reinterpret_cast<const MfmaVPlan *>(arena + it.vplan_off);
-    const MfmaStrip sp = *reinterpret_cast<const MfmaStrip *>(arena + it.strip_off);
+    // The item this workgroup is on: the descriptors are read again at the top of every trip of the item loop below (nothing but the
+    // item's number is carried around the loop: the kernel has no registers to spare), everything derived from them is set in `enter_item`.
+    uint32_t item = blockIdx.x;
+    MfmaItem it;
+    Job jb;
+    MfmaVPlan vp;
+    MfmaStrip sp;
+    auto load_item = [&]() __attribute__((always_inline)) {
+        it = items[item];
+        jb = jobs[it.job];
+        vp = *reinterpret_cast<const MfmaVPlan *>(arena + it.vplan_off);
+        sp = *reinterpret_cast<const MfmaStrip *>(arena + it.strip_off);
+    };
     constexpr uint32_t np = mfma_out_pitch(LAYOUT); // words per output-tile row (compile-time: the row offsets of the LDS adds become immediates); column sp.nout is a dummy
 
     // (packed arithmetic: two output tiles that alternate; full width: ONE -- a wave converts its rows of a tile in the pass after
@@ -106,15 +118,15 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     uint32_t *conv_cnt = add_cnt + 2;
     const u32x4 *ops_lds = reinterpret_cast<const u32x4 *>(mfma_lds + NBUF * ot_words * 4u + CNT_BYTES);
     uint8_t *ring = mfma_ring + wave * RING_BYTES;
-    const u32x4 *ops_glb = reinterpret_cast<const u32x4 *>(arena + sp.ops_off);
+    const u32x4 *ops_glb = nullptr; // (set per item)
 
+    // once per workgroup: the output tile(s) and the counters start at zero (afterwards the conversions leave the tile zeroed and
+    // the counters run on)
     for (uint32_t k = tid; k < NBUF * ot_words + CNT_BYTES / 4u; k += THREADS) otile[k] = 0u;
-    if (HLDS && (!FW || sp.lds_ops))
-        for (uint32_t k = tid; k < sp.n_ops * 64u; k += THREADS) reinterpret_cast<u32x4 *>(mfma_lds + NBUF * ot_words * 4u + CNT_BYTES)[k] = ops_glb[k];
 
     // Letterbox frame: every workgroup paints the part next to its own band and strip (same split as the streaming kernel).
-    const uint32_t y_first = vp.y0 + 16u * it.tile0, y_end = min(vp.y0 + 16u * it.tile1, vp.y0 + vp.rows);
-    if (LB) {
+    auto paint_frame = [&]() __attribute__((always_inline)) {
+        const uint32_t y_first = vp.y0 + 16u * it.tile0, y_end = min(vp.y0 + 16u * it.tile1, vp.y0 + vp.rows);
         const uint32_t dx0 = sp.x0 == jb.cx ? 0u : jb.ox + sp.x0 - jb.cx;
         const uint32_t dx1 = sp.x1 == jb.cx + jb.cw ? jb.dw : jb.ox + sp.x1 - jb.cx;
         const uint32_t dy0 = y_first == jb.cy ? 0u : jb.oy + y_first - jb.cy;
@@ -133,55 +145,65 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         const uint32_t rx0 = max(dx0, jb.ox + jb.cw);
         const uint32_t rcols = dx1 > rx0 ? dx1 - rx0 : 0u;
         for (uint32_t k = tid; k < mrows * rcols; k += THREADS) d32[(my0 + k / rcols) * jb.dw + rx0 + k % rcols] = jb.fill;
-    }
-    __syncthreads();
+    };
 
     // ---- source rows -> LDS ---------------------------------------------------------------------------------------
     // Load instruction u of a K-block (u = 0..7): row octet u >> 1, column half u & 1.  Lane: row q = lane & 7 of the
     // octet, 16-byte column tile t = lane >> 3 of the half; the data lands lane-linear, i.e. as eight [8 rows][16 bytes]
     // tiles of 128 bytes, which is the block ds_read_b64_tr_b8 transposes.  Odd octets swap neighbouring tiles so that
     // the two 16-lane groups of a transposed read hit different banks.
-    const uint32_t pitch = jb.sw * (uint32_t)CS;
     const uint32_t lq = lane & 7u, lt = lane >> 3;
-    // Addresses: an SGPR base per row octet of the K-block + a 32-bit byte offset per lane that never changes (the lane's row of
-    // the octet times the pitch + its 16-byte column tile; descriptors promise < 4 GiB per picture): the eight requests of a
+    // Addresses: an SGPR base per row octet of the K-block + a 32-bit byte offset per lane that changes only with the item (the lane's
+    // row of the octet times the pitch + its 16-byte column tile; descriptors promise < 4 GiB per picture): the eight requests of a
     // K-block cost scalar adds only.  (Round 3 computed eight per-lane offsets per K-block: ~30 vector instructions and eight
     // registers in every pass.)  The picture's last K-block, whose rows past the end are clamped to the last row -- their
     // weights are zero, the bytes must merely be readable --, computes its offsets per lane.
     uint32_t voff[2][2]; // [column half][octet parity]
+    auto set_voff = [&](uint32_t pitch_, uint32_t byte0_) __attribute__((always_inline)) {
 #pragma unroll
-    for (uint32_t hh = 0; hh < 2; ++hh)
+        for (uint32_t hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (uint32_t par = 0; par < 2; ++par)
-            voff[hh][par] = lq * pitch + min(sp.byte0 + wave * kMfmaWaveCols + hh * 128u + ((lt ^ par) * 16u), pitch - 16u); // (clamped so that 16 bytes stay inside the row)
-    const uint32_t last_row = jb.sh - 1u;
+            for (uint32_t par = 0; par < 2; ++par)
+                voff[hh][par] = lq * pitch_ + min(byte0_ + wave * kMfmaWaveCols + hh * 128u + ((lt ^ par) * 16u), pitch_ - 16u); // (clamped so that 16 bytes stay inside the row)
+    };
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring);
     // (the requests go out the moment the transposed reads have returned: between "the rows have landed" and "the next rows are
     // requested" the wave's 8 KB of LDS are not in flight, and with one K-block in flight per wave every such cycle is missing
     // bandwidth.)
-    auto request = [&](uint32_t s) __attribute__((always_inline)) {
+    // K-block s of the picture at `src_` (rows of `pitch_` bytes, the last one `last_row_`); voff must be set for that picture
+    auto request_from = [&](const void *src_, uint32_t pitch_, uint32_t last_row_, uint32_t s) __attribute__((always_inline)) {
         // (in slot order: slots 2 ro and 2 ro + 1 are the two 128-byte halves of the same eight 256-byte row pieces, and memory
         // serves them best back to back -- requesting the even slots as soon as "their" transposed reads had returned and the odd
         // ones later measured 6 % SLOWER)
-        const uint8_t *kb_base = static_cast<const uint8_t *>(jb.src) + (size_t)(s * kMfmaKRows) * pitch;
-        if (s * kMfmaKRows + kMfmaKRows - 1u <= last_row) {
+        const uint8_t *kb_base = static_cast<const uint8_t *>(src_) + (size_t)(s * kMfmaKRows) * pitch_;
+        if (s * kMfmaKRows + kMfmaKRows - 1u <= last_row_) {
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
                 // (inline asm: hipcc orders EVERY later LDS access behind a global_load_lds it knows about -- s_waitcnt vmcnt(0) in
                 // front of the first counter or operand read -- which would park the whole horizontal stage behind the K-block just
                 // requested.  The transfers are waited for by hand, wait_vm0() in front of the transposed reads.)
-                const uint8_t *ob = kb_base + (size_t)((u >> 1) * 8u) * pitch;
+                const uint8_t *ob = kb_base + (size_t)((u >> 1) * 8u) * pitch_;
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[u & 1u][(u >> 1) & 1u]), "s"(ob), "s"(ring_lds + u * 1024u) : "memory");
             }
         } else {
-            const uint32_t rows_left = last_row - s * kMfmaKRows; // < 31
+            const uint32_t rows_left = last_row_ - s * kMfmaKRows; // < 31
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t o = voff[u & 1u][(u >> 1) & 1u] + (min((u >> 1) * 8u + lq, rows_left) - lq) * pitch;
+                const uint32_t o = voff[u & 1u][(u >> 1) & 1u] + (min((u >> 1) * 8u + lq, rows_left) - lq) * pitch_;
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(o), "s"(kb_base), "s"(ring_lds + u * 1024u) : "memory");
             }
         }
     };
+    uint32_t pitch = 0, last_row = 0;
+    auto request = [&](uint32_t s) __attribute__((always_inline)) { request_from(jb.src, pitch, last_row, s); };
+    // the first K-block of item `which` (its MfmaReq record: one scalar load); leaves voff set for that item
+    auto request_first_of = [&](uint32_t which) __attribute__((always_inline)) {
+        const MfmaReq r = reqs[which];
+        set_voff(r.pitch, r.byte0);
+        request_from(r.src, r.pitch, r.last_row, r.kb0);
+    };
+    // The first item's first K-block goes out before anything else: it flies under the set-up below.
+    request_first_of(item);
 
     f32x4 acc[2][16];
 #pragma unroll
@@ -190,31 +212,64 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         for (int ct = 0; ct < 16; ++ct) acc[s2][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const uint32_t traddr = (i >> 1) * 16u + (i & 1u) * 8u;
-    const u32x4 *vw = reinterpret_cast<const u32x4 *>(arena + vp.w_off);
+    const u32x4 *vw = nullptr; // (set per item)
     // this wave's 4 chunks x 3 tiles x { first output, operand of each weight digit, high digit first }, kept in SGPRs
     constexpr int CE = FW ? 4 : 3, NT = FW ? 3 : 2; // words per tile slot; f16 terms per vertical weight
-    int32_t ctab[12 * CE];
-    {
-        const int32_t *cp = reinterpret_cast<const int32_t *>(arena + sp.ctab_off) + wave * (12u * CE);
-#pragma unroll
-        for (int k = 0; k < 12 * CE; ++k) ctab[k] = __builtin_amdgcn_readfirstlane(cp[k]);
-    }
-    const uint32_t hs = sp.hs;
+    // (full width: two words per unit -- { first output (signed) | high digit's operand << 16 }, { middle digit's operand | low
+    // digit's << 16 }: 24 scalar registers instead of 48, in a kernel that has none to spare; unpacking is scalar work)
+    int32_t ctab[FW ? 24 : 12 * CE];
+    uint32_t hs = 0;
     // packed: sums are (value - 128) * 2^(hs + 6) with the low plane offset by 128; full: value * 2^20 + (2^22 - 0x8080) * 2^6 - 2^27
     // (the byte planes carry 2^22 + x - 0x8080 for x = (value - 128) * 2^14, the weights of an output sum to exactly 2^hs, and every
     // wave shifts its part of the sum down to 2^-20 steps before it adds it to the tile, see the stage)
-    const int32_t round_add = FW ? (int32_t)(-132112384 + (1 << (kMfmaOutFracBitsFull - 1u))) : (int32_t)((128u << hs) + (1u << (hs + kMfmaXFracBits - 1u)));
-    const uint32_t out_shift = hs + kMfmaXFracBits; // (packed arithmetic)
-    const uint32_t pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
-    const uint32_t npx = sp.x1 - sp.x0;
+    int32_t round_add = 0;
+    uint32_t out_shift = 0; // (packed arithmetic)
+    uint32_t pix_base = 0, npx = 0;
+    uint32_t ops_resident = 0xffffffffu; // arena offset of the operands the LDS operand area holds (a workgroup's consecutive items often share a strip)
+    // Everything that hangs on the item: called once per trip of the item loop, with the item's first K-block already in flight.
+    // The LDS operand area may be written here: every wave has finished the previous item's last stage (its epilogue waited for all
+    // eight waves' adds of the last tile).
+    auto enter_item = [&]() __attribute__((always_inline)) {
+        pitch = jb.sw * (uint32_t)CS; last_row = jb.sh - 1u;
+        vw = reinterpret_cast<const u32x4 *>(arena + vp.w_off);
+        ops_glb = reinterpret_cast<const u32x4 *>(arena + sp.ops_off);
+        hs = sp.hs;
+        round_add = FW ? (int32_t)(-132112384 + (1 << (kMfmaOutFracBitsFull - 1u))) : (int32_t)((128u << hs) + (1u << (hs + kMfmaXFracBits - 1u)));
+        out_shift = hs + kMfmaXFracBits;
+        pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
+        npx = sp.x1 - sp.x0;
+        {
+            const int32_t *cp = reinterpret_cast<const int32_t *>(arena + sp.ctab_off) + wave * (12u * CE);
+            if constexpr (FW) {
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int32_t o = __builtin_amdgcn_readfirstlane(cp[u * 4]), i2 = __builtin_amdgcn_readfirstlane(cp[u * 4 + 1]),
+                                  i1 = __builtin_amdgcn_readfirstlane(cp[u * 4 + 2]), i0 = __builtin_amdgcn_readfirstlane(cp[u * 4 + 3]);
+                    // (a slot not in use has first output 2^30: any value that puts every lane past the strip's outputs does)
+                    const int32_t oc = (o > 32767 || o < -32768) ? -32768 : o;
+                    ctab[2 * u] = (int32_t)(((uint32_t)oc & 0xffffu) | ((uint32_t)i2 << 16));
+                    ctab[2 * u + 1] = (int32_t)(((uint32_t)i1 & 0xffffu) | ((uint32_t)i0 << 16));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 12 * CE; ++k) ctab[k] = __builtin_amdgcn_readfirstlane(cp[k]);
+            }
+        }
+        if (HLDS && (!FW || sp.lds_ops) && sp.ops_off != ops_resident) {
+            for (uint32_t k = tid; k < sp.n_ops * 64u; k += THREADS) reinterpret_cast<u32x4 *>(mfma_lds + NBUF * ot_words * 4u + CNT_BYTES)[k] = ops_glb[k];
+            ops_resident = sp.ops_off;
+        }
+        if (LB) paint_frame();
+    };
 
     constexpr uint32_t CONV_G = (mfma_max_outputs(LAYOUT) / (uint32_t)CS + 63u) / 64u;
     // One wave's share (2 of the 16 rows) of a finished output tile: i32 sums -> bytes -> destination.  A strip row has
     // at most kMfmaMaxStripOutputs[Wide] / CS pixels = CONV_G groups of 64 lanes.  All LDS reads of the share are issued before the first of
     // them is used; lanes past the row's end repeat its last pixel (same words read, same value stored to the same address), so
-    // nothing here switches lanes off; rows past the picture's end (short last tile) are skipped as a whole -- their LDS words
-    // are not cleared, the workgroup does not use the buffer again.
-    auto convert_rows = [&](uint32_t tile, uint32_t buf) __attribute__((always_inline)) {
+    // nothing here switches lanes off; rows past the picture's end (short last tile) are skipped as a whole.  `whole_rows` (the
+    // item's last tile, full-width arithmetic): the wave's two rows of the LDS tile are zeroed from end to end afterwards -- the
+    // skipped rows and the dummy columns too: the next item of this workgroup may have a wider strip.
+    auto convert_rows = [&](uint32_t tile, uint32_t buf, bool whole_rows) __attribute__((always_inline)) {
         uint32_t *ot = otile + buf * ot_words;
         const uint32_t ngrp = (npx + 63u) >> 6; // lane groups in use (wave-uniform)
         // (both rows' sums are fetched up front where the registers allow it -- Rgb8, the flagship: 12 of them; the other
@@ -281,11 +336,11 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 }
             }
         }
+        if (whole_rows) {
+            for (uint32_t k = lane; k < 2u * np; k += 64u) ot[2u * wave * np + k] = 0u;
+        }
     };
 
-#ifdef FL_MFMA_TIMING
-    const unsigned long long tm_loop0 = __builtin_readcyclecounter();
-#endif
     // A K-block's weights (64 or 96 bytes per lane, served by the L2) and its meta word are fetched one K-block ahead: the vmcnt(0)
     // in front of the transposed reads covers them for free, while fetched at the top of their own K-block they would add one L2
     // round trip to every pass of the loop.  They are requested right BEHIND the pass's vertical matrix instructions, into the
@@ -297,15 +352,13 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     uint32_t vzero = 0u;
     asm("" : "+v"(vzero));
     u32x4 wv[2 * NT];
-    uint32_t meta_n = arena[vp.meta_off + it.kb0 + vzero];
-#pragma unroll
-    for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(it.kb0 * (2u * NT) + k) * 64u + lane];
-    request(it.kb0);
+    uint32_t meta_n = 0u;
     // Full-width arithmetic, one LDS output tile: a wave converts its two rows of a tile not inside the NEXT tile's stage (the packed
     // form, two tiles) but as soon as every wave has added its sums -- in the passes right after the tile's own stage, which wait
-    // for rows anyway.  pend_li: the tile (band-local number) this wave has added to but not converted yet.
-    uint32_t pend_li = 0xffffffffu;
-    auto try_convert = [&](bool must) __attribute__((always_inline)) {
+    // for rows anyway.  pend_li: the tile this wave has added to but not converted yet, numbered through the workgroup's whole
+    // walk (gl_base = tiles of the items before this one: the counters run on across items).
+    uint32_t pend_li = 0xffffffffu, gl_base = 0u;
+    auto try_convert = [&](bool must, bool whole_rows) __attribute__((always_inline)) {
         const uint32_t need = kMfmaWaves * (pend_li + 1u);
         uint32_t spin = 0;
         for (;;) {
@@ -317,23 +370,35 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             __builtin_amdgcn_s_sleep(2);
         }
         if (spin >= spin_limit) wg_error = 1u; // (as in the packed form's wait: a limit of 0 -- the tests' -- reports every wait)
-        if (!(ablate & 2u)) convert_rows(it.tile0 + pend_li, 0u);
+        if (!(ablate & 2u)) convert_rows(it.tile0 + (pend_li - gl_base), 0u, whole_rows);
         pend_li = 0xffffffffu;
         if (lane == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __hip_atomic_fetch_add(&conv_cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
+    for (;;) { // ---- the items of this workgroup ----------------------------------------------------------------------------------
+    const uint32_t next_item = item + gridDim.x;
+    const bool has_next_item = FW && next_item < nitems;
+    load_item();
+    enter_item();
+    meta_n = arena[vp.meta_off + it.kb0 + vzero];
+#pragma unroll
+    for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(it.kb0 * (2u * NT) + k) * 64u + lane];
+    // the output tile is zero (first item: the clear above; later ones: every wave zeroed its rows in the epilogue and the first
+    // stage waits for all of them, conv_cnt) and the operands are in place for every wave
+    __syncthreads();
+    if ((variant & 4u) && wave >= 4u) {
+        for (int k = 0; k < 2; ++k) __builtin_amdgcn_s_sleep(100); // 2 x 100 x 64 cycles = 5.4 us, a pass and a half
+    }
     // (kb_end: one pass more than the band has K-blocks when the picture's short last tile ends together with the tile before
     // it -- that pass runs on the table's all-zero K-block, index vp.nkb, whose meta word names the last tile: the matrix unit
     // adds zeros to whatever the transposed reads deliver, nothing is requested, and the loop body stays as it is)
     const uint32_t kb_end = it.kb1 + ((vp.tail && it.tile1 == vp.ntiles) ? 1u : 0u);
     for (uint32_t s = it.kb0; s < kb_end; ++s) {
         const bool have_next = s + 1u < it.kb1;
-        TM_A();
         __builtin_amdgcn_s_setprio(3); // (from here to the next request this wave's instructions go first on its SIMD: its LDS is not in flight)
         wait_vm0();
-        TM_B(tm_wait);
         const uint32_t meta = __builtin_amdgcn_readfirstlane(meta_n);
         v2i raw[16];
 #pragma unroll
@@ -343,11 +408,15 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         }
         wait_lgkm0();
         if (have_next) request(s + 1u);
+        else if (has_next_item && s + 1u == kb_end) {
+            // this item's last pass: the wave's 8 KB are free for good -- the NEXT item's first K-block flies under the last tile's
+            // stage, the epilogue and the next item's set-up
+            request_first_of(next_item);
+        }
         __builtin_amdgcn_s_setprio(0);
         if constexpr (FW) {
-            if (pend_li != 0xffffffffu) try_convert(false);
+            if (pend_li != 0xffffffffu) try_convert(false, false);
         }
-        TM_B(tm_read);
         // (the meta word says whether the K-block has weights for a second, younger tile (set 1) at all: about a third of the
         // K-blocks touch one tile only, and a matrix instruction on zeros costs the same time and nearly the same power --
         // this kernel runs at the socket's power limit, so what it does not compute is what makes it faster)
@@ -382,7 +451,6 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #pragma unroll
             for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(sn * (2u * NT) + k) * 64u + lane];
         }
-        TM_B(tm_mfma);
         const uint32_t ft = meta & 0xffffu;
         if (ft != 0xffffu) { // output tile ft is complete
             const bool mine = ft >= it.tile0 && ft < it.tile1 && !(ablate & 4u);
@@ -419,8 +487,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     // inside); its three bytes are the planes: the top one (7 bits) as it is, the lower two offset by 128 so that they are
                     // signed (the offsets and the 2^22 come out again as constants, round_add above).
                     u32x4 p2[4], p1[4], p0[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                    auto make_planes = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             const f32x4 v = acc[0][4 * c + a];
@@ -431,6 +498,9 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                             p1[c][a] = __builtin_amdgcn_perm(t1, t0, 0x07060302u) ^ 0x80808080u;
                             p2[c][a] = __builtin_amdgcn_perm(x1, x0, 0x0c0c0602u) | __builtin_amdgcn_perm(x3, x2, 0x06020c0cu);       // (x0.b2, x1.b2, x2.b2, x3.b2)
                         }
+                    };
+                    make_planes(0);
+                    if (!(variant & 16u)) { make_planes(1); make_planes(2); make_planes(3); }
                     // Units (chunk c of 64 byte columns, tile slot t of 16 outputs) as in the packed form; per unit three operands (weight
                     // digits 2, 1, 0) and all nine digit products, summed by the matrix unit into five scales: L[k] = sum over i + j = k of
                     // plane i x digit j, exact in i32 (|L| < 2^22: 64 products of at most 2^14, three of them per term at most).
@@ -449,7 +519,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     auto stage = [&](auto in_lds) __attribute__((always_inline)) {
                         constexpr bool OL = decltype(in_lds)::value;
                         auto load_ops = [&](int k, int u) __attribute__((always_inline)) { // operands of unit u = 3 c + t into buffer k & 1
-                            uint32_t i2 = (uint32_t)ctab[u * 4 + 1], i1 = (uint32_t)ctab[u * 4 + 2], i0 = (uint32_t)ctab[u * 4 + 3];
+                            uint32_t i2 = (uint32_t)ctab[2 * u] >> 16, i1 = (uint32_t)ctab[2 * u + 1] & 0xffffu, i0 = (uint32_t)ctab[2 * u + 1] >> 16;
                             asm volatile("" : "+s"(i2), "+s"(i1), "+s"(i0)); // (see the packed form)
                             hb[k & 1][0] = OL ? ops_lds[i2 * 64u + lane] : ops_glb[i2 * 64u + lane];
                             hb[k & 1][1] = OL ? ops_lds[i1 * 64u + lane] : ops_glb[i1 * 64u + lane];
@@ -464,7 +534,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                             l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, z, 0, 0, 0);
                             l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, z, 0, 0, 0);
                             l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, i32x4{rnd, rnd, rnd, rnd}, 0, 0, 0);
-                            l[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, z, 0, 0, 0);
+                            if (!(variant & 2u)) l[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, z, 0, 0, 0);
                             l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, l[3], 0, 0, 0);
                             l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, l[2], 0, 0, 0);
                             l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, l[1], 0, 0, 0);
@@ -473,13 +543,21 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                         auto recombine = [&](int k, int u) __attribute__((always_inline)) {
                             // lanes outside the strip's outputs (and every lane of a slot not in use: operand 0, first output 2^30) add
                             // into dummy columns of their own, nout + i: no lane is switched off, no two lanes share an address
-                            const uint32_t o = (uint32_t)(ctab[u * 4] + (int32_t)i);
+                            const uint32_t o = (uint32_t)((int32_t)(int16_t)(ctab[2 * u] & 0xffff) + (int32_t)i);
                             const uint32_t col = o < sp.nout ? o : sp.nout + i;
                             const i32x4 *l = L[k & 1];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int32_t low = (((l[2][r] << 8) + l[1][r]) + (l[0][r] >> 8)) >> slo;
-                                const uint32_t p = ((uint32_t)l[4][r] << s4) + ((uint32_t)l[3][r] << s3) + (uint32_t)low;
+                                uint32_t p;
+                                if (variant & 2u) {
+                                    // (plane 0 x digit 0 -- at most 2^20 in units of 2^-38 of a pixel step, i.e. below 2^-18 of a step --
+                                    // is not computed: eight products, and the recombination is two shift-adds, a shift and a shift-add)
+                                    const int32_t low = (int32_t)shl8_add((uint32_t)l[2][r], (uint32_t)l[1][r]) >> slo;
+                                    p = ((uint32_t)l[4][r] << s4) + (((uint32_t)l[3][r] << s3) + (uint32_t)low);
+                                } else {
+                                    const int32_t low = (((l[2][r] << 8) + l[1][r]) + (l[0][r] >> 8)) >> slo;
+                                    p = ((uint32_t)l[4][r] << s4) + ((uint32_t)l[3][r] << s3) + (uint32_t)low;
+                                }
                                 if (ablate & 128u) { asm volatile("" : : "v"(p), "v"(col)); continue; }
                                 __hip_atomic_fetch_add(&ot[(4u * g + r) * np + col], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
@@ -491,12 +569,12 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                         // one tile: this wave's rows of the previous tile, if no pass since has found them complete, and then every
                         // other wave's -- the tile must be all zeros again before the first add
                         (void)wait_for_the_tiles;
-                        if (pend_li != 0xffffffffu) try_convert(true);
+                        if (pend_li != 0xffffffffu) try_convert(true, false);
                         uint32_t spin = 0;
                         for (;;) {
                             const uint32_t cv = __hip_atomic_load(&conv_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                            if (cv >= kMfmaWaves * li || ++spin >= spin_limit) break;
+                            if (cv >= kMfmaWaves * (gl_base + li) || ++spin >= spin_limit) break;
                             __builtin_amdgcn_s_sleep(1);
                         }
                         if (spin >= spin_limit) wg_error = 1u;
@@ -507,6 +585,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                             for (int k = 0; k < 8; ++k) {
                                 if (k + 1 < 8) unit_mfma(k + 1, FL_U01(k + 1));
                                 if (k + 2 < 8) load_ops(k + 2, FL_U01(k + 2)); // (into the registers unit k's matrix instructions have just read)
+                                if ((variant & 16u) && k % 2 == 0 && k < 6) make_planes(k / 2 + 1); // (the next chunk's planes beside this chunk's matrix instructions)
                                 recombine(k, FL_U01(k));
                             }
                             if (sp.slots > 2u) {
@@ -562,7 +641,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     };
                     if (!(ablate & 1u)) { load_ops(0); load_ops(1); }
                     wait_for_the_tiles();
-                    if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u); // this wave's two rows of the previous tile
+                    if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u, false); // this wave's two rows of the previous tile
                     if (!(ablate & 1u)) {
                         unit_mfma(0);
     #pragma unroll
@@ -587,7 +666,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     __hip_atomic_fetch_add(&add_cnt[buf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (!FW && li >= 1u) __hip_atomic_fetch_add(&conv_cnt[buf ^ 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if constexpr (FW) pend_li = li;
+                if constexpr (FW) pend_li = gl_base + li;
             }
             // The younger tile becomes the older one: set 0 <- set 1, set 1 <- 0, so that the finished tile is always read from
             // compile-time registers (set 0).  Plain moves: at the power limit 128 moves are cheaper than the 32 matrix
@@ -597,32 +676,26 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 acc[0][ct] = acc[1][ct];
                 acc[1][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
-            TM_B(tm_flush);
         }
     }
-#ifdef FL_MFMA_TIMING
-    if ((blockIdx.x == 8u || blockIdx.x == 1500u || blockIdx.x == 2900u) && lane == 0) {
-        unsigned long long *d = dbg + ((blockIdx.x == 8u ? 0u : blockIdx.x == 1500u ? 1u : 2u) * 8u + wave) * 8u;
-        d[0] = tm_wait; d[1] = tm_read; d[2] = tm_mfma; d[3] = tm_flush;
-        d[4] = __builtin_readcyclecounter() - tm_t0;
-        d[5] = tm_loop0 - tm_t0;
-        d[6] = __builtin_amdgcn_s_memrealtime() - tm_rt0;
-        d[7] = tm_rt0;
-    }
-    if (tid == 0u) { // every workgroup: when it ran and where (XCC_ID: hardware register 20, bits 3:0; HW_ID: register 4, CU 11:8, SH 12, SE 15:13)
-        unsigned long long *d = dbg + 3u * 64u + (size_t)blockIdx.x * 4u;
-        d[0] = tm_rt0;
-        d[1] = __builtin_amdgcn_s_memrealtime();
-        d[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-        d[3] = __builtin_readcyclecounter() - tm_t0;
-    }
-#endif
-    __syncthreads(); // every wave has added its sums of the last tile
+    // ---- the item's epilogue -----------------------------------------------------------------------------------------------------
     if constexpr (FW) {
-        if (pend_li != 0xffffffffu && !(ablate & 6u)) convert_rows(it.tile0 + pend_li, 0u);
+        // this wave's two rows of the last tile, once every wave has added its sums (a bounded spin; the next item's first K-block is
+        // in flight meanwhile).  The rows are zeroed from end to end: the LDS tile is the next item's.
+        if (pend_li != 0xffffffffu) try_convert(true, true);
     } else {
-        if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u);
+        __syncthreads(); // every wave has added its sums of the last tile
+        if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u, false);
     }
+    if (!has_next_item) break;
+    gl_base += it.tile1 - it.tile0;
+    item = next_item;
+    // (a band's younger accumulator set may hold rows of the tile after the band: every item starts from zero)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) acc[s2][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    } // ---- items ---------------------------------------------------------------------------------------------------------------
     if (wg_error && lane == 0) atomicOr(err_word, FLGPU_DEVERR_MFMA_WAIT);
 }
 
@@ -643,52 +716,35 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 {
     constexpr bool WIDE = LAYOUT == 1;
     const size_t lds = FW ? mfma_lds_bytes_full(LAYOUT) : mfma_lds_bytes(m.max_nout, HLDS, WIDE);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the attribute is per function and device (the size is a constant of the instantiation): set once per (instantiation, device)
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-#ifdef FL_MFMA_TIMING
-    static unsigned long long *dbg = nullptr;
-    static int launches = 0;
-    constexpr size_t kDbgWgs = 16384;
-    if (!dbg) { (void)hipMalloc(&dbg, (3 * 64 + kDbgWgs * 4) * 8); (void)hipMemset(dbg, 0, (3 * 64 + kDbgWgs * 4) * 8); }
-    if (m.nitems > kDbgWgs) return hipErrorInvalidValue;
-    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word, dbg);
-    if ((++launches == 5 || launches == 100) && m.nitems > 2900) {
-        unsigned long long h[3 * 64];
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-        for (int b = 0; b < 3; ++b)
-            for (int w = 0; w < 8; ++w) {
-                const unsigned long long *d = h + (b * 8 + w) * 8;
-                fprintf(stderr, "mfma timing launch %d wg %d wave %d: wait %llu, reads+request %llu, vertical mfma %llu, tile stage %llu, total %llu cycles (%llu before the loop) in %.2f us = %.0f MHz, started at %.2f us\n",
-                        launches, b, w, d[0], d[1], d[2], d[3], d[4], d[5], d[6] * 0.01, d[6] ? d[4] / (d[6] * 0.01) : 0.0, (d[7] - h[7]) * 0.01);
-            }
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
-    if (launches == 100 && m.nitems > 2900) { // where and when every workgroup of this launch ran
-        std::vector<unsigned long long> w((size_t)m.nitems * 4);
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(w.data(), dbg + 3 * 64, w.size() * 8, hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (uint32_t i = 0; i < m.nitems; ++i) { t0 = std::min(t0, w[4 * i]); t1 = std::max(t1, w[4 * i + 1]); }
-        double xend[8] = {0}, xdur[8] = {0}, xcyc[8] = {0}; unsigned xn[8] = {0};
-        std::map<unsigned, unsigned> per_cu;
-        double dmin = 1e30, dmax = 0, dsum = 0;
-        for (uint32_t i = 0; i < m.nitems; ++i) {
-            const unsigned xcc = (unsigned)(w[4 * i + 2] >> 32) & 15u, hw = (unsigned)w[4 * i + 2];
-            const double dur = (double)(w[4 * i + 1] - w[4 * i]) * 0.01, end = (double)(w[4 * i + 1] - t0) * 0.01;
-            xend[xcc & 7] = std::max(xend[xcc & 7], end); xdur[xcc & 7] += dur; xcyc[xcc & 7] += (double)w[4 * i + 3]; xn[xcc & 7]++;
-            per_cu[(xcc << 16) | (hw & 0xff00u)]++;
-            dmin = std::min(dmin, dur); dmax = std::max(dmax, dur); dsum += dur;
-        }
-        unsigned cmin = ~0u, cmax = 0;
-        for (auto &kv : per_cu) { cmin = std::min(cmin, kv.second); cmax = std::max(cmax, kv.second); }
-        fprintf(stderr, "mfma wg times: launch span %.1f us; workgroup duration min %.1f mean %.1f max %.1f us; %zu CUs ran %u .. %u workgroups each\n",
-                (double)(t1 - t0) * 0.01, dmin, dsum / m.nitems, dmax, per_cu.size(), cmin, cmax);
-        for (int x = 0; x < 8; ++x)
-            fprintf(stderr, "  xcc %d: %u workgroups, mean %.1f us (%.0f cycles), last one ends at %.1f us\n", x, xn[x], xn[x] ? xdur[x] / xn[x] : 0.0, xn[x] ? xcyc[x] / xn[x] : 0.0, xend[x]);
-    }
+    // full-width arithmetic: persistent workgroups, one per CU, each walking items blockIdx.x, blockIdx.x + gridDim.x, ... (the
+    // kernel's header says why); the packed arithmetic keeps one item per workgroup
+    uint32_t grid = m.nitems;
+#ifdef FL_VARIANT
+    constexpr bool persistent = !(FL_VARIANT & 8); // (experiment: 8 = one item per workgroup, as the packed arithmetic)
 #else
-    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<m.nitems, THREADS, lds, st>>>(m.jobs, m.items, m.arena, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word);
+    constexpr bool persistent = true;
 #endif
+    if (FW && persistent) {
+        static std::atomic<int> cus[64];
+        int n = cus[dev & 63].load(std::memory_order_acquire);
+        if (!n) {
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            cus[dev & 63].store(n, std::memory_order_release);
+        }
+        grid = std::min<uint32_t>(m.nitems, (uint32_t)n);
+    }
+    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<grid, THREADS, lds, st>>>(m.jobs, m.items, m.reqs, m.arena, m.nitems, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word);
     return hipGetLastError();
 }
 

@@ -469,7 +469,7 @@ try {
             // device then work side by side, and a burst of callers no longer queues for CPUs.
             // No more host decoders at once than the process has CPUs: sixty-four runnable decoders on sixteen CPUs all finish late
             // (p99 of the request 60 ms against 20 ms with 32 callers, profiles/r03_latency_jpeg_sources.txt).
-            const int policy = device_huffman_policy(src->capacity);
+            const int policy = device_huffman_policy(c, src->capacity);
             bool on_host = policy == 0;
             {
                 std::unique_lock<std::mutex> lk(c->dec_mu);

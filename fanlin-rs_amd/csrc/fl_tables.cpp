@@ -177,8 +177,12 @@ void build_strip(const HostAxis &h, uint32_t x0, uint32_t x1, uint32_t lanes, ui
         out.jmax = std::max(out.jmax, cnt[t]);
     }
     {   // the kernel unrolls its column loop by 4 and finishes odd counts in a remainder loop
-        const char *pad = getenv("FLGPU_JMAX_PAD"); // experiment knob: 4 restores the padded tables
+#ifdef FL_EXPERIMENT
+        const char *pad = getenv("FLGPU_JMAX_PAD"); // experiment builds only: 4 restores the padded tables
         const uint32_t m = pad ? (uint32_t)std::max(1, atoi(pad)) : 1u;
+#else
+        const uint32_t m = 1u;
+#endif
         out.jmax = std::max(1u, (out.jmax + m - 1u) / m * m);
     }
     const uint32_t dummy = n * out.ks * 16u;

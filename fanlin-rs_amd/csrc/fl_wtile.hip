@@ -3,6 +3,7 @@
 // (src/handler.rs:229-255 of the reference).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <type_traits>
 
@@ -131,7 +132,10 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
         cached[s] = 0xffffffffu;
         uint32_t nk = 0;
         if (NSLOT == 1 && sp.common_ops != 0xffffffffu && sp.common_nk <= (uint32_t)NKMAX) { cached[s] = sp.common_ops; nk = sp.common_nk; }
-        else if (nt < sp.n1) { cached[s] = nts[nt].ops; nk = nts[nt].nk; }
+        // (only what the NKMAX register steps hold: a tile with more K-steps -- a blur of sigma > ~21 whose tiles need 7 or 8 --
+        // stays uncached and goes through fly(), which walks all of its steps; cached with its first NKMAX steps it would
+        // match okA below and pair() would drop the rest of its taps)
+        else if (nt < sp.n1 && nts[nt].nk <= (uint32_t)NKMAX) { cached[s] = nts[nt].ops; nk = nts[nt].nk; }
         const u32x4 *src = reinterpret_cast<const u32x4 *>(plan + (cached[s] != 0xffffffffu ? cached[s] : 0u));
 #pragma unroll
         for (int k = 0; k < NKMAX; ++k)
@@ -390,10 +394,17 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
 template <int NSLOT, int NKMAX>
 hipError_t launch_wtile_t(const LaunchWtile &m, hipStream_t st)
 {
-    static bool attr_set = false; // (per instantiation; the attribute is per function and device, contexts on other devices set it again harmlessly)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_wtile_kernel<NSLOT, NKMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr_set;
+    // the attribute is per function and device: set once per (instantiation, device), not with every launch
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_wtile_kernel<NSLOT, NKMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.fetch_or(bit, std::memory_order_release);
+    }
     resample_wtile_kernel<NSLOT, NKMAX><<<m.nitems, kWtThreads, m.lds_bytes, st>>>(m.jobs, m.items, m.arena, m.letterbox, m.invert);
     return hipGetLastError();
 }

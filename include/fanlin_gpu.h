@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define FLGPU_ABI_VERSION 5
+#define FLGPU_ABI_VERSION 6
 
 typedef enum flgpu_status {
     FLGPU_OK = 0,
@@ -380,6 +380,18 @@ int flgpu_import_tables(flgpu_ctx *ctx, const void *src_device, uint64_t bytes);
 
 int flgpu_get_stats(flgpu_ctx *ctx, flgpu_stats *out);
 int flgpu_reset_stats(flgpu_ctx *ctx);
+
+/* Test and experiment switches of a context (ABI 6).  The reference shares ONE Arc<State> between all its worker threads
+ * (src/main.rs:108-112), so nothing in the library may depend on the process environment after start-up: getenv races setenv in a
+ * multi-threaded server, and a stray variable must not change output bytes.  The environment is read exactly once, in flgpu_create
+ * (FLGPU_<KEY IN CAPITALS> seeds the switch `key`); afterwards a switch changes only through this call, atomically, for the
+ * context, its queue lanes and its device shards.  Keys (csrc/fl_context.h DebugKey): "no_mfma", "force_generic", "no_wtile",
+ * "wtile_blur_always", "wtile_first", "mfma_arith" (0 full width, 1 packed), "force_bands", "no_tile", "no_place4", "host_huffman",
+ * "device_huffman_always", "device_huffman_min_bytes", "mfma_spin_limit", "debug_mfma", "debug_jh"; "reset" restores every default.
+ * Only "no_mfma", "force_generic", "no_wtile", "wtile_first" and "mfma_arith" can change a result, by at most 1 LSB (they pick
+ * another resample kernel).  Unknown key: FLGPU_ERR_INVALID_ARG. */
+int flgpu_debug_set(flgpu_ctx *ctx, const char *key, int64_t value);
+int flgpu_debug_get(flgpu_ctx *ctx, const char *key, int64_t *value);
 
 /* ---- diagnostics (host only; used by the CPU test-suite) ------------------- */
 

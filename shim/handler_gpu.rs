@@ -57,6 +57,7 @@ extern "C" {
     fn flgpu_transform_batch(ctx: *mut c_void, n: usize, srcs: *const FlImage, ps: *const FlParams, dsts: *mut FlImage) -> c_int;
     fn flgpu_strerror(status: c_int) -> *const c_char;
     fn flgpu_abi_version() -> u32;
+    fn flgpu_debug_set(ctx: *mut c_void, key: *const c_char, value: i64) -> c_int;
 }
 
 /// Owned by handler::State next to `cmyk2rgb` (src/handler.rs:14-21); created once at boot (src/main.rs:74-76).
@@ -79,7 +80,7 @@ impl Gpu {
     /// `devices`: HIP ordinals of the node's GPUs (`&[0]` for one); all of them serve the one shared State,
     /// as all tokio workers share one `Arc<State>` (src/main.rs:108-112).
     pub fn new(max_clients: u32, devices: &[i32], use_embedded_profile: bool) -> Result<Self, String> {
-        assert_eq!(unsafe { flgpu_abi_version() }, 5, "libfanlin_gpu.so / shim mismatch");
+        assert_eq!(unsafe { flgpu_abi_version() }, 6, "libfanlin_gpu.so / shim mismatch");
         let mut cfg = FlConfig { device: devices.first().copied().unwrap_or(-1), max_batch: max_clients.max(1),
                                  flush_timeout_us: 200, use_embedded_profile: use_embedded_profile as u32, ..Default::default() };
         if devices.len() > 1 {
@@ -89,6 +90,14 @@ impl Gpu {
         let mut st = 0;
         let p = unsafe { flgpu_create(&cfg, &mut st) };
         if p.is_null() { Err(err(st)) } else { Ok(Gpu(p)) }
+    }
+
+    /// A test / experiment switch of the context ("no_mfma", "host_huffman", ...; include/fanlin_gpu.h).  The library reads the process
+    /// environment only inside `flgpu_create`: with one `Arc<State>` shared by all workers (src/main.rs:108-112) nothing may call
+    /// getenv while another thread may call setenv.
+    pub fn debug_set(&self, key: &str, value: i64) -> Result<(), Box<dyn std::error::Error>> {
+        let k = std::ffi::CString::new(key)?;
+        check(unsafe { flgpu_debug_set(self.0, k.as_ptr(), value) })
     }
 
     /// main.rs:74-76 `create_cmyk_to_rgb_converter(path)` -> `gpu.set_cmyk_profile(&std::fs::read(path)?)`

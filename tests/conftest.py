@@ -55,9 +55,27 @@ def require_device():
     pytest.skip("needs a HIP device (run with -m gpu on the GPU box)")
 
 
+_SESSION_STATE = None
+
+
 @pytest.fixture(scope="session")
 def gpu_state(fl):
+    global _SESSION_STATE
     require_device()
     st = fl.State(device=0, profile=True)
+    _SESSION_STATE = st
+    import parity
+    parity.STATE = st   # (parity.packed_arithmetic asks the context which arithmetic it runs)
     yield st
+    _SESSION_STATE = None
+    parity.STATE = None
     st.close()
+
+
+@pytest.fixture(autouse=True)
+def _switches_back_to_their_defaults():
+    """Tests flip the context's switches with gpu_state.debug_set (the library reads no environment after flgpu_create); whatever a
+    test set is undone here, so the session's one context starts every test as flgpu_create left it."""
+    yield
+    if _SESSION_STATE is not None:
+        _SESSION_STATE.debug_set("reset")

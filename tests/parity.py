@@ -24,9 +24,12 @@ MFMA_OFF_BY_ONE = 0.006         # matrix-pipe kernel, packed arithmetic: at most
 MFMA_OFF_BY_ONE_FULL = 0.0002   # full-width arithmetic: at most 200 bytes per million (measured 0-30; the f32 streaming kernel: 0-23)
 
 
+STATE = None   # the session's context (tests/conftest.py gpu_state)
+
+
 def packed_arithmetic():
-    """True while FLGPU_MFMA_ARITH=packed is set (read by the library per batch, csrc/fl_batch.cpp)."""
-    return os.environ.get("FLGPU_MFMA_ARITH", "")[:1] == "p"
+    """True while the session's context runs the packed arithmetic (its `mfma_arith` switch, flgpu_debug_set)."""
+    return STATE is not None and STATE.debug_get("mfma_arith") == 1
 
 
 def mfma_off_by_one_bar():
@@ -74,16 +77,13 @@ def device_pixels(fl, st, img, **kw):
 
 def check_resample(fl, st, oracle, img, **kw):
     """One request through the device, against the bars of whichever kernel served it; then the SAME request with the
-    matrix-pipe kernel switched off (FLGPU_NO_MFMA=1, read per batch), so that the streaming kernel keeps its own,
+    matrix-pipe kernel switched off (the context's `no_mfma` switch), so that the streaming kernel keeps its own,
     bit-exact bar on every geometry the tests use."""
     got, used = device_pixels(fl, st, img, **kw)
     check_pixels(oracle, got, img, used, **oracle_kwargs(kw))
     if used:
-        os.environ["FLGPU_NO_MFMA"] = "1"
-        try:
+        with st.switches(no_mfma=1):
             other, used2 = device_pixels(fl, st, img, **kw)
-        finally:
-            del os.environ["FLGPU_NO_MFMA"]
         assert not used2
         check_pixels(oracle, other, img, False, **oracle_kwargs(kw))
         assert maxdiff(got, other) <= TOL_LSB
@@ -107,7 +107,7 @@ def check_pixels_any_kernel(oracle, got, img, **okw):
 
 def mfma_model(fl, img, rw, rh):
     """A numpy restatement of the matrix-pipe kernel's arithmetic for a plain resize_exact of `img` to rw x rh (no crop, no
-    letterbox), in the arithmetic the library is running (full width, or packed under FLGPU_MFMA_ARITH=packed).
+    letterbox), in the arithmetic the library is running (full width, or packed under the `mfma_arith` switch).
     Full width: vertical weights as three f16 terms of 2^15 w (= the f32 weight), exact vertical sums, the intermediate rounded
     (half to even) to 2^-14 around 128, horizontal weights round(w 2^hs), hs = 24, with the largest tap absorbing the rounding,
     exact integer horizontal sums, round half up, clamp.  Packed: two f16 terms of 256 w, the intermediate in 1/64 steps, hs =

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(fl):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(fl.EXPORTED_SYMBOLS) == names, "python binding list is out of date with the header"
-    assert lib.flgpu_abi_version() == 5   # 3: flgpu_plan::max_out_bytes, flgpu_config::n_devices / devices; 4: flgpu_stats::jpeg_device_huffman[_retries]; 5: flgpu_stats::wtile_launches
+    assert lib.flgpu_abi_version() == 6   # 3: flgpu_plan::max_out_bytes, flgpu_config::n_devices / devices; 4: flgpu_stats::jpeg_device_huffman[_retries]; 5: flgpu_stats::wtile_launches; 6: flgpu_debug_set / flgpu_debug_get (no getenv after flgpu_create)
 
 
 def test_struct_layouts_match_the_header(fl):
@@ -93,7 +93,7 @@ def test_rust_shim_mirrors_the_structs(fl):
     # fields in the header's order (the ctypes mirrors are already checked against the header above)
     import re
     text = open(os.path.join(ROOT, "shim", "handler_gpu.rs")).read()
-    assert "flgpu_abi_version() }, 5" in text
+    assert "flgpu_abi_version() }, 6" in text
     mirrors = {"FlImage": fl.flgpu_image, "FlParams": fl.flgpu_params, "FlPlan": fl.flgpu_plan, "FlConfig": fl.flgpu_config, "FlJpegInfo": fl.flgpu_jpeg_info}
     declared = set(re.findall(r"#\[repr\(C\)\](?:\s*#\[derive\([^)]*\)\])?\s*pub struct (\w+)", text))
     assert declared == set(mirrors), declared                      # every #[repr(C)] struct of the shim is checked

@@ -43,7 +43,7 @@ def test_placement_four_pixels_per_thread_equals_the_pixel_wise_kernel(fl, gpu_s
     offsets that are not multiples of four, every channel count, against the one-pixel-per-thread kernel (FLGPU_NO_PLACE4=1)."""
     img = synth.uniform(37, 53, c, index=40 + c)
     got = gpu_state.process_pixels(img, fl.make_params(**kw))
-    monkeypatch.setenv("FLGPU_NO_PLACE4", "1")
+    gpu_state.debug_set("no_place4", 1)
     want = gpu_state.process_pixels(img, fl.make_params(**kw))
     assert got.shape == want.shape and np.array_equal(got, want)
     if kw == dict(grayscale=True):
@@ -180,7 +180,7 @@ def test_fill_colour_and_crop_geometry(fl, gpu_state, oracle, crop):
 @pytest.mark.parametrize("w", [1919, 1366, 1001, 513])
 def test_unaligned_row_pitch_uses_the_fused_kernel(fl, gpu_state, oracle, w, monkeypatch):
     # Rgb8 rows whose byte pitch is not a multiple of 4 (3 * w): funnel-shift variant of the streaming kernel
-    monkeypatch.setenv("FLGPU_NO_WTILE", "1")   # (w = 513 is ratio 2.7: the window-tile kernel's by default since round 4, any pitch -- tests/test_wtile.py)
+    gpu_state.debug_set("no_wtile", 1)   # (w = 513 is ratio 2.7: the window-tile kernel's by default since round 4, any pitch -- tests/test_wtile.py)
     img = synth.uniform(540, w, 3, index=w)
     before = gpu_state.stats()
     check_resample(fl, gpu_state, oracle, img, w=300, h=200)
@@ -224,7 +224,7 @@ def test_edge_distributions(fl, gpu_state, oracle, monkeypatch):
 
 @pytest.mark.parametrize("sigma", [10.0, 20.0])
 def test_blur_only(fl, gpu_state, oracle, sigma, monkeypatch):
-    monkeypatch.setenv("FLGPU_NO_WTILE", "1")   # the f32 vector blur kernel and its bit-exact bar (the matrix-pipe blur: tests/test_wtile.py)
+    gpu_state.debug_set("no_wtile", 1)   # the f32 vector blur kernel and its bit-exact bar (the matrix-pipe blur: tests/test_wtile.py)
     img = synth.uniform(200, 300, 4, index=20)
     got = gpu_state.process_pixels(img, fl.make_params(blur_sigma=sigma))
     assert np.array_equal(got, oracle.blur(img, sigma, arith=oracle_lib.ARITH_FMA))
@@ -250,7 +250,7 @@ def test_blur_channel_shortcuts_are_exact(fl, gpu_state, oracle, kw):
 
 
 def test_blur_wide_image_tiles(fl, gpu_state, oracle, monkeypatch):
-    monkeypatch.setenv("FLGPU_NO_WTILE", "1")   # (as above)
+    gpu_state.debug_set("no_wtile", 1)   # (as above)
     img = synth.uniform(90, 700, 3, index=23)       # several column tiles, halo across tile borders
     got = gpu_state.process_pixels(img, fl.make_params(blur_sigma=20.0))
     assert np.array_equal(got, oracle.blur(img, 20.0, arith=oracle_lib.ARITH_FMA))
@@ -467,16 +467,16 @@ def test_mixed_size_batch_with_webp_front_end(fl, gpu_state, oracle):
 def test_band_split_small_batch_matches(fl, gpu_state, oracle, monkeypatch):
     img = synth.uniform(1080, 1920, 3, index=60)
     for bands in ("1", "3", "7"):
-        monkeypatch.setenv("FLGPU_FORCE_BANDS", bands)
+        gpu_state.debug_set("force_bands", int(bands))
         both_bars(fl, gpu_state, oracle, gpu_state.process_pixels(img, fl.make_params(300, 200)), img, w=300, h=200)
 
 
 def test_generic_and_stream_kernels_agree(fl, gpu_state, monkeypatch):
     img = synth.uniform(1080, 1920, 3, index=61)
     m = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the matrix-pipe kernel
-    monkeypatch.setenv("FLGPU_NO_MFMA", "1")
+    gpu_state.debug_set("no_mfma", 1)
     a = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the streaming kernel
-    monkeypatch.setenv("FLGPU_FORCE_GENERIC", "1")
+    gpu_state.debug_set("force_generic", 1)
     b = gpu_state.process_pixels(img, fl.make_params(300, 200))           # the two-pass generic kernels
     assert np.array_equal(a, b) and maxdiff(m, a) <= TOL_LSB and not np.array_equal(m, a)
 
@@ -543,11 +543,11 @@ def test_two_pass_resample_through_an_lds_tile_equals_the_one_through_hbm(fl, gp
     f32 intermediate in HBM.  Same arithmetic, same order: bit-identical to the HBM form (FLGPU_NO_TILE=1) and to the oracle's
     fused-order mode, within 1 LSB of the reference arithmetic (parity.check_pixels holds both bars)."""
     import parity
-    monkeypatch.setenv("FLGPU_NO_WTILE", "1")   # (round 4: down-scales among these go to the window-tile matrix-pipe kernel by default, tests/test_wtile.py)
+    gpu_state.debug_set("no_wtile", 1)   # (round 4: down-scales among these go to the window-tile matrix-pipe kernel by default, tests/test_wtile.py)
     img = synth.uniform(*shape, index=shape[0] + shape[1])
     got, used = parity.device_pixels(fl, gpu_state, img, **kw)
     assert not used
     parity.check_pixels(oracle, got, img, False, **parity.oracle_kwargs(kw))
-    monkeypatch.setenv("FLGPU_NO_TILE", "1")
+    gpu_state.debug_set("no_tile", 1)
     other, _ = parity.device_pixels(fl, gpu_state, img, **kw)
     assert np.array_equal(got, other)

@@ -569,8 +569,8 @@ def test_device_entropy_decoder_reads_the_host_decoders_coefficients(fl, gpu_sta
     subsequence decoding, re-synchronisation rounds, prefix sums, write pass): the decoded picture must be the oracle decoder's, bit
     for bit -- i.e. every coefficient the host decoder would have read -- and the statistics must say the device did the decoding."""
     h, w, c, q, sub, dist = case
-    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_MIN_BYTES", "0")
-    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_ALWAYS", "1")   # (by default a lone request is decoded by its own thread: a CPU is idle)
+    gpu_state.debug_set("device_huffman_min_bytes", 0)
+    gpu_state.debug_set("device_huffman_always", 1)   # (by default a lone request is decoded by its own thread: a CPU is idle)
     img = getattr(synth, dist)(h, w, c, index=h + q)
     data = _save(img, quality=q, **({"subsampling": sub} if c == 3 else {}))
     s0 = gpu_state.stats()
@@ -578,15 +578,15 @@ def test_device_entropy_decoder_reads_the_host_decoders_coefficients(fl, gpu_sta
     s1 = gpu_state.stats()
     assert s1["jpeg_device_huffman"] == s0["jpeg_device_huffman"] + 1 and s1["jpeg_device_huffman_retries"] == s0["jpeg_device_huffman_retries"]
     assert np.array_equal(got, oracle.jpeg_decode(data))
-    monkeypatch.setenv("FLGPU_HOST_HUFFMAN", "1")                     # the host decoder stays selectable, and agrees
+    gpu_state.debug_set("host_huffman", 1)                     # the host decoder stays selectable, and agrees
     assert np.array_equal(gpu_state.decode_jpeg(data), got)
     assert gpu_state.stats()["jpeg_device_huffman"] == s1["jpeg_device_huffman"]
 
 
 @pytest.mark.gpu
 def test_device_entropy_decoder_in_batches_and_whole_requests(fl, gpu_state, oracle, monkeypatch):
-    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_MIN_BYTES", "0")
-    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_ALWAYS", "1")   # (by default a lone request is decoded by its own thread: a CPU is idle)
+    gpu_state.debug_set("device_huffman_min_bytes", 0)
+    gpu_state.debug_set("device_huffman_always", 1)   # (by default a lone request is decoded by its own thread: a CPU is idle)
     files = [make_jpeg(360 + 8 * k, 640 - 16 * k, 3, 60 + 5 * k, k % 3, 0, index=40 + k) for k in range(6)]
     files.append(make_jpeg(200, 300, 3, 80, 2, 5, index=9))           # a restart interval: this one stays with the host decoder
     files.append(_save(synth.photo(240, 320, 3, index=3), progressive=True, quality=80))   # progressive: host, too
@@ -594,9 +594,9 @@ def test_device_entropy_decoder_in_batches_and_whole_requests(fl, gpu_state, ora
     before = gpu_state.stats()["jpeg_device_huffman"]
     outs = gpu_state.process_batch(files, [p] * len(files))            # flgpu_transform_batch: one set of launches for all eight
     assert gpu_state.stats()["jpeg_device_huffman"] - before == 6
-    monkeypatch.setenv("FLGPU_HOST_HUFFMAN", "1")
+    gpu_state.debug_set("host_huffman", 1)
     host = gpu_state.process_batch(files, [p] * len(files))
-    monkeypatch.delenv("FLGPU_HOST_HUFFMAN")
+    gpu_state.debug_set("host_huffman", 0)
     for f, o, hh in zip(files, outs, host):
         assert np.array_equal(o, hh)
         if not fl.jpeg_info(f)["progressive"]:
@@ -604,7 +604,7 @@ def test_device_entropy_decoder_in_batches_and_whole_requests(fl, gpu_state, ora
     # the whole request of the metric from file bytes: the same stream whichever side decodes the entropy-coded segment
     big = make_jpeg(1080, 1920, 3, 85, 2, 0, index=5)
     a = gpu_state.process_jpeg(big, "w=300&h=200")
-    monkeypatch.setenv("FLGPU_HOST_HUFFMAN", "1")
+    gpu_state.debug_set("host_huffman", 1)
     b = gpu_state.process_jpeg(big, "w=300&h=200")
     assert a[1] == fl.RESULT_JPEG_STREAM and a[2] == b[2]
 
@@ -613,23 +613,41 @@ def test_device_entropy_decoder_in_batches_and_whole_requests(fl, gpu_state, ora
 def test_device_entropy_decoder_on_broken_streams(fl, gpu_state, monkeypatch):
     """Mutated and truncated segments: the device decoder reports an invalid code word (or a chain of states that did not settle)
     and the request is decoded on the host once more -- which returns an error or a picture, as before; never a crash or a hang."""
-    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_MIN_BYTES", "0")
-    monkeypatch.setenv("FLGPU_DEVICE_HUFFMAN_ALWAYS", "1")   # (by default a lone request is decoded by its own thread: a CPU is idle)
+    gpu_state.debug_set("device_huffman_min_bytes", 0)
+    gpu_state.debug_set("device_huffman_always", 1)   # (by default a lone request is decoded by its own thread: a CPU is idle)
     rng = np.random.default_rng(11)
     data = bytearray(make_jpeg(240, 320, 3, 85, 2, 0, index=21))
     sos = data.find(b"\xff\xda") + 14
+
+    def outcome(blob):
+        """(status, pixels) of one file with the switches as they are."""
+        try:
+            return 0, gpu_state.decode_jpeg(blob)
+        except fl.FanlinError as e:
+            assert e.status in (fl.ERR_INVALID_ARG, fl.ERR_UNSUPPORTED)
+            return e.status, None
+
+    def same_on_both_sides(blob, what):
+        """Which side decodes the entropy-coded segment depends on how busy the host is: a broken file must come out the same either
+        way -- the same error, or the same pixels (an HTTP cache in front of the service must not see the difference)."""
+        dev = outcome(blob)
+        with gpu_state.switches(host_huffman=1):
+            host = outcome(blob)
+        assert dev[0] == host[0], (what, dev[0], host[0])
+        if dev[1] is not None:
+            assert np.array_equal(dev[1], host[1]), what
+
     for trial in range(40):
         d = bytearray(data)
         for _ in range(int(rng.integers(1, 4))):
             d[int(rng.integers(sos, len(d) - 2))] = int(rng.integers(0, 255))    # (255 would start a marker: a different path)
-        try:
-            gpu_state.decode_jpeg(bytes(d))
-        except fl.FanlinError as e:
-            assert e.status in (fl.ERR_INVALID_ARG, fl.ERR_UNSUPPORTED)
+        same_on_both_sides(bytes(d), ("mutation", trial))
     for cut in (len(data) - 2, len(data) // 2, sos + 40):
-        try:
-            gpu_state.decode_jpeg(bytes(data[:cut]))
-        except fl.FanlinError as e:
-            assert e.status in (fl.ERR_INVALID_ARG, fl.ERR_UNSUPPORTED)
+        same_on_both_sides(bytes(data[:cut]), ("cut", cut))
+    # cuts at and around whole subsequences of the segment (kJhSubBits = 1024 bits = 128 bytes): the last walk then ends at the
+    # segment's end without meeting the padding -- no invalid code word, but blocks are missing
+    for nsub in (3, 8, 17, 40):
+        for delta in (-1, 0, 1, 2):
+            same_on_both_sides(bytes(data[:sos + 128 * nsub + delta]) + b"\xff\xd9", ("cut at subsequence", nsub, delta))
     good = gpu_state.decode_jpeg(bytes(data))                                   # the context is fine afterwards
     assert good.shape == (240, 320, 3)

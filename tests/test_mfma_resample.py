@@ -87,7 +87,7 @@ def test_device_matches_the_fixed_point_model(fl, gpu_state, h, w, c, rw, rh, ar
     packed arithmetic (1/64 steps): measured 1-2 bytes in 10,000 (profiles/r02_mfma_model_rate.txt); full width (2^-14 steps,
     sums handed over in 2^-20 steps): a few bytes per million."""
     if arith == "packed":
-        monkeypatch.setenv("FLGPU_MFMA_ARITH", "packed")
+        gpu_state.debug_set("mfma_arith", 1)
     img = synth.uniform(h, w, c, index=7 * c + rw)
     got, used = parity.device_pixels(fl, gpu_state, img, w=rw, h=rh)
     assert used and got.shape == (rh, rw, c)
@@ -106,7 +106,7 @@ def test_packed_arithmetic_stays_selectable(fl, gpu_state, oracle, monkeypatch, 
     full, used = parity.device_pixels(fl, gpu_state, img, w=ow, h=oh, crop=crop)
     assert used
     parity.check_pixels(oracle, full, img, True, **parity.oracle_kwargs(dict(w=ow, h=oh, crop=crop)))
-    monkeypatch.setenv("FLGPU_MFMA_ARITH", "packed")
+    gpu_state.debug_set("mfma_arith", 1)
     packed, used = parity.device_pixels(fl, gpu_state, img, w=ow, h=oh, crop=crop)
     assert used
     parity.check_pixels(oracle, packed, img, True, **parity.oracle_kwargs(dict(w=ow, h=oh, crop=crop)))
@@ -129,10 +129,10 @@ def test_band_splits_and_batches_give_the_same_bytes(fl, gpu_state, oracle, monk
     img = synth.uniform(1080, 1920, 3, index=77)
     alone = parity.expected_pixels(fl, gpu_state, oracle, img, w=300, h=200)
     for bands in ("1", "2", "5", "11", "16"):
-        monkeypatch.setenv("FLGPU_FORCE_BANDS", bands)
+        gpu_state.debug_set("force_bands", int(bands))
         got, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)
         assert used and np.array_equal(got, alone), bands
-    monkeypatch.delenv("FLGPU_FORCE_BANDS")
+    gpu_state.debug_set("force_bands", 0)
     others = [synth.uniform(1080, 1920, 3, index=78 + i) for i in range(5)]
     outs = gpu_state.process_batch([others[0], img, others[1], img] + others[2:], [fl.make_params(300, 200)] * 7)
     assert np.array_equal(outs[1], alone) and np.array_equal(outs[3], alone)
@@ -144,7 +144,7 @@ def test_band_splits_and_batches_give_the_same_bytes(fl, gpu_state, oracle, monk
 def test_requests_the_kernel_does_not_take(fl, gpu_state, oracle, monkeypatch):
     """Unaligned rows, pre-ops and mild ratios stay with the streaming / generic kernels (the window-tile matrix-pipe kernel, which
     takes the mild ratios among them since round 4, is switched off here: tests/test_wtile.py)."""
-    monkeypatch.setenv("FLGPU_NO_WTILE", "1")
+    gpu_state.debug_set("no_wtile", 1)
     cases = [(synth.uniform(540, 961, 3, index=1), dict(w=300, h=200)),            # 2883-byte rows
              (synth.uniform(540, 962, 4, index=2), dict(w=150, h=100)),            # Rgba8, 3848-byte rows: not a multiple of 16
              (synth.uniform(540, 1000, 1, index=3), dict(w=150, h=100)),           # Luma8, 1000-byte rows
@@ -160,7 +160,7 @@ def test_requests_the_kernel_does_not_take(fl, gpu_state, oracle, monkeypatch):
 
 def test_switch_keeps_the_streaming_kernel(fl, gpu_state, oracle, monkeypatch):
     img = synth.uniform(1080, 1920, 3, index=11)
-    monkeypatch.setenv("FLGPU_NO_MFMA", "1")
+    gpu_state.debug_set("no_mfma", 1)
     got, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)
     assert not used
     parity.check_pixels(oracle, got, img, False, w=300, h=200)
@@ -176,7 +176,7 @@ def test_expired_wait_is_an_error_not_a_picture(fl, gpu_state, monkeypatch):
     img = synth.uniform(1080, 1920, 3, index=123)
     good, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)
     assert used
-    monkeypatch.setenv("FLGPU_MFMA_SPIN_LIMIT", "0")
+    gpu_state.debug_set("mfma_spin_limit", 0)
     with pytest.raises(fl.FanlinError) as e:
         gpu_state.process_pixels(img, fl.make_params(300, 200))
     assert e.value.status == fl.ERR_DEVICE and "wait" in str(e.value)
@@ -186,7 +186,7 @@ def test_expired_wait_is_an_error_not_a_picture(fl, gpu_state, monkeypatch):
     with pytest.raises(fl.FanlinError) as e:
         gpu_state.batch_results()
     assert e.value.status == fl.ERR_DEVICE
-    monkeypatch.delenv("FLGPU_MFMA_SPIN_LIMIT")
+    gpu_state.debug_set("mfma_spin_limit", 1 << 22)
     again, used = parity.device_pixels(fl, gpu_state, img, w=300, h=200)   # the context is fine afterwards
     assert used and np.array_equal(again, good)
     gpu_state.process_batch_device([src.data_ptr()], [img.shape], fl.make_params(300, 200), [dst.data_ptr()], [240000])

@@ -1,6 +1,7 @@
 """A/B of library builds (and of FLGPU_* switches) inside one process on the same buffers, for the flagship batch:
     python tools/experiments/ab_env.py lib1.so[:ENV=VAL,...] lib2.so ... [--rounds 5] [--launches 30] [--channels 3] [--w 300 --h 200]
-A bare name 'default' means the library in the tree."""
+A bare name 'default' means the library in the tree.  The library reads the environment only in flgpu_create (round 5), so a variant's
+FLGPU_* values are in the environment while ITS context is created and nowhere else."""
 import argparse, importlib.util, os, statistics, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,7 +31,12 @@ for i, v in enumerate(a.variants):
     pkg = os.path.join(ROOT, "fanlin-rs_amd")
     spec = importlib.util.spec_from_file_location("fl_%d" % i, os.path.join(pkg, "__init__.py"), submodule_search_locations=[pkg])
     fl = importlib.util.module_from_spec(spec); sys.modules["fl_%d" % i] = fl; spec.loader.exec_module(fl); fl.load_library()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     st = fl.State(device=0, profile=True); st.__enter__()
+    for k, v in old.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
     p = fl.make_params(a.w, a.h, crop=a.crop, grayscale=a.gray, blur_sigma=a.blur) if a.w else fl.make_params(blur_sigma=a.blur)
     plan = fl.plan_output(p, W, H, C)
     stride = (int(plan.out_bytes) + 255) // 256 * 256
@@ -39,7 +45,7 @@ for i, v in enumerate(a.variants):
     run = st.prepared_batch([src.data_ptr() + k * H * W * C for k in range(n)], [(H, W, C)] * n, p, [dst.data_ptr() + k * stride for k in range(n)], [stride] * n)
     runs.append((v, st, run, env))
 KEYS = ("FLGPU_NO_SMALL", "FLGPU_MFMA_ARITH", "FLGPU_NO_MFMA", "FLGPU_FORCE_BANDS", "FLGPU_NO_WTILE", "FLGPU_WTILE_ALWAYS", "FLGPU_WTILE_FIRST", "FLGPU_WTILE_NO_OVERLAP")
-def setenv(env):
+def setenv(env):   # (libraries of earlier rounds read these per batch)
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(env)
 times = {v: [] for v, _, _, _ in runs}
