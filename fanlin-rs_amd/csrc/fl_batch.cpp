@@ -89,6 +89,83 @@ uint32_t wtile_bands(const DebugSwitches &dbg, const WtPlan &p, size_t pictures)
     return (uint32_t)std::min<size_t>(p.n_mt, std::max<size_t>(1, (512 + wgs - 1) / wgs));
 }
 
+// Item order of a UNIFORM matrix-pipe launch (full-width arithmetic: persistent workgroups, fl_mfma.hip) -- every picture the same
+// plan, cut into the same S strips, whole pictures (one band).  Workgroup b of the launch's G walks items b, b + G, b + 2 G, ...; the
+// order makes those share their STRIP, so that the walk goes from one picture's rows into the next one's without a new set-up (a
+// "light" transition: no operand copy, no tile table, no barrier, the last tile converted on the way), and keeps the S strips of
+// a picture on one XCD in the same round (hardware deals workgroup b to XCD b mod 8; the strips share halo columns through that
+// XCD's L2).  Per XCD: floor(slots / S) triples of neighbouring slots; the slots left over form cross-XCD triples; the last
+// G mod S workgroups take whole pictures strip after strip (heavy transitions).  Only FULL rounds are laid out (every slot filled);
+// returns how many items that covered -- the caller orders the rest the classic way.  0 = not a uniform launch.
+uint32_t persistent_order(MfmaItem *items, uint32_t n, uint32_t G)
+{
+    if (n < 2 || G < 16) return 0;
+    // strips per picture, and that the launch is pictures x the same strips
+    std::vector<uint32_t> strips;
+    for (uint32_t k = 0; k < n && items[k].job == items[0].job; ++k) strips.push_back(items[k].strip_off);
+    const uint32_t S = (uint32_t)strips.size();
+    if (S < 2 || S > 8 || n % S != 0 || G < 8u * S) return 0;
+    const uint32_t P = n / S;
+    for (uint32_t p = 0; p < P; ++p)
+        for (uint32_t s = 0; s < S; ++s) {
+            const MfmaItem &a = items[p * S + s];
+            if (a.job != items[p * S].job || a.strip_off != strips[s] || a.vplan_off != items[0].vplan_off || a.kb0 != items[0].kb0 || a.kb1 != items[0].kb1 ||
+                a.tile0 != items[0].tile0 || a.tile1 != items[0].tile1)
+                return 0;
+        }
+    // the strip of every workgroup, and which triple it belongs to
+    std::vector<int32_t> wg_strip(G, -1), wg_triple(G, -1);
+    std::vector<uint32_t> leftover;
+    uint32_t T = 0;
+    for (uint32_t x = 0; x < 8; ++x) {
+        const uint32_t slots = (G - x + 7u) / 8u, t_x = slots / S;
+        for (uint32_t j = 0; j < slots; ++j) {
+            const uint32_t b = 8u * j + x;
+            if (j < t_x * S) { wg_strip[b] = (int32_t)(j % S); wg_triple[b] = (int32_t)(T + j / S); }
+            else leftover.push_back(b);
+        }
+        T += t_x;
+    }
+    std::sort(leftover.begin(), leftover.end());
+    const uint32_t cross = (uint32_t)leftover.size() / S, r = (uint32_t)leftover.size() % S;
+    for (uint32_t q = 0; q < cross * S; ++q) { wg_strip[leftover[q]] = (int32_t)(q % S); wg_triple[leftover[q]] = (int32_t)(T + q / S); }
+    T += cross;
+    std::vector<uint32_t> rotating(leftover.end() - r, leftover.end());
+    if (!T) return 0;
+    // rounds: a triple takes one picture per round, a rotating workgroup one strip of its picture (a new picture every S rounds)
+    std::vector<MfmaItem> src(items, items + n), out;
+    out.reserve(n);
+    std::vector<uint32_t> rot_pic(r, 0);
+    uint32_t next_pic = 0, rounds = 0;
+    for (;; ++rounds) {
+        const uint32_t need = T + ((rounds % S == 0) ? r : 0u);
+        if (next_pic + need > P) break;
+        std::vector<MfmaItem> round(G);
+        const uint32_t base = next_pic;
+        next_pic += T;
+        if (rounds % S == 0) for (uint32_t q = 0; q < r; ++q) rot_pic[q] = next_pic++;
+        for (uint32_t b = 0; b < G; ++b) {
+            if (wg_triple[b] >= 0) round[b] = src[(base + (uint32_t)wg_triple[b]) * S + (uint32_t)wg_strip[b]];
+        }
+        for (uint32_t q = 0; q < r; ++q) round[rotating[q]] = src[rot_pic[q] * S + rounds % S];
+        out.insert(out.end(), round.begin(), round.end());
+    }
+    // (rotating workgroups in the middle of a picture: the round structure ends where their picture does)
+    while (rounds % S != 0 && r) { out.resize(out.size() - G); --rounds; }
+    if (out.empty()) return 0;
+    // (pictures are handed out in order: the rounds kept cover pictures [0, covered) completely)
+    uint32_t covered = 0;
+    {
+        uint32_t np2 = 0;
+        for (uint32_t k = 0; k < rounds; ++k) np2 += T + ((k % S == 0) ? r : 0u);
+        covered = np2;
+    }
+    std::copy(out.begin(), out.end(), items);
+    uint32_t w = (uint32_t)out.size();
+    for (uint32_t p = covered; p < P; ++p) for (uint32_t s = 0; s < S; ++s) items[w++] = src[p * S + s];
+    return (uint32_t)out.size();
+}
+
 void fill_job(const Work &w, Job &j)
 {
     memset(&j, 0, sizeof(j));
@@ -761,10 +838,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             L.njobs++;
         }
         if ((k.kind & 255u) == S1_MFMA && L.nitems > 1) {
-            // longest workgroups first and strips of a picture on one XCD, as for the streaming kernel below
             auto first = mitems.begin() + L.item_base;
-            std::stable_sort(first, first + L.nitems, [](const MfmaItem &a, const MfmaItem &b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
-            xcd_interleave(&*first, L.nitems, [](const MfmaItem &x) { return x.kb1 - x.kb0; });
+            // full-width arithmetic, a uniform launch (every picture the same plan, whole pictures): the persistent workgroups' order
+            uint32_t done = 0;
+            if ((k.kind >> 10) & 1u) done = persistent_order(&*first, L.nitems, std::min(L.nitems, c->cu_count));
+            // the rest (or everything): longest workgroups first and strips of a picture on one XCD, as for the streaming kernel below
+            std::stable_sort(first + done, first + L.nitems, [](const MfmaItem &a, const MfmaItem &b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
+            xcd_interleave(&*first + done, L.nitems - done, [](const MfmaItem &x) { return x.kb1 - x.kb0; });
         }
         if ((k.kind & 255u) == S1_WTILE && L.nitems > 1) {
             // strips and bands of a picture on one XCD (their source windows overlap: the halo then comes from that XCD's L2)
@@ -895,7 +975,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             const MfmaItem &mi = mitems[k];
             const Job &j = jobs[mi.job];
             MfmaReq &r = mreqs[k];
-            r.src = j.src; r.pitch = j.sw * L.k.cs; r.last_row = j.sh - 1u; r.kb0 = mi.kb0;
+            r.src = j.src; r.pitch = j.sw * L.k.cs; r.last_row = j.sh - 1u; r.kb0 = mi.kb0; r.kb1 = mi.kb1; r.job = mi.job;
+            r.strip_off = mi.strip_off; r.vplan_off = mi.vplan_off; r.pad[0] = r.pad[1] = 0;
             r.byte0 = reinterpret_cast<const MfmaStrip *>(c->h_arena.data() + mi.strip_off)->byte0;
         }
     }
@@ -1000,6 +1081,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         } else if ((L.k.kind & 255u) == S1_MFMA) {
             LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
             m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.reqs = d_mreqs + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
+            m.grid = std::min(L.nitems, c->cu_count);
             m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.wide = (L.k.kind >> 9) & 1u; m.full = (L.k.kind >> 10) & 1u; m.compact = (L.k.kind >> 11) & 1u; m.max_nout = L.max_nout;
             m.spin_limit = mfma_spin_limit; m.err_word = status_dev + 2 * n;
             {
@@ -1195,3 +1277,19 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
 }
 
 } // namespace fl
+
+// ---- diagnostics -----------------------------------------------------------------------------------------------------------------
+extern "C" int flgpu_debug_persistent_order(uint32_t pictures, uint32_t strips, uint32_t workgroups, uint32_t *job_of, uint32_t *strip_of, uint32_t *covered)
+{
+    if (!pictures || !strips || !job_of || !strip_of || !covered) return FLGPU_ERR_INVALID_ARG;
+    std::vector<MfmaItem> v((size_t)pictures * strips);
+    for (uint32_t p = 0; p < pictures; ++p)
+        for (uint32_t s = 0; s < strips; ++s) {
+            MfmaItem &m = v[(size_t)p * strips + s];
+            memset(&m, 0, sizeof(m));
+            m.job = p; m.strip_off = 1000u + s; m.vplan_off = 7u; m.kb0 = 0u; m.kb1 = 34u; m.tile0 = 0u; m.tile1 = 11u;
+        }
+    *covered = persistent_order(v.data(), (uint32_t)v.size(), std::min<uint32_t>((uint32_t)v.size(), workgroups));
+    for (size_t k = 0; k < v.size(); ++k) { job_of[k] = v[k].job; strip_of[k] = v[k].strip_off - 1000u; }
+    return FLGPU_OK;
+}

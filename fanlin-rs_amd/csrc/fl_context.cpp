@@ -409,6 +409,7 @@ static flgpu_ctx *create_on_device(const flgpu_config &cfg, int dev, int *status
     }
     c->dbg = dbg;
     c->arena_cap_words = arena_words;
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) c->cu_count = (uint32_t)n; }
     if (hipMalloc(reinterpret_cast<void **>(&c->d_arena), kArenaWords * 4) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; set(FLGPU_ERR_OOM); return nullptr;
     }

@@ -179,6 +179,7 @@ inline uint64_t jpeg_worst_bytes(uint32_t plane_w, uint32_t plane_h)
 
 struct flgpu_ctx {
     int device = 0;
+    uint32_t cu_count = 256; // compute units of the device: the persistent matrix-pipe launch has one workgroup per CU
     hipStream_t stream = nullptr;
     flgpu_config cfg{};
     std::shared_ptr<fl::DebugSwitches> dbg; // the root context's switch block, shared with its lanes and shards

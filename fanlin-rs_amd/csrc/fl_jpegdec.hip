@@ -7,8 +7,11 @@
 //                    only up to the last non-zero one (the host decoder's compact blob); they are dequantised while being
 //                    scattered into an LDS tile (9-word row pitch, 73-word block pitch: column and row passes are both
 //                    conflict free), lane t then runs the butterfly on column t, then on row t, and stores 8 samples.
-// jpeg_color_kernel  one thread per 4 output pixels of a row: fetch Y, interpolate Cb / Cr (separable (3a + b + 2) >> 2
-//                    steps, vertical first), convert, store 12 bytes (or copy 4 luma bytes for grayscale files).
+// jpeg_color_kernel  round 5: one thread = 4 pixels x 2 rows of a three-component YCbCr picture (4:2:0, 4:2:2 or 4:4:4) -- the luma
+//                    and the three chroma rows the pair needs as unaligned dword loads, Cb / Cr interpolated (separable
+//                    (3a + b + 2) >> 2 steps, vertical first), converted, stored as three dwords per row; a flat grid over
+//                    (width / 4) x (height / 2) groups, so no lane idles on a 1920-pixel row.  Pixels next to the left and right
+//                    edges, grayscale, CMYK / YCCK, RGB and unusual samplings take the pixel-wise form (round 2's kernel).
 // Both are memory-light (a few MB per picture) and sit in front of the resample kernel, whose input they produce in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -135,32 +138,128 @@ __device__ __forceinline__ int chroma_at(const uint8_t *plane, uint32_t pw, uint
     return (3 * a + b + 2) >> 2;
 }
 
-__global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegDecJob *__restrict__ jobs)
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+// one pixel, every case: planes through zune-jpeg's interpolation (a plain read at full resolution), then the colour transform
+__device__ __forceinline__ void color_pixel(const JpegDecJob &jb, const JpegBlobHeader *H, uint32_t x, uint32_t y)
 {
-    const JpegDecJob jb = jobs[blockIdx.z];
-    const JpegBlobHeader *H = reinterpret_cast<const JpegBlobHeader *>(jb.blob);
-    const uint32_t W = H->width, Hh = H->height, nc = H->nc;
-    const uint32_t y = blockIdx.y, x0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-    if (y >= Hh || x0 >= W) return;
-    uint8_t *o = jb.dst + ((size_t)y * W + x0) * nc;
-    for (uint32_t k = 0; k < 4u && x0 + k < W; ++k) {
-        const uint32_t x = x0 + k;
-        int s[4];
-        for (uint32_t i = 0; i < nc; ++i) { // every plane through zune-jpeg's interpolation (a plain read at full resolution)
-            const JpegComponent &C = H->comp[i];
-            s[i] = chroma_at(jb.planes + C.plane_off, C.bw * 8u, C.w, C.hpx, H->hmax / C.h, H->vmax / C.v, x, y);
-        }
-        if (nc == 1u) { o[k] = (uint8_t)s[0]; continue; }
-        if (nc == 4u) { // CMYK / YCCK: the raw samples, as JpegDecoder with out_colorspace = the input colour space returns them (handler.rs:417-419)
-            o[4 * k] = (uint8_t)s[0]; o[4 * k + 1] = (uint8_t)s[1]; o[4 * k + 2] = (uint8_t)s[2]; o[4 * k + 3] = (uint8_t)s[3];
+    const uint32_t nc = H->nc;
+    uint8_t *o = jb.dst + ((size_t)y * H->width + x) * nc;
+    int s[4];
+    for (uint32_t i = 0; i < nc; ++i) {
+        const JpegComponent &C = H->comp[i];
+        s[i] = chroma_at(jb.planes + C.plane_off, C.bw * 8u, C.w, C.hpx, H->hmax / C.h, H->vmax / C.v, x, y);
+    }
+    if (nc == 1u) { o[0] = (uint8_t)s[0]; return; }
+    if (nc == 4u) { // CMYK / YCCK: the raw samples, as JpegDecoder with out_colorspace = the input colour space returns them (handler.rs:417-419)
+        o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; o[3] = (uint8_t)s[3];
+        return;
+    }
+    if (H->is_rgb) { o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; return; }
+    // zune-jpeg color_convert/scalar.rs: i16 arithmetic with 5/6-bit constants, arithmetic shifts
+    const int cb = s[1] - 128, cr = s[2] - 128;
+    o[0] = (uint8_t)clamp8(s[0] + ((45 * cr) >> 5));
+    o[1] = (uint8_t)clamp8(s[0] - ((11 * cb + 23 * cr) >> 5));
+    o[2] = (uint8_t)clamp8(s[0] + ((113 * cb) >> 6));
+}
+
+// Four interior pixels x0 .. x0 + 3 (x0 a multiple of 4, 4 <= x0, x0 + 6 <= W) of rows y and y + 1 (y even), SH x SV chroma sampling.
+template <int SH, int SV>
+__device__ __forceinline__ void color_group(const JpegDecJob &jb, const JpegBlobHeader *H, uint32_t x0, uint32_t y, uint32_t rows)
+{
+    const uint32_t W = H->width;
+    const JpegComponent &CY = H->comp[0];
+    const uint8_t *py = jb.planes + CY.plane_off;
+    const uint32_t ypw = CY.bw * 8u;
+    uint32_t yv[2];
+    yv[0] = *reinterpret_cast<const uint32_t *>(py + (size_t)y * ypw + x0);
+    yv[1] = rows > 1u ? *reinterpret_cast<const uint32_t *>(py + (size_t)(y + 1u) * ypw + x0) : 0u;
+    int cv[2][2][4]; // [Cb, Cr][row][pixel]
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const JpegComponent &C = H->comp[1 + ci];
+        const uint8_t *pl = jb.planes + C.plane_off;
+        const uint32_t pw = C.bw * 8u;
+        if (SH == 1 && SV == 1) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const uint32_t w = (rr == 0 || rows > 1u) ? *reinterpret_cast<const uint32_t *>(pl + (size_t)(y + rr) * pw + x0) : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cv[ci][rr][k] = (int)((w >> (8 * k)) & 255u);
+            }
             continue;
         }
-        if (H->is_rgb) { o[3 * k] = (uint8_t)s[0]; o[3 * k + 1] = (uint8_t)s[1]; o[3 * k + 2] = (uint8_t)s[2]; continue; }
-        // zune-jpeg color_convert/scalar.rs: i16 arithmetic with 5/6-bit constants, arithmetic shifts
-        const int cb = s[1] - 128, cr = s[2] - 128;
-        o[3 * k] = (uint8_t)clamp8(s[0] + ((45 * cr) >> 5));
-        o[3 * k + 1] = (uint8_t)clamp8(s[0] - ((11 * cb + 23 * cr) >> 5));
-        o[3 * k + 2] = (uint8_t)clamp8(s[0] + ((113 * cb) >> 6));
+        // samples ix - 1 .. ix + 2 (ix = x0 / 2) of the rows involved, vertically interpolated first
+        const uint32_t ix = x0 >> 1;
+        int a[2][4];
+        if (SV == 1) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const uint32_t w = (rr == 0 || rows > 1u) ? *reinterpret_cast<const u32_unaligned *>(pl + (size_t)(y + rr) * pw + ix - 1u) : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[rr][k] = (int)((w >> (8 * k)) & 255u);
+            }
+        } else {
+            const uint32_t r = y >> 1; // both rows of the pair share the near chroma row; the far ones are r - 1 and r + 1, clamped
+            const uint32_t ru = r ? r - 1u : 0u, rd = min(r + 1u, C.hpx - 1u);
+            const uint32_t wn = *reinterpret_cast<const u32_unaligned *>(pl + (size_t)r * pw + ix - 1u);
+            const uint32_t wu = *reinterpret_cast<const u32_unaligned *>(pl + (size_t)ru * pw + ix - 1u);
+            const uint32_t wd = *reinterpret_cast<const u32_unaligned *>(pl + (size_t)rd * pw + ix - 1u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = (int)((wn >> (8 * k)) & 255u);
+                a[0][k] = (3 * n + (int)((wu >> (8 * k)) & 255u) + 2) >> 2;
+                a[1][k] = (3 * n + (int)((wd >> (8 * k)) & 255u) + 2) >> 2;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) { // a[rr][1] = sample ix, a[rr][2] = ix + 1
+            cv[ci][rr][0] = (3 * a[rr][1] + a[rr][0] + 2) >> 2;
+            cv[ci][rr][1] = (3 * a[rr][1] + a[rr][2] + 2) >> 2;
+            cv[ci][rr][2] = (3 * a[rr][2] + a[rr][1] + 2) >> 2;
+            cv[ci][rr][3] = (3 * a[rr][2] + a[rr][3] + 2) >> 2;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        if (rr == 1 && rows < 2u) break;
+        uint32_t b[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yy = (int)((yv[rr] >> (8 * k)) & 255u), cb = cv[0][rr][k] - 128, cr = cv[1][rr][k] - 128;
+            b[3 * k] = clamp8(yy + ((45 * cr) >> 5));
+            b[3 * k + 1] = clamp8(yy - ((11 * cb + 23 * cr) >> 5));
+            b[3 * k + 2] = clamp8(yy + ((113 * cb) >> 6));
+        }
+        u32_unaligned *o = reinterpret_cast<u32_unaligned *>(jb.dst + ((size_t)(y + rr) * W + x0) * 3u);
+        o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegDecJob *__restrict__ jobs)
+{
+    const JpegDecJob jb = jobs[blockIdx.y];
+    const JpegBlobHeader *H = reinterpret_cast<const JpegBlobHeader *>(jb.blob);
+    const uint32_t W = H->width, Hh = H->height, nc = H->nc;
+    const uint32_t ngx = (W + 3u) / 4u, ngy = (Hh + 1u) / 2u;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= ngx * ngy) return;
+    const uint32_t gy = idx / ngx, gx = idx - gy * ngx, x0 = 4u * gx, y = 2u * gy, rows = min(2u, Hh - y);
+    // the fast form: YCbCr, luma at full resolution, both chroma planes 2x2, 2x1 or 1x1, and the group away from the row's ends
+    int mode = 0; // 0 = pixel-wise
+    if (nc == 3u && !H->is_rgb && H->comp[0].h == H->hmax && H->comp[0].v == H->vmax && H->comp[1].h == H->comp[2].h && H->comp[1].v == H->comp[2].v &&
+        x0 >= 4u && x0 + 6u <= W) {
+        const uint32_t sh = H->hmax / H->comp[1].h, sv = H->vmax / H->comp[1].v;
+        mode = (sh == 2u && sv == 2u) ? 1 : (sh == 2u && sv == 1u) ? 2 : (sh == 1u && sv == 1u) ? 3 : 0;
+    }
+    if (mode == 1) color_group<2, 2>(jb, H, x0, y, rows);
+    else if (mode == 2) color_group<2, 1>(jb, H, x0, y, rows);
+    else if (mode == 3) color_group<1, 1>(jb, H, x0, y, rows);
+    else {
+        for (uint32_t rr = 0; rr < rows; ++rr)
+            for (uint32_t k = 0; k < 4u && x0 + k < W; ++k) color_pixel(jb, H, x0 + k, y + rr);
     }
 }
 
@@ -173,7 +272,8 @@ hipError_t launch_jpeg_decode(const JpegDecJob *jobs, uint32_t njobs, uint32_t m
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_blocks + BLOCKS_PER_WG - 1) / BLOCKS_PER_WG, njobs), dim3(256), 0, st, jobs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_w + 1023u) / 1024u, max_h, njobs), dim3(256), 0, st, jobs);
+    const uint32_t groups = ((max_w + 3u) / 4u) * ((max_h + 1u) / 2u);
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((groups + 255u) / 256u, njobs), dim3(256), 0, st, jobs);
     return hipGetLastError();
 }
 

@@ -48,13 +48,14 @@ constexpr uint32_t kMfmaOutPitchWide = 748;
 static_assert(kMfmaOutPitchWide >= kMfmaMaxStripOutputsWide + 16 && (4 * kMfmaOutPitchWide) % 32 == 16, "LDS output tile pitch (wide)");
 // The three LDS layouts of the kernel (template parameter LAYOUT): words per output-tile row / outputs per strip / operands
 // (1 KB each) that fit next to the two output tiles and the rows' 64 KB.
-constexpr uint32_t kMfmaMaxStripOutputsCompact = 300;
-constexpr uint32_t kMfmaOutPitchCompact = 316;
+constexpr uint32_t kMfmaMaxStripOutputsCompact = 312; // (104 Rgb8 pixels: what three strips of 1080p -> 300 columns need when every strip starts on a 128-byte line)
+constexpr uint32_t kMfmaOutPitchCompact = 332;
 static_assert(kMfmaOutPitchCompact >= kMfmaMaxStripOutputsCompact + 16 && (4 * kMfmaOutPitchCompact) % 32 == 16, "LDS output tile pitch (compact)");
 constexpr uint32_t mfma_out_pitch(int layout) { return layout == 1 ? kMfmaOutPitchWide : layout == 2 ? kMfmaOutPitchCompact : kMfmaOutPitch; }
 constexpr uint32_t mfma_max_outputs(int layout) { return layout == 1 ? kMfmaMaxStripOutputsWide : layout == 2 ? kMfmaMaxStripOutputsCompact : kMfmaMaxStripOutputs; }
 // full-width arithmetic: operands the LDS operand area of a layout holds (160 KB - the rows' 64 KB - ONE output tile - counters)
-constexpr uint32_t mfma_lds_operand_capacity(int layout) { return (160u * 1024u - 64u * 1024u - 16u * mfma_out_pitch(layout) * 4u - 16u) / 1024u; } // 69 / 49 (wide) / 76 (compact)
+constexpr uint32_t kMfmaCntBytes = 16u + 64u; // LDS counters add_cnt[2], conv_cnt[2] + two conversion contexts of 8 words (fl_mfma.hip)
+constexpr uint32_t mfma_lds_operand_capacity(int layout) { return (160u * 1024u - 64u * 1024u - 16u * mfma_out_pitch(layout) * 4u - kMfmaCntBytes) / 1024u; } // 69 / 49 (wide) / 75 (compact)
 constexpr uint32_t kMfmaDefaultSpinLimit = 1u << 22; // polls of an LDS counter before a wave gives up and reports FLGPU_DEVERR_MFMA_WAIT
 constexpr uint32_t FLGPU_DEVERR_MFMA_WAIT = 1u;      // bit of the batch's device error word
 constexpr uint32_t kMfmaVScaleLog2 = 8;     // packed arithmetic: vertical weights are stored times 2^8 (keeps the low f16 term normal)
@@ -70,8 +71,11 @@ constexpr uint32_t kMfmaOutFracBitsFull = 20; // the horizontal sums reach the L
 //                        fixed-point weights -> exact i32.  Within 1 LSB of the reference on every byte, ~0.1 % of them off by one.
 //   FULL   (round 4):    no operand narrower than the reference's f32: u8 (exact, f16 subnormal) x the f32 weight itself (three f16
 //                        terms) -> f32 sums in the matrix unit; intermediate rounded to 2^-14 of a pixel step (23 bits + sign,
-//                        three byte planes) x weights rounded to 2^-24 (three byte digits, sums forced to exactly 1) -> all nine
-//                        digit products, exact in i32, recombined to 2^-20 of a pixel step.
+//                        three byte planes) x weights rounded to 2^-24 (three byte digits, sums forced to exactly 1) -> the digit
+//                        products, exact in i32, recombined to 2^-20 of a pixel step.  Round 5: EIGHT of the nine products -- the
+//                        lowest plane x the lowest digit is at most 2^20 in units of 2^-38 of a pixel step per 64 columns, i.e. less
+//                        than 2^-18 of a step (below half an f32 ulp of any value above 64), and is not computed; every operand
+//                        still enters with all of its 24 bits.
 enum MfmaArith : uint32_t { MFMA_ARITH_PACKED = 0, MFMA_ARITH_FULL = 1 };
 
 // One workgroup.
@@ -86,14 +90,17 @@ struct alignas(16) MfmaItem {
 
 // What the request of an item's FIRST K-block needs, one record per item in item order (the persistent workgroups of the full-width
 // kernel issue that request in the last pass of the item before: one scalar load there, nothing of the next item in registers earlier).
-struct alignas(32) MfmaReq {
+struct alignas(16) MfmaReq {
     const void *src;       // the job's source picture
     uint32_t pitch;        // bytes per source row
     uint32_t last_row;     // source rows - 1
     uint32_t byte0;        // MfmaStrip::byte0 of the item's strip
-    uint32_t kb0;          // the item's first K-block
+    uint32_t kb0, kb1;     // the item's K-blocks
+    uint32_t job;          // MfmaItem::job
+    uint32_t strip_off, vplan_off; // MfmaItem's: an item whose strip, plan and K-blocks equal its predecessor's needs no new set-up
     uint32_t pad[2];
 };
+static_assert(sizeof(MfmaReq) == 48, "MfmaReq layout");
 
 // Vertical plan of one (axis, kept rows) pair.  All offsets are arena word offsets.
 //   kb_meta[nkb + 1] per K-block: bits 0-15 = tile that is complete after it (0xffff: none), bit 16/17 = set 0/1 has weights in it;
@@ -150,6 +157,7 @@ struct LaunchMfma {
     const MfmaReq *reqs;   // one per item (full-width arithmetic)
     const uint32_t *arena;
     uint32_t nitems;
+    uint32_t grid;         // full-width arithmetic: workgroups of the persistent launch (min(nitems, CUs): the host's item order is built for it)
     uint32_t cs;           // channels of the source (1..4)
     uint32_t letterbox;
     uint32_t ops_in_lds;   // every strip of the launch has <= kMfmaLdsOperands distinct operands

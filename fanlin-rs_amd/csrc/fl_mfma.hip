@@ -31,7 +31,7 @@ typedef __attribute__((address_space(1))) uint8_t *gptr8;
 
 constexpr uint32_t THREADS = kMfmaWaves * 64;
 constexpr uint32_t RING_BYTES = kMfmaKRows * kMfmaWaveCols; // one K-block of one wave
-constexpr uint32_t CNT_BYTES = 16;                          // add_cnt[2], conv_cnt[2]
+constexpr uint32_t CNT_BYTES = kMfmaCntBytes;               // add_cnt[2], conv_cnt[2], then two conversion contexts of 8 words (the item a pending tile belongs to: destination, row pitch, first pixel, fill)
 
 __shared__ __attribute__((aligned(16))) uint8_t mfma_ring[kMfmaWaves * RING_BYTES]; // the rows' landing zone (static), everything else is dynamic
 extern __shared__ __attribute__((aligned(16))) uint8_t mfma_lds[];
@@ -68,14 +68,32 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f
 // blockIdx.x, blockIdx.x + gridDim.x, ... -- with 160 KB of LDS and 512 x 256 registers a CU holds ONE workgroup, so with one item per
 // workgroup every item paid a dispatch, a prologue, the latency of its first K-block and the drain of its last tile with nothing in
 // flight for that CU (15-17 us of ~130).  Now the first K-block of item n + 1 is requested in the LAST pass of item n (the wave's
-// 8 KB of LDS are free once the transposed reads have returned) and flies under the last tile's stage, the conversion of its rows
-// and the next item's set-up.  The LDS counters run on across items (a tile's global number = tiles of earlier items + its number
-// in this one); the packed arithmetic keeps one item per workgroup (its launch has gridDim.x = nitems).
+// 8 KB of LDS are free once the transposed reads have returned).  Two kinds of transition:
+//   light   the next item has the same strip, plan and K-blocks (another picture of the same geometry: the host orders a uniform
+//           launch so that a workgroup's items share their strip, fl_batch.cpp persistent_order): NOTHING is waited for -- the walk
+//           goes on into the next picture's rows, the last tile's rows are converted in the passes that follow like any other
+//           tile's (what the conversion needs of the old item -- destination, pitch, first pixel -- sits in an LDS context, two of
+//           them, by item parity), the frame is painted and the new context written behind the first request;
+//   heavy   anything else: this wave's rows of the last tile once all eight waves have added (a bounded spin), then descriptors,
+//           tile table, operands, a barrier -- the first K-block flies under all of it.
+// The LDS counters run on across items (a tile's global number = tiles of earlier items + its number in this one); the packed
+// arithmetic keeps one item per workgroup (its launch has gridDim.x = nitems).
 template <int CS, bool LB, bool HLDS, int LAYOUT, bool FW>
 __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items, const MfmaReq *__restrict__ reqs,
                                                                    const uint32_t *__restrict__ arena, uint32_t nitems, uint32_t ot_words, uint32_t spin_limit,
-                                                                   uint32_t *__restrict__ err_word)
+                                                                   uint32_t *__restrict__ err_word
+#ifdef FL_MFMA_STAMPS
+                                                                   , unsigned long long *__restrict__ stamps
+#endif
+)
 {
+#ifdef FL_MFMA_STAMPS // development aid (-DFL_MFMA_STAMPS): 100 MHz timestamps of wave 0 and wave 5 of workgroups 0, 100, 200: [wg][wave][item][event]
+    unsigned long long *my_stamps = nullptr;
+    uint32_t stamp_item = 0;
+#define FL_STAMP(ev_) do { if (my_stamps && stamp_item < 16u && lane == 0) my_stamps[stamp_item * 8u + (ev_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FL_STAMP(ev_) do { } while (0)
+#endif
     // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh): 1 = no horizontal MFMAs / LDS adds, 2 = no conversion of
     // finished tiles, 32 = conversion without its global stores, 4 = no horizontal stage at all, 8 = no vertical MFMAs,
     // 128 = no LDS adds, 8192 (with 4) = the vertical pass alone, its sums kept alive
@@ -84,13 +102,18 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #else
     constexpr uint32_t ablate = 0;
 #endif
-    // experiments (-DFL_VARIANT=mask): 2 = eight digit products per unit (plane 0 x digit 0 dropped) and the four-instruction
-    // recombination, 4 = waves 4-7 start every item a few microseconds late (their stages then run beside the other waves' vertical
-    // passes), 16 = a chunk's planes are made beside the matrix instructions of the chunk before
+    // experiments (-DFL_VARIANT=mask): 16 = a chunk's planes are made beside the matrix instructions of the chunk before (spills),
+    // 8 (launcher) = one item per workgroup; -DFL_NINE_PRODUCTS: the ninth digit product, plane 0 x digit 0, is computed too (round 4);
+    // -DFL_STAGGER_N=n: waves 4-7 start the workgroup's walk n x 1.35 us late
 #ifdef FL_VARIANT
     constexpr uint32_t variant = FL_VARIANT;
 #else
     constexpr uint32_t variant = 0;
+#endif
+#ifdef FL_NINE_PRODUCTS
+    constexpr bool EIGHT = false;
+#else
+    constexpr bool EIGHT = true; // fl_mfma.h: the full-width arithmetic's horizontal pass
 #endif
     const uint32_t tid = threadIdx.x, lane = tid & 63u, g = lane >> 4, i = lane & 15u;
     uint32_t wg_error = 0u; // a bounded wait expired in this lane's wave
@@ -98,6 +121,11 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // The item this workgroup is on: the descriptors are read again at the top of every trip of the item loop below (nothing but the
     // item's number is carried around the loop: the kernel has no registers to spare), everything derived from them is set in `enter_item`.
     uint32_t item = blockIdx.x;
+#ifdef FL_MFMA_STAMPS
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+    if ((blockIdx.x == 0u || blockIdx.x == 8u || blockIdx.x == 16u) && (wave == 0u || wave == 5u))
+        my_stamps = stamps + ((blockIdx.x / 8u) * 2u + (wave ? 1u : 0u)) * 16u * 8u;
+#endif
     MfmaItem it;
     Job jb;
     MfmaVPlan vp;
@@ -194,16 +222,19 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             }
         }
     };
-    uint32_t pitch = 0, last_row = 0;
-    auto request = [&](uint32_t s) __attribute__((always_inline)) { request_from(jb.src, pitch, last_row, s); };
-    // the first K-block of item `which` (its MfmaReq record: one scalar load); leaves voff set for that item
-    auto request_first_of = [&](uint32_t which) __attribute__((always_inline)) {
-        const MfmaReq r = reqs[which];
+    // what the K loop needs of the picture it walks: the item's request record (src, pitch, last row), and the next item's once its
+    // first K-block has been requested
+    // (single fields, not the records: only these four are alive through the K loop, and of the next item only what is named here)
+    const void *rq_src, *nx_src = nullptr;
+    uint32_t rq_pitch, rq_last_row, rq_job, nx_pitch = 0, nx_last_row = 0, nx_job = 0;
+    bool light_next = false; // the next item continues this walk: same strip, plan and K-blocks
+    auto request = [&](uint32_t s) __attribute__((always_inline)) { request_from(rq_src, rq_pitch, rq_last_row, s); };
+    {   // The first item's first K-block goes out before anything else: it flies under the set-up below.
+        const MfmaReq r = reqs[item];
+        rq_src = r.src; rq_pitch = r.pitch; rq_last_row = r.last_row; rq_job = r.job;
         set_voff(r.pitch, r.byte0);
-        request_from(r.src, r.pitch, r.last_row, r.kb0);
-    };
-    // The first item's first K-block goes out before anything else: it flies under the set-up below.
-    request_first_of(item);
+        request(r.kb0);
+    }
 
     f32x4 acc[2][16];
 #pragma unroll
@@ -224,19 +255,17 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // wave shifts its part of the sum down to 2^-20 steps before it adds it to the tile, see the stage)
     int32_t round_add = 0;
     uint32_t out_shift = 0; // (packed arithmetic)
-    uint32_t pix_base = 0, npx = 0;
+    uint32_t npx = 0;
     uint32_t ops_resident = 0xffffffffu; // arena offset of the operands the LDS operand area holds (a workgroup's consecutive items often share a strip)
     // Everything that hangs on the item: called once per trip of the item loop, with the item's first K-block already in flight.
     // The LDS operand area may be written here: every wave has finished the previous item's last stage (its epilogue waited for all
     // eight waves' adds of the last tile).
     auto enter_item = [&]() __attribute__((always_inline)) {
-        pitch = jb.sw * (uint32_t)CS; last_row = jb.sh - 1u;
         vw = reinterpret_cast<const u32x4 *>(arena + vp.w_off);
         ops_glb = reinterpret_cast<const u32x4 *>(arena + sp.ops_off);
         hs = sp.hs;
         round_add = FW ? (int32_t)(-132112384 + (1 << (kMfmaOutFracBitsFull - 1u))) : (int32_t)((128u << hs) + (1u << (hs + kMfmaXFracBits - 1u)));
         out_shift = hs + kMfmaXFracBits;
-        pix_base = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx);
         npx = sp.x1 - sp.x0;
         {
             const int32_t *cp = reinterpret_cast<const int32_t *>(arena + sp.ctab_off) + wave * (12u * CE);
@@ -259,7 +288,19 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             for (uint32_t k = tid; k < sp.n_ops * 64u; k += THREADS) reinterpret_cast<u32x4 *>(mfma_lds + NBUF * ot_words * 4u + CNT_BYTES)[k] = ops_glb[k];
             ops_resident = sp.ops_off;
         }
-        if (LB) paint_frame();
+    };
+    // The conversion context of the item with parity `par` (seq & 1): what convert_rows needs of the item a tile belongs to.  One
+    // thread writes it; a wave reads it only for a tile all eight waves have added to, i.e. after the writer's own add (release /
+    // acquire on add_cnt) -- or after the barrier of a heavy transition.
+    uint32_t *ctxbuf = conv_cnt + 2;
+    auto write_ctx = [&](uint32_t par) __attribute__((always_inline)) {
+        if (tid == 0) {
+            uint32_t *cx = ctxbuf + 8u * par;
+            cx[0] = (uint32_t)(uintptr_t)jb.dst; cx[1] = (uint32_t)((uintptr_t)jb.dst >> 32);
+            cx[2] = jb.dw;
+            cx[3] = (jb.oy - jb.cy) * jb.dw + jb.ox + (sp.x0 - jb.cx); // first pixel of the strip's row y0
+            cx[4] = jb.fill;
+        }
     };
 
     constexpr uint32_t CONV_G = (mfma_max_outputs(LAYOUT) / (uint32_t)CS + 63u) / 64u;
@@ -269,8 +310,12 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // nothing here switches lanes off; rows past the picture's end (short last tile) are skipped as a whole.  `whole_rows` (the
     // item's last tile, full-width arithmetic): the wave's two rows of the LDS tile are zeroed from end to end afterwards -- the
     // skipped rows and the dummy columns too: the next item of this workgroup may have a wider strip.
-    auto convert_rows = [&](uint32_t tile, uint32_t buf, bool whole_rows) __attribute__((always_inline)) {
+    auto convert_rows = [&](uint32_t tile, uint32_t buf, bool whole_rows, uint32_t par) __attribute__((always_inline)) {
         uint32_t *ot = otile + buf * ot_words;
+        // (the item's context as per-lane values: every lane reads the same LDS words -- no scalar registers are held for it)
+        const u32x4 cx = *reinterpret_cast<const u32x4 *>(ctxbuf + 8u * par);
+        const uint32_t cx_fill = ctxbuf[8u * par + 4u];
+        const uint64_t cx_dst = (uint64_t)cx[0] | ((uint64_t)cx[1] << 32);
         const uint32_t ngrp = (npx + 63u) >> 6; // lane groups in use (wave-uniform)
         // (both rows' sums are fetched up front where the registers allow it -- Rgb8, the flagship: 12 of them; the other
         // instantiations fetch one lane group at a time: 16-24 registers of sums at this point pushed them into scratch, whose reloads wait on vmcnt,
@@ -294,9 +339,14 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             const bool live = 16u * tile + row < vp.rows;
 #pragma unroll
             for (uint32_t k = 0; k < CONV_G; ++k) {
-                if (k >= ngrp || !live) continue;
+                if (k >= ngrp) continue;
                 const uint32_t xo = min(lane + 64u * k, npx - 1u);
                 uint32_t *o = ot + row * np + (uint32_t)CS * xo;
+                if (!live) { // (a row past the picture's end: its sums are of zero weights, and the LDS tile goes on to the next tile -- of this item or the next)
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) o[c] = 0u;
+                    continue;
+                }
                 if (!BOTH) { // (one lane group at a time: CS registers of sums)
 #pragma unroll
                     for (int c = 0; c < CS; ++c) sums[0][0][c] = o[c];
@@ -318,19 +368,19 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 uint32_t v;
                 if (LB) { // DynamicImage -> Rgba8 (to_rgba8) and imageops::overlay onto the fill colour, as in the streaming kernel
                     if (CS == 1) v = c8[0] | (c8[0] << 8) | (c8[0] << 16) | 0xff000000u;
-                    else if (CS == 2) v = blend_over_fill(jb.fill, c8[0], c8[0], c8[0], c8[CS > 1 ? 1 : 0]);
+                    else if (CS == 2) v = blend_over_fill(cx_fill, c8[0], c8[0], c8[0], c8[CS > 1 ? 1 : 0]);
                     else if (CS == 3) v = c8[0] | (c8[CS > 1 ? 1 : 0] << 8) | (c8[CS > 2 ? 2 : 0] << 16) | 0xff000000u;
-                    else v = blend_over_fill(jb.fill, c8[0], c8[CS > 1 ? 1 : 0], c8[CS > 2 ? 2 : 0], c8[CS > 3 ? 3 : 0]);
+                    else v = blend_over_fill(cx_fill, c8[0], c8[CS > 1 ? 1 : 0], c8[CS > 2 ? 2 : 0], c8[CS > 3 ? 3 : 0]);
                 } else {
                     v = c8[0] | (c8[CS > 1 ? 1 : 0] << 8) | (c8[CS > 2 ? 2 : 0] << 16) | (c8[CS > 3 ? 3 : 0] << 24);
                 }
                 if (ablate & 32u) { asm volatile("" : : "v"(v)); continue; } // (experiment: everything but the store itself)
                 // (a pointer read from a descriptor has no address space the compiler could know; the destination is device
                 // memory by contract, see gptr32)
-                const uint32_t pix = pix_base + (vp.y0 + 16u * tile + row) * jb.dw + xo;
-                if (LB) ((gptr32)(uintptr_t)jb.dst)[pix] = v;
+                const uint32_t pix = cx[3] + (vp.y0 + 16u * tile + row) * cx[2] + xo;
+                if (LB) ((gptr32)(uintptr_t)cx_dst)[pix] = v;
                 else {
-                    gptr8 p = (gptr8)(uintptr_t)jb.dst + (size_t)pix * CS;
+                    gptr8 p = (gptr8)(uintptr_t)cx_dst + (size_t)pix * CS;
 #pragma unroll
                     for (int c = 0; c < CS; ++c) p[c] = (uint8_t)(v >> (8 * c));
                 }
@@ -358,6 +408,8 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // for rows anyway.  pend_li: the tile this wave has added to but not converted yet, numbered through the workgroup's whole
     // walk (gl_base = tiles of the items before this one: the counters run on across items).
     uint32_t pend_li = 0xffffffffu, gl_base = 0u;
+    uint32_t pend_tile = 0u, pend_par = 0u; // ... its number inside its item, and that item's parity (conversion context)
+    uint32_t seq = 0u;                      // items this workgroup has finished
     auto try_convert = [&](bool must, bool whole_rows) __attribute__((always_inline)) {
         const uint32_t need = kMfmaWaves * (pend_li + 1u);
         uint32_t spin = 0;
@@ -370,27 +422,44 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             __builtin_amdgcn_s_sleep(2);
         }
         if (spin >= spin_limit) wg_error = 1u; // (as in the packed form's wait: a limit of 0 -- the tests' -- reports every wait)
-        if (!(ablate & 2u)) convert_rows(it.tile0 + (pend_li - gl_base), 0u, whole_rows);
+        if (!(ablate & 2u)) convert_rows(pend_tile, 0u, whole_rows, pend_par);
         pend_li = 0xffffffffu;
         if (lane == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __hip_atomic_fetch_add(&conv_cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
+    bool heavy = true;  // how this item is entered: the first one with a full set-up
     for (;;) { // ---- the items of this workgroup ----------------------------------------------------------------------------------
     const uint32_t next_item = item + gridDim.x;
     const bool has_next_item = FW && next_item < nitems;
-    load_item();
-    enter_item();
-    meta_n = arena[vp.meta_off + it.kb0 + vzero];
-#pragma unroll
-    for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(it.kb0 * (2u * NT) + k) * 64u + lane];
-    // the output tile is zero (first item: the clear above; later ones: every wave zeroed its rows in the epilogue and the first
-    // stage waits for all of them, conv_cnt) and the operands are in place for every wave
-    __syncthreads();
-    if ((variant & 4u) && wave >= 4u) {
-        for (int k = 0; k < 2; ++k) __builtin_amdgcn_s_sleep(100); // 2 x 100 x 64 cycles = 5.4 us, a pass and a half
+    FL_STAMP(0);
+    if (heavy) {
+        load_item();
+        enter_item();
+    } else {
+        // entered lightly: strip, plan, K-blocks, tile table, operands and weights stay; only the picture is another one
+        jb = jobs[rq_job];
     }
+    // the item's frame and its conversion context (no tile of this item is converted before every wave -- the writer too -- has added
+    // to it, several passes from here)
+    if (LB) paint_frame();
+    write_ctx(seq & 1u);
+    if (heavy) {
+        meta_n = arena[vp.meta_off + it.kb0 + vzero];
+#pragma unroll
+        for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(it.kb0 * (2u * NT) + k) * 64u + lane];
+        // the output tile is zero (first item: the clear above; later ones: every wave zeroed its rows in the epilogue and the first
+        // stage waits for all of them, conv_cnt), the operands and the conversion context are in place for every wave
+        __syncthreads();
+    }
+    FL_STAMP(1);
+#ifdef FL_STAGGER_N
+    if (seq == 0u && wave >= 4u) {
+        // experiment: waves 4-7 start the workgroup's walk late, so that their tile stages run beside the other waves' vertical passes
+        for (int k = 0; k < FL_STAGGER_N; ++k) __builtin_amdgcn_s_sleep(50); // n x 50 x 64 cycles = n x 1.35 us
+    }
+#endif
     // (kb_end: one pass more than the band has K-blocks when the picture's short last tile ends together with the tile before
     // it -- that pass runs on the table's all-zero K-block, index vp.nkb, whose meta word names the last tile: the matrix unit
     // adds zeros to whatever the transposed reads deliver, nothing is requested, and the loop body stays as it is)
@@ -399,6 +468,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         const bool have_next = s + 1u < it.kb1;
         __builtin_amdgcn_s_setprio(3); // (from here to the next request this wave's instructions go first on its SIMD: its LDS is not in flight)
         wait_vm0();
+        if (s == it.kb0) FL_STAMP(2);
         const uint32_t meta = __builtin_amdgcn_readfirstlane(meta_n);
         v2i raw[16];
 #pragma unroll
@@ -411,7 +481,12 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         else if (has_next_item && s + 1u == kb_end) {
             // this item's last pass: the wave's 8 KB are free for good -- the NEXT item's first K-block flies under the last tile's
             // stage, the epilogue and the next item's set-up
-            request_first_of(next_item);
+            const MfmaReq r = reqs[next_item];
+            set_voff(r.pitch, r.byte0);
+            request_from(r.src, r.pitch, r.last_row, r.kb0);
+            nx_src = r.src; nx_pitch = r.pitch; nx_last_row = r.last_row; nx_job = r.job;
+            light_next = r.strip_off == it.strip_off && r.vplan_off == it.vplan_off && r.kb0 == it.kb0 && r.kb1 == it.kb1;
+            FL_STAMP(3);
         }
         __builtin_amdgcn_s_setprio(0);
         if constexpr (FW) {
@@ -445,8 +520,10 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                 for (int t = 0; t < NT; ++t) acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, wv[NT + t]), acc[1][ct], 0, 0, 0);
             }
         }
-        if (s + 1u < kb_end) {
-            const uint32_t sn = s + 1u < it.kb1 ? s + 1u : vp.nkb;
+        // (the item's last pass: if the next item continues this walk -- same strip, plan and K-blocks -- the weights of ITS first
+        // K-block, which are this item's first again)
+        if (s + 1u < kb_end || light_next) {
+            const uint32_t sn = s + 1u < it.kb1 ? s + 1u : (s + 1u < kb_end ? vp.nkb : it.kb0);
             meta_n = arena[vp.meta_off + sn + vzero];
 #pragma unroll
             for (int k = 0; k < 2 * NT; ++k) wv[k] = vw[(sn * (2u * NT) + k) * 64u + lane];
@@ -534,7 +611,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                             l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, z, 0, 0, 0);
                             l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, z, 0, 0, 0);
                             l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, i32x4{rnd, rnd, rnd, rnd}, 0, 0, 0);
-                            if (!(variant & 2u)) l[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, z, 0, 0, 0);
+                            if (!EIGHT) l[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, z, 0, 0, 0);
                             l[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, l[3], 0, 0, 0);
                             l[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, l[2], 0, 0, 0);
                             l[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, l[1], 0, 0, 0);
@@ -549,7 +626,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 uint32_t p;
-                                if (variant & 2u) {
+                                if (EIGHT) {
                                     // (plane 0 x digit 0 -- at most 2^20 in units of 2^-38 of a pixel step, i.e. below 2^-18 of a step --
                                     // is not computed: eight products, and the recombination is two shift-adds, a shift and a shift-add)
                                     const int32_t low = (int32_t)shl8_add((uint32_t)l[2][r], (uint32_t)l[1][r]) >> slo;
@@ -641,7 +718,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     };
                     if (!(ablate & 1u)) { load_ops(0); load_ops(1); }
                     wait_for_the_tiles();
-                    if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u, false); // this wave's two rows of the previous tile
+                    if (li >= 1u && !(ablate & 2u)) convert_rows(ft - 1u, buf ^ 1u, false, 0u); // this wave's two rows of the previous tile
                     if (!(ablate & 1u)) {
                         unit_mfma(0);
     #pragma unroll
@@ -666,7 +743,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
                     __hip_atomic_fetch_add(&add_cnt[buf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (!FW && li >= 1u) __hip_atomic_fetch_add(&conv_cnt[buf ^ 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if constexpr (FW) pend_li = gl_base + li;
+                if constexpr (FW) { pend_li = gl_base + li; pend_tile = ft; pend_par = seq & 1u; }
             }
             // The younger tile becomes the older one: set 0 <- set 1, set 1 <- 0, so that the finished tile is always read from
             // compile-time registers (set 0).  Plain moves: at the power limit 128 moves are cheaper than the 32 matrix
@@ -678,24 +755,43 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             }
         }
     }
-    // ---- the item's epilogue -----------------------------------------------------------------------------------------------------
+    FL_STAMP(4);
+    // ---- on to the next item ------------------------------------------------------------------------------------------------------
+    const bool light = light_next;
     if constexpr (FW) {
-        // this wave's two rows of the last tile, once every wave has added its sums (a bounded spin; the next item's first K-block is
-        // in flight meanwhile).  The rows are zeroed from end to end: the LDS tile is the next item's.
-        if (pend_li != 0xffffffffu) try_convert(true, true);
+        if (!light) {
+            // heavy transition, or the end: this wave's two rows of the last tile, once every wave has added its sums (a bounded
+            // spin; the next item's first K-block is in flight meanwhile).  The rows are zeroed from end to end: the next item's
+            // strip may be wider.  (Every wave is then past its last stage: the LDS operand area may be rewritten.)
+            if (pend_li != 0xffffffffu) try_convert(true, true);
+        }
     } else {
         __syncthreads(); // every wave has added its sums of the last tile
-        if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u, false);
+        if (!(ablate & 6u)) convert_rows(it.tile1 - 1u, (it.tile1 - 1u - it.tile0) & 1u, false, 0u);
     }
+    FL_STAMP(5);
+#ifdef FL_MFMA_STAMPS
+    ++stamp_item;
+#endif
     if (!has_next_item) break;
     gl_base += it.tile1 - it.tile0;
     item = next_item;
+    rq_src = nx_src; rq_pitch = nx_pitch; rq_last_row = nx_last_row; rq_job = nx_job;
+    ++seq;
+    heavy = !light;
+    light_next = false;
     // (a band's younger accumulator set may hold rows of the tile after the band: every item starts from zero)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) acc[s2][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     } // ---- items ---------------------------------------------------------------------------------------------------------------
+#ifdef FL_MFMA_STAMPS
+    if (tid == 0u && blockIdx.x < 512u) { // every workgroup: start, end, XCC_ID (hardware register 20, bits 3:0), items done
+        unsigned long long *d = stamps + 3 * 2 * 16 * 8 + (size_t)blockIdx.x * 4u;
+        d[0] = wg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20); d[3] = seq + 1u;
+    }
+#endif
     if (wg_error && lane == 0) atomicOr(err_word, FLGPU_DEVERR_MFMA_WAIT);
 }
 
@@ -735,16 +831,34 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 #else
     constexpr bool persistent = true;
 #endif
-    if (FW && persistent) {
-        static std::atomic<int> cus[64];
-        int n = cus[dev & 63].load(std::memory_order_acquire);
-        if (!n) {
-            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-            cus[dev & 63].store(n, std::memory_order_release);
-        }
-        grid = std::min<uint32_t>(m.nitems, (uint32_t)n);
+    if (FW && persistent) grid = std::max(1u, std::min(m.nitems, m.grid ? m.grid : 256u));
+#ifdef FL_MFMA_STAMPS
+    static unsigned long long *stamps = nullptr;
+    static int launches = 0;
+    constexpr size_t kStampWords = 3 * 2 * 16 * 8 + 512 * 4;
+    if (!stamps) { (void)hipMalloc(&stamps, kStampWords * 8); (void)hipMemset(stamps, 0, kStampWords * 8); }
+    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<grid, THREADS, lds, st>>>(m.jobs, m.items, m.reqs, m.arena, m.nitems, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word, stamps);
+    if (++launches == 50 && m.nitems > 2900) {
+        unsigned long long h[kStampWords];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 6; ++w)
+            for (int k = 0; k < 13; ++k) {
+                const unsigned long long *d = h + (w * 16 + k) * 8;
+                if (!d[0]) continue;
+                fprintf(stderr, "mfma stamps wg %d wave %d item %d: set-up %.2f us, first K-block ready +%.2f, K loop to the last request %.2f, last pass + stage %.2f, epilogue %.2f; item %.2f us%s\n",
+                        (w / 2) * 8, (w % 2) ? 5 : 0, k, (d[1] - d[0]) * 0.01, (d[2] - d[1]) * 0.01, (d[3] - d[2]) * 0.01, (d[4] - d[3]) * 0.01, (d[5] - d[4]) * 0.01, (d[5] - d[0]) * 0.01,
+                        k ? "" : " (first)");
+            }
+        const unsigned long long *wt = h + 3 * 2 * 16 * 8;
+        unsigned long long t0 = ~0ull;
+        for (uint32_t b = 0; b < grid && b < 512u; ++b) t0 = std::min(t0, wt[4 * b]);
+        for (uint32_t b = 0; b < grid && b < 512u; ++b)
+            fprintf(stderr, "mfma wg %u: xcc %llu, start %.2f us, end %.2f us, %llu items\n", b, wt[4 * b + 2] & 15ull, (wt[4 * b] - t0) * 0.01, (wt[4 * b + 1] - t0) * 0.01, wt[4 * b + 3]);
     }
+#else
     resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<grid, THREADS, lds, st>>>(m.jobs, m.items, m.reqs, m.arena, m.nitems, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word);
+#endif
     return hipGetLastError();
 }
 

@@ -141,6 +141,13 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
     // (Equal strips, round 2's rule, needed a fourth strip for 1080p -> 256 columns: the edge strips have one halo, the inner ones
     // two, so 88 + 80 + 88 fits where 86 + 85 + 85 does not.  The result does not depend on the split: the horizontal sums are
     // exact integers.)
+    // Where a strip starts in the row.  The kernel moves 16-byte pieces, so any multiple of 16 works -- but a wave's 256-byte row piece that
+    // does not start on a 128-byte line touches three lines instead of two, and the load path alone runs 8 % slower on such strips
+    // (tools/microbench/align_probe.hip, profiles/r05_align_probe.txt: 1.139 against 1.049 ms for the flagship's strips; splitting the
+    // requests at the line boundary instead buys back a quarter of that).  Rows that start on a line (pitch a multiple of 128: 1080p
+    // Rgb8 is 45 lines) get line-aligned strips; the up to 112 bytes a strip loses on its left are part of the fit test below.
+    // (only where that costs no extra strip: a strip is a whole walk over the picture's rows)
+    uint32_t al = (cs * sw) % 128u == 0u ? 128u : 16u;
     const uint32_t max_px = max_outputs / cs;
     std::vector<uint32_t> bounds; // x0 of every strip, then cx + cw
     auto split = [&](uint32_t cap, std::vector<uint32_t> *b) -> uint32_t {
@@ -150,7 +157,7 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
             uint32_t L = h.left[x0], R = h.left[x0] + h.count[x0], x1 = x0;
             while (x1 < cx + cw && x1 - x0 < cap) {
                 const uint32_t L2 = std::min(L, h.left[x1]), R2 = std::max(R, h.left[x1] + h.count[x1]);
-                if (cs * R2 - (cs * L2) / 16u * 16u > kMfmaStripBytes) break;
+                if (cs * R2 - (cs * L2) / al * al > kMfmaStripBytes) break;
                 L = L2; R = R2; ++x1;
             }
             if (x1 == x0) return 0; // one output column alone does not fit
@@ -161,7 +168,12 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
         return n;
     };
     if (!max_px) return;
-    const uint32_t ns = split(max_px, nullptr);
+    uint32_t ns = split(max_px, nullptr);
+    if (al > 16u) {
+        al = 16u;
+        const uint32_t ns16 = split(max_px, nullptr);
+        if (ns && ns <= ns16) al = 128u; else ns = ns16;
+    }
     if (!ns) return;
     uint32_t cap = (cw + ns - 1u) / ns;
     while (cap < max_px && split(cap, nullptr) != ns) ++cap;
@@ -186,7 +198,7 @@ void build_mfma_plan(const HostAxis &v, const HostAxis &h, uint32_t cs, uint32_t
         const uint32_t x0 = bounds[si], x1 = bounds[si + 1];
         uint32_t L = 0xffffffffu;
         for (uint32_t x = x0; x < x1; ++x) L = std::min(L, h.left[x]);
-        S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (cs * L) / 16u * 16u; S.hdr.nout = (x1 - x0) * cs; S.hdr.hs = (uint32_t)hs; S.hdr.slots = 2;
+        S.hdr.x0 = x0; S.hdr.x1 = x1; S.hdr.byte0 = (cs * L) / al * al; S.hdr.nout = (x1 - x0) * cs; S.hdr.hs = (uint32_t)hs; S.hdr.slots = 2;
         const int32_t nout = (int32_t)S.hdr.nout;
         // operand 0 is all zeros: the tile slots a chunk does not need multiply by it and add into the dummy column, which keeps
         // the kernel's horizontal stage free of branches (12 matrix instructions back to back per chunk instead of 4 + a wait)

@@ -426,6 +426,12 @@ int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t 
 int flgpu_debug_mfma_plan_arith(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
                                 uint32_t cw, uint32_t ch, uint32_t arith, uint32_t info[8], double err[2]);
 
+/* Item order of a uniform matrix-pipe launch (csrc/fl_batch.cpp persistent_order): `pictures` pictures of `strips` strips each for a
+ * launch of `workgroups` persistent workgroups; job_of / strip_of [pictures * strips] receive the picture and strip of every item in
+ * launch order, *covered the number of items laid out in full rounds (workgroup b walks items b, b + workgroups, ...: inside the
+ * rounds all of them have b's strip, and a picture's strips sit on one XCD, b mod 8, in one round).  Needs no device. */
+int flgpu_debug_persistent_order(uint32_t pictures, uint32_t strips, uint32_t workgroups, uint32_t *job_of, uint32_t *strip_of, uint32_t *covered);
+
 const char *flgpu_strerror(int status);
 const char *flgpu_last_error(flgpu_ctx *ctx); /* detail of the last FLGPU_ERR_DEVICE on this context */
 uint32_t flgpu_abi_version(void);
