@@ -111,7 +111,7 @@ EXPORTED_SYMBOLS = (
     "flgpu_cmyk_to_rgb", "flgpu_cmyk_to_rgb_device", "flgpu_export_tables", "flgpu_copy_tables",
     "flgpu_import_tables", "flgpu_get_stats",
     "flgpu_reset_stats", "flgpu_debug_set", "flgpu_debug_get", "flgpu_strerror", "flgpu_last_error", "flgpu_abi_version", "flgpu_build_info",
-    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob", "flgpu_debug_mfma_plan", "flgpu_debug_mfma_plan_arith", "flgpu_debug_persistent_order",
+    "flgpu_debug_axis_table", "flgpu_debug_stream_schedulable", "flgpu_debug_jpeg_blob", "flgpu_debug_mfma_plan", "flgpu_debug_mfma_plan_arith", "flgpu_debug_assign_items",
 )
 
 _lib = None
@@ -442,14 +442,18 @@ def debug_mfma_plan(sw: int, sh: int, channels: int, rw: int, rh: int, crop=None
     return d
 
 
-def debug_persistent_order(pictures: int, strips: int, workgroups: int = 256):
-    """(job_of, strip_of, covered): the item order the persistent matrix-pipe launch gives a uniform batch (csrc/fl_batch.cpp)."""
+def debug_assign_items(pictures: int, strips: int, tiles: int = 11, workgroups: int = 256):
+    """(job, strip, tile0, tile1, lists): the items of a uniform persistent matrix-pipe launch in launch order and, per workgroup,
+    (first item, count) -- csrc/fl_batch.cpp assign_items."""
     lib = load_library()
-    n = pictures * strips
-    job, strip, cov = (C.c_uint32 * n)(), (C.c_uint32 * n)(), C.c_uint32()
-    lib.flgpu_debug_persistent_order.argtypes = [C.c_uint32] * 3 + [C.POINTER(C.c_uint32)] * 3
-    _check(lib.flgpu_debug_persistent_order(pictures, strips, workgroups, job, strip, C.byref(cov)))
-    return np.array(job[:], np.int64), np.array(strip[:], np.int64), int(cov.value)
+    cap = pictures * strips * tiles
+    arrs = [(C.c_uint32 * cap)() for _ in range(4)]
+    lists, n = (C.c_uint32 * (2 * workgroups))(), C.c_uint32()
+    lib.flgpu_debug_assign_items.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32)] * 6
+    _check(lib.flgpu_debug_assign_items(pictures, strips, tiles, workgroups, cap, *arrs, lists, C.byref(n)))
+    k = int(n.value)
+    g = min(workgroups, pictures * strips)
+    return tuple(np.array(a[:k], np.int64) for a in arrs) + (np.array(lists[:2 * g], np.int64).reshape(g, 2),)
 
 
 def debug_stream_schedulable(in_size: int, out_size: int, y0: int = 0, y1: Optional[int] = None) -> Tuple[bool, int]:

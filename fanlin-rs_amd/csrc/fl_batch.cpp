@@ -45,6 +45,7 @@ struct Work {
     const uint8_t *raw_src = nullptr;
     const WtPlan *wplan = nullptr;   // S1_WTILE: the window-tile matrix-pipe kernel's tables
     const WtPlan *bwplan = nullptr;  // ... for the blur stage, where that kernel serves it
+    bool luma_mid = false;           // grey picture on a grey frame + blur on that kernel: stage 1 leaves the UNFRAMED Luma8 picture, the blur reads it through a virtual frame and writes Rgba8
 };
 
 struct GroupKey {
@@ -73,11 +74,13 @@ bool wtile_resample_wanted(const Work &)
     return true;
 }
 
-// Blurs the window-tile matrix-pipe kernel takes: all but the one-channel shortcut (a grey picture on a grey frame: the vector
-// kernel filters one byte column in four there, the matrix kernel would filter all four).
-bool wtile_blur_wanted(const DebugSwitches &dbg, const Work &w)
+// Blurs the window-tile matrix-pipe kernel takes: every one its planner accepts.  (Round 4 left the one-channel shortcut -- a grey
+// picture on a grey frame, config 2 -- to the vector kernel, which filters one byte column in four there: the matrix kernel would have
+// filtered all four.  Round 5: stage 1 leaves the unframed Luma8 picture, the matrix kernel filters ONE channel, reading the frame's
+// rows and columns as the fill value, and expands to Rgba8 in its store -- Work::luma_mid.)
+bool wtile_blur_wanted(const DebugSwitches &, const Work &)
 {
-    return dbg.on(DBG_WTILE_BLUR_ALWAYS) || blur_channels(w) != 1u;
+    return true;
 }
 
 // Row bands per picture for the window-tile kernel: small batches are cut so that the chip still sees a few hundred workgroups
@@ -89,81 +92,107 @@ uint32_t wtile_bands(const DebugSwitches &dbg, const WtPlan &p, size_t pictures)
     return (uint32_t)std::min<size_t>(p.n_mt, std::max<size_t>(1, (512 + wgs - 1) / wgs));
 }
 
-// Item order of a UNIFORM matrix-pipe launch (full-width arithmetic: persistent workgroups, fl_mfma.hip) -- every picture the same
-// plan, cut into the same S strips, whole pictures (one band).  Workgroup b of the launch's G walks items b, b + G, b + 2 G, ...; the
-// order makes those share their STRIP, so that the walk goes from one picture's rows into the next one's without a new set-up (a
-// "light" transition: no operand copy, no tile table, no barrier, the last tile converted on the way), and keeps the S strips of
-// a picture on one XCD in the same round (hardware deals workgroup b to XCD b mod 8; the strips share halo columns through that
-// XCD's L2).  Per XCD: floor(slots / S) triples of neighbouring slots; the slots left over form cross-XCD triples; the last
-// G mod S workgroups take whole pictures strip after strip (heavy transitions).  Only FULL rounds are laid out (every slot filled);
-// returns how many items that covered -- the caller orders the rest the classic way.  0 = not a uniform launch.
-uint32_t persistent_order(MfmaItem *items, uint32_t n, uint32_t G)
+// Which items each persistent workgroup of a matrix-pipe launch walks (full-width arithmetic, fl_mfma.hip): `items` come in the classic
+// order (pictures x strips [x bands], longest first, strips of a picture on one XCD) and leave in WORKGROUP-MAJOR order; lists[2 b],
+// lists[2 b + 1] = first item and item count of workgroup b.
+//
+// General launch: workgroup b takes items b, b + G, b + 2 G, ... of the classic order.
+//
+// Uniform launch (every picture the same plan, cut into the same S strips, whole pictures): a workgroup keeps ONE strip, so that its walk
+// goes from one picture's rows into the next one's without a new set-up (fl_mfma.hip: a "light" transition -- no operand copy, no tile
+// table, no barrier, the last tile converted on the way), and the S strips of a picture run on one XCD at the same time (hardware
+// deals workgroup b to XCD (b + const) mod 8; the strips share their halo columns through that XCD's L2): per XCD floor(slots / S)
+// triples of neighbouring slots, the slots left over form cross-XCD triples, and G mod S workgroups stay free.  Every triple takes
+// R = floor(pictures / triples) pictures.  The pictures left over are cut into row bands of `plan` (an item each: a band computes
+// exactly what the full walk computes for its rows) and dealt to the workgroups with the least work -- the free ones first --, so
+// that the launch ends within one band of its average instead of one picture.
+void assign_items(std::vector<MfmaItem> &mitems, size_t base, uint32_t &nitems, uint32_t G, MfmaPlan *plan, std::vector<uint32_t> &lists)
 {
-    if (n < 2 || G < 16) return 0;
-    // strips per picture, and that the launch is pictures x the same strips
-    std::vector<uint32_t> strips;
-    for (uint32_t k = 0; k < n && items[k].job == items[0].job; ++k) strips.push_back(items[k].strip_off);
-    const uint32_t S = (uint32_t)strips.size();
-    if (S < 2 || S > 8 || n % S != 0 || G < 8u * S) return 0;
-    const uint32_t P = n / S;
-    for (uint32_t p = 0; p < P; ++p)
-        for (uint32_t s = 0; s < S; ++s) {
-            const MfmaItem &a = items[p * S + s];
-            if (a.job != items[p * S].job || a.strip_off != strips[s] || a.vplan_off != items[0].vplan_off || a.kb0 != items[0].kb0 || a.kb1 != items[0].kb1 ||
-                a.tile0 != items[0].tile0 || a.tile1 != items[0].tile1)
-                return 0;
+    MfmaItem *items = mitems.data() + base;
+    const uint32_t n = nitems;
+    std::vector<std::vector<MfmaItem>> per_wg(G);
+    auto classic = [&]() {
+        for (uint32_t k = 0; k < n; ++k) per_wg[k % G].push_back(items[k]);
+    };
+    // uniform?  (the classic order of a uniform launch: 8 pictures interleaved strip by strip; recover pictures x strips from the jobs)
+    bool uniform = plan && n >= 2 && G >= 16;
+    std::vector<uint32_t> strips, jobs_in_order;
+    if (uniform) {
+        std::map<uint32_t, std::vector<MfmaItem>> by_job;
+        for (uint32_t k = 0; k < n; ++k) {
+            if (!by_job.count(items[k].job)) jobs_in_order.push_back(items[k].job);
+            by_job[items[k].job].push_back(items[k]);
         }
-    // the strip of every workgroup, and which triple it belongs to
-    std::vector<int32_t> wg_strip(G, -1), wg_triple(G, -1);
-    std::vector<uint32_t> leftover;
-    uint32_t T = 0;
-    for (uint32_t x = 0; x < 8; ++x) {
-        const uint32_t slots = (G - x + 7u) / 8u, t_x = slots / S;
-        for (uint32_t j = 0; j < slots; ++j) {
-            const uint32_t b = 8u * j + x;
-            if (j < t_x * S) { wg_strip[b] = (int32_t)(j % S); wg_triple[b] = (int32_t)(T + j / S); }
-            else leftover.push_back(b);
+        for (const MfmaItem &a : by_job[jobs_in_order[0]]) strips.push_back(a.strip_off);
+        const uint32_t S = (uint32_t)strips.size();
+        uniform = S >= 2 && S <= 8 && G >= 8u * S && n == S * jobs_in_order.size();
+        for (uint32_t j : jobs_in_order) {
+            if (!uniform) break;
+            const auto &v = by_job[j];
+            if (v.size() != S) { uniform = false; break; }
+            for (uint32_t s2 = 0; s2 < S; ++s2)
+                if (v[s2].strip_off != strips[s2] || v[s2].vplan_off != items[0].vplan_off || v[s2].kb0 != items[0].kb0 || v[s2].kb1 != items[0].kb1 ||
+                    v[s2].tile0 != items[0].tile0 || v[s2].tile1 != items[0].tile1 || v[s2].tile0 != 0u || v[s2].tile1 != (uint32_t)plan->tiles.size())
+                    uniform = false;
         }
-        T += t_x;
-    }
-    std::sort(leftover.begin(), leftover.end());
-    const uint32_t cross = (uint32_t)leftover.size() / S, r = (uint32_t)leftover.size() % S;
-    for (uint32_t q = 0; q < cross * S; ++q) { wg_strip[leftover[q]] = (int32_t)(q % S); wg_triple[leftover[q]] = (int32_t)(T + q / S); }
-    T += cross;
-    std::vector<uint32_t> rotating(leftover.end() - r, leftover.end());
-    if (!T) return 0;
-    // rounds: a triple takes one picture per round, a rotating workgroup one strip of its picture (a new picture every S rounds)
-    std::vector<MfmaItem> src(items, items + n), out;
-    out.reserve(n);
-    std::vector<uint32_t> rot_pic(r, 0);
-    uint32_t next_pic = 0, rounds = 0;
-    for (;; ++rounds) {
-        const uint32_t need = T + ((rounds % S == 0) ? r : 0u);
-        if (next_pic + need > P) break;
-        std::vector<MfmaItem> round(G);
-        const uint32_t base = next_pic;
-        next_pic += T;
-        if (rounds % S == 0) for (uint32_t q = 0; q < r; ++q) rot_pic[q] = next_pic++;
-        for (uint32_t b = 0; b < G; ++b) {
-            if (wg_triple[b] >= 0) round[b] = src[(base + (uint32_t)wg_triple[b]) * S + (uint32_t)wg_strip[b]];
+        if (uniform) {
+            const uint32_t P = (uint32_t)jobs_in_order.size();
+            // triples of workgroups: inside an XCD first, then across
+            std::vector<std::vector<uint32_t>> triples;
+            std::vector<uint32_t> leftover;
+            for (uint32_t x = 0; x < 8; ++x) {
+                const uint32_t slots = (G - x + 7u) / 8u, t_x = slots / S;
+                for (uint32_t j = 0; j < slots; ++j) {
+                    const uint32_t b = 8u * j + x;
+                    if (j < t_x * S) { if (j % S == 0) triples.emplace_back(); triples.back().push_back(b); }
+                    else leftover.push_back(b);
+                }
+            }
+            std::sort(leftover.begin(), leftover.end());
+            for (uint32_t q = 0; q + S <= leftover.size(); q += S) triples.emplace_back(leftover.begin() + q, leftover.begin() + q + S);
+            const uint32_t T = (uint32_t)triples.size(), R = T ? P / T : 0u;
+            if (!R) uniform = false;
+            else {
+                for (uint32_t r = 0; r < R; ++r)
+                    for (uint32_t t = 0; t < T; ++t) {
+                        const auto &v = by_job[jobs_in_order[r * T + t]];
+                        for (uint32_t s2 = 0; s2 < S; ++s2) per_wg[triples[t][s2]].push_back(v[s2]);
+                    }
+                // the pictures left over, in bands
+                const uint32_t Lp = P - R * T;
+                if (Lp) {
+                    const uint32_t nt = (uint32_t)plan->tiles.size();
+                    const uint32_t nb = std::max(1u, std::min(nt, (2u * G + Lp * S - 1u) / (Lp * S)));
+                    const std::vector<MfmaItem> &bands = plan->items_for(nb);
+                    std::vector<MfmaItem> units;
+                    for (uint32_t p2 = R * T; p2 < P; ++p2)
+                        for (MfmaItem u : bands) { u.job = jobs_in_order[p2]; units.push_back(u); }
+                    std::stable_sort(units.begin(), units.end(), [](const MfmaItem &x, const MfmaItem &y) { return x.kb1 - x.kb0 > y.kb1 - y.kb0; });
+                    // least-loaded workgroup first (load in K-blocks; a transition counts like two)
+                    std::vector<uint64_t> load(G, 0);
+                    for (uint32_t b = 0; b < G; ++b) for (const MfmaItem &a : per_wg[b]) load[b] += a.kb1 - a.kb0;
+                    for (const MfmaItem &u : units) {
+                        uint32_t best = 0;
+                        for (uint32_t b = 1; b < G; ++b) if (load[b] < load[best]) best = b;
+                        per_wg[best].push_back(u);
+                        load[best] += u.kb1 - u.kb0 + 2u;
+                    }
+                }
+            }
         }
-        for (uint32_t q = 0; q < r; ++q) round[rotating[q]] = src[rot_pic[q] * S + rounds % S];
-        out.insert(out.end(), round.begin(), round.end());
     }
-    // (rotating workgroups in the middle of a picture: the round structure ends where their picture does)
-    while (rounds % S != 0 && r) { out.resize(out.size() - G); --rounds; }
-    if (out.empty()) return 0;
-    // (pictures are handed out in order: the rounds kept cover pictures [0, covered) completely)
-    uint32_t covered = 0;
-    {
-        uint32_t np2 = 0;
-        for (uint32_t k = 0; k < rounds; ++k) np2 += T + ((k % S == 0) ? r : 0u);
-        covered = np2;
+    if (!uniform) { for (auto &v : per_wg) v.clear(); classic(); }
+    // flatten, workgroup-major
+    std::vector<MfmaItem> flat;
+    lists.assign(2u * G, 0u);
+    for (uint32_t b = 0; b < G; ++b) {
+        lists[2 * b] = (uint32_t)flat.size();
+        lists[2 * b + 1] = (uint32_t)per_wg[b].size();
+        flat.insert(flat.end(), per_wg[b].begin(), per_wg[b].end());
     }
-    std::copy(out.begin(), out.end(), items);
-    uint32_t w = (uint32_t)out.size();
-    for (uint32_t p = covered; p < P; ++p) for (uint32_t s = 0; s < S; ++s) items[w++] = src[p * S + s];
-    return (uint32_t)out.size();
+    mitems.resize(base);
+    mitems.insert(mitems.end(), flat.begin(), flat.end());
+    nitems = (uint32_t)flat.size();
 }
 
 void fill_job(const Work &w, Job &j)
@@ -184,6 +213,7 @@ void fill_job(const Work &w, Job &j)
     }
     j.dw = pl.out_w; j.dh = pl.out_h;
     j.ox = pl.place_x; j.oy = pl.place_y;
+    if (w.luma_mid) { j.dw = j.cw; j.dh = j.ch; j.ox = 0; j.oy = 0; } // (the picture alone, tightly packed: the blur supplies the frame)
     j.fill = (uint32_t)w.p->fill_r | ((uint32_t)w.p->fill_g << 8) | ((uint32_t)w.p->fill_b << 16) | (255u << 24);
     j.vtab = w.vtab; j.htab = w.htab;
     j.pad1 = w.tile_w;
@@ -697,12 +727,22 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if (w.p->blur_sigma > 0.0f) {
                 AxisKey k; const HostAxis *h;
                 AxisKey kv; const HostAxis *hv;
+                w.bwplan = nullptr; w.luma_mid = false; // (a second attempt after an arena reset plans again)
                 if (!get_axis(c, w.plan.out_h, w.plan.out_h, FILTER_GAUSSIAN, w.p->blur_sigma, &kv, &hv) ||
                     !get_axis(c, w.plan.out_w, w.plan.out_w, FILTER_GAUSSIAN, w.p->blur_sigma, &k, &h)) full = true;
                 else if (use_wtile && wtile_blur_wanted(dbg, w)) {
-                    WtPlan *wp = get_wtile_plan(c, kv, *hv, k, *h, 0, 0, w.plan.out_w, w.plan.out_h, w.plan.out_c);
-                    if (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) full = true;
-                    else if (wp->ok) w.bwplan = wp;
+                    // a grey picture on a grey frame (R == G == B everywhere, alpha 255): one channel is filtered, if that plan is one of
+                    // the single-register-set kind (the kernel's framed source exists in that instantiation only)
+                    const bool one = w.plan.letterboxed && w.plan.out_c == 4u && blur_channels(w) == 1u && w.s1 != S1_NONE && w.s1 != S1_NEAREST;
+                    WtPlan *wp = one ? get_wtile_plan(c, kv, *hv, k, *h, 0, 0, w.plan.out_w, w.plan.out_h, 1u) : nullptr;
+                    if (wp && !wp->arena_full && wp->ok && wp->nslot == 1u) { w.bwplan = wp; w.luma_mid = true; }
+                    else {
+                        if (wp && wp->arena_full) full = true;
+                        wp = full ? nullptr : get_wtile_plan(c, kv, *hv, k, *h, 0, 0, w.plan.out_w, w.plan.out_h, w.plan.out_c);
+                        if (wp && (wp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024)) full = true;
+                        else if (wp && wp->ok) w.bwplan = wp;
+                    }
+                    if (c->h_arena.size() >= c->arena_cap_words - 1024) full = true;
                 }
                 if (!full && !w.bwplan) {
                     const uint32_t ty = blur_band_rows(blur_channels(w));
@@ -742,10 +782,10 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::map<GroupKey, std::vector<size_t>> s1_groups, blur_groups, fe_groups;
     for (size_t i = 0; i < n; ++i) {
         const Work &w = work[i];
-        if (w.s1 == S1_WTILE) s1_groups[{(uint32_t)S1_WTILE | (w.wplan->nslot << 8), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
-        else if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u) | (w.mplan->wide ? 1u << 9 : 0u) | (w.mplan->full ? 1u << 10 : 0u) | (w.mplan->compact ? 1u << 11 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
-        else if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed}].push_back(i);
-        if (w.p->blur_sigma > 0.0f && w.bwplan) blur_groups[{kBlurWtileKind | w.bwplan->nslot, w.plan.out_c, 0, 0}].push_back(i);
+        if (w.s1 == S1_WTILE) s1_groups[{(uint32_t)S1_WTILE | (w.wplan->nslot << 8), w.cs, w.pre, w.plan.letterboxed && !w.luma_mid}].push_back(i);
+        else if (w.s1 == S1_MFMA) s1_groups[{(uint32_t)S1_MFMA | (w.mplan->ops_in_lds ? 1u << 8 : 0u) | (w.mplan->wide ? 1u << 9 : 0u) | (w.mplan->full ? 1u << 10 : 0u) | (w.mplan->compact ? 1u << 11 : 0u), w.cs, w.pre, w.plan.letterboxed && !w.luma_mid}].push_back(i);
+        else if (w.s1 != S1_NONE) s1_groups[{(uint32_t)w.s1 | (w.splan ? w.splan->nacc << 8 : 0u) | (w.s1 == S1_STREAM && w.unaligned ? 1u << 16 : 0u), w.cs, w.pre, w.plan.letterboxed && !w.luma_mid}].push_back(i);
+        if (w.p->blur_sigma > 0.0f && w.bwplan) blur_groups[{kBlurWtileKind | w.bwplan->nslot, w.luma_mid ? 1u : w.plan.out_c, 0, w.luma_mid ? 1u : 0u}].push_back(i);
         else if (w.p->blur_sigma > 0.0f) {
             const uint32_t ce = blur_channels(w);
             // pictures of one launch share the workgroup width the kernel is instantiated for
@@ -759,6 +799,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     std::vector<Job> jobs;
     std::vector<StreamItem> items;
     std::vector<MfmaItem> mitems;
+    std::vector<uint32_t> mwg; // matrix-pipe launches with persistent workgroups: {first item, items} of every workgroup
     std::vector<FrontendJob> fjobs;
     // EXIF orientation pre-pass jobs, grouped by channel count
     struct OrientLaunch { uint32_t cs, base, n, mw, mh; };
@@ -776,7 +817,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         }
         if (O.n) orient_launches.push_back(O);
     }
-    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc, max_nout; LaunchGeneric g; size_t lds; size_t mid_floats; uint32_t blur_grid_x; bool blur_tiled; };
+    struct S1Launch { GroupKey k; uint32_t job_base, njobs, item_base, nitems, nacc, max_nout, grid = 0, wg_base = 0; LaunchGeneric g; size_t lds; size_t mid_floats; uint32_t blur_grid_x; bool blur_tiled; };
     std::vector<S1Launch> s1_launches, blur_launches;
     struct FeLaunch { uint32_t kind, base, n, mw, mh; bool rgba; };
     std::vector<FeLaunch> fe_launches;
@@ -792,6 +833,8 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
     for (auto &kv : s1_groups) {
         const GroupKey &k = kv.first;
         S1Launch L = new_launch(k);
+        MfmaPlan *launch_plan = nullptr; // the matrix-pipe plan every picture of the launch shares, if they all do
+        bool launch_plan_set = false;
         for (size_t idx : kv.second) {
             const Work &w = work[idx];
             Job j; fill_job(w, j);
@@ -820,6 +863,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 c->stats.resample_dst_bytes += w.plan.pixel_bytes;
             }
             if ((k.kind & 255u) == S1_MFMA) {
+                launch_plan = (!launch_plan_set || launch_plan == w.mplan) ? const_cast<MfmaPlan *>(w.mplan) : nullptr; launch_plan_set = true; // (one plan for the whole launch, or none)
                 for (MfmaItem it2 : *w.mitems) { it2.job = (uint32_t)jobs.size(); mitems.push_back(it2); }
                 L.nitems += (uint32_t)w.mitems->size();
                 L.max_nout = std::max(L.max_nout, w.mplan->max_nout);
@@ -837,14 +881,21 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             jobs.push_back(j);
             L.njobs++;
         }
-        if ((k.kind & 255u) == S1_MFMA && L.nitems > 1) {
-            auto first = mitems.begin() + L.item_base;
-            // full-width arithmetic, a uniform launch (every picture the same plan, whole pictures): the persistent workgroups' order
-            uint32_t done = 0;
-            if ((k.kind >> 10) & 1u) done = persistent_order(&*first, L.nitems, std::min(L.nitems, c->cu_count));
-            // the rest (or everything): longest workgroups first and strips of a picture on one XCD, as for the streaming kernel below
-            std::stable_sort(first + done, first + L.nitems, [](const MfmaItem &a, const MfmaItem &b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
-            xcd_interleave(&*first + done, L.nitems - done, [](const MfmaItem &x) { return x.kb1 - x.kb0; });
+        if ((k.kind & 255u) == S1_MFMA) {
+            if (L.nitems > 1) {
+                // longest workgroups first and strips of a picture on one XCD, as for the streaming kernel below
+                auto first = mitems.begin() + L.item_base;
+                std::stable_sort(first, first + L.nitems, [](const MfmaItem &a, const MfmaItem &b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
+                xcd_interleave(&*first, L.nitems, [](const MfmaItem &x) { return x.kb1 - x.kb0; });
+            }
+            if ((k.kind >> 10) & 1u) {
+                // full-width arithmetic: persistent workgroups, each with its own list of items
+                L.grid = std::max(1u, std::min(L.nitems, c->cu_count));
+                L.wg_base = (uint32_t)mwg.size();
+                std::vector<uint32_t> lists;
+                assign_items(mitems, L.item_base, L.nitems, L.grid, launch_plan, lists);
+                mwg.insert(mwg.end(), lists.begin(), lists.end());
+            }
         }
         if ((k.kind & 255u) == S1_WTILE && L.nitems > 1) {
             // strips and bands of a picture on one XCD (their source windows overlap: the halo then comes from that XCD's L2)
@@ -878,6 +929,13 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
                 j.pad0 = bt != c->blur_plans.end() ? bt->second : 0u; // table block of the blur kernel
             }
             if (k.kind & kBlurWtileKind) {
+                if (w.luma_mid) {
+                    // the source is stage 1's unframed Luma8 picture (rw x rh) at (cx, cy) of a virtual sw x sh frame of value `fill`
+                    j.rw = std::min(pl.resized_w - pl.crop_x, pl.out_w - pl.place_x); j.rh = std::min(pl.resized_h - pl.crop_y, pl.out_h - pl.place_y);
+                    j.cx = pl.place_x; j.cy = pl.place_y;
+                    j.src_bytes = j.rw * j.rh;
+                    j.fill = (uint32_t)w.p->fill_r * 0x01010101u;
+                }
                 const size_t before = mitems.size();
                 w.bwplan->items_for(wtile_bands(dbg, *w.bwplan, kv.second.size()), (uint32_t)jobs.size(), mitems);
                 L.nitems += (uint32_t)(mitems.size() - before);
@@ -980,16 +1038,17 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             r.byte0 = reinterpret_cast<const MfmaStrip *>(c->h_arena.data() + mi.strip_off)->byte0;
         }
     }
-    // one staging slot: [jobs][items][fjobs][jjobs][mitems][mreqs]
+    // one staging slot: [jobs][items][fjobs][jjobs][mitems][mreqs][mwg]
     const size_t jobs_b = align_up(jobs.size() * sizeof(Job), 256), items_b = align_up(items.size() * sizeof(StreamItem), 256),
                  fjobs_b = align_up(fjobs.size() * sizeof(FrontendJob), 256), jjobs_b = align_up(jjobs.size() * sizeof(JpegJob), 256),
-                 mitems_b = align_up(mitems.size() * sizeof(MfmaItem), 256), mreqs_b = align_up(mreqs.size() * sizeof(MfmaReq), 256);
-    const size_t stat_off = jobs_b + items_b + fjobs_b + jjobs_b + mitems_b + mreqs_b, stat_b = (has_results || has_err_word) ? align_up(n * 8 + 8, 256) : 0;
+                 mitems_b = align_up(mitems.size() * sizeof(MfmaItem), 256), mreqs_b = align_up(mreqs.size() * sizeof(MfmaReq), 256), mwg_b = align_up(mwg.size() * sizeof(uint32_t), 256);
+    const size_t stat_off = jobs_b + items_b + fjobs_b + jjobs_b + mitems_b + mreqs_b + mwg_b, stat_b = (has_results || has_err_word) ? align_up(n * 8 + 8, 256) : 0;
     const size_t desc_b = stat_off + stat_b;
     uint32_t *status_dev = nullptr;
     const Job *d_jobs = nullptr; const StreamItem *d_items = nullptr; const FrontendJob *d_fjobs = nullptr; const JpegJob *d_jjobs = nullptr;
     const MfmaItem *d_mitems = nullptr;
     const MfmaReq *d_mreqs = nullptr;
+    const uint32_t *d_mwg = nullptr;
     DescSlot *slot = nullptr;
     if (desc_b) {
         slot = &c->slots[c->next_slot];
@@ -1011,6 +1070,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (!jjobs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b, jjobs.data(), jjobs.size() * sizeof(JpegJob));
         if (!mitems.empty()) memcpy(hp + jobs_b + items_b + fjobs_b + jjobs_b, mitems.data(), mitems.size() * sizeof(MfmaItem));
         if (!mreqs.empty()) memcpy(hp + jobs_b + items_b + fjobs_b + jjobs_b + mitems_b, mreqs.data(), mreqs.size() * sizeof(MfmaReq));
+        if (!mwg.empty()) memcpy(hp + jobs_b + items_b + fjobs_b + jjobs_b + mitems_b + mreqs_b, mwg.data(), mwg.size() * sizeof(uint32_t));
         // While a previous batch is still running, the block goes up on the context's upload stream: the slot is free (its last
         // batch has ended, see above), so the copy runs under that batch's kernels, and this batch's first kernel follows its
         // last one without a copy engine in between.  A lone request on an idle device sends the block down its own stream (no
@@ -1033,6 +1093,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         d_jjobs = reinterpret_cast<const JpegJob *>(dp + jobs_b + items_b + fjobs_b);
         d_mitems = reinterpret_cast<const MfmaItem *>(dp + jobs_b + items_b + fjobs_b + jjobs_b);
         d_mreqs = reinterpret_cast<const MfmaReq *>(dp + jobs_b + items_b + fjobs_b + jjobs_b + mitems_b);
+        d_mwg = reinterpret_cast<const uint32_t *>(dp + jobs_b + items_b + fjobs_b + jjobs_b + mitems_b + mreqs_b);
     }
 
     range_plan.reset();
@@ -1081,7 +1142,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         } else if ((L.k.kind & 255u) == S1_MFMA) {
             LaunchMfma m{}; // (paints the letterbox frame itself, like the streaming kernel)
             m.jobs = d_jobs; m.items = d_mitems + L.item_base; m.reqs = d_mreqs + L.item_base; m.arena = c->d_arena; m.nitems = L.nitems;
-            m.grid = std::min(L.nitems, c->cu_count);
+            m.grid = L.grid; m.wg_lists = L.grid ? d_mwg + L.wg_base : nullptr;
             m.cs = L.k.cs; m.letterbox = L.k.lb; m.ops_in_lds = (L.k.kind >> 8) & 1u; m.wide = (L.k.kind >> 9) & 1u; m.full = (L.k.kind >> 10) & 1u; m.compact = (L.k.kind >> 11) & 1u; m.max_nout = L.max_nout;
             m.spin_limit = mfma_spin_limit; m.err_word = status_dev + 2 * n;
             {
@@ -1109,7 +1170,7 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
         if (L.k.kind & kBlurWtileKind) {
             LaunchWtile m{};
             m.jobs = d_jobs; m.items = reinterpret_cast<const WtItem *>(d_mitems + L.item_base); m.arena = c->d_arena; m.nitems = L.nitems;
-            m.nslot = L.k.kind & 255u; m.nkmax = kWtOperandRegs / m.nslot; m.letterbox = 0; m.lds_bytes = (uint32_t)L.lds;
+            m.nslot = L.k.kind & 255u; m.nkmax = kWtOperandRegs / m.nslot; m.letterbox = L.k.lb; m.framed = L.k.lb; m.lds_bytes = (uint32_t)L.lds;
             FL_HIP(c, launch_wtile(m, st), "window-tile matrix-pipe kernel (blur)");
             c->stats.mfma_launches++;
             c->stats.wtile_launches++;
@@ -1279,17 +1340,26 @@ int run_batch_host(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgpu_
 } // namespace fl
 
 // ---- diagnostics -----------------------------------------------------------------------------------------------------------------
-extern "C" int flgpu_debug_persistent_order(uint32_t pictures, uint32_t strips, uint32_t workgroups, uint32_t *job_of, uint32_t *strip_of, uint32_t *covered)
+extern "C" int flgpu_debug_assign_items(uint32_t pictures, uint32_t strips, uint32_t tiles, uint32_t workgroups, uint32_t capacity, uint32_t *job_of, uint32_t *strip_of,
+                                        uint32_t *tile0_of, uint32_t *tile1_of, uint32_t *lists, uint32_t *nitems)
 {
-    if (!pictures || !strips || !job_of || !strip_of || !covered) return FLGPU_ERR_INVALID_ARG;
-    std::vector<MfmaItem> v((size_t)pictures * strips);
+    if (!pictures || !strips || !tiles || !workgroups || !job_of || !strip_of || !tile0_of || !tile1_of || !lists || !nitems) return FLGPU_ERR_INVALID_ARG;
+    MfmaPlan plan;
+    plan.ok = true; plan.vplan_off = 7u;
+    for (uint32_t s = 0; s < strips; ++s) plan.strip_offs.push_back(1000u + s);
+    for (uint32_t t = 0; t < tiles; ++t) plan.tiles.push_back({3u * t, 3u * t + 4u}); // (a tile needs five K-blocks, a new one ends every third)
+    std::vector<MfmaItem> v;
     for (uint32_t p = 0; p < pictures; ++p)
-        for (uint32_t s = 0; s < strips; ++s) {
-            MfmaItem &m = v[(size_t)p * strips + s];
-            memset(&m, 0, sizeof(m));
-            m.job = p; m.strip_off = 1000u + s; m.vplan_off = 7u; m.kb0 = 0u; m.kb1 = 34u; m.tile0 = 0u; m.tile1 = 11u;
-        }
-    *covered = persistent_order(v.data(), (uint32_t)v.size(), std::min<uint32_t>((uint32_t)v.size(), workgroups));
-    for (size_t k = 0; k < v.size(); ++k) { job_of[k] = v[k].job; strip_of[k] = v[k].strip_off - 1000u; }
+        for (MfmaItem m : plan.items_for(1)) { m.job = p; v.push_back(m); }
+    uint32_t n = (uint32_t)v.size();
+    std::stable_sort(v.begin(), v.end(), [](const MfmaItem &a, const MfmaItem &b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
+    xcd_interleave(v.data(), n, [](const MfmaItem &x) { return x.kb1 - x.kb0; });
+    const uint32_t G = std::max(1u, std::min(n, workgroups));
+    std::vector<uint32_t> l;
+    assign_items(v, 0, n, G, &plan, l);
+    *nitems = n;
+    if (n > capacity) return FLGPU_ERR_BUFFER_TOO_SMALL;
+    for (uint32_t k = 0; k < n; ++k) { job_of[k] = v[k].job; strip_of[k] = v[k].strip_off - 1000u; tile0_of[k] = v[k].tile0; tile1_of[k] = v[k].tile1; }
+    for (uint32_t k = 0; k < 2u * G; ++k) lists[k] = l[k];
     return FLGPU_OK;
 }

@@ -157,7 +157,8 @@ struct LaunchMfma {
     const MfmaReq *reqs;   // one per item (full-width arithmetic)
     const uint32_t *arena;
     uint32_t nitems;
-    uint32_t grid;         // full-width arithmetic: workgroups of the persistent launch (min(nitems, CUs): the host's item order is built for it)
+    uint32_t grid;         // full-width arithmetic: workgroups of the persistent launch (min(nitems, CUs))
+    const uint32_t *wg_lists; // ... and, per workgroup, {first item, items} (fl_batch.cpp assign_items); packed arithmetic: null, one item per workgroup
     uint32_t cs;           // channels of the source (1..4)
     uint32_t letterbox;
     uint32_t ops_in_lds;   // every strip of the launch has <= kMfmaLdsOperands distinct operands

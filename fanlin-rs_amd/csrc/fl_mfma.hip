@@ -64,8 +64,8 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f
 // FW: full-width arithmetic (fl_mfma.h MFMA_ARITH_FULL) -- bytes as f16 subnormals x three-term weights, a 23-bit intermediate in
 // three byte planes x three weight digits; otherwise the packed arithmetic of rounds 2-3.  With FW, HLDS only says that the
 // launch's LDS has an operand area: whether a strip's operands live there is the strip's own flag (MfmaStrip::lds_ops).
-// Persistent workgroups (round 5, full-width arithmetic): the launch has one workgroup per CU and each walks the items
-// blockIdx.x, blockIdx.x + gridDim.x, ... -- with 160 KB of LDS and 512 x 256 registers a CU holds ONE workgroup, so with one item per
+// Persistent workgroups (round 5, full-width arithmetic): the launch has one workgroup per CU and each walks its own list of items
+// (consecutive in the item array; the host deals them out, fl_batch.cpp assign_items) -- with 160 KB of LDS and 512 x 256 registers a CU holds ONE workgroup, so with one item per
 // workgroup every item paid a dispatch, a prologue, the latency of its first K-block and the drain of its last tile with nothing in
 // flight for that CU (15-17 us of ~130).  Now the first K-block of item n + 1 is requested in the LAST pass of item n (the wave's
 // 8 KB of LDS are free once the transposed reads have returned).  Two kinds of transition:
@@ -79,7 +79,7 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f
 // The LDS counters run on across items (a tile's global number = tiles of earlier items + its number in this one); the packed
 // arithmetic keeps one item per workgroup (its launch has gridDim.x = nitems).
 template <int CS, bool LB, bool HLDS, int LAYOUT, bool FW>
-__global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items, const MfmaReq *__restrict__ reqs,
+__global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__restrict__ jobs, const MfmaItem *__restrict__ items, const MfmaReq *__restrict__ reqs, const uint32_t *__restrict__ wg_lists,
                                                                    const uint32_t *__restrict__ arena, uint32_t nitems, uint32_t ot_words, uint32_t spin_limit,
                                                                    uint32_t *__restrict__ err_word
 #ifdef FL_MFMA_STAMPS
@@ -103,8 +103,9 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     constexpr uint32_t ablate = 0;
 #endif
     // experiments (-DFL_VARIANT=mask): 16 = a chunk's planes are made beside the matrix instructions of the chunk before (spills),
-    // 8 (launcher) = one item per workgroup; -DFL_NINE_PRODUCTS: the ninth digit product, plane 0 x digit 0, is computed too (round 4);
-    // -DFL_STAGGER_N=n: waves 4-7 start the workgroup's walk n x 1.35 us late
+    // 8 (launcher) = one item per workgroup; -DFL_NINE_PRODUCTS: the ninth digit product, plane 0 x digit 0, is computed too (round 4)
+    // (tried and dropped, profiles/r05_kernel_experiments.txt: waves 4-7 started late so that their stages run beside the other waves'
+    // vertical passes -- paid for its own delay when the delay was per item, nothing once it was per workgroup)
 #ifdef FL_VARIANT
     constexpr uint32_t variant = FL_VARIANT;
 #else
@@ -120,7 +121,10 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // The item this workgroup is on: the descriptors are read again at the top of every trip of the item loop below (nothing but the
     // item's number is carried around the loop: the kernel has no registers to spare), everything derived from them is set in `enter_item`.
-    uint32_t item = blockIdx.x;
+    // (persistent launch: this workgroup's list of items, consecutive in the launch's item array; else one item)
+    uint32_t item = wg_lists ? wg_lists[2u * blockIdx.x] : blockIdx.x;
+    uint32_t items_left = wg_lists ? wg_lists[2u * blockIdx.x + 1u] : 1u;
+    if (!items_left) return;
 #ifdef FL_MFMA_STAMPS
     const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
     if ((blockIdx.x == 0u || blockIdx.x == 8u || blockIdx.x == 16u) && (wave == 0u || wave == 5u))
@@ -431,8 +435,8 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     };
     bool heavy = true;  // how this item is entered: the first one with a full set-up
     for (;;) { // ---- the items of this workgroup ----------------------------------------------------------------------------------
-    const uint32_t next_item = item + gridDim.x;
-    const bool has_next_item = FW && next_item < nitems;
+    const uint32_t next_item = item + 1u;
+    const bool has_next_item = FW && items_left > 1u;
     FL_STAMP(0);
     if (heavy) {
         load_item();
@@ -454,12 +458,6 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
         __syncthreads();
     }
     FL_STAMP(1);
-#ifdef FL_STAGGER_N
-    if (seq == 0u && wave >= 4u) {
-        // experiment: waves 4-7 start the workgroup's walk late, so that their tile stages run beside the other waves' vertical passes
-        for (int k = 0; k < FL_STAGGER_N; ++k) __builtin_amdgcn_s_sleep(50); // n x 50 x 64 cycles = n x 1.35 us
-    }
-#endif
     // (kb_end: one pass more than the band has K-blocks when the picture's short last tile ends together with the tile before
     // it -- that pass runs on the table's all-zero K-block, index vp.nkb, whose meta word names the last tile: the matrix unit
     // adds zeros to whatever the transposed reads deliver, nothing is requested, and the loop body stays as it is)
@@ -776,6 +774,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     if (!has_next_item) break;
     gl_base += it.tile1 - it.tile0;
     item = next_item;
+    --items_left;
     rq_src = nx_src; rq_pitch = nx_pitch; rq_last_row = nx_last_row; rq_job = nx_job;
     ++seq;
     heavy = !light;
@@ -831,13 +830,13 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
 #else
     constexpr bool persistent = true;
 #endif
-    if (FW && persistent) grid = std::max(1u, std::min(m.nitems, m.grid ? m.grid : 256u));
+    if (FW && persistent && m.wg_lists && m.grid) grid = m.grid;
 #ifdef FL_MFMA_STAMPS
     static unsigned long long *stamps = nullptr;
     static int launches = 0;
     constexpr size_t kStampWords = 3 * 2 * 16 * 8 + 512 * 4;
     if (!stamps) { (void)hipMalloc(&stamps, kStampWords * 8); (void)hipMemset(stamps, 0, kStampWords * 8); }
-    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<grid, THREADS, lds, st>>>(m.jobs, m.items, m.reqs, m.arena, m.nitems, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word, stamps);
+    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<grid, THREADS, lds, st>>>(m.jobs, m.items, m.reqs, (FW && persistent) ? m.wg_lists : nullptr, m.arena, m.nitems, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word, stamps);
     if (++launches == 50 && m.nitems > 2900) {
         unsigned long long h[kStampWords];
         (void)hipDeviceSynchronize();
@@ -857,7 +856,7 @@ static hipError_t launch_mfma_t(const LaunchMfma &m, hipStream_t st)
             fprintf(stderr, "mfma wg %u: xcc %llu, start %.2f us, end %.2f us, %llu items\n", b, wt[4 * b + 2] & 15ull, (wt[4 * b] - t0) * 0.01, (wt[4 * b + 1] - t0) * 0.01, wt[4 * b + 3]);
     }
 #else
-    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<grid, THREADS, lds, st>>>(m.jobs, m.items, m.reqs, m.arena, m.nitems, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word);
+    resample_mfma_kernel<CS, LB, HLDS, LAYOUT, FW><<<grid, THREADS, lds, st>>>(m.jobs, m.items, m.reqs, (FW && persistent) ? m.wg_lists : nullptr, m.arena, m.nitems, 16u * mfma_out_pitch(LAYOUT), m.spin_limit, m.err_word);
 #endif
     return hipGetLastError();
 }

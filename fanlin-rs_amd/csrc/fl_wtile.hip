@@ -42,7 +42,7 @@ __device__ __forceinline__ void lds_barrier()
 // for its whole walk (<1, 6> also serves strips whose N-tiles mostly share ONE operand block: a blur's interior columns).
 template <int NSLOT, int NKMAX>
 __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job *__restrict__ jobs, const WtItem *__restrict__ items,
-                                                                       const uint32_t *__restrict__ arena, uint32_t lb, uint32_t invert)
+                                                                       const uint32_t *__restrict__ arena, uint32_t lb, uint32_t invert, uint32_t framed)
 {
     static_assert(NSLOT * NKMAX == (int)kWtOperandRegs, "operand register budget");
     // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh with ABL_FILE=fl_wtile.hip): 1 = no vertical pass, 2 = no horizontal pass,
@@ -82,6 +82,18 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     const uint32_t inv = !invert ? 0u : hd.cs == 4u ? 0x00ffffffu : hd.cs == 2u ? 0x00ff00ffu : 0xffffffffu;
     auto fetch = [&](uint32_t r) -> u32x4 {
         const uint32_t row = min(r, hd.src_rows - 1u); // rows past the picture carry zero weights: any finite bytes do
+        if (NSLOT == 1 && framed) { // (blur plans; this instantiation only: the others have no register to spare)
+            // the plan's image is a frame of value jb.fill around the picture at jb.src (jb.rw x jb.rh bytes, tightly packed, at
+            // column jb.cx, row jb.cy): reference src/handler.rs:238-248 builds exactly that image before img.blur()
+            const uint32_t sr = row - jb.cy, sc = sp.col0 + 16u * tcol - jb.cx; // (wrap around for rows / columns in front of the picture)
+            u32x4 v = {jb.fill, jb.fill, jb.fill, jb.fill};
+            if (sr >= jb.rh) return v;
+            const uint32_t o2 = sr * jb.rw + sc;
+            if (sc < jb.rw && sc + 16u <= jb.rw) return *(const __attribute__((address_space(1))) u32x4_unaligned *)(gsrc + o2);
+            for (uint32_t b = 0; b < 16u; ++b)
+                if (sc + b < jb.rw) v[b >> 2] = (v[b >> 2] & ~(255u << (8u * (b & 3u)))) | ((uint32_t)gsrc[o2 + b] << (8u * (b & 3u)));
+            return v;
+        }
         const uint32_t off = row * pitch + sp.col0 + 16u * tcol;
         if (off + 16u <= jb.src_bytes) return *(const __attribute__((address_space(1))) u32x4_unaligned *)(gsrc + off);
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -405,7 +417,7 @@ hipError_t launch_wtile_t(const LaunchWtile &m, hipStream_t st)
         if (e != hipSuccess) return e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    resample_wtile_kernel<NSLOT, NKMAX><<<m.nitems, kWtThreads, m.lds_bytes, st>>>(m.jobs, m.items, m.arena, m.letterbox, m.invert);
+    resample_wtile_kernel<NSLOT, NKMAX><<<m.nitems, kWtThreads, m.lds_bytes, st>>>(m.jobs, m.items, m.arena, m.letterbox, m.invert, m.framed);
     return hipGetLastError();
 }
 
@@ -415,6 +427,7 @@ hipError_t launch_wtile(const LaunchWtile &m, hipStream_t st)
 {
     if (!m.nitems) return hipSuccess;
     if (m.lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
+    if (m.framed && m.nslot != 1) return hipErrorInvalidValue; // (fl_batch.cpp asks for the framed source only with single-register-set plans)
     if (m.nslot == 6 && m.nkmax == 1) return launch_wtile_t<6, 1>(m, st);
     if (m.nslot == 3 && m.nkmax == 2) return launch_wtile_t<3, 2>(m, st);
     if (m.nslot == 2 && m.nkmax == 3) return launch_wtile_t<2, 3>(m, st);

@@ -426,11 +426,12 @@ int flgpu_debug_mfma_plan(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t 
 int flgpu_debug_mfma_plan_arith(uint32_t sw, uint32_t sh, uint32_t channels, uint32_t rw, uint32_t rh, uint32_t cx, uint32_t cy,
                                 uint32_t cw, uint32_t ch, uint32_t arith, uint32_t info[8], double err[2]);
 
-/* Item order of a uniform matrix-pipe launch (csrc/fl_batch.cpp persistent_order): `pictures` pictures of `strips` strips each for a
- * launch of `workgroups` persistent workgroups; job_of / strip_of [pictures * strips] receive the picture and strip of every item in
- * launch order, *covered the number of items laid out in full rounds (workgroup b walks items b, b + workgroups, ...: inside the
- * rounds all of them have b's strip, and a picture's strips sit on one XCD, b mod 8, in one round).  Needs no device. */
-int flgpu_debug_persistent_order(uint32_t pictures, uint32_t strips, uint32_t workgroups, uint32_t *job_of, uint32_t *strip_of, uint32_t *covered);
+/* Which items each persistent workgroup of a uniform matrix-pipe launch walks (csrc/fl_batch.cpp assign_items): `pictures` pictures of
+ * `strips` strips and `tiles` 16-row output tiles for a launch of `workgroups` workgroups.  job_of / strip_of / tile0_of / tile1_of
+ * [capacity] receive picture, strip and tile range of every item in launch order (*nitems of them: pictures left over after the
+ * whole rounds are cut into row bands), lists[2 b], lists[2 b + 1] the first item and item count of workgroup b.  Needs no device. */
+int flgpu_debug_assign_items(uint32_t pictures, uint32_t strips, uint32_t tiles, uint32_t workgroups, uint32_t capacity, uint32_t *job_of, uint32_t *strip_of,
+                             uint32_t *tile0_of, uint32_t *tile1_of, uint32_t *lists, uint32_t *nitems);
 
 const char *flgpu_strerror(int status);
 const char *flgpu_last_error(flgpu_ctx *ctx); /* detail of the last FLGPU_ERR_DEVICE on this context */

@@ -194,6 +194,37 @@ def test_expired_wait_is_an_error_not_a_picture(fl, gpu_state, monkeypatch):
     assert np.array_equal(dst.cpu().numpy().reshape(200, 300, 4), good)
 
 
+def test_uniform_batch_on_persistent_workgroups(fl, gpu_state, oracle):
+    """Round 5: a launch of many pictures of one geometry runs on persistent workgroups that keep their strip and walk from one
+    picture's rows into the next one's (light transitions: no new set-up, the last tile converted on the way, the conversion
+    context of the previous picture in LDS), with the pictures left over after the whole rounds cut into row bands.  300 pictures
+    of two strips each: every result equals the picture sent alone (which runs as bands on workgroups of its own)."""
+    import torch
+    n, h, w = 300, 96, 1024                                # 3072-byte rows: two strips; ratio 4
+    imgs = [synth.uniform(h, w, 3, index=500 + k) for k in range(n)]
+    p = fl.make_params(256, 24)
+    src = torch.from_numpy(np.stack(imgs)).cuda()
+    plan = fl.plan_output(p, w, h, 3)
+    nb = int(plan.out_bytes)
+    dst = torch.zeros((n, nb), dtype=torch.uint8, device="cuda")
+    before = gpu_state.stats()["mfma_launches"]
+    gpu_state.process_batch_device([src.data_ptr() + k * h * w * 3 for k in range(n)], [(h, w, 3)] * n, p, [dst.data_ptr() + k * nb for k in range(n)], [nb] * n)
+    gpu_state.batch_results()
+    assert gpu_state.stats()["mfma_launches"] == before + 1
+    got = dst.cpu().numpy()
+    for k in list(range(0, n, 37)) + [n - 2, n - 1]:       # whole-round pictures and banded leftovers
+        alone, used = parity.device_pixels(fl, gpu_state, imgs[k], w=256, h=24)
+        assert used
+        assert np.array_equal(got[k].reshape(alone.shape), alone), k
+    parity.check_pixels(oracle, got[5].reshape(alone.shape), imgs[5], True, **parity.oracle_kwargs(dict(w=256, h=24)))
+    # the same batch again (the workgroups' LDS state is fresh per launch) and a batch whose size leaves no picture over
+    dst.zero_()
+    m = 256                                                  # 512 items on 256 workgroups: two whole rounds of 128 pairs
+    gpu_state.process_batch_device([src.data_ptr() + k * h * w * 3 for k in range(m)], [(h, w, 3)] * m, p, [dst.data_ptr() + k * nb for k in range(m)], [nb] * m)
+    gpu_state.batch_results()
+    assert np.array_equal(dst[:m].cpu().numpy(), got[:m])
+
+
 def test_bytes_do_not_depend_on_the_base_address_of_a_device_source(fl, gpu_state):
     """Which resample kernel serves a request is decided by the request alone: the same picture at device addresses 0, 4, 8
     and 12 bytes past a 16-byte boundary gives identical bytes through flgpu_transform_batch_device (misaligned sources of a

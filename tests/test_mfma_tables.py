@@ -9,6 +9,7 @@ plain per-axis weight tables (image 0.25.6 imageops/sample.rs index and weight m
     fixed-point weight (full: three byte digits, 2^-24 steps; packed: two digits, 2^-14..2^-17) within one rounding of the f32
     weight, and each output's weights sum to exactly 1;
   * nothing else is non-zero (rows and columns outside a window, outputs outside a strip, lanes of unused tile slots)."""
+import numpy as np
 import pytest
 
 GEOMETRIES = [
@@ -74,3 +75,43 @@ def test_strips_are_as_few_as_the_source_bytes_allow(fl, packed):
 def test_short_last_tile_is_flagged(fl):
     assert fl.debug_mfma_plan(1920, 1080, 3, 317, 178)["tail"] == 1   # rows 176-177 end with the tile before them
     assert fl.debug_mfma_plan(1920, 1080, 3, 300, 169)["tail"] == 0
+
+
+@pytest.mark.parametrize("pictures,strips,workgroups", [(1024, 3, 256), (1025, 3, 256), (1100, 3, 256), (100, 3, 256), (1000, 4, 256), (512, 2, 256),
+                                                       (7, 3, 256), (300, 3, 304), (90, 2, 64)])
+def test_persistent_workgroups_get_every_item_once_and_keep_their_strip(fl, pictures, strips, workgroups):
+    """Round 5: the full-width kernel's workgroups are persistent and walk lists of items (csrc/fl_batch.cpp assign_items).  For a uniform
+    launch every (picture, strip, tile) is covered exactly once; a workgroup's whole-picture items all have ONE strip (so that it goes
+    from picture to picture without a new set-up); the S strips of a picture run in the same position of S workgroups' lists (same
+    time), most of them on one XCD; the pictures left over after the whole rounds are cut into row bands, and no workgroup ends up
+    with more than one band's worth of work above the lightest."""
+    tiles = 11
+    job, strip, t0, t1, lists = fl.debug_assign_items(pictures, strips, tiles, workgroups)
+    seen = set()
+    for j, s, a, b in zip(job, strip, t0, t1):
+        for t in range(a, b):
+            assert (j, s, t) not in seen
+            seen.add((j, s, t))
+    assert len(seen) == pictures * strips * tiles
+    assert lists[:, 1].sum() == len(job) and (lists[1:, 0] == lists[:-1, 0] + lists[:-1, 1]).all() and lists[0, 0] == 0
+    whole = (t1 - t0) == tiles
+    where = {}                                            # (picture, strip) of a whole item -> (workgroup, position in its list)
+    for b, (first, cnt) in enumerate(lists):
+        ks = np.arange(first, first + cnt)
+        assert len(set(strip[ks][whole[ks]])) <= 1, "a workgroup changes strips between whole pictures"
+        for pos, k in enumerate(ks):
+            if whole[k]:
+                where[(job[k], strip[k])] = (b, pos)
+    if pictures * strips >= 3 * workgroups:              # a launch with whole rounds
+        assert whole.sum() >= (pictures * strips) * 0.75
+        same_xcd = 0
+        pics = {j for j, _ in where}
+        for j in pics:
+            at = [where[(j, s)] for s in range(strips)]
+            assert len({pos for _, pos in at}) == 1, "the strips of a picture run in different rounds"
+            same_xcd += len({b % 8 for b, _ in at}) == 1
+        assert same_xcd >= 0.9 * len(pics)
+    # balance, in K-blocks of the debug plan (a tile ends every third K-block and needs five; an item's set-up counts like two)
+    load = np.array([sum(3 * (t1[k] - t0[k]) + 2 + 2 for k in range(f, f + c)) for f, c in lists])
+    if len(job) >= workgroups:
+        assert load.max() - load.min() <= 3 * tiles + 2 + 12, (load.min(), load.max())

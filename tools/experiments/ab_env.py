@@ -18,6 +18,7 @@ ap.add_argument("--channels", type=int, default=3)
 ap.add_argument("--srcw", type=int, default=1920)
 ap.add_argument("--srch", type=int, default=1080)
 ap.add_argument("--blur", type=float, default=0.0)
+ap.add_argument("--stat", default="", help="resample | blur | both: which stage time to print (default: blur for a blur-only request, else resample)")
 a = ap.parse_args()
 n, H, W, C = a.n, a.srch, a.srcw, a.channels
 src = torch.randint(0, 256, (n, H, W, C), dtype=torch.uint8, device="cuda")
@@ -60,7 +61,9 @@ for r in range(a.rounds):
         for _ in range(a.launches): run(stream)
         torch.cuda.synchronize()
         s = st.stats()
-        times[v].append((s["blur_ms"] / max(s["blur_launches"], 1)) if a.blur > 0 and not a.w else s["resample_ms"] / max(s["resample_launches"], 1))
+        tb, tr = s["blur_ms"] / max(s["blur_launches"], 1), s["resample_ms"] / max(s["resample_launches"], 1)
+        which = a.stat or ("blur" if a.blur > 0 and not a.w else "resample")
+        times[v].append(tb if which == "blur" else tr if which == "resample" else tb + tr)
 for v, _, _, _ in runs:
     t = times[v]
     print(f"{os.path.basename(v):56s} median {statistics.median(t):.4f} ms  min {min(t):.4f}  max {max(t):.4f}   ({' '.join(f'{x:.3f}' for x in t)})", flush=True)
