@@ -293,6 +293,97 @@ def latency_probe_c(args, query: str, front_end: int, pinned: int = 0, jpeg_file
         return None
 
 
+def config4_one_gpu(fl, st, dev, stream, steps):
+    import numpy as np
+    import torch
+    n = 1000
+    kinds = [(2160, 3840)] * (n // 10) + [(1080, 1920)] * (6 * n // 10) + [(120, 160)] * (3 * n // 10)
+    rng = np.random.default_rng(4)
+    rng.shuffle(kinds)
+    q = fl.Query.parse("w=300&h=200&webp=true&quality=85")
+    params, _ = q.to_params(fl.Format.from_accept_header("image/webp"), input_is_jpeg=True)
+    srcs = {k: torch.randint(0, 256, (sum(1 for x in kinds if x == k), k[0], k[1], 3), dtype=torch.uint8, device=dev) for k in set(kinds)}
+    idx = {k: 0 for k in srcs}
+    ptrs, shapes = [], []
+    for k in kinds:
+        ptrs.append(srcs[k].data_ptr() + idx[k] * k[0] * k[1] * 3)
+        idx[k] += 1
+        shapes.append((k[0], k[1], 3))
+    plan = fl.plan_output(params, 1920, 1080, 3)
+    stride = (int(plan.out_bytes) + 255) // 256 * 256
+    dst = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    run = st.prepared_batch(ptrs, shapes, params, [dst.data_ptr() + i * stride for i in range(n)], [stride] * n)
+    for _ in range(2):
+        run(stream)
+    torch.cuda.synchronize()
+    st.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run(stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    s2 = st.stats()
+    alg = sum(h * w * 3 for h, w in kinds) + n * int(plan.pixel_bytes)
+    k_ms = s2["resample_ms"] / steps
+    out = {"images_per_s": n / dt, "ms_per_step": dt * 1e3, "images_per_step": n,
+           "stage_ms_per_step": {"resample": k_ms, "frontend": s2["frontend_ms"] / steps},
+           "resample_launches_per_step": s2["resample_launches"] / steps, "matrix_pipe_launches_per_step": s2["mfma_launches"] / steps,
+           "roofline": {"bound": "hbm", "kernel": "all resample kernels of the step (matrix-pipe: 4K and 1080p; window-tile: thumbnails)", "kernel_ms": k_ms,
+                        "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else 0.0, "algorithmic_bytes_per_step": alg}}
+    del run, dst, srcs
+    torch.cuda.empty_cache()
+    return out
+
+
+def config3_share(fl, dev, stream, n):
+    """8,192 x 1080p = 51 GB of sources resident in HBM, one flgpu_transform_batch_device call with an `rgb=` fill; pictures from all
+    over the batch are compared with the same request sent alone."""
+    import numpy as np
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    need = n * SRC_W * SRC_H * SRC_C + n * 240128 + (4 << 30)
+    if free < need:
+        return {"skipped": f"{free / 2**30:.0f} GiB free, {need / 2**30:.0f} GiB needed"}
+    p = fl.make_params(REQ_W, REQ_H, fill=(200, 16, 99), front_end=fl.FE_NONE)
+    plan = fl.plan_output(p, SRC_W, SRC_H, SRC_C)
+    stride = (int(plan.out_bytes) + 255) // 256 * 256
+    src = torch.empty((n, SRC_H, SRC_W, SRC_C), dtype=torch.uint8, device=dev)
+    for k in range(0, n, 512):   # (filled in pieces: randint's temporaries are int64)
+        src[k:k + 512].random_(0, 256)
+    dst = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    img = SRC_W * SRC_H * SRC_C
+    out = {}
+    for label, kw in (("one device context", dict(device=0)), ("two shards on this device (devices = [0, 0])", dict(devices=[0, 0]))):
+        with fl.State(profile=True, **kw) as st:
+            run = st.prepared_batch([src.data_ptr() + k * img for k in range(n)], [(SRC_H, SRC_W, SRC_C)] * n, p, [dst.data_ptr() + k * stride for k in range(n)], [stride] * n)
+            run(stream)
+            torch.cuda.synchronize()
+            st.reset_stats()
+            steps = 3
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run(stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            s2 = st.stats()
+            st.batch_results()
+            k_ms = s2["resample_ms"] / steps
+            alg = n * (img + int(plan.pixel_bytes))
+            bad = 0
+            for k in (0, 1, n // 3, n // 2 + 7, n - 2, n - 1):
+                alone = st.process_pixels(src[k].cpu().numpy(), p)
+                bad += int(not np.array_equal(dst[k, :alone.size].cpu().numpy().reshape(alone.shape), alone))
+            out[label] = {"images_per_s": n / dt, "ms_per_step": dt * 1e3, "kernel_ms_per_step": k_ms, "pictures_differing_from_the_request_sent_alone": bad,
+                          "source_bytes": n * img,
+                          "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else 0.0}}
+            del run
+    del src, dst
+    torch.cuda.empty_cache()
+    return out
+
+
 def latency_probe(fl, st, params, n_requests: int, n_threads: int):
     """Per-image latency of the drop-in entry point: concurrent callers of flgpu_transform with HOST buffers
     (PCIe in both directions included), packed into shared launches by the library's request queue."""
@@ -470,6 +561,8 @@ def main():
                     help="requests of the per-image latency probe through flgpu_transform (0 = skip)")
     ap.add_argument("--latency-threads", type=int, default=64, help="concurrent caller threads of the latency probe")
     ap.add_argument("--config0-runs", type=int, default=200, help="runs of BASELINE config 0 (lenna.jpg, CPU oracle and one GPU request at a time); 0 = skip")
+    ap.add_argument("--config4", type=int, default=1, help="1 = BASELINE config 4's mixed batch on this GPU as an `extra` entry")
+    ap.add_argument("--config3-share", type=int, default=8192, help="pictures of BASELINE config 3's per-GPU share run as one device batch (an `extra` entry; 0 = skip)")
     ap.add_argument("--queue-lanes", type=int, default=0, help="batches the request queue keeps in flight (0 = library default)")
     ap.add_argument("--queue-max-batch", type=int, default=0, help="largest batch the request queue forms (0 = library default)")
     args = ap.parse_args()
@@ -636,6 +729,21 @@ def main():
                 fl.make_params(REQ_W, REQ_H, blur_sigma=10.0, grayscale=True, front_end=fl.FE_NONE))
             extra["config2 + JPEG encode"] = measure(
                 fl.make_params(REQ_W, REQ_H, blur_sigma=10.0, grayscale=True, front_end=fl.FE_JPEG, quality=args.quality))
+        # BASELINE config 4 on ONE GPU: a mixed-size batch (3840x2160 : 1920x1080 : 160x120 = 1 : 6 : 3, seed-shuffled),
+        # `w=300&h=200&webp=true&quality=85`: resize + letterbox + libwebp-style YUV420 front end, inputs resident in HBM
+        if args.config4:
+            try:
+                extra["config4 on one GPU (4K : 1080p : thumbnail = 1 : 6 : 3, WebP 4:2:0 front end)"] = config4_one_gpu(fl, st, dev, stream, max(4, args.extra_steps // 4))
+            except Exception as e:
+                extra["config4 on one GPU (4K : 1080p : thumbnail = 1 : 6 : 3, WebP 4:2:0 front end)"] = {"skipped": repr(e)[:200]}
+        # BASELINE config 3's per-GPU share: 65,536 pictures over 8 GPUs = 8,192 x 1080p (51 GB) resident on THIS GPU, one
+        # flgpu_transform_batch_device call, `rgb=` fill -- and the same over a two-shard context on this one device
+        if args.config3_share > 0:
+            del run
+            try:
+                extra[f"config3 per-GPU share ({args.config3_share} x 1080p resident, rgb= fill, one device batch)"] = config3_share(fl, dev, stream, args.config3_share)
+            except Exception as e:
+                extra[f"config3 per-GPU share ({args.config3_share} x 1080p resident, rgb= fill, one device batch)"] = {"skipped": repr(e)[:200]}
 
     if rank == 0:
         total_images = n * world * args.steps
@@ -702,6 +810,26 @@ def main():
                         jh["path"] = "the same with FLGPU_HOST_HUFFMAN=1: every file entropy-decoded on its caller's thread"
                         line["latency_jpeg_sources_host_huffman"] = jh
                     line["latency_jpeg_sources"] = jp
+                    # north_star's own end-to-end wording -- "resize+blur on 1080p -> 300x200", >= 50 k images/s on 8 GPUs: the same
+                    # 64 callers with `blur=10` in the query, JPEG files in, JPEG streams out
+                    if not args.blur:
+                        jb = latency_probe_c(args, query + "&blur=10", fe, 0, synthetic_jpeg_files())
+                        if jb:
+                            jb["path"] = "the same files, query w=300&h=200&blur=10: decode + resize + letterbox + blur sigma 10 + JPEG encode"
+                            line["latency_jpeg_sources_blur10"] = jb
+                    # what a node of 8 such GPUs needs for north_star's 50 k images/s: 6.25 k per GPU, and host CPU for the callers
+                    best = max((x.get("images_per_s", 0.0) for x in (jp, line.get("latency_jpeg_sources_blur10") or {}) if x), default=0.0)
+                    cpu_ms = jp.get("host_cpu_ms_per_request")
+                    line["node_budget"] = {
+                        "north_star_images_per_s_at_8_gpus": 50000, "needed_per_gpu": 6250,
+                        "measured_per_gpu_jpeg_files_in_jpeg_out": jp.get("images_per_s"),
+                        "measured_per_gpu_with_blur10": (line.get("latency_jpeg_sources_blur10") or {}).get("images_per_s"),
+                        "host_cpu_ms_per_request": cpu_ms,
+                        "host_cores_busy_at_50k_per_s": (cpu_ms * 50.0) if cpu_ms else None,   # ms per request x 50,000 requests / 1000 ms
+                        "host_cores_visible": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+                        "note": "one GPU measured; the 8-GPU figure is 8 x the per-GPU rate only if every GPU keeps this CPU share",
+                    }
+                    _ = best
             except Exception as e:  # Pillow missing: the probe is optional
                 line["latency_jpeg_sources"] = {"skipped": repr(e)[:120]}
         if args.config0_runs > 0 and args.cpu_images > 0 and world == 1 and ok_flag:  # (--cpu-images 0 switches every CPU leg off)

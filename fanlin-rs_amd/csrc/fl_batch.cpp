@@ -111,8 +111,17 @@ void assign_items(std::vector<MfmaItem> &mitems, size_t base, uint32_t &nitems, 
     MfmaItem *items = mitems.data() + base;
     const uint32_t n = nitems;
     std::vector<std::vector<MfmaItem>> per_wg(G);
+    // General launch: the classic order has the strips of a picture at positions that agree modulo 8 (the XCD they should run on);
+    // item k goes to the least-loaded workgroup of ITS class b = k (mod 8) -- round-robin would do for equal items, but a mixed
+    // launch (config 4: 4K items walk twice the K-blocks of 1080p ones) needs the balance a dynamic dispatch used to give
     auto classic = [&]() {
-        for (uint32_t k = 0; k < n; ++k) per_wg[k % G].push_back(items[k]);
+        std::vector<uint64_t> load(G, 0);
+        for (uint32_t k = 0; k < n; ++k) {
+            uint32_t best = k % 8u < G ? k % 8u : 0u;
+            for (uint32_t b = best; b < G; b += 8u) if (load[b] < load[best]) best = b;
+            per_wg[best].push_back(items[k]);
+            load[best] += items[k].kb1 - items[k].kb0 + 2u;
+        }
     };
     // uniform?  (the classic order of a uniform launch: 8 pictures interleaved strip by strip; recover pictures x strips from the jobs)
     bool uniform = plan && n >= 2 && G >= 16;

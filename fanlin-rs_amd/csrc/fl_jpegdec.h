@@ -84,7 +84,7 @@ hipError_t launch_jpeg_decode(const JpegDecJob *jobs, uint32_t njobs, uint32_t m
 // kernels do not know the difference.
 namespace fl {
 
-constexpr uint32_t kJhSubBits = 1024;          // bits per subsequence
+constexpr uint32_t kJhSubBits = 1024;          // bits per subsequence (round 5 tried 512: twice the walks at half the length -- the first kernel took 961 us against 907, profiles/r05_jpeg_decode_kernels.txt)
 constexpr uint32_t kJhLookBits = 10;           // the one-step table's lookahead (= the host decoder's kAcBits)
 constexpr uint32_t kJhTableWords = 1408;       // per code table: fastx[1024], look9[512 x u16], maxcode[18], valoff[17], vals[256 x u8]
 constexpr uint32_t kJhSyncRounds = 2;          // launches of the re-synchronisation kernel after the speculative one (each iterates inside its workgroups)

@@ -139,6 +139,9 @@ __device__ __forceinline__ int chroma_at(const uint8_t *plane, uint32_t pw, uint
 }
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+// (pointers read from a descriptor are flat to the compiler; planes and pixels are device memory by contract: global loads and stores)
+typedef const __attribute__((address_space(1))) uint8_t *gcptr8;
+typedef __attribute__((address_space(1))) uint8_t *gptr8;
 
 // one pixel, every case: planes through zune-jpeg's interpolation (a plain read at full resolution), then the colour transform
 __device__ __forceinline__ void color_pixel(const JpegDecJob &jb, const JpegBlobHeader *H, uint32_t x, uint32_t y)
@@ -169,21 +172,21 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, const JpegBlob
 {
     const uint32_t W = H->width;
     const JpegComponent &CY = H->comp[0];
-    const uint8_t *py = jb.planes + CY.plane_off;
+    gcptr8 py = (gcptr8)(jb.planes + CY.plane_off);
     const uint32_t ypw = CY.bw * 8u;
     uint32_t yv[2];
-    yv[0] = *reinterpret_cast<const uint32_t *>(py + (size_t)y * ypw + x0);
-    yv[1] = rows > 1u ? *reinterpret_cast<const uint32_t *>(py + (size_t)(y + 1u) * ypw + x0) : 0u;
+    yv[0] = *(const __attribute__((address_space(1))) uint32_t *)(py + (size_t)y * ypw + x0);
+    yv[1] = rows > 1u ? *(const __attribute__((address_space(1))) uint32_t *)(py + (size_t)(y + 1u) * ypw + x0) : 0u;
     int cv[2][2][4]; // [Cb, Cr][row][pixel]
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
         const JpegComponent &C = H->comp[1 + ci];
-        const uint8_t *pl = jb.planes + C.plane_off;
+        gcptr8 pl = (gcptr8)(jb.planes + C.plane_off);
         const uint32_t pw = C.bw * 8u;
         if (SH == 1 && SV == 1) {
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const uint32_t w = (rr == 0 || rows > 1u) ? *reinterpret_cast<const uint32_t *>(pl + (size_t)(y + rr) * pw + x0) : 0u;
+                const uint32_t w = (rr == 0 || rows > 1u) ? *(const __attribute__((address_space(1))) uint32_t *)(pl + (size_t)(y + rr) * pw + x0) : 0u;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) cv[ci][rr][k] = (int)((w >> (8 * k)) & 255u);
             }
@@ -195,16 +198,16 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, const JpegBlob
         if (SV == 1) {
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const uint32_t w = (rr == 0 || rows > 1u) ? *reinterpret_cast<const u32_unaligned *>(pl + (size_t)(y + rr) * pw + ix - 1u) : 0u;
+                const uint32_t w = (rr == 0 || rows > 1u) ? *(const __attribute__((address_space(1))) u32_unaligned *)(pl + (size_t)(y + rr) * pw + ix - 1u) : 0u;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a[rr][k] = (int)((w >> (8 * k)) & 255u);
             }
         } else {
             const uint32_t r = y >> 1; // both rows of the pair share the near chroma row; the far ones are r - 1 and r + 1, clamped
             const uint32_t ru = r ? r - 1u : 0u, rd = min(r + 1u, C.hpx - 1u);
-            const uint32_t wn = *reinterpret_cast<const u32_unaligned *>(pl + (size_t)r * pw + ix - 1u);
-            const uint32_t wu = *reinterpret_cast<const u32_unaligned *>(pl + (size_t)ru * pw + ix - 1u);
-            const uint32_t wd = *reinterpret_cast<const u32_unaligned *>(pl + (size_t)rd * pw + ix - 1u);
+            const uint32_t wn = *(const __attribute__((address_space(1))) u32_unaligned *)(pl + (size_t)r * pw + ix - 1u);
+            const uint32_t wu = *(const __attribute__((address_space(1))) u32_unaligned *)(pl + (size_t)ru * pw + ix - 1u);
+            const uint32_t wd = *(const __attribute__((address_space(1))) u32_unaligned *)(pl + (size_t)rd * pw + ix - 1u);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int n = (int)((wn >> (8 * k)) & 255u);
@@ -231,10 +234,12 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, const JpegBlob
             b[3 * k + 1] = clamp8(yy - ((11 * cb + 23 * cr) >> 5));
             b[3 * k + 2] = clamp8(yy + ((113 * cb) >> 6));
         }
-        u32_unaligned *o = reinterpret_cast<u32_unaligned *>(jb.dst + ((size_t)(y + rr) * W + x0) * 3u);
-        o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-        o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        // (one 12-byte store per lane: a wave writes 768 contiguous bytes with ONE instruction -- three dword stores 12 bytes apart
+        // touched every line three times)
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        typedef u32x3 __attribute__((aligned(1))) u32x3_unaligned;
+        const u32x3 px = {b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24), b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24)};
+        *(__attribute__((address_space(1))) u32x3_unaligned *)((gptr8)jb.dst + ((size_t)(y + rr) * W + x0) * 3u) = px;
     }
 }
 

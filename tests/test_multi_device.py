@@ -134,6 +134,36 @@ def test_config3_shape_on_two_shards(fl, gpu_state, two_shards, oracle):
 
 
 @pytest.mark.gpu
+def test_config3_true_per_gpu_share_in_one_batch(fl, gpu_state, two_shards, oracle):
+    """BASELINE config 3 on 8 GPUs is 65,536 x 1080p = 8,192 pictures per GPU: 51 GB of sources resident on the one device, ONE
+    flgpu_transform_batch_device call with an `rgb=` fill (24,576 items on 256 persistent workgroups, a 3 MB descriptor block,
+    every picture its own 6.2 MB source -- no 32-bit offset may wrap), then the same over two shards of 4,096.  Pictures from
+    all over the batch must equal the same request sent alone."""
+    import torch
+    n, h, w = 8192, 1080, 1920
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * h * w * 3 + n * 240128 + (6 << 30):
+        pytest.skip("needs 60 GB of free device memory")
+    src = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    for k in range(0, n, 512):
+        src[k:k + 512].random_(0, 256)
+    cap = 300 * 200 * 4
+    dst = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+    params = fl.make_params(300, 200, fill=(12, 200, 77))
+    picks = [0, 1, 255, 256, 2047, 4095, 4096, 4097, 6000, n - 2, n - 1]
+    alone = {k: parity.expected_pixels(fl, gpu_state, oracle, src[k].cpu().numpy(), w=300, h=200, fill=(12, 200, 77)) for k in picks}
+    for st in (gpu_state, two_shards):
+        dst.zero_()
+        st.process_batch_device([src.data_ptr() + k * h * w * 3 for k in range(n)], [(h, w, 3)] * n, params, [dst.data_ptr() + k * cap for k in range(n)], [cap] * n)
+        st.batch_results()
+        for k in picks:
+            assert np.array_equal(dst[k].cpu().numpy().reshape(200, 300, 4), alone[k]), k
+        assert int((dst[:, 3] != 255).sum().item()) == 0                # every picture's first pixel is opaque frame: nothing was skipped
+    del src, dst
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
 def test_host_batches_and_the_request_queue_on_two_shards(fl, gpu_state, two_shards, oracle):
     imgs = [synth.photo(200 + 13 * i, 260 + 7 * i, 3 + (i % 2), index=960 + i) for i in range(24)]
     # (ratios 2 .. 5: the window-tile matrix-pipe kernel and the fused ones side by side; every fifth request with a blur behind it)
