@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/profiles_raw
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-images 0 --latency-requests 0 --extra-steps 0 --verify-images 0"
+B="python3 $R/bench.py --cpu-images 0 --latency-requests 0 --extra-steps 0 --verify-images 0 --config3-share 0 --config4 0"
 run() { echo "== $*" >&2; timeout -k 10 300 "$@"; }
 # kernel time summaries (the same commands bench.py is judged on, fewer steps)
 run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config1 -o c1 -- $B --steps 20 --warmup 3 > $O/config1.log 2>&1   # the default workload: resize + letterbox + JPEG encode
@@ -31,7 +31,7 @@ run rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUS
 cd $R
 for name_args in "config1:" "config1_resize_only:--frontend none" "config1_crop:--crop --frontend none" "config2_gray_blur:--blur 10 --grayscale --frontend none" "config1_jfif444:--frontend jfif444" "config1_webp420:--frontend webp420"; do
   name=${name_args%%:*}; args=${name_args#*:}
-  extra="--cpu-images 0 --latency-requests 0 --extra-steps 0 --steps 100"; [ "$name" = config1 ] && extra=""
+  extra="--cpu-images 0 --latency-requests 0 --extra-steps 0 --steps 100 --config3-share 0 --config4 0"; [ "$name" = config1 ] && extra=""
   run python3 bench.py $args $extra > $O/bench_$name.json 2> $O/bench_$name.err
 done
 ls $O

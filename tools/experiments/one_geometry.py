@@ -1,4 +1,5 @@
-"""Runs one geometry of the sweep a few times (for rocprofv3 --kernel-trace --stats): python tools/experiments/one_geometry.py W H [n] [src_h src_w]"""
+"""Runs one geometry of the sweep a few times (for rocprofv3 --kernel-trace --stats): python tools/experiments/one_geometry.py W H [n] [src_h src_w] [blur sigma]
+(W = 0: a blur-only request)"""
 import importlib, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -9,7 +10,8 @@ H, W = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1080, 192
 C = 3
 src = torch.randint(0, 256, (n, H, W, C), dtype=torch.uint8, device="cuda")
 with fl.State(device=0) as st:
-    p = fl.make_params(w, h)
+    sigma = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+    p = fl.make_params(w, h, blur_sigma=sigma) if w else fl.make_params(blur_sigma=sigma)
     plan = fl.plan_output(p, W, H, C)
     stride = (int(plan.out_bytes) + 255) // 256 * 256
     dst = torch.zeros((n, stride), dtype=torch.uint8, device="cuda")
