@@ -98,6 +98,7 @@ struct LaunchWtile {
     uint32_t letterbox;
     uint32_t lds_bytes;
     uint32_t invert;       // PRE_INVERT: the colour channels enter as 255 - c
+    uint32_t half_waves;   // 1 = four waves per workgroup where the plan allows (fl_wtile.hip launch_wtile)
     uint32_t framed;       // one-channel blur of a letterboxed grey picture: the source is the UNFRAMED Luma8 picture (Job rw x rh at (cx, cy) of the sw x sh
                            // image the plan was built for); everything around it reads as Job::fill, and with `letterbox` the store expands to Rgba8
 };

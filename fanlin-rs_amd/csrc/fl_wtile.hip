@@ -40,11 +40,16 @@ __device__ __forceinline__ void lds_barrier()
 
 // NSLOT x NKMAX = kWtOperandRegs: a wave keeps the horizontal operands of NSLOT N-tiles of up to NKMAX K-steps each in registers
 // for its whole walk (<1, 6> also serves strips whose N-tiles mostly share ONE operand block: a blur's interior columns).
-template <int NSLOT, int NKMAX>
-__global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job *__restrict__ jobs, const WtItem *__restrict__ items,
+// WAVES: 8, or 4 for single-register-set plans of small pictures (round 5: a 300 x 200 blur is thirteen short steps of three barriers
+// each -- with 4 waves per workgroup TWO workgroups share a CU (the register file holds 8 waves of 256 registers either way) and one
+// picture's barriers and LDS round trips hide behind the other's work).
+template <int NSLOT, int NKMAX, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void resample_wtile_kernel(const Job *__restrict__ jobs, const WtItem *__restrict__ items,
                                                                        const uint32_t *__restrict__ arena, uint32_t lb, uint32_t invert, uint32_t framed)
 {
     static_assert(NSLOT * NKMAX == (int)kWtOperandRegs, "operand register budget");
+    constexpr uint32_t kWtWaves = (uint32_t)WAVES, kWtThreads = 64u * (uint32_t)WAVES; // (shadow the header's: this instantiation's workgroup)
+    constexpr uint32_t WPRE = (kWtMaxKV * 192u + kWtThreads - 1u) / kWtThreads;      // 16-byte pieces of vertical operands a thread carries
     // experiments only (-DFL_ABLATE=mask, tools/build_ablate.sh with ABL_FILE=fl_wtile.hip): 1 = no vertical pass, 2 = no horizontal pass,
     // 4 = no stores to the destination, 8 = no row / operand traffic after a band's first window, 16 = horizontal MFMAs without the
     // recombination and the byte writes
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     auto put = [&](uint32_t r, u32x4 v) { *reinterpret_cast<u32x4 *>(ring + rmod(r) * SP + 16u * tcol) = v ^ inv; };
     u32x4 pre[kWtPrefetch];
     uint32_t pre_r0 = 0, pre_r1 = 0;      // rows requested for the coming step: [pre_r0, pre_r1)
-    u32x4 wpre[2];                        // ... and its vertical operands (nkv x 192 16-byte pieces over 512 threads)
+    u32x4 wpre[WPRE];                     // ... and its vertical operands (nkv x 192 16-byte pieces over the workgroup's threads)
     uint32_t wpre_n = 0;
     auto request = [&](uint32_t r0, uint32_t r1, const WtMTile &m) __attribute__((always_inline)) {
         pre_r0 = r0; pre_r1 = r1;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
         wpre_n = m.nk * 192u;
         const u32x4 *src = reinterpret_cast<const u32x4 *>(plan + m.ops);
 #pragma unroll
-        for (uint32_t k = 0; k < 2; ++k)
+        for (uint32_t k = 0; k < WPRE; ++k)
             if (tid + k * kWtThreads < wpre_n) wpre[k] = src[tid + k * kWtThreads];
     };
     auto commit = [&]() __attribute__((always_inline)) {
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
         if (trow < rpp)
             for (uint32_t r = pre_r0 + trow + kWtPrefetch * rpp; r < pre_r1; r += rpp) put(r, fetch(r));
 #pragma unroll
-        for (uint32_t k = 0; k < 2; ++k)
+        for (uint32_t k = 0; k < WPRE; ++k)
             if (tid + k * kWtThreads < wpre_n) wv_lds[tid + k * kWtThreads] = wpre[k];
     };
 
@@ -238,8 +243,8 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
         emit(L, jt);
     };
     // output tile -> destination: 32 threads per row
-    auto store_tile = [&](uint32_t mt) __attribute__((always_inline)) {
-        const uint32_t rr = tid >> 5, t32 = tid & 31u, y = 16u * mt + rr;
+    auto store_rows = [&](uint32_t mt, uint32_t rr) __attribute__((always_inline)) {
+        const uint32_t t32 = tid & 31u, y = 16u * mt + rr;
         const uint32_t b0 = 16u * sp.n0, b1 = min(16u * sp.n1, hd.nout);
         if (y >= hd.rows) return;
         const uint8_t *orow = otile + rr * OP;
@@ -277,6 +282,10 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
                 else for (uint32_t k = 0; b + k < nb; ++k) d[b + k] = (uint8_t)(v >> (8u * k));
             }
         }
+    };
+    auto store_tile = [&](uint32_t mt) __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t r0 = 0; r0 < 16u; r0 += kWtThreads / 32u) store_rows(mt, r0 + (tid >> 5));
     };
 
     WtMTile m = mts[it.mt0];
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(kWtThreads, 1) void resample_wtile_kernel(const Job
     if (!(ablate & 4u)) store_tile(it.mt1 - 1u);
 }
 
-template <int NSLOT, int NKMAX>
+template <int NSLOT, int NKMAX, int WAVES>
 hipError_t launch_wtile_t(const LaunchWtile &m, hipStream_t st)
 {
     // the attribute is per function and device: set once per (instantiation, device), not with every launch
@@ -413,11 +422,11 @@ hipError_t launch_wtile_t(const LaunchWtile &m, hipStream_t st)
     if (e != hipSuccess) return e;
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_wtile_kernel<NSLOT, NKMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_wtile_kernel<NSLOT, NKMAX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    resample_wtile_kernel<NSLOT, NKMAX><<<m.nitems, kWtThreads, m.lds_bytes, st>>>(m.jobs, m.items, m.arena, m.letterbox, m.invert, m.framed);
+    resample_wtile_kernel<NSLOT, NKMAX, WAVES><<<m.nitems, 64 * WAVES, m.lds_bytes, st>>>(m.jobs, m.items, m.arena, m.letterbox, m.invert, m.framed);
     return hipGetLastError();
 }
 
@@ -428,10 +437,11 @@ hipError_t launch_wtile(const LaunchWtile &m, hipStream_t st)
     if (!m.nitems) return hipSuccess;
     if (m.lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
     if (m.framed && m.nslot != 1) return hipErrorInvalidValue; // (fl_batch.cpp asks for the framed source only with single-register-set plans)
-    if (m.nslot == 6 && m.nkmax == 1) return launch_wtile_t<6, 1>(m, st);
-    if (m.nslot == 3 && m.nkmax == 2) return launch_wtile_t<3, 2>(m, st);
-    if (m.nslot == 2 && m.nkmax == 3) return launch_wtile_t<2, 3>(m, st);
-    if (m.nslot == 1 && m.nkmax == 6) return launch_wtile_t<1, 6>(m, st);
+    if (m.nslot == 6 && m.nkmax == 1) return launch_wtile_t<6, 1, 8>(m, st);
+    if (m.nslot == 3 && m.nkmax == 2) return launch_wtile_t<3, 2, 8>(m, st);
+    if (m.nslot == 2 && m.nkmax == 3) return launch_wtile_t<2, 3, 8>(m, st);
+    // (single-register-set plans that leave room for a second workgroup on the CU run with 4 waves per workgroup)
+    if (m.nslot == 1 && m.nkmax == 6) return (m.lds_bytes <= 78u * 1024u && m.half_waves) ? launch_wtile_t<1, 6, 4>(m, st) : launch_wtile_t<1, 6, 8>(m, st);
     return hipErrorInvalidValue;
 }
 
