@@ -50,7 +50,8 @@ def shard_batches(global_images: int, world: int):
 
 KERNEL_DTYPE_FULL = ("u8 (exact, as f16 subnormals) x the reference's f32 weights as three f16 terms -> f32 sums (vertical, v_mfma_f32_16x16x32_f16); "
                      "24-bit fixed-point intermediate (2^-14 steps, three i8 planes) x 24-bit fixed-point weights (2^-24 steps, three i8 digits), "
-                     "all nine digit products -> exact i32 (horizontal, v_mfma_i32_16x16x64_i8): no operand narrower than f32's 24 bits")
+                     "eight of the nine digit products -> exact i32 (horizontal, v_mfma_i32_16x16x64_i8; lowest plane x lowest digit, < 2^-18 of a pixel step, not computed): "
+                     "no operand narrower than f32's 24 bits")
 KERNEL_DTYPE_PACKED = ("u8 x f16-pair weights (22 bit) -> f32 acc (vertical, MFMA); i16 (1/64 steps) x 17-bit fixed weights -> i32 exact (horizontal, MFMA) "
                        "[switch mfma_arith=1: rounds 2-3's arithmetic, narrower than the reference's]")
 KERNEL_DTYPE_STREAM = "f32 (one fused multiply-add per tap, vertical then horizontal)"

@@ -1,25 +1,39 @@
-// fl_mfma.h -- the matrix-pipe resample kernel (fl_mfma.hip): descriptors, table layout and the host-side builders.
+// fl_mfma.h -- the streaming matrix-pipe resample kernel (fl_mfma.hip): descriptors, table layout and the host-side builders.
 //
-// Same job as the streaming kernel (fused vertical + horizontal Lanczos3 down-scale of an Rgb8 picture,
-// reference image 0.25.6 imageops/sample.rs vertical_sample + horizontal_sample), arranged for gfx950's MFMA units:
+// Fused vertical + horizontal Lanczos3 down-scale (ratio >= 2) of an 8-bit picture (reference: image 0.25.6 imageops/sample.rs
+// vertical_sample + horizontal_sample, called by resize_exact from src/handler.rs:229-255), arranged for gfx950's MFMA units.
 //
-//   one workgroup (8 waves) = one picture x one strip of <= 2048 source bytes per row x a band of 16-row output tiles.
-//   vertical pass    the source rows stream once, in K-blocks of 32 rows, from HBM straight into LDS
-//                    (global_load_lds_dwordx4, a wave-private 8 KB image per K-block, no VGPRs, no barrier);
-//                    ds_read_b64_tr_b8 hands every lane the 8 rows of one byte column, two v_perm_b32 turn them into
-//                    f16 (0x6400 | byte = 1024 + byte, exact) and v_mfma_f32_16x16x32_f16 multiplies 16 byte columns
-//                    x 32 rows by the 32 x 16 slice of the banded weight matrix (two f16 terms per weight = 22 bits).
-//                    At most two 16-row output tiles are alive per K-block; their sums stay in registers.
-//   horizontal pass  a finished tile goes f32 -> 16-bit fixed point (1/64 steps around 128) -> two byte planes, which
-//                    are already laid out as the A operand of v_mfma_i32_16x16x64_i8; the B operand holds the
-//                    horizontal weights as two signed byte digits, and the three digit products are summed exactly
-//                    in i32.  Waves add their partial sums into a shared [16][outputs] LDS tile (integer adds
-//                    commute, so the result does not depend on the order); rounding, clamping and the store follow.
+// THE SHIPPED KERNEL is the full-width form (template parameter FW, MFMA_ARITH_FULL, the default since round 4):
 //
-// Arithmetic: vertical weights are the reference's f32 weights split into two f16 terms, summed in f32 by the matrix
-// unit (error < 2^-12 of a pixel step); horizontal weights are rounded to 2^-hs (hs = 14..17: the largest that keeps every weight below 2^15; sums forced to exactly
-// 1) and the intermediate to 1/64.  Worst case |error| < 0.1 before the final rounding, so every output byte is
-// within 1 of the reference's (tests/test_mfma_resample.py measures the rate of such off-by-one bytes).
+//   work item        one picture x one strip of <= 2048 source bytes per row (strips start on 128-byte lines where the picture's
+//                    rows do) x a band of 16-row output tiles.  Since round 5 the launch is PERSISTENT: min(items, CUs) workgroups
+//                    of 8 waves, each walking its own item list (LaunchMfma::wg_lists, fl_batch.cpp assign_items).  A workgroup
+//                    keeps one strip where the launch allows: an item whose strip, vertical plan and K-blocks equal its
+//                    predecessor's ("light" transition) reuses the operands in LDS and the packed tile table in SGPRs, and its
+//                    first K-block is requested during the predecessor's last pass (MfmaReq).
+//   vertical pass    the source rows stream once, in K-blocks of 32 rows, from HBM straight into LDS (global_load_lds_dwordx4,
+//                    a wave-private 8 KB image per K-block, no VGPRs, no barrier); ds_read_b64_tr_b8 hands every lane the 8 rows
+//                    of one byte column; the bytes enter v_mfma_f32_16x16x32_f16 as exact f16 subnormals (b * 2^-24) against the
+//                    reference's f32 weight, split into three f16 terms of 2^15 w.  At most two 16-row output tiles are alive
+//                    per K-block; their f32 sums (= value * 2^-9) stay in registers.
+//   horizontal pass  a finished tile is rounded once to 2^-14 of a pixel step, 2^22 + round((value - 128) * 2^14), and split
+//                    into three byte planes -- already the A operand of v_mfma_i32_16x16x64_i8.  The B operands hold the
+//                    horizontal weights round(w * 2^hs) (sums forced to exactly 2^hs) as three balanced signed byte digits; eight
+//                    of the nine plane x digit products (all but lowest x lowest, < 2^-18 of a step) are summed exactly in i32 and
+//                    recombined to 2^-20 of a step.  Waves add their partial sums into ONE shared [16][outputs] LDS tile
+//                    (integer adds commute: the result does not depend on the order; add_cnt / conv_cnt hand the tile over
+//                    without a workgroup barrier); one rounding to the byte, clamp, store (letterbox placement, Rgba8 expansion).
+//   LDS              rows 64 KB | one output tile (layout-dependent pitch, below) | counters + two conversion contexts | the
+//                    strip's B operands (1 KB each) when they fit, else they are read through the L2 (MfmaStrip::lds_ops).
+//
+// Error budget: no operand is narrower than the reference's f32; the two roundings (2^-14 between the passes, 2^-20 before the
+// byte) leave every output byte within 1 of the reference's, and ~3e-5 of them off by one (tests/test_mfma_resample.py measures
+// the rate; tests/test_mfma_tables.py bounds the tables).
+//
+// THE PACKED FORM (rounds 2-3; FW = false, MFMA_ARITH_PACKED, selected by flgpu_config / the mfma_arith switch) is kept as the
+// measured comparison: bytes as f16 1024 + b, weights as two f16 terms, the intermediate as (value - 128) * 64 in i16 (two byte
+// planes), horizontal weights of 14..17 bits as two digits, three digit products; one item per workgroup, two output tiles in LDS.
+// ~0.1 % of its bytes are off by one.  Constants marked "packed" below belong to it.
 #pragma once
 #include <stdint.h>
 

@@ -27,7 +27,7 @@ for i in range(n):
         kw["h"] = max(1, kw["h"] * int(rng.integers(2, 4)))   # letterboxed top and bottom (or a narrow crop)
     img = synth.uniform(sh, sw, c, index=i) if i % 3 else synth.photo(sh, sw, c, index=i)
     bands = str(int(rng.integers(1, 9)))
-    os.environ["FLGPU_FORCE_BANDS"] = bands
+    st.debug_set("force_bands", int(bands))
     try:
         got, used = parity.device_pixels(fl, st, img, **kw)
         parity.check_pixels(oracle, got, img, used, **parity.oracle_kwargs(kw))

@@ -33,7 +33,7 @@ for i in range(n):
         kw["blur_sigma"] = float(rng.choice([0.3, 0.8, 1.5, 3.0, 7.0, 10.0, 14.5, 20.0]))
     img = synth.uniform(sh, sw, c, index=i) if i % 3 else synth.photo(sh, sw, c, index=i)
     bands = str(int(rng.integers(1, 9)))
-    os.environ["FLGPU_FORCE_BANDS"] = bands
+    st.debug_set("force_bands", int(bands))
     try:
         before = st.stats()["wtile_launches"]
         got, used = parity.device_pixels(fl, st, img, **kw)

@@ -12,8 +12,7 @@ h, w, c, ow, oh = [int(x) for x in (sys.argv[1:6] if len(sys.argv) > 5 else (108
 img = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
 with fl.State() as st:
     for bands in ("1", None):
-        if bands: os.environ["FLGPU_FORCE_BANDS"] = bands
-        else: os.environ.pop("FLGPU_FORCE_BANDS", None)
+        st.debug_set("force_bands", int(bands) if bands else 0)
         got = st.process_pixels(img, fl.make_params(w=ow, h=oh))
         want = oracle.process_pixels(img, ow, oh)
         d = np.abs(got.astype(np.int32) - want.astype(np.int32)).max(axis=2)

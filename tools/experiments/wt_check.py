@@ -25,10 +25,13 @@ ap.add_argument("--only", type=int, default=-1)
 a = ap.parse_args()
 
 
-def set_mode(m):
+def set_mode(m, st=None):
+    """The window-tile kernel on or off: through the context's switch when there is one, else through the variable flgpu_create reads."""
     os.environ.pop("FLGPU_NO_WTILE", None)
     if m == "vector":
         os.environ["FLGPU_NO_WTILE"] = "1"
+    if st is not None:
+        st.debug_set("no_wtile", int(m == "vector"))
 
 
 bad = 0
@@ -56,7 +59,7 @@ if not a.no_check:
             want = oracle.process_pixels(img, kw.get("w"), kw.get("h"), crop=kw.get("crop", False), blur_sigma=kw.get("blur_sigma", 0.0))
             line = f"{shape[1]}x{shape[0]}x{shape[2]} {kw}:"
             for m in ("wtile", "vector"):
-                set_mode(m)
+                set_mode(m, st)
                 before = st.stats()["wtile_launches"]
                 got = st.process_pixels(img, p)
                 used = st.stats()["wtile_launches"] - before
