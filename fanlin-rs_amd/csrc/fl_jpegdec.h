@@ -85,8 +85,8 @@ hipError_t launch_jpeg_decode(const JpegDecJob *jobs, uint32_t njobs, uint32_t m
 namespace fl {
 
 constexpr uint32_t kJhSubBits = 1024;          // bits per subsequence (round 5 tried 512: twice the walks at half the length -- the first kernel took 961 us against 907, profiles/r05_jpeg_decode_kernels.txt)
-constexpr uint32_t kJhLookBits = 10;           // the one-step table's lookahead (= the host decoder's kAcBits)
-constexpr uint32_t kJhTableWords = 1408;       // per code table: fastx[1024], look9[512 x u16], maxcode[18], valoff[17], vals[256 x u8]
+constexpr uint32_t kJhLookBits = 12;           // lookahead of the device's code table: every code of up to 12 bits in one LDS read (Annex K: all but the 15- and 16-bit ones)
+constexpr uint32_t kJhTableWords = 2148;       // per code table: look[4096 x u16] = code length | symbol << 8 (0: a longer code), maxcode[18], valoff[17], vals[256 x u8]
 constexpr uint32_t kJhSyncRounds = 2;          // launches of the re-synchronisation kernel after the speculative one (each iterates inside its workgroups)
 constexpr uint32_t kJhMagic = 0x32444a46u;     // "FJD2": a staged entropy-coded segment instead of coefficients
 

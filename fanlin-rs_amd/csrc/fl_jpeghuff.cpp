@@ -24,6 +24,7 @@ struct Huff {
     int32_t maxcode[18];  // per length, -1 = none; [17] = sentinel
     int32_t valoff[17];   // symbol index of the first code of a length minus that code
     uint8_t vals[256];
+    uint8_t counts[16];   // codes per length 1..16 (the DHT segment's, for the device's table)
     // The single-pass decoder's table (AC and DC tables alike): kAcBits of lookahead resolve code + magnitude (or the end-of-block and
     // ZRL codes) in one step: bits 0-4 = bits to drop, 5-8 = zero run, 12 = no value (13 = end of block, else ZRL),
     // 16-31 = value; 0 = slow path
@@ -34,6 +35,7 @@ struct Huff {
 bool build_huff(Huff &h, const uint8_t *bits /*[16] counts of lengths 1..16*/, const uint8_t *vals, int total)
 {
     memcpy(h.vals, vals, (size_t)total);
+    memcpy(h.counts, bits, 16);
     memset(h.fast, 0, sizeof(h.fast));
     int code = 0, k = 0;
     for (int l = 1; l <= 16; ++l) {
@@ -576,6 +578,8 @@ int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, 
     uint32_t nslots = 0;
     uint32_t *tables = reinterpret_cast<uint32_t *>(out + sizeof(JpegBlobHeader) + sizeof(JpegHuffStage));
     memset(tables, 0, 4u * kJhTableWords * 4u);
+    int pair_of[4] = {-1, -1, -1, -1}; // per table slot: the slot of the AC table whose end-of-block code may follow its symbols (-2: more than one)
+    const Huff *huff_of[4] = {nullptr, nullptr, nullptr, nullptr};
     for (uint32_t i = 0; i < nc; ++i)
         for (int cls = 0; cls < 2; ++cls) {
             const uint32_t id = cls ? P.c[i].ta : P.c[i].td;
@@ -584,17 +588,58 @@ int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, 
                 if (nslots == 4) return -2;
                 slot_of[cls][id] = (int)nslots;
                 const Huff &h = P.ht[cls][id];
+                huff_of[nslots] = &h;
                 uint32_t *t = tables + (size_t)nslots * kJhTableWords;
-                static_assert(sizeof(h.fastx) == 1024 * 4 && sizeof(h.fast) == 512 * 2, "device table layout (fl_jpegdec.h kJhTableWords)");
-                memcpy(t, h.fastx, sizeof(h.fastx));
-                memcpy(t + 1024, h.fast, sizeof(h.fast));
-                memcpy(t + 1280, h.maxcode, 18 * 4);
-                memcpy(t + 1298, h.valoff, 17 * 4);
-                memcpy(t + 1315, h.vals, 256);
+                // the device's layout (fl_jpeghuff_dev.hip): look[2^kJhLookBits] halfwords = code length | symbol << 8 for every code of
+                // up to kJhLookBits bits (canonical order, as build_huff assigns them; 0 = a longer code or none), maxcode, valoff, vals
+                constexpr uint32_t kLookWords = (1u << kJhLookBits) / 2u;
+                static_assert(kLookWords + 18 + 17 + 64 <= kJhTableWords, "device table layout (fl_jpegdec.h kJhTableWords)");
+                uint16_t *look = reinterpret_cast<uint16_t *>(t);
+                uint32_t code = 0, k = 0;
+                for (uint32_t l = 1; l <= kJhLookBits; ++l) {
+                    for (uint32_t q = 0; q < h.counts[l - 1]; ++q, ++k, ++code) {
+                        const uint32_t first = code << (kJhLookBits - l), cnt = 1u << (kJhLookBits - l);
+                        const uint16_t e = (uint16_t)(l | ((uint32_t)h.vals[k] << 8));
+                        for (uint32_t f = 0; f < cnt; ++f) look[first + f] = e; // (build_huff has checked the code space)
+                    }
+                    code <<= 1;
+                }
+                memcpy(t + kLookWords, h.maxcode, 18 * 4);
+                memcpy(t + kLookWords + 18, h.valoff, 17 * 4);
+                memcpy(t + kLookWords + 35, h.vals, 256);
                 ++nslots;
             }
             (cls ? S.ac_tab : S.dc_tab)[i] = (uint8_t)slot_of[cls][id];
         }
+    for (uint32_t i = 0; i < nc; ++i) {
+        const int d = S.dc_tab[i], a = S.ac_tab[i];
+        pair_of[d] = (pair_of[d] == -1 || pair_of[d] == a) ? a : -2;
+        pair_of[a] = (pair_of[a] == -1 || pair_of[a] == a) ? a : -2; // (a slot used as DC table by one component and as AC table by another: no pairing)
+    }
+    // An end-of-block code right behind a symbol's magnitude bits, all inside the lookahead: bits 5-7 of the entry = its length, and the
+    // device consumes it with the symbol (one decoding step for the "DC difference, end of block" blocks of flat regions, one step less
+    // for every block whose last coefficient is a short code).  Symbols that carry no coefficient (end of block, ZRL) and DC categories
+    // above 11 stay plain.
+    for (uint32_t sl = 0; sl < nslots; ++sl) {
+        if (pair_of[sl] < 0) continue;
+        const Huff &ha = *huff_of[pair_of[sl]];
+        uint32_t el = 0, ec = 0, code = 0, k = 0;
+        for (uint32_t l = 1; l <= 16 && !el; ++l) {
+            for (uint32_t q = 0; q < ha.counts[l - 1]; ++q, ++k, ++code)
+                if (ha.vals[k] == 0x00) { el = l; ec = code; break; }
+            code <<= 1;
+        }
+        if (!el || el > 7) continue;
+        const bool is_ac = (uint32_t)pair_of[sl] == sl;
+        uint16_t *look = reinterpret_cast<uint16_t *>(tables + (size_t)sl * kJhTableWords);
+        for (uint32_t idx = 0; idx < (1u << kJhLookBits); ++idx) {
+            const uint32_t e = look[idx], l = e & 31u, sym = e >> 8, sz = sym & 15u;
+            if (!l || (is_ac ? sz == 0u : sym > 11u)) continue;
+            const uint32_t tot = l + sz + el;
+            if (tot > kJhLookBits) continue;
+            if (((idx >> (kJhLookBits - tot)) & ((1u << el) - 1u)) == ec) look[idx] = (uint16_t)(e | (el << 5));
+        }
+    }
     // blocks of one MCU in coding order (A.2.3): component by component, rows of its h x v group
     uint32_t bpm = 0;
     for (uint32_t i = 0; i < nc; ++i)

@@ -31,17 +31,25 @@ namespace fl {
 namespace {
 
 constexpr uint32_t TW = kJhTableWords;
-constexpr uint32_t T_LOOK = 1024, T_MAXCODE = 1024 + 256, T_VALOFF = T_MAXCODE + 18, T_VALS = T_VALOFF + 17; // word offsets inside a table
+constexpr uint32_t LB = kJhLookBits;
+constexpr uint32_t T_MAXCODE = (1u << LB) / 2u, T_VALOFF = T_MAXCODE + 18, T_VALS = T_VALOFF + 17; // word offsets inside a table
+static_assert(T_VALS + 64u <= TW, "device code table layout (fl_jpegdec.h kJhTableWords)");
 
 struct Ctx {
     const JpegBlobHeader *H;
     const JpegHuffStage *S;
     const uint32_t *words;  // the unstuffed segment as big-endian words
     uint32_t nwords;
-    const uint32_t *lwords; // the workgroup's window of it in LDS: words [lbase, lbase + kWinWords)
+    const uint32_t *lwords; // the workgroup's window of it in LDS, byte-swapped: words [lbase, lbase + kWinWords)
     uint32_t lbase;
+    uint32_t bpm, total_blocks, mcux;
+    uint64_t comp_of, tabs_of; // per block of the MCU, four bits each: its component; its DC (2 bits) and AC (2 bits) table
 };
 constexpr uint32_t kWinWords = 256u * kJhSubBits / 32u + 8u; // 256 subsequences + the words a walk may read past its end
+
+// LDS of the walking kernels (dynamic: 4 tables + window + per-block records + states = 69 KB, beyond the static 64 KB)
+constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 4u, kLdsWords = kLdsStates + 2u * 258u;
+static_assert(kLdsStates % 2u == 0u && kLdsBinfo % 4u == 0u, "LDS alignment of the 64-bit states / 16-byte block records");
 
 __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
 {
@@ -51,143 +59,181 @@ __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
     c.words = reinterpret_cast<const uint32_t *>(jb.stage + c.S->stream_off);
     c.nwords = (c.S->stream_bits / 8u + 16u) / 4u; // (the stage is padded with 16 bytes of ones)
     c.lwords = nullptr; c.lbase = 0u;
+    c.bpm = c.S->bpm; c.total_blocks = c.S->total_blocks; c.mcux = c.S->mcux;
+    c.comp_of = 0; c.tabs_of = 0; // (uniform: once per kernel, in scalar registers -- a walk shifts them by its block number)
+    for (uint32_t b = 0; b < c.bpm; ++b) {
+        const uint32_t cb = c.S->blk_comp[b];
+        c.comp_of |= (uint64_t)cb << (4u * b);
+        c.tabs_of |= (uint64_t)(c.S->dc_tab[cb] | (c.S->ac_tab[cb] << 2)) << (4u * b);
+    }
     return c;
 }
 
-// The 256 subsequences of a workgroup are one contiguous piece of the segment: it is copied to LDS once (coalesced), and the walks
-// read their words there -- a walk consumes a word every five symbols or so, and fetched one by one from the L2 those loads were
-// most of its time.
+// The 256 subsequences of a workgroup are one contiguous piece of the segment: it is copied to LDS once (coalesced, already in the
+// byte order the bit buffer wants), and the walks read their words there -- a walk consumes a word every five symbols or so, and
+// fetched one by one from the L2 those loads were most of its time.
 __device__ __forceinline__ void stage_window(Ctx &c, uint32_t first_sub, uint32_t *win)
 {
     const uint32_t base = first_sub * (kJhSubBits / 32u);
     for (uint32_t k = threadIdx.x; k < kWinWords; k += blockDim.x) {
         const uint32_t i = base + k;
-        win[k] = c.words[i < c.nwords ? i : c.nwords - 1u];
+        win[k] = __builtin_bswap32(c.words[i < c.nwords ? i : c.nwords - 1u]);
     }
     c.lwords = win; c.lbase = base;
     __syncthreads();
 }
 
-__device__ __forceinline__ void stage_tables(const JhJob &jb, const Ctx &c, uint32_t *lut)
+// the picture's four code tables, and per block of the MCU where its block words are: {first, step per MCU column, step per MCU row}
+__device__ __forceinline__ void stage_tables(const JhJob &jb, const Ctx &c, uint32_t *lut, uint32_t *binfo)
 {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(jb.stage + c.S->tables_off);
     for (uint32_t k = threadIdx.x; k < 4u * TW; k += blockDim.x) lut[k] = src[k];
+    if (threadIdx.x < c.bpm) {
+        const uint32_t jj = threadIdx.x;
+        const JpegComponent &cc = c.H->comp[c.S->blk_comp[jj]];
+        binfo[4u * jj] = cc.block_base + c.S->blk_v[jj] * cc.bw + c.S->blk_h[jj];
+        binfo[4u * jj + 1u] = cc.h;
+        binfo[4u * jj + 2u] = cc.v * cc.bw;
+        binfo[4u * jj + 3u] = 0u;
+    }
     __syncthreads();
 }
 
 __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t j, uint32_t k) { return (uint64_t)p | ((uint64_t)j << 32) | ((uint64_t)k << 40); }
 
 // One walk over the code words from state (p, j, k) until the bit position reaches p_end.
-// MODE 0: states only.  MODE 1: + blocks completed and DC difference sums.  MODE 2: + the coefficients are stored (q0 = number of the
-// block the walk starts in, dc0 = the components' DC predictors there) and invalid code words of real blocks are reported.
+// MODE 1: states, blocks completed and DC difference sums.  MODE 2: + the coefficients are stored (q0 = number of the block the walk
+// starts in, dc0 = the components' DC predictors there) and invalid code words of real blocks are reported.
+//
+// The 64 lanes of a wave are in 64 different places of their blocks, so every branch of the loop body is taken by SOME lane in almost
+// every iteration: an iteration costs the sum of all its paths, and (one wave per SIMD, a dependent chain) every instruction is on
+// the critical path.  Hence ONE symbol path for every lane -- a kJhLookBits lookahead gives (code length, symbol) for every code the
+// files in practice use, the magnitude bits are taken arithmetically (T.81 F.2.2.1 EXTEND without a branch) -- the block's tables
+// are looked up when the block changes, not per symbol, block numbers advance by increments (no division), and only codes longer
+// than the lookahead (Annex K: the 15- and 16-bit ones) leave the path, for the canonical search of F.2.2.3.
+// (Round 4's walk resolved code + magnitude in one 10-bit lookup and sent everything longer -- one symbol in eight at quality 85 --
+// through a second table and a search; with 64 lanes that path ran in every iteration: ~350 instructions per symbol step, this: ~90.)
 template <int MODE>
-__device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, uint64_t state, uint32_t p_end, int32_t *cnt4, uint32_t q0, const int32_t *dc0,
-                                            int16_t *coef, uint32_t *err)
+__device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, const uint32_t *binfo, uint64_t state, uint32_t p_end, int32_t *cnt4, uint32_t q0,
+                                            const int32_t *dc0, int16_t *coef, uint32_t *err)
 {
-    const JpegHuffStage &S = *c.S;
+    static_assert(MODE == 1 || MODE == 2, "walk mode");
+    const uint16_t *look = reinterpret_cast<const uint16_t *>(lut);
     uint32_t p = (uint32_t)state, j = (uint32_t)(state >> 32) & 15u, k = (uint32_t)(state >> 40) & 127u;
-    uint32_t wi = p >> 5;
-    auto word = [&](uint32_t i) {
-        const uint32_t k = i - c.lbase;
-        return __builtin_bswap32(k < kWinWords ? c.lwords[k] : c.words[i < c.nwords ? i : c.nwords - 1u]);
-    };
+    uint32_t wi = (p >> 5) - c.lbase; // (inside the window by construction: a walk starts in or behind its own subsequence and ends within two words of its end)
+    auto word = [&](uint32_t i) { return c.lwords[i < kWinWords ? i : kWinWords - 1u]; };
     uint64_t buf = (((uint64_t)word(wi) << 32) | word(wi + 1u)) << (p & 31u);
     int cnt = 64 - (int)(p & 31u);
     wi += 2u;
     uint32_t next_word = word(wi);
-    int32_t nblk = 0, dcs[3] = {0, 0, 0};
-    uint32_t q = q0, gidx = 0;
+    int32_t nblk = 0;
+    int64_t dacc = 0;        // MODE 1: the three DC difference sums as 21-bit signed fields of one 64-bit sum (|sum| < 2^20: at most 79 blocks of |difference| <= 2047 fit 1024 bits)
+    int32_t d0 = 0, d1 = 0, d2 = 0; // MODE 2: the components' DC predictors
+    uint32_t q = q0, gidx = 0, mx = 0, my = 0;
     bool bad = false;
-    const uint32_t bpm = S.bpm;
-    // per block of the MCU, four bits: component (2) ... and eight more: its DC and AC table (2 + 2) -- in registers, not re-read per symbol
-    uint64_t comp_of = 0, tabs_of = 0;
-    for (uint32_t b = 0; b < bpm; ++b) {
-        const uint32_t cb = S.blk_comp[b];
-        comp_of |= (uint64_t)cb << (4u * b);
-        tabs_of |= (uint64_t)(S.dc_tab[cb] | (S.ac_tab[cb] << 2)) << (4u * b);
-    }
-    auto block_index = [&](uint32_t qq, uint32_t jj) { // decode-order block number -> index of its block word
-        const uint32_t m = qq / bpm, mx = m % S.mcux, my = m / S.mcux, comp = S.blk_comp[jj];
-        const JpegComponent &cc = c.H->comp[comp];
-        return cc.block_base + (my * cc.v + S.blk_v[jj]) * cc.bw + mx * cc.h + S.blk_h[jj];
+    // halfword offsets in `lut` of the lookahead tables: the block's DC and AC table, the NEXT block's DC table; the block's component
+    uint32_t dcb, acb, dcb_n, comp;
+    auto dc_table = [&](uint32_t jj) { return ((uint32_t)(c.tabs_of >> (4u * jj)) & 3u) * (2u * TW); };
+    auto enter = [&](uint32_t jj) { // (dcb is the caller's: the table the block before had as "next")
+        acb = (((uint32_t)(c.tabs_of >> (4u * jj)) >> 2) & 3u) * (2u * TW);
+        comp = (uint32_t)(c.comp_of >> (4u * jj)) & 3u;
+        dcb_n = dc_table(jj + 1u == c.bpm ? 0u : jj + 1u);
     };
-    if (MODE == 2) gidx = q < S.total_blocks ? block_index(q, j) : 0u;
-    while (p < p_end) {
-        if (MODE == 2 && q >= S.total_blocks) break;
-        if (cnt <= 32) { buf |= (uint64_t)next_word << (32 - cnt); cnt += 32; ++wi; next_word = word(wi); } // (the word after is requested at once: its latency hides behind the symbols in between)
-        const uint32_t comp = (uint32_t)(comp_of >> (4u * j)) & 3u;
-        const uint32_t tsel = (uint32_t)(tabs_of >> (4u * j)) & 15u;
-        const uint32_t *tab = lut + (k == 0u ? (tsel & 3u) : (tsel >> 2)) * TW;
-        const uint32_t e = tab[(uint32_t)(buf >> (64 - kJhLookBits))];
-        uint32_t nb, run = 0, flags = 0; // flags: 1 = end of block / category 0, 2 = ZRL
-        int32_t val = 0;
-        if (e) {
-            nb = e & 31u;
-            if (e & (1u << 12)) flags = (e & (1u << 13)) ? 1u : 2u;
-            else { run = (e >> 5) & 15u; val = (int32_t)(int16_t)(e >> 16); }
-        } else {
-            // code + magnitude longer than the lookahead: the code alone from the 9-bit table or the canonical search, then the magnitude
-            const uint32_t f = (tab[T_LOOK + ((uint32_t)(buf >> 55) >> 1)] >> (16u * ((uint32_t)(buf >> 55) & 1u))) & 0xffffu;
-            uint32_t len, sym;
-            if (f) { len = f >> 8; sym = f & 255u; }
+    auto place = [&](uint32_t jj) { // index of the block word of block jj of MCU (mx, my)
+        const uint4 bi = *reinterpret_cast<const uint4 *>(binfo + 4u * jj);
+        return bi.x + my * bi.z + mx * bi.y;
+    };
+    if (j >= c.bpm) j = 0u; // (a state is only ever one a walk produced; this keeps a corrupt one inside the tables)
+    dcb = dc_table(j);
+    enter(j);
+    if (MODE == 2) {
+        d0 = dc0[0]; d1 = dc0[1]; d2 = dc0[2];
+        const uint32_t m = q / c.bpm;
+        my = m / c.mcux; mx = m - my * c.mcux;
+        gidx = q < c.total_blocks ? place(j) : 0u;
+    }
+    // The table entry of the NEXT symbol is requested as soon as the bit buffer has moved past this one -- from the block's AC table and
+    // from the next block's DC table at once, since which of the two it is (did this symbol end the block?) comes out of the
+    // bookkeeping that runs while the two reads are under way.  The recurrence of an iteration is then bits -> entry -> lengths -> bits.
+    uint32_t e = look[(k == 0u ? dcb : acb) + (uint32_t)(buf >> (64u - LB))];
+    while (p < p_end && (MODE != 2 || q < c.total_blocks)) {
+#ifdef FL_JH_TRACE
+        if (MODE == 1 && cnt4) ++cnt4[4];
+#endif
+        // entry: bits 0-4 code length (0: longer than the lookahead), 5-7 length of an END-OF-BLOCK code that follows the symbol's
+        // magnitude bits inside the lookahead (0: none there) -- it is consumed with the symbol: blocks of flat regions (a DC
+        // difference, then end of block: 5 bits or so) are the longest walks of a wave, and take one step this way --, 8-15 the symbol
+        uint32_t len = e & 31u, sym = e >> 8;
+        uint32_t el = (e >> 5) & 7u;
+        if (len == 0u) {
+            // a code longer than the lookahead: canonical search (F.2.2.3) from the next length on
+            const uint32_t top = (uint32_t)(buf >> 32);
+            const uint32_t *tab = lut + ((k == 0u ? dcb : acb) >> 1);
+            const int32_t *maxcode = reinterpret_cast<const int32_t *>(tab + T_MAXCODE), *valoff = reinterpret_cast<const int32_t *>(tab + T_VALOFF);
+            len = LB + 1u;
+            while (len <= 16u && (int32_t)(top >> (32u - len)) > maxcode[len]) ++len;
+            sym = 0u;
+            if (len > 16u) { bad = true; len = 16u; }
             else {
-                len = 10u;
-                const int32_t *maxcode = reinterpret_cast<const int32_t *>(tab + T_MAXCODE), *valoff = reinterpret_cast<const int32_t *>(tab + T_VALOFF);
-                while (len <= 16u && (int32_t)(uint32_t)(buf >> (64u - len)) > maxcode[len]) ++len;
-                if (len > 16u) { bad = true; len = 16u; sym = 0u; }
-                else {
-                    const int32_t idx = (int32_t)(uint32_t)(buf >> (64u - len)) + valoff[len];
-                    if (idx < 0 || idx > 255) { bad = true; sym = 0u; }
-                    else sym = (tab[T_VALS + ((uint32_t)idx >> 2)] >> (8u * ((uint32_t)idx & 3u))) & 255u;
-                }
+                const int32_t idx = (int32_t)(top >> (32u - len)) + valoff[len];
+                if (idx < 0 || idx > 255) bad = true;
+                else sym = (tab[T_VALS + ((uint32_t)idx >> 2)] >> (8u * ((uint32_t)idx & 3u))) & 255u;
             }
-            const uint32_t s = sym & 15u;
-            run = sym >> 4;
-            nb = len + s;
-            if (s == 0u) flags = (run == 15u && k != 0u) ? 2u : 1u;
-            else {
-                const int32_t v = (int32_t)(uint32_t)((buf << len) >> (64u - s));
-                val = v < (1 << (s - 1u)) ? v - (1 << s) + 1 : v;
-            }
-            if (k == 0u && (sym > 11u)) bad = true;            // a DC symbol is a bare category 0..11
-            if (k != 0u && s == 0u && run != 0u && run != 15u) bad = true; // (run, 0) other than end of block / ZRL: not a baseline code
         }
+        const uint32_t s = sym & 15u, run = sym >> 4;
+        if (k + run >= 63u) el = 0u; // (coefficient 63 ends its block without an end-of-block code: what follows is the next block's DC code)
+        const uint32_t t = (uint32_t)((buf << len) >> 32); // the bits behind the code
+        const uint32_t nb = len + s + el; // <= 16 + 15 (el != 0: <= the lookahead)
         buf <<= nb; cnt -= (int)nb; p += nb;
+        if (cnt <= 32) { buf |= (uint64_t)next_word << (32 - cnt); cnt += 32; ++wi; next_word = word(wi); } // (the word after is requested at once: its latency hides behind the symbols in between)
+        const uint32_t nidx = (uint32_t)(buf >> (64u - LB));
+        const uint32_t e_ac = look[acb + nidx], e_dc = look[dcb_n + nidx];
+        // RECEIVE + EXTEND: the s bits behind the code; a leading 0 bit means negative, value - 2^s + 1 (s = 0: no bits, 0)
+        const int32_t val = (int32_t)((t >> 1) >> (31u - s)) + (((int32_t)t >> 31) ? 0 : (int32_t)((0xffffffffu << s) + 1u));
         if (k == 0u) {
-            if (flags == 2u || (flags == 0u && run != 0u)) bad = true;
-            if (MODE >= 1 && comp < 3u) dcs[comp] += val;
+            if (MODE == 1) dacc += (int64_t)val << (21u * comp);
             if (MODE == 2) {
-                const int32_t dc = dc0[comp < 3u ? comp : 0u] + dcs[comp < 3u ? comp : 0u];
+                if (sym > 11u) bad = true; // a DC symbol is a bare category 0..11
+                const int32_t dc = (comp == 0u ? d0 : comp == 1u ? d1 : d2) + val;
+                d0 = comp == 0u ? dc : d0; d1 = comp == 1u ? dc : d1; d2 = comp == 2u ? dc : d2;
                 if (dc < -32768 || dc > 32767) bad = true;
                 coef[(size_t)gidx * 64u] = (int16_t)dc;
             }
-            k = 1u;
-        } else if (flags == 1u) k = 64u;
-        else if (flags == 2u) k += 16u;
-        else {
-            k += run;
-            if (k > 63u) { bad = true; k = 64u; }
-            else {
-                if (MODE == 2) coef[(size_t)gidx * 64u + k] = (int16_t)val;
-                ++k;
+            k = el ? 64u : 1u;
+        } else {
+            const uint32_t kn = k + run;
+            if (MODE == 2) {
+                if (s == 0u) { if (run != 0u && run != 15u) bad = true; } // (run, 0) other than end of block / ZRL: not a baseline code
+                else if (kn > 63u) bad = true;
+                else coef[(size_t)gidx * 64u + kn] = (int16_t)val;
             }
+            k = s == 0u ? (run == 15u ? k + 16u : 64u) : (el ? 64u : kn + 1u);
         }
         if (k >= 64u) { // block complete
             k = 0u;
-            j = j + 1u == bpm ? 0u : j + 1u;
+            j = j + 1u == c.bpm ? 0u : j + 1u;
             ++nblk;
+            dcb = dcb_n;
+            enter(j);
             if (MODE == 2) {
                 if (bad) atomicOr(err, 2u); // (an invalid code word inside a real block: the file is broken, or the states were wrong)
                 bad = false;
                 ++q;
-                if (q < S.total_blocks) gidx = block_index(q, j);
+                if (j == 0u && ++mx == c.mcux) { mx = 0u; ++my; }
+                if (q < c.total_blocks) gidx = place(j);
             }
         }
+        e = k == 0u ? e_dc : e_ac; // (e_dc was read from what was then the next block's table: this block's, if the block has just changed)
     }
     // (a block that straddles the subsequence's end: the next walk continues it with a clean flag, so what this part of it saw is
     // reported here -- the host decoder rejects the same file, and which of the two runs must not decide whether a corrupt file is served)
     if (MODE == 2 && bad) atomicOr(err, 2u);
-    if (MODE >= 1 && cnt4) { cnt4[0] = nblk; cnt4[1] = dcs[0]; cnt4[2] = dcs[1]; cnt4[3] = dcs[2]; }
+    if (MODE == 1 && cnt4) {
+        const int32_t c0 = (int32_t)((dacc << 43) >> 43);
+        const int64_t a1 = (dacc - c0) >> 21;
+        const int32_t c1 = (int32_t)((a1 << 43) >> 43);
+        cnt4[0] = nblk; cnt4[1] = c0; cnt4[2] = c1; cnt4[3] = (int32_t)((a1 - c1) >> 21);
+    }
     return pack_state(p, j, k);
 }
 
@@ -221,33 +267,57 @@ constexpr int kJhInnerRounds = 24;
 template <bool FIRST>
 __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const JhItem *items)
 {
-    __shared__ uint32_t lut[4 * TW];
-    __shared__ uint32_t win[kWinWords];
-    __shared__ uint64_t st[257];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *lut = lds + kLdsLut, *win = lds + kLdsWin, *binfo = lds + kLdsBinfo;
+    uint64_t *st = reinterpret_cast<uint64_t *>(lds + kLdsStates);
     __shared__ int changed;
     const JhItem it = items[blockIdx.x];
     const JhJob jb = jobs[it.job];
     Ctx c = make_ctx(jb);
-    stage_tables(jb, c, lut);
+    stage_tables(jb, c, lut, binfo);
     stage_window(c, it.first_sub, win);
     const uint32_t t = threadIdx.x, sub = it.first_sub + t;
     const bool active = sub < jb.nsub;
     const uint32_t p_end = (sub + 1u) * kJhSubBits;
     uint64_t last_in = ~0ull; // the start state this subsequence was last decoded from
+#ifdef FL_JH_TRACE
+    int32_t cnt4[5] = {0, 0, 0, 0, 0};
+#else
     int32_t cnt4[4] = {0, 0, 0, 0}; // ... and what that walk counted: blocks completed, DC difference sums per component
+#endif
     bool walked = false;
+#ifdef FL_JH_TRACE
+    const uint64_t tr0 = wall_clock64();
+    const uint64_t cy0 = clock64();
+    uint64_t tr1 = tr0;
+    int tr_rounds = 0, tr_active[32] = {};
+#endif
     if (FIRST) {
         if (t == 0) st[0] = pack_state(it.first_sub * kJhSubBits, 0u, 0u); // (exact for the picture's first subsequence, a guess for every other workgroup)
         if (active) {
             last_in = pack_state(sub * kJhSubBits, 0u, 0u);
-            st[t + 1u] = jh_walk<1>(c, lut, last_in, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
+            st[t + 1u] = jh_walk<1>(c, lut, binfo, last_in, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
             walked = true;
         }
     } else {
         if (t == 0) st[0] = jb.states[it.first_sub];
         if (active) { st[t + 1u] = jb.states[sub + 1u]; last_in = jb.used[sub]; }
     }
+#ifdef FL_JH_TRACE
+    tr1 = wall_clock64();
+    const uint64_t cy1 = clock64();
+    __shared__ int tr_max, tr_sum;
+    if (t == 0) { tr_max = 0; tr_sum = 0; }
+    __syncthreads();
+    atomicMax(&tr_max, cnt4[4]); atomicAdd(&tr_sum, cnt4[4]);
+    __syncthreads();
+    if (t == 0 && blockIdx.x < 12) printf("jh_sync<%d> wg %u: first walk %.1f us = %llu shader cycles, steps max %d mean %d\n", (int)FIRST, blockIdx.x, (double)(tr1 - tr0) / 100.0, (unsigned long long)(cy1 - cy0), tr_max, tr_sum / 256);
+#endif
     for (int r = 0; r < kJhInnerRounds; ++r) {
+#ifdef FL_JH_TRACE
+        tr_rounds = r + 1;
+        tr_active[r] = __syncthreads_count(active && st[t] != last_in);
+#endif
         if (t == 0) changed = 0;
         __syncthreads();
         const uint64_t start = st[t];
@@ -256,7 +326,7 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
         if (active && start != last_in) {
             // (a start beyond this subsequence -- a walk that ran through it -- just passes on)
             if ((uint32_t)start >= p_end) { end = start; cnt4[0] = cnt4[1] = cnt4[2] = cnt4[3] = 0; }
-            else end = jh_walk<1>(c, lut, start, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
+            else end = jh_walk<1>(c, lut, binfo, start, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
             walked = true;
             last_in = start;
             redo = end != st[t + 1u];
@@ -266,6 +336,14 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
         __syncthreads();
         if (!changed) break;
     }
+#ifdef FL_JH_TRACE
+    if (t == 0 && blockIdx.x < 12) {
+        const uint64_t tr2 = wall_clock64();
+        printf("jh_sync<%d> wg %u: set-up+first walk %.1f us, %d rounds %.1f us; active per round:", (int)FIRST, blockIdx.x, (double)(tr1 - tr0) / 100.0, tr_rounds, (double)(tr2 - tr1) / 100.0);
+        for (int r = 0; r < tr_rounds; ++r) printf(" %d", tr_active[r]);
+        printf("\n");
+    }
+#endif
     if (active) {
         jb.states[sub + 1u] = st[t + 1u];
         jb.used[sub] = last_in;
@@ -317,12 +395,12 @@ __global__ __launch_bounds__(256) void jh_scan_kernel(const JhJob *jobs)
 
 __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const JhItem *items)
 {
-    __shared__ uint32_t lut[4 * TW];
-    __shared__ uint32_t win[kWinWords];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *lut = lds + kLdsLut, *win = lds + kLdsWin, *binfo = lds + kLdsBinfo;
     const JhItem it = items[blockIdx.x];
     const JhJob jb = jobs[it.job];
     Ctx c = make_ctx(jb);
-    stage_tables(jb, c, lut);
+    stage_tables(jb, c, lut, binfo);
     stage_window(c, it.first_sub, win);
     const uint32_t sub = it.first_sub + threadIdx.x;
     if (sub >= jb.nsub) return;
@@ -331,7 +409,7 @@ __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const 
     if ((uint32_t)start >= p_end) return;
     const int32_t dc0[3] = {jb.prefix[sub * 4u + 1u], jb.prefix[sub * 4u + 2u], jb.prefix[sub * 4u + 3u]};
     int16_t *coef = reinterpret_cast<int16_t *>(jb.blob + c.H->coef_off);
-    (void)jh_walk<2>(c, lut, start, p_end, nullptr, (uint32_t)jb.prefix[sub * 4u], dc0, coef, jb.err);
+    (void)jh_walk<2>(c, lut, binfo, start, p_end, nullptr, (uint32_t)jb.prefix[sub * 4u], dc0, coef, jb.err);
 }
 
 } // namespace
@@ -344,10 +422,20 @@ hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t n
     (void)h_jobs;
     if (!njobs || !nitems) return hipSuccess;
     jh_init_kernel<<<dim3((max_blocks + 255u) / 256u, njobs), 256, 0, st>>>(d_jobs, max_blocks);
-    jh_sync_kernel<true><<<nitems, 256, 0, st>>>(d_jobs, d_items);
-    for (uint32_t r = 0; r < kJhSyncRounds; ++r) jh_sync_kernel<false><<<nitems, 256, 0, st>>>(d_jobs, d_items); // (each moves the chain across one more workgroup boundary)
+    constexpr uint32_t lds = kLdsWords * 4u;
+    static bool attr_done[16] = {};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16 || !attr_done[dev]) { // (more than the 64 KB a kernel gets without asking; idempotent, so a race between two lanes only repeats it)
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&jh_sync_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&jh_sync_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&jh_write_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    }
+    jh_sync_kernel<true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
+    for (uint32_t r = 0; r < kJhSyncRounds; ++r) jh_sync_kernel<false><<<nitems, 256, lds, st>>>(d_jobs, d_items); // (each moves the chain across one more workgroup boundary)
     jh_scan_kernel<<<njobs, 256, 0, st>>>(d_jobs);
-    jh_write_kernel<<<nitems, 256, 0, st>>>(d_jobs, d_items);
+    jh_write_kernel<<<nitems, 256, lds, st>>>(d_jobs, d_items);
     return hipGetLastError();
 }
 
