@@ -11,7 +11,11 @@
 //               in -- (bit position, block of the MCU, coefficient index) -- is stored
 //   jh_sync<0>  x kJhSyncRounds: every subsequence is decoded again from the stored end state of the one before it; where the end
 //               state changes it is stored again.  Subsequence 0 starts at the true start, so after round r the first r states are
-//               exact, and in practice (self-synchronisation) all of them are after one or two rounds
+//               exact; self-synchronisation does the rest.  Measured on a 4:2:0 photograph (FL_JH_TRACE, tools/experiments/jh_trace.py):
+//               code words and the position inside the block fall into step within a block or two, but WHICH block of the MCU
+//               (luma or chroma tables) only by chance -- about one time in six per MCU -- so a workgroup of 256 subsequences
+//               iterates 5..9 times (255, ~100, ~35, ~17, ... subsequences decoded again per round) and the kernel's time is
+//               rounds x one walk (53 us), whatever the batch
 //               (every walk also counts the blocks it completes and the sum of DC differences per component; the counts of a
 //               subsequence's LAST walk are the ones that stay)
 //   jh_scan     checks that the chain of states is consistent (else error bit 1: the host decodes the file instead); exclusive prefix
@@ -43,12 +47,11 @@ struct Ctx {
     const uint32_t *lwords; // the workgroup's window of it in LDS, byte-swapped: words [lbase, lbase + kWinWords)
     uint32_t lbase;
     uint32_t bpm, total_blocks, mcux;
-    uint64_t comp_of, tabs_of; // per block of the MCU, four bits each: its component; its DC (2 bits) and AC (2 bits) table
 };
 constexpr uint32_t kWinWords = 256u * kJhSubBits / 32u + 8u; // 256 subsequences + the words a walk may read past its end
 
 // LDS of the walking kernels (dynamic: 4 tables + window + per-block records + states = 69 KB, beyond the static 64 KB)
-constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 4u, kLdsWords = kLdsStates + 2u * 258u;
+constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 8u, kLdsWords = kLdsStates + 2u * 258u;
 static_assert(kLdsStates % 2u == 0u && kLdsBinfo % 4u == 0u, "LDS alignment of the 64-bit states / 16-byte block records");
 
 __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
@@ -60,12 +63,6 @@ __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
     c.nwords = (c.S->stream_bits / 8u + 16u) / 4u; // (the stage is padded with 16 bytes of ones)
     c.lwords = nullptr; c.lbase = 0u;
     c.bpm = c.S->bpm; c.total_blocks = c.S->total_blocks; c.mcux = c.S->mcux;
-    c.comp_of = 0; c.tabs_of = 0; // (uniform: once per kernel, in scalar registers -- a walk shifts them by its block number)
-    for (uint32_t b = 0; b < c.bpm; ++b) {
-        const uint32_t cb = c.S->blk_comp[b];
-        c.comp_of |= (uint64_t)cb << (4u * b);
-        c.tabs_of |= (uint64_t)(c.S->dc_tab[cb] | (c.S->ac_tab[cb] << 2)) << (4u * b);
-    }
     return c;
 }
 
@@ -89,12 +86,17 @@ __device__ __forceinline__ void stage_tables(const JhJob &jb, const Ctx &c, uint
     const uint32_t *src = reinterpret_cast<const uint32_t *>(jb.stage + c.S->tables_off);
     for (uint32_t k = threadIdx.x; k < 4u * TW; k += blockDim.x) lut[k] = src[k];
     if (threadIdx.x < c.bpm) {
-        const uint32_t jj = threadIdx.x;
-        const JpegComponent &cc = c.H->comp[c.S->blk_comp[jj]];
-        binfo[4u * jj] = cc.block_base + c.S->blk_v[jj] * cc.bw + c.S->blk_h[jj];
-        binfo[4u * jj + 1u] = cc.h;
-        binfo[4u * jj + 2u] = cc.v * cc.bw;
-        binfo[4u * jj + 3u] = 0u;
+        const uint32_t jj = threadIdx.x, cb = c.S->blk_comp[jj];
+        const JpegComponent &cc = c.H->comp[cb];
+        // what a walk needs of block jj of the MCU: its AC and DC table (byte offsets in LDS), its component as the shift of its field in the
+        // DC sums; and where its block words are: {first, step per MCU column, step per MCU row}
+        binfo[8u * jj] = (uint32_t)c.S->ac_tab[cb] * (4u * TW) | ((uint32_t)c.S->dc_tab[cb] * (4u * TW)) << 16;
+        binfo[8u * jj + 1u] = 21u * cb;
+        binfo[8u * jj + 2u] = binfo[8u * jj + 3u] = 0u;
+        binfo[8u * jj + 4u] = cc.block_base + c.S->blk_v[jj] * cc.bw + c.S->blk_h[jj];
+        binfo[8u * jj + 5u] = cc.h;
+        binfo[8u * jj + 6u] = cc.v * cc.bw;
+        binfo[8u * jj + 7u] = 0u;
     }
     __syncthreads();
 }
@@ -106,122 +108,121 @@ __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t j, uint32_t 
 // starts in, dc0 = the components' DC predictors there) and invalid code words of real blocks are reported.
 //
 // The 64 lanes of a wave are in 64 different places of their blocks, so every branch of the loop body is taken by SOME lane in almost
-// every iteration: an iteration costs the sum of all its paths, and (one wave per SIMD, a dependent chain) every instruction is on
-// the critical path.  Hence ONE symbol path for every lane -- a kJhLookBits lookahead gives (code length, symbol) for every code the
-// files in practice use, the magnitude bits are taken arithmetically (T.81 F.2.2.1 EXTEND without a branch) -- the block's tables
-// are looked up when the block changes, not per symbol, block numbers advance by increments (no division), and only codes longer
-// than the lookahead (Annex K: the 15- and 16-bit ones) leave the path, for the canonical search of F.2.2.3.
-// (Round 4's walk resolved code + magnitude in one 10-bit lookup and sent everything longer -- one symbol in eight at quality 85 --
-// through a second table and a search; with 64 lanes that path ran in every iteration: ~350 instructions per symbol step, this: ~90.)
+// every step: a step costs the sum of all its paths, and with one wave per SIMD walking a dependent chain the walk's time is its
+// instruction count (measured: ~7 cycles per instruction, FL_JH_TRACE).  Hence ONE straight-line symbol path for every lane:
+//   * a kJhLookBits lookahead gives (code length, symbol) for every code the files in practice use; the magnitude bits are taken
+//     arithmetically (T.81 F.2.2.1 EXTEND without a branch); only codes longer than the lookahead (Annex K: the 15- and 16-bit
+//     ones) leave the path, for the canonical search of F.2.2.3;
+//   * the bit window is 32 bits cut from two register words (v_alignbit), the word after them requested in every step;
+//   * the block's tables come from a record per block of the MCU (LDS), rotated cur <- next <- after-next when a block ends -- no
+//     64-bit shifts per symbol, no division in the write pass (block numbers advance by increments);
+//   * the NEXT symbol's table entry is requested -- from the block's AC table and the next block's DC table at once -- before this
+//     symbol's bookkeeping, which then runs while the reads are under way;
+//   * an end-of-block code that follows a symbol inside the lookahead is consumed with it.
+// Round 4's walk resolved code + magnitude in one 10-bit lookup and sent everything longer -- one symbol in eight at quality 85 --
+// through a second table and a search; with 64 lanes that path ran in every step: ~350 instructions per step, this one ~90
+// (first kernel 911 -> 650 us, write pass 261 -> 155 us per batch of 17 files; profiles/r05_jpeg_decode_kernels.txt).
 template <int MODE>
 __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, const uint32_t *binfo, uint64_t state, uint32_t p_end, int32_t *cnt4, uint32_t q0,
                                             const int32_t *dc0, int16_t *coef, uint32_t *err)
 {
     static_assert(MODE == 1 || MODE == 2, "walk mode");
-    const uint16_t *look = reinterpret_cast<const uint16_t *>(lut);
-    uint32_t p = (uint32_t)state, j = (uint32_t)(state >> 32) & 15u, k = (uint32_t)(state >> 40) & 127u;
-    uint32_t wi = (p >> 5) - c.lbase; // (inside the window by construction: a walk starts in or behind its own subsequence and ends within two words of its end)
+    const char *lds0 = reinterpret_cast<const char *>(lut); // (the tables start the workgroup's LDS block; block records hold BYTE offsets from here)
+    auto look = [&](uint32_t byte_off) { return (uint32_t)*reinterpret_cast<const uint16_t *>(lds0 + byte_off); };
     auto word = [&](uint32_t i) { return c.lwords[i < kWinWords ? i : kWinWords - 1u]; };
-    uint64_t buf = (((uint64_t)word(wi) << 32) | word(wi + 1u)) << (p & 31u);
-    int cnt = 64 - (int)(p & 31u);
-    wi += 2u;
-    uint32_t next_word = word(wi);
+    auto info = [&](uint32_t jj) { return *reinterpret_cast<const uint2 *>(binfo + 8u * jj); }; // {AC table | DC table << 16 (byte offsets), 21 * component}
+    auto after = [&](uint32_t jj) { return jj + 1u >= c.bpm ? jj + 1u - c.bpm : jj + 1u; };
+    uint32_t j = (uint32_t)(state >> 32) & 15u, k = (uint32_t)(state >> 40) & 127u;
+    if (j >= c.bpm) j = 0u; // (a state is only ever one a walk produced; this keeps a corrupt one inside the tables)
+    // bit position inside the LDS window (a walk starts in or behind its own subsequence and ends within a word of its end: inside by construction)
+    uint32_t pr = (uint32_t)state - 32u * c.lbase;
+    const uint32_t pr_end = p_end - 32u * c.lbase;
+    // the 32 bits at pr: words W and W + 1 of the window in registers, W + 2 requested in every step (it has arrived when a step crosses into W + 1)
+    uint32_t W = pr >> 5;
+    uint32_t hi = word(W), lo = word(W + 1u), nx = word(W + 2u);
+    auto bits_at = [&](uint32_t pos) { const uint32_t sh = pos & 31u; return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi; };
+    uint32_t win = bits_at(pr);
+    // block records: of the block the walk is in, of the next one, and (requested in every step) of the one after -- a block can be one step long
+    uint2 cur = info(j), nxt = info(after(j)), nn = info(after(after(j)));
     int32_t nblk = 0;
     int64_t dacc = 0;        // MODE 1: the three DC difference sums as 21-bit signed fields of one 64-bit sum (|sum| < 2^20: at most 79 blocks of |difference| <= 2047 fit 1024 bits)
     int32_t d0 = 0, d1 = 0, d2 = 0; // MODE 2: the components' DC predictors
     uint32_t q = q0, gidx = 0, mx = 0, my = 0;
     bool bad = false;
-    // halfword offsets in `lut` of the lookahead tables: the block's DC and AC table, the NEXT block's DC table; the block's component
-    uint32_t dcb, acb, dcb_n, comp;
-    auto dc_table = [&](uint32_t jj) { return ((uint32_t)(c.tabs_of >> (4u * jj)) & 3u) * (2u * TW); };
-    auto enter = [&](uint32_t jj) { // (dcb is the caller's: the table the block before had as "next")
-        acb = (((uint32_t)(c.tabs_of >> (4u * jj)) >> 2) & 3u) * (2u * TW);
-        comp = (uint32_t)(c.comp_of >> (4u * jj)) & 3u;
-        dcb_n = dc_table(jj + 1u == c.bpm ? 0u : jj + 1u);
-    };
     auto place = [&](uint32_t jj) { // index of the block word of block jj of MCU (mx, my)
-        const uint4 bi = *reinterpret_cast<const uint4 *>(binfo + 4u * jj);
+        const uint4 bi = *reinterpret_cast<const uint4 *>(binfo + 8u * jj + 4u);
         return bi.x + my * bi.z + mx * bi.y;
     };
-    if (j >= c.bpm) j = 0u; // (a state is only ever one a walk produced; this keeps a corrupt one inside the tables)
-    dcb = dc_table(j);
-    enter(j);
     if (MODE == 2) {
         d0 = dc0[0]; d1 = dc0[1]; d2 = dc0[2];
         const uint32_t m = q / c.bpm;
         my = m / c.mcux; mx = m - my * c.mcux;
         gidx = q < c.total_blocks ? place(j) : 0u;
     }
-    // The table entry of the NEXT symbol is requested as soon as the bit buffer has moved past this one -- from the block's AC table and
+    // The table entry of the NEXT symbol is requested as soon as the window has moved past this one -- from the block's AC table and
     // from the next block's DC table at once, since which of the two it is (did this symbol end the block?) comes out of the
-    // bookkeeping that runs while the two reads are under way.  The recurrence of an iteration is then bits -> entry -> lengths -> bits.
-    uint32_t e = look[(k == 0u ? dcb : acb) + (uint32_t)(buf >> (64u - LB))];
-    while (p < p_end && (MODE != 2 || q < c.total_blocks)) {
+    // bookkeeping that runs while the reads are under way.  The recurrence of a step is then bits -> entry -> lengths -> bits.
+    uint32_t e = look((k == 0u ? cur.x >> 16 : cur.x & 0xffffu) + 2u * (win >> (32u - LB)));
+    while (pr < pr_end && (MODE != 2 || q < c.total_blocks)) {
 #ifdef FL_JH_TRACE
         if (MODE == 1 && cnt4) ++cnt4[4];
 #endif
+        const bool isdc = k == 0u;
         // entry: bits 0-4 code length (0: longer than the lookahead), 5-7 length of an END-OF-BLOCK code that follows the symbol's
-        // magnitude bits inside the lookahead (0: none there) -- it is consumed with the symbol: blocks of flat regions (a DC
-        // difference, then end of block: 5 bits or so) are the longest walks of a wave, and take one step this way --, 8-15 the symbol
+        // magnitude bits inside the lookahead (0: none there) -- it is consumed with the symbol: one step for the "DC difference, end of
+        // block" blocks of flat regions, one step less for every block whose last coefficient is a short code --, 8-15 the symbol
         uint32_t len = e & 31u, sym = e >> 8;
-        uint32_t el = (e >> 5) & 7u;
         if (len == 0u) {
             // a code longer than the lookahead: canonical search (F.2.2.3) from the next length on
-            const uint32_t top = (uint32_t)(buf >> 32);
-            const uint32_t *tab = lut + ((k == 0u ? dcb : acb) >> 1);
+            const uint32_t *tab = reinterpret_cast<const uint32_t *>(lds0 + (isdc ? cur.x >> 16 : cur.x & 0xffffu));
             const int32_t *maxcode = reinterpret_cast<const int32_t *>(tab + T_MAXCODE), *valoff = reinterpret_cast<const int32_t *>(tab + T_VALOFF);
             len = LB + 1u;
-            while (len <= 16u && (int32_t)(top >> (32u - len)) > maxcode[len]) ++len;
+            while (len <= 16u && (int32_t)(win >> (32u - len)) > maxcode[len]) ++len;
             sym = 0u;
             if (len > 16u) { bad = true; len = 16u; }
             else {
-                const int32_t idx = (int32_t)(top >> (32u - len)) + valoff[len];
+                const int32_t idx = (int32_t)(win >> (32u - len)) + valoff[len];
                 if (idx < 0 || idx > 255) bad = true;
                 else sym = (tab[T_VALS + ((uint32_t)idx >> 2)] >> (8u * ((uint32_t)idx & 3u))) & 255u;
             }
         }
-        const uint32_t s = sym & 15u, run = sym >> 4;
-        if (k + run >= 63u) el = 0u; // (coefficient 63 ends its block without an end-of-block code: what follows is the next block's DC code)
-        const uint32_t t = (uint32_t)((buf << len) >> 32); // the bits behind the code
-        const uint32_t nb = len + s + el; // <= 16 + 15 (el != 0: <= the lookahead)
-        buf <<= nb; cnt -= (int)nb; p += nb;
-        if (cnt <= 32) { buf |= (uint64_t)next_word << (32 - cnt); cnt += 32; ++wi; next_word = word(wi); } // (the word after is requested at once: its latency hides behind the symbols in between)
-        const uint32_t nidx = (uint32_t)(buf >> (64u - LB));
-        const uint32_t e_ac = look[acb + nidx], e_dc = look[dcb_n + nidx];
+        const uint32_t s = sym & 15u, run = sym >> 4, kr = k + run;
+        // (coefficient 63 ends its block without an end-of-block code: what follows it is the next block's DC code)
+        const uint32_t el = kr >= 63u ? 0u : (e >> 5) & 7u;
+        const uint32_t t = win << len; // the bits behind the code
+        pr += len + s + el;            // <= 16 + 15 bits (el != 0: <= the lookahead)
+        const uint32_t Wn = pr >> 5;
+        hi = Wn != W ? lo : hi; lo = Wn != W ? nx : lo; W = Wn;
+        nx = word(Wn + 2u);
+        win = bits_at(pr);
+        const uint32_t nidx = 2u * (win >> (32u - LB));
+        const uint32_t e_ac = look((cur.x & 0xffffu) + nidx), e_dc = look((nxt.x >> 16) + nidx);
         // RECEIVE + EXTEND: the s bits behind the code; a leading 0 bit means negative, value - 2^s + 1 (s = 0: no bits, 0)
         const int32_t val = (int32_t)((t >> 1) >> (31u - s)) + (((int32_t)t >> 31) ? 0 : (int32_t)((0xffffffffu << s) + 1u));
-        if (k == 0u) {
-            if (MODE == 1) dacc += (int64_t)val << (21u * comp);
-            if (MODE == 2) {
-                if (sym > 11u) bad = true; // a DC symbol is a bare category 0..11
-                const int32_t dc = (comp == 0u ? d0 : comp == 1u ? d1 : d2) + val;
-                d0 = comp == 0u ? dc : d0; d1 = comp == 1u ? dc : d1; d2 = comp == 2u ? dc : d2;
-                if (dc < -32768 || dc > 32767) bad = true;
-                coef[(size_t)gidx * 64u] = (int16_t)dc;
-            }
-            k = el ? 64u : 1u;
-        } else {
-            const uint32_t kn = k + run;
-            if (MODE == 2) {
-                if (s == 0u) { if (run != 0u && run != 15u) bad = true; } // (run, 0) other than end of block / ZRL: not a baseline code
-                else if (kn > 63u) bad = true;
-                else coef[(size_t)gidx * 64u + kn] = (int16_t)val;
-            }
-            k = s == 0u ? (run == 15u ? k + 16u : 64u) : (el ? 64u : kn + 1u);
+        if (MODE == 1) dacc += (int64_t)(isdc ? val : 0) << cur.y;
+        if (MODE == 2) {
+            const uint32_t comp = cur.y == 0u ? 0u : cur.y == 21u ? 1u : 2u;
+            const int32_t dc = (comp == 0u ? d0 : comp == 1u ? d1 : d2) + val;
+            if (isdc) { d0 = comp == 0u ? dc : d0; d1 = comp == 1u ? dc : d1; d2 = comp == 2u ? dc : d2; }
+            // a DC symbol is a bare category 0..11 and the predictor stays 16-bit; (run, 0) other than end of block / ZRL is not a baseline code; no coefficient 64
+            bad |= isdc ? (sym > 11u || dc < -32768 || dc > 32767) : (s == 0u ? (run != 0u && run != 15u) : kr > 63u);
+            if (isdc || (s != 0u && kr <= 63u)) coef[(size_t)gidx * 64u + (isdc ? 0u : kr)] = (int16_t)(isdc ? dc : val);
         }
-        if (k >= 64u) { // block complete
-            k = 0u;
-            j = j + 1u == c.bpm ? 0u : j + 1u;
-            ++nblk;
-            dcb = dcb_n;
-            enter(j);
-            if (MODE == 2) {
-                if (bad) atomicOr(err, 2u); // (an invalid code word inside a real block: the file is broken, or the states were wrong)
-                bad = false;
-                ++q;
-                if (j == 0u && ++mx == c.mcux) { mx = 0u; ++my; }
-                if (q < c.total_blocks) gidx = place(j);
-            }
+        const uint32_t k_ac = s == 0u ? (run == 15u ? k + 16u : 64u) : (el ? 64u : kr + 1u);
+        k = isdc ? (el ? 64u : 1u) : k_ac;
+        const bool done = k >= 64u; // block complete
+        k = done ? 0u : k;
+        nblk += done ? 1 : 0;
+        j = done ? after(j) : j;
+        cur.x = done ? nxt.x : cur.x; cur.y = done ? nxt.y : cur.y;
+        nxt.x = done ? nn.x : nxt.x; nxt.y = done ? nn.y : nxt.y;
+        nn = info(after(after(j)));
+        if (MODE == 2 && done) {
+            if (bad) atomicOr(err, 2u); // (an invalid code word inside a real block: the file is broken, or the states were wrong)
+            bad = false;
+            ++q;
+            if (j == 0u && ++mx == c.mcux) { mx = 0u; ++my; }
+            if (q < c.total_blocks) gidx = place(j);
         }
         e = k == 0u ? e_dc : e_ac; // (e_dc was read from what was then the next block's table: this block's, if the block has just changed)
     }
@@ -234,7 +235,7 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
         const int32_t c1 = (int32_t)((a1 << 43) >> 43);
         cnt4[0] = nblk; cnt4[1] = c0; cnt4[2] = c1; cnt4[3] = (int32_t)((a1 - c1) >> 21);
     }
-    return pack_state(p, j, k);
+    return pack_state(pr + 32u * c.lbase, j, k);
 }
 
 __global__ __launch_bounds__(256) void jh_init_kernel(const JhJob *jobs, uint32_t max_blocks)

@@ -93,8 +93,8 @@ uint32_t usable_cpus()
     return std::max(1u, n);
 }
 
-uint32_t lanes_per_device(const flgpu_ctx *c) { return std::min<uint32_t>(std::max<uint32_t>(c->cfg.queue_lanes ? c->cfg.queue_lanes : 3u, 1u), 8u); }
-uint32_t batch_per_device(const flgpu_ctx *c) { return c->cfg.max_batch ? c->cfg.max_batch : 32u; } // measured: 3 lanes x 32 keeps the PCIe link busiest
+uint32_t lanes_per_device(const flgpu_ctx *c) { return std::min<uint32_t>(std::max<uint32_t>(c->cfg.queue_lanes ? c->cfg.queue_lanes : 4u, 1u), 8u); }
+uint32_t batch_per_device(const flgpu_ctx *c) { return c->cfg.max_batch ? c->cfg.max_batch : 16u; } // measured (round 5, tools/experiments/jh_lanes.sh, 64 callers on 16 cores): 4 lanes x 16 against round 4's 3 x 32 -- the same or more requests per second for files, pixels and blurred pixels, p99 14-19 ms -> 12-14 ms; equal at 128 callers
 
 // One shard of a flushed batch on one lane: sources already sit in pinned blocks (copied there by the calling
 // threads), results are left in pinned blocks for the callers to copy out.
