@@ -64,11 +64,17 @@ __device__ __forceinline__ void butterfly(const int *d, int bias, int *o)
     o[3] = x3 + t0; o[4] = x3 - t0;
 }
 
+// The blob's header is written by the host or by an earlier kernel and only read here: through the constant address space its
+// fields are scalar loads (through a flat pointer the compiler must assume the kernel's own stores may change them, and every
+// thread loaded every field it used -- 36 vector loads in the colour kernel).
+typedef const __attribute__((address_space(4))) JpegBlobHeader *HdrPtr;
+typedef const __attribute__((address_space(4))) JpegComponent &CompRef;
+
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegDecJob *__restrict__ jobs)
 {
     __shared__ int tile[BLOCKS_PER_WG * BLK_PITCH];
     const JpegDecJob jb = jobs[blockIdx.y];
-    const JpegBlobHeader *H = reinterpret_cast<const JpegBlobHeader *>(jb.blob);
+    const HdrPtr H = (HdrPtr)(uintptr_t)jb.blob;
     const uint32_t tid = threadIdx.x, t = tid & 7u, lb = tid >> 3;
     const uint32_t b = blockIdx.x * BLOCKS_PER_WG + lb;
     const uint32_t nblocks = H->nblocks;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegDecJob *__rest
     for (int c = 0; c < 8; ++c) d[c] = my[t * 9 + c]; // row t
     butterfly(d, 65536 + (128 << 17), o);
     if (live) {
-        const JpegComponent &C = H->comp[ci];
+        CompRef C = H->comp[ci];
         const uint32_t bi = b - C.block_base, by = bi / C.bw, bx = bi - by * C.bw;
         uint8_t *p = jb.planes + C.plane_off + (size_t)(by * 8u + t) * (C.bw * 8u) + bx * 8u;
         const uint32_t lo = sat17(o[0]) | (sat17(o[1]) << 8) | (sat17(o[2]) << 16) | (sat17(o[3]) << 24);
@@ -143,14 +149,26 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef const __attribute__((address_space(1))) uint8_t *gcptr8;
 typedef __attribute__((address_space(1))) uint8_t *gptr8;
 
+// Four bytes at any address of a plane as ONE dword-aligned 8-byte load and a funnel shift (the chroma samples ix - 1 .. ix + 2 of a
+// group start at an odd byte: a misaligned dword load is split by the memory pipeline).  Reads up to 3 bytes past the four -- inside
+// the picture's scratch (the planes are followed by its pixels, fl_batch.cpp).
+__device__ __forceinline__ uint32_t load4_at(gcptr8 p)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32x2 __attribute__((aligned(4))) u32x2_a4;
+    const uintptr_t a = (uintptr_t)p;
+    const u32x2 w = *(const __attribute__((address_space(1))) u32x2_a4 *)(a & ~(uintptr_t)3);
+    return __builtin_amdgcn_alignbit(w.y, w.x, ((uint32_t)a & 3u) * 8u);
+}
+
 // one pixel, every case: planes through zune-jpeg's interpolation (a plain read at full resolution), then the colour transform
-__device__ __forceinline__ void color_pixel(const JpegDecJob &jb, const JpegBlobHeader *H, uint32_t x, uint32_t y)
+__device__ __forceinline__ void color_pixel(const JpegDecJob &jb, HdrPtr H, uint32_t x, uint32_t y)
 {
     const uint32_t nc = H->nc;
     uint8_t *o = jb.dst + ((size_t)y * H->width + x) * nc;
     int s[4];
     for (uint32_t i = 0; i < nc; ++i) {
-        const JpegComponent &C = H->comp[i];
+        CompRef C = H->comp[i];
         s[i] = chroma_at(jb.planes + C.plane_off, C.bw * 8u, C.w, C.hpx, H->hmax / C.h, H->vmax / C.v, x, y);
     }
     if (nc == 1u) { o[0] = (uint8_t)s[0]; return; }
@@ -168,10 +186,10 @@ __device__ __forceinline__ void color_pixel(const JpegDecJob &jb, const JpegBlob
 
 // Four interior pixels x0 .. x0 + 3 (x0 a multiple of 4, 4 <= x0, x0 + 6 <= W) of rows y and y + 1 (y even), SH x SV chroma sampling.
 template <int SH, int SV>
-__device__ __forceinline__ void color_group(const JpegDecJob &jb, const JpegBlobHeader *H, uint32_t x0, uint32_t y, uint32_t rows)
+__device__ __forceinline__ void color_group(const JpegDecJob &jb, HdrPtr H, uint32_t x0, uint32_t y, uint32_t rows)
 {
     const uint32_t W = H->width;
-    const JpegComponent &CY = H->comp[0];
+    CompRef CY = H->comp[0];
     gcptr8 py = (gcptr8)(jb.planes + CY.plane_off);
     const uint32_t ypw = CY.bw * 8u;
     uint32_t yv[2];
@@ -180,7 +198,7 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, const JpegBlob
     int cv[2][2][4]; // [Cb, Cr][row][pixel]
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
-        const JpegComponent &C = H->comp[1 + ci];
+        CompRef C = H->comp[1 + ci];
         gcptr8 pl = (gcptr8)(jb.planes + C.plane_off);
         const uint32_t pw = C.bw * 8u;
         if (SH == 1 && SV == 1) {
@@ -198,16 +216,14 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, const JpegBlob
         if (SV == 1) {
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const uint32_t w = (rr == 0 || rows > 1u) ? *(const __attribute__((address_space(1))) u32_unaligned *)(pl + (size_t)(y + rr) * pw + ix - 1u) : 0u;
+                const uint32_t w = (rr == 0 || rows > 1u) ? load4_at(pl + (size_t)(y + rr) * pw + ix - 1u) : 0u;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a[rr][k] = (int)((w >> (8 * k)) & 255u);
             }
         } else {
             const uint32_t r = y >> 1; // both rows of the pair share the near chroma row; the far ones are r - 1 and r + 1, clamped
             const uint32_t ru = r ? r - 1u : 0u, rd = min(r + 1u, C.hpx - 1u);
-            const uint32_t wn = *(const __attribute__((address_space(1))) u32_unaligned *)(pl + (size_t)r * pw + ix - 1u);
-            const uint32_t wu = *(const __attribute__((address_space(1))) u32_unaligned *)(pl + (size_t)ru * pw + ix - 1u);
-            const uint32_t wd = *(const __attribute__((address_space(1))) u32_unaligned *)(pl + (size_t)rd * pw + ix - 1u);
+            const uint32_t wn = load4_at(pl + (size_t)r * pw + ix - 1u), wu = load4_at(pl + (size_t)ru * pw + ix - 1u), wd = load4_at(pl + (size_t)rd * pw + ix - 1u);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int n = (int)((wn >> (8 * k)) & 255u);
@@ -246,7 +262,7 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, const JpegBlob
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegDecJob *__restrict__ jobs)
 {
     const JpegDecJob jb = jobs[blockIdx.y];
-    const JpegBlobHeader *H = reinterpret_cast<const JpegBlobHeader *>(jb.blob);
+    const HdrPtr H = (HdrPtr)(uintptr_t)jb.blob;
     const uint32_t W = H->width, Hh = H->height, nc = H->nc;
     const uint32_t ngx = (W + 3u) / 4u, ngy = (Hh + 1u) / 2u;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;

@@ -274,11 +274,14 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
     __shared__ int changed;
     const JhItem it = items[blockIdx.x];
     const JhJob jb = jobs[it.job];
+    const uint32_t t = threadIdx.x, sub = it.first_sub + t;
+    const bool active = sub < jb.nsub;
+    // a later launch has work in a workgroup only where a subsequence's start state is no longer the one it was decoded from (the
+    // chain has moved across the workgroup's front, or the rounds before ran out): everyone else leaves before the 67 KB of set-up
+    if (!FIRST && !__syncthreads_or(active && jb.used[sub] != jb.states[sub])) return;
     Ctx c = make_ctx(jb);
     stage_tables(jb, c, lut, binfo);
     stage_window(c, it.first_sub, win);
-    const uint32_t t = threadIdx.x, sub = it.first_sub + t;
-    const bool active = sub < jb.nsub;
     const uint32_t p_end = (sub + 1u) * kJhSubBits;
     uint64_t last_in = ~0ull; // the start state this subsequence was last decoded from
 #ifdef FL_JH_TRACE
