@@ -41,7 +41,9 @@ constexpr uint32_t kWtLdsBudget = 150 * 1024;
 constexpr uint32_t kWtPrefetch = 4;       // 16-byte pieces a thread keeps in flight for the next step's rows
 
 // LDS layout of a workgroup: ring | three planes of 16 rows | the M-tile's vertical operands | output tile | the strip's N-tile records
-__host__ __device__ constexpr uint32_t wt_out_pitch(uint32_t tn) { return 16u * tn + 24u; } // (= 8 mod 32: the four row groups of a byte write land on different banks)
+// (= 16 mod 32 bytes, i.e. an odd multiple of 4 dwords: lane (row i, g) of the horizontal pass writes dword i * pitch / 4 + 4 tile + g, and the
+// sixteen rows x four dwords of a wave's write land on the 64 banks once each)
+__host__ __device__ constexpr uint32_t wt_out_pitch(uint32_t tn) { return 16u * tn + ((tn & 1u) ? 32u : 16u); }
 __host__ __device__ constexpr uint32_t wt_lds_bytes(uint32_t ring_rows, uint32_t sp, uint32_t nkv_max, uint32_t tn)
 {
     return ring_rows * sp + 48u * sp + nkv_max * 3072u + 16u * wt_out_pitch(tn) + 16u * tn;

@@ -175,27 +175,32 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void resample_wtile_kernel(c
         const i32x4 a2 = __builtin_bit_cast(i32x4, a2u), a1 = __builtin_bit_cast(i32x4, a1u), a0 = __builtin_bit_cast(i32x4, a0u);
         const i32x4 b2 = __builtin_bit_cast(i32x4, b2u), b1 = __builtin_bit_cast(i32x4, b1u), b0 = __builtin_bit_cast(i32x4, b0u);
         const i32x4 z = {0, 0, 0, 0};
-        L[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, FIRST ? z : L[4], 0, 0, 0);
-        L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b1, FIRST ? i32x4{c3, c3, c3, c3} : L[3], 0, 0, 0);
-        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b0, FIRST ? z : L[2], 0, 0, 0);
-        L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b0, FIRST ? i32x4{rnd, rnd, rnd, rnd} : L[1], 0, 0, 0);
-        L[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, FIRST ? z : L[0], 0, 0, 0);
-        L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b2, L[3], 0, 0, 0);
-        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, L[2], 0, 0, 0);
-        L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b1, L[1], 0, 0, 0);
-        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b2, L[2], 0, 0, 0);
+        // (the WEIGHTS go in as the matrix unit's first operand, the plane bytes as its second -- both are "16 bytes of K per lane", so the
+        // registers are the same either way -- and the product comes out transposed: lane (row i, g) holds output bytes 4 g .. 4 g + 3
+        // of ITS row, one dword of the output tile, instead of four rows of one byte column)
+        L[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2, a2, FIRST ? z : L[4], 0, 0, 0);
+        L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, a2, FIRST ? i32x4{c3, c3, c3, c3} : L[3], 0, 0, 0);
+        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b0, a2, FIRST ? z : L[2], 0, 0, 0);
+        L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b0, a1, FIRST ? i32x4{rnd, rnd, rnd, rnd} : L[1], 0, 0, 0);
+        L[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b0, a0, FIRST ? z : L[0], 0, 0, 0);
+        L[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2, a1, L[3], 0, 0, 0);
+        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, a1, L[2], 0, 0, 0);
+        L[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, a0, L[1], 0, 0, 0);
+        L[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b2, a0, L[2], 0, 0, 0);
     };
     // sum = L4 2^32 + L3 2^24 + L2 2^16 + L1 2^8 + L0 in units of 2^-(14 + hs) of a pixel step -> 2^-20, then the byte
     auto emit = [&](const i32x4 (&L)[5], uint32_t jt) __attribute__((always_inline)) {
         if (ablate & 16u) { asm volatile("" : : "v"(L[0]), "v"(L[1]), "v"(L[2]), "v"(L[3]), "v"(L[4])); return; }
-        uint8_t *ow = otile + 16u * jt + i; // lane (output byte i of the tile, rows 4 g .. 4 g + 3)
+        uint32_t packed = 0u; // lane (row i, g): output bytes 4 g .. 4 g + 3 of the tile's row i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int32_t low = (((L[2][r] << 8) + L[1][r]) + (L[0][r] >> 8)) >> slo;
             const int32_t x = (int32_t)(((uint32_t)L[4][r] << s4) + ((uint32_t)L[3][r] << s3) + (uint32_t)low);
             // (clamp-then-shift: clamp(x >> 20, 0, 255) is the pattern hipcc fuses into gfx950's broken v_ashr_pk_u8_i32)
-            ow[(4u * g + (uint32_t)r) * OP] = (uint8_t)((uint32_t)min(max(x, 0), (256 << 20) - 1) >> 20);
+            packed |= ((uint32_t)min(max(x, 0), (256 << 20) - 1) >> 20) << (8 * r);
         }
+        // one dword per lane, every bank once (wt_out_pitch); round 4 wrote four bytes per lane, sixteen lanes into the same four dwords
+        *reinterpret_cast<uint32_t *>(otile + i * OP + 16u * jt + 4u * g) = packed;
     };
     // Two N-tiles whose operands sit in registers, side by side: their 2 x 9 matrix instructions per K-step are independent of one another
     // (two waves per SIMD leave a lone tile's accumulator chains exposed).  K-steps past a tile's own count multiply by zero operands.
