@@ -434,7 +434,7 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
                 JhJob j{};
                 j.stage = static_cast<const uint8_t *>(dsrc[i].data);
                 j.nsub = nsub;
-                for (uint32_t f = 0; f < nsub; f += 256) items.push_back({(uint32_t)jobs.size(), f});
+                for (uint32_t f = 0; f < nsub; f += kJhSubsPerItem) items.push_back({(uint32_t)jobs.size(), f});
                 c->last_jh_slot[i] = (int32_t)jobs.size();
                 jobs.push_back(j);
                 max_blocks = std::max(max_blocks, H->nblocks);

@@ -116,7 +116,8 @@ struct alignas(16) JhJob {
     uint32_t nsub;
     uint32_t pad;
 };
-struct JhItem { uint32_t job, first_sub; }; // one workgroup of the per-subsequence kernels: 256 consecutive subsequences of one picture
+constexpr uint32_t kJhSubsPerItem = 240;       // subsequences a workgroup owns (its 256 threads also decode kJhWarm = 16 in front of them in the speculative kernel)
+struct JhItem { uint32_t job, first_sub; }; // one workgroup of the per-subsequence kernels: kJhSubsPerItem consecutive subsequences of one picture
 
 // Host half: parses `data`, and if the file is one the device entropy decoder takes (sequential, one interleaved scan, no restart
 // interval, 1 or 3 components) writes the staged blob to `out`: 0 ok (*used = its size), -1 malformed, -2 not for this path.

@@ -48,10 +48,18 @@ struct Ctx {
     uint32_t lbase;
     uint32_t bpm, total_blocks, mcux;
 };
-constexpr uint32_t kWinWords = 256u * kJhSubBits / 32u + 8u; // 256 subsequences + the words a walk may read past its end
+// The speculative kernel's workgroups also decode the kJhWarm subsequences IN FRONT of their own kJhSubsPerItem (results discarded): by
+// the time the chain of states reaches the workgroup's own first subsequence it has fallen into step (a chain longer than sixteen
+// subsequences: (5/6)^51, one in 10^4 workgroups -- the later launches and the scan are still there for it), so the launches that used
+// to carry the chain across workgroup fronts find nothing to do and leave at once (148 -> 18 us each, profiles/r05_jpeg_decode_kernels.txt).
+// 240 + 16 = the four waves of a workgroup: a fifth wave for the warm-up shared a SIMD and cost the speculative kernel 12 %.
+constexpr uint32_t kJhOwn = kJhSubsPerItem;
+constexpr uint32_t kJhWarm = 256u - kJhOwn;
+constexpr uint32_t kJhMaxSubs = 256u;
+constexpr uint32_t kWinWords = kJhMaxSubs * kJhSubBits / 32u + 8u; // the subsequences + the words a walk may read past its end
 
 // LDS of the walking kernels (dynamic: 4 tables + window + per-block records + states = 69 KB, beyond the static 64 KB)
-constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 8u, kLdsWords = kLdsStates + 2u * 258u;
+constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 8u, kLdsWords = kLdsStates + 2u * (kJhMaxSubs + 2u);
 static_assert(kLdsStates % 2u == 0u && kLdsBinfo % 4u == 0u, "LDS alignment of the 64-bit states / 16-byte block records");
 
 __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
@@ -69,10 +77,10 @@ __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
 // The 256 subsequences of a workgroup are one contiguous piece of the segment: it is copied to LDS once (coalesced, already in the
 // byte order the bit buffer wants), and the walks read their words there -- a walk consumes a word every five symbols or so, and
 // fetched one by one from the L2 those loads were most of its time.
-__device__ __forceinline__ void stage_window(Ctx &c, uint32_t first_sub, uint32_t *win)
+__device__ __forceinline__ void stage_window(Ctx &c, uint32_t first_sub, uint32_t *win, uint32_t nsubs = kJhOwn)
 {
-    const uint32_t base = first_sub * (kJhSubBits / 32u);
-    for (uint32_t k = threadIdx.x; k < kWinWords; k += blockDim.x) {
+    const uint32_t base = first_sub * (kJhSubBits / 32u), nwords = nsubs * (kJhSubBits / 32u) + 8u;
+    for (uint32_t k = threadIdx.x; k < nwords; k += blockDim.x) {
         const uint32_t i = base + k;
         win[k] = __builtin_bswap32(c.words[i < c.nwords ? i : c.nwords - 1u]);
     }
@@ -274,14 +282,16 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
     __shared__ int changed;
     const JhItem it = items[blockIdx.x];
     const JhJob jb = jobs[it.job];
-    const uint32_t t = threadIdx.x, sub = it.first_sub + t;
-    const bool active = sub < jb.nsub;
+    // FIRST: threads [0, warm) decode the subsequences in front of the workgroup's own (none in front of a picture's first workgroup)
+    const uint32_t warm = FIRST ? min(kJhWarm, it.first_sub) : 0u, base_sub = it.first_sub - warm;
+    const uint32_t t = threadIdx.x, sub = base_sub + t;
+    const bool active = sub < jb.nsub && t < kJhOwn + warm, own = active && t >= warm;
     // a later launch has work in a workgroup only where a subsequence's start state is no longer the one it was decoded from (the
-    // chain has moved across the workgroup's front, or the rounds before ran out): everyone else leaves before the 67 KB of set-up
+    // chain has moved across the workgroup's front, or the rounds before ran out): everyone else leaves before the 77 KB of set-up
     if (!FIRST && !__syncthreads_or(active && jb.used[sub] != jb.states[sub])) return;
     Ctx c = make_ctx(jb);
     stage_tables(jb, c, lut, binfo);
-    stage_window(c, it.first_sub, win);
+    stage_window(c, base_sub, win, kJhOwn + warm);
     const uint32_t p_end = (sub + 1u) * kJhSubBits;
     uint64_t last_in = ~0ull; // the start state this subsequence was last decoded from
 #ifdef FL_JH_TRACE
@@ -297,14 +307,14 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
     int tr_rounds = 0, tr_active[32] = {};
 #endif
     if (FIRST) {
-        if (t == 0) st[0] = pack_state(it.first_sub * kJhSubBits, 0u, 0u); // (exact for the picture's first subsequence, a guess for every other workgroup)
+        if (t == 0) st[0] = pack_state(base_sub * kJhSubBits, 0u, 0u); // (exact for the picture's first subsequence, a guess for every other workgroup)
         if (active) {
             last_in = pack_state(sub * kJhSubBits, 0u, 0u);
             st[t + 1u] = jh_walk<1>(c, lut, binfo, last_in, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
             walked = true;
         }
     } else {
-        if (t == 0) st[0] = jb.states[it.first_sub];
+        if (t == 0) st[0] = jb.states[base_sub];
         if (active) { st[t + 1u] = jb.states[sub + 1u]; last_in = jb.used[sub]; }
     }
 #ifdef FL_JH_TRACE
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
         printf("\n");
     }
 #endif
-    if (active) {
+    if (own) {
         jb.states[sub + 1u] = st[t + 1u];
         jb.used[sub] = last_in;
         if (walked) {
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const 
     stage_tables(jb, c, lut, binfo);
     stage_window(c, it.first_sub, win);
     const uint32_t sub = it.first_sub + threadIdx.x;
-    if (sub >= jb.nsub) return;
+    if (threadIdx.x >= kJhOwn || sub >= jb.nsub) return;
     const uint32_t p_end = (sub + 1u) * kJhSubBits;
     const uint64_t start = jb.states[sub];
     if ((uint32_t)start >= p_end) return;
