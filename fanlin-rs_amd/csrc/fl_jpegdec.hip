@@ -92,6 +92,20 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegDecJob *__rest
         const uint8_t *data = jb.blob + H->coef_off + (size_t)first * 2u;
         const int16_t *c16 = reinterpret_cast<const int16_t *>(data);
         const int8_t *c8 = reinterpret_cast<const int8_t *>(data) + 2u * kJpegWideHead;
+        if (wide && cnt == 64u && (reinterpret_cast<uintptr_t>(c16) & 15u) == 0u) {
+            // a full "wide" block (every block the device's entropy decoder writes): thread t takes coefficients 8 t .. 8 t + 7 of the
+            // zig-zag sequence as ONE 16-byte load, their quantiser steps as another (the general loop: eight 2-byte loads each)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 cv = *(const __attribute__((address_space(1))) u32x4 *)(uintptr_t)(c16 + 8u * t);
+            const u32x4 qv = *reinterpret_cast<const __attribute__((address_space(4))) u32x4 *>(&H->qt[ci][8u * t]);
+#pragma unroll
+            for (uint32_t e = 0; e < 8u; ++e) {
+                const int q = (int)(int16_t)(cv[e >> 1] >> (16u * (e & 1u)));
+                const int v = q * (int)(uint16_t)(qv[e >> 1] >> (16u * (e & 1u)));
+                const uint32_t nat = kUnzig[8u * t + e];
+                my[(nat >> 3) * 9 + (nat & 7u)] = v;
+            }
+        } else
         for (uint32_t k = t; k < cnt; k += 8u) {
             const int q = (wide || k < kJpegWideHead) ? (int)c16[k] : (int)c8[k - kJpegWideHead];
             const int v = q * (int)H->qt[ci][k]; // dequantised in i32, as zune-jpeg does while decoding
@@ -117,7 +131,8 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegDecJob *__rest
         uint8_t *p = jb.planes + C.plane_off + (size_t)(by * 8u + t) * (C.bw * 8u) + bx * 8u;
         const uint32_t lo = sat17(o[0]) | (sat17(o[1]) << 8) | (sat17(o[2]) << 16) | (sat17(o[3]) << 24);
         const uint32_t hi = sat17(o[4]) | (sat17(o[5]) << 8) | (sat17(o[6]) << 16) | (sat17(o[7]) << 24);
-        reinterpret_cast<uint2 *>(p)[0] = make_uint2(lo, hi);
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *(__attribute__((address_space(1))) u32x2 *)(uintptr_t)p = u32x2{lo, hi};
     }
 }
 

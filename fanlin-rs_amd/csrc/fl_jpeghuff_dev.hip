@@ -214,7 +214,9 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
             if (isdc) { d0 = comp == 0u ? dc : d0; d1 = comp == 1u ? dc : d1; d2 = comp == 2u ? dc : d2; }
             // a DC symbol is a bare category 0..11 and the predictor stays 16-bit; (run, 0) other than end of block / ZRL is not a baseline code; no coefficient 64
             bad |= isdc ? (sym > 11u || dc < -32768 || dc > 32767) : (s == 0u ? (run != 0u && run != 15u) : kr > 63u);
-            if (isdc || (s != 0u && kr <= 63u)) coef[(size_t)gidx * 64u + (isdc ? 0u : kr)] = (int16_t)(isdc ? dc : val);
+            // (a GLOBAL store with a 32-bit index: a flat one also counts as an LDS operation, and the wait for the next table entry at the
+            // top of the loop then waited for the store's trip to memory as well -- the write pass ran at a third of the counting walks' speed)
+            if (isdc || (s != 0u && kr <= 63u)) ((__attribute__((address_space(1))) int16_t *)coef)[gidx * 64u + (isdc ? 0u : kr)] = (int16_t)(isdc ? dc : val);
         }
         const uint32_t k_ac = s == 0u ? (run == 15u ? k + 16u : 64u) : (el ? 64u : kr + 1u);
         k = isdc ? (el ? 64u : 1u) : k_ac;
