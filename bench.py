@@ -60,7 +60,7 @@ KERNEL_DTYPE_STREAM = "f32 (one fused multiply-add per tap, vertical then horizo
 def kernel_dtype(stats, st=None) -> str:
     """The arithmetic the dominant kernel really computes in (not a precision claim: every byte is checked to lie within 1 LSB of
     the reference's f32 arithmetic, see verified_against)."""
-    if not stats.get("mfma_launches"):
+    if stats.get("mfma_launches", 0) <= stats.get("wtile_launches", 0):   # (the resample ran on the f32 streaming kernel; a blur on the window-tile kernel also counts as a matrix-pipe launch)
         return KERNEL_DTYPE_STREAM
     return KERNEL_DTYPE_PACKED if (st is not None and st.debug_get("mfma_arith") == 1) else KERNEL_DTYPE_FULL
 
@@ -519,7 +519,7 @@ def main_one_context(args):
                        "mode": "one process, one context over the node's GPUs (flgpu_config.devices[]), shards by flgpu_plan_shards",
                        "devices": devices, "shard_images": [int((shard_of == k).sum()) for k in range(N)], "images_per_gpu_per_step": args.batch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "resample_mfma_kernel" if stats.get("mfma_launches") else "resample_stream_kernel", "kernel_ms": k_ms,
+                         "kernel": "resample_mfma_kernel" if stats.get("mfma_launches", 0) > stats.get("wtile_launches", 0) else "resample_stream_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "note": "per launch and device: average over the shards' launches"},
             "stage_ms_per_step": {"resample": stats["resample_ms"] / args.steps, "blur": stats["blur_ms"] / args.steps, "frontend": stats["frontend_ms"] / args.steps},
             "cpu_baseline": None}
@@ -769,7 +769,7 @@ def main():
                        "images_per_gpu_per_step": n, "sharding": "one independent batch per rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "resample_mfma_kernel" if stats.get("mfma_launches") else "resample_stream_kernel",
+                         "kernel": "resample_mfma_kernel" if stats.get("mfma_launches", 0) > stats.get("wtile_launches", 0) else "resample_stream_kernel",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "per_image_us_kernel": k_ms * 1e3 / n if n else None,
             "stage_ms_per_step": {"resample": stats["resample_ms"] / args.steps, "blur": stats["blur_ms"] / args.steps,
