@@ -10,12 +10,12 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --cpu-images 0 --latency-requests 0 --extra-steps 0 --verify-images 0 --config3-share 0 --config4 0"
 run() { echo "== $*" >&2; timeout -k 10 300 "$@"; }
 # kernel time summaries (the same commands bench.py is judged on, fewer steps)
-run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config1 -o c1 -- $B --steps 20 --warmup 3 > $O/config1.log 2>&1   # the default workload: resize + letterbox + JPEG encode
+run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config1 -o c1 -- $B --steps 100 --warmup 3 > $O/config1.log 2>&1   # the default workload: resize + letterbox + JPEG encode
 run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config2 -o c2 -- $B --steps 5 --warmup 2 --blur 10 --grayscale --frontend none > $O/config2.log 2>&1
 run rocprofv3 --kernel-trace --stats --output-format csv -d $O/jpeg -o jp -- $B --steps 5 --warmup 2 --frontend none > $O/jpeg.log 2>&1   # resize only
 # the packed arithmetic of rounds 2-3 (narrower than the reference's: an extra of the bench line, not its headline), same workload
 export FLGPU_MFMA_ARITH=packed
-run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config1_packed -o c1p -- $B --steps 20 --warmup 3 > $O/config1_packed.log 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d $O/config1_packed -o c1p -- $B --steps 100 --warmup 3 > $O/config1_packed.log 2>&1
 unset FLGPU_MFMA_ARITH
 # roctx ranges of the runtime (FLGPU_ROCTX=1) next to the kernels
 export FLGPU_ROCTX=1
