@@ -670,6 +670,11 @@ int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, 
     }
     const size_t stream_bytes = (size_t)(o - (out + S.stream_off));
     if (stream_bytes > (1u << 28)) return -2;                      // (bit positions are 32-bit on the device)
+    // A picture of one colour is a PERIODIC stream ("DC difference 0, end of block" over and over, ~5 bits per block): a decoder started at
+    // a wrong bit falls into a shifted parse that is just as valid and never meets the true one, so the device's chain of states would have
+    // to walk the file subsequence by subsequence (tests/tools/fuzz_jpegdec.py: every flat picture ended in the host retry, after ~3 ms of
+    // kernels).  Such files are tiny and the host decodes them in a fraction of that: below 7 bits per block the file is not for this path.
+    if ((uint64_t)stream_bytes * 8u < 7ull * H.nblocks) return -2;
     memset(o, 0xFF, 32);                                           // the device reads whole words, up to 16 bytes past the end
     S.stream_bits = (uint32_t)(stream_bytes * 8u);
     S.staged_bytes = (uint32_t)(S.stream_off + ((stream_bytes + 16u + 15u) & ~(size_t)15u));
