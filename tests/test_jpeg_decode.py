@@ -584,6 +584,25 @@ def test_device_entropy_decoder_reads_the_host_decoders_coefficients(fl, gpu_sta
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("c,sub", [(3, 2), (3, 0), (1, 0)])
+def test_one_colour_pictures_stay_with_the_host_decoder(fl, gpu_state, oracle, c, sub):
+    """A picture of one colour is a periodic stream ("DC difference 0, end of block", ~5 bits per block): a decoder started at a wrong
+    bit falls into a shifted parse that is as valid as the true one, so the device's subsequences never fall into step.  The staging step
+    (csrc/fl_jpeghuff.cpp jpeg_entropy_stage) leaves files below 7 bits per block to the host decoder instead of letting them end in the
+    host retry; the pixels are the oracle decoder's either way."""
+    gpu_state.debug_set("device_huffman_min_bytes", 0)
+    gpu_state.debug_set("device_huffman_always", 1)
+    img = np.full((1000, 1400, c), 77, np.uint8)
+    img[..., 0] = 190
+    data = _save(img, quality=85, **({"subsampling": sub} if c == 3 else {}))
+    s0 = gpu_state.stats()
+    got = gpu_state.decode_jpeg(data)
+    s1 = gpu_state.stats()
+    assert s1["jpeg_device_huffman"] == s0["jpeg_device_huffman"] and s1["jpeg_device_huffman_retries"] == s0["jpeg_device_huffman_retries"]
+    assert np.array_equal(got, oracle.jpeg_decode(data))
+
+
+@pytest.mark.gpu
 def test_device_entropy_decoder_in_batches_and_whole_requests(fl, gpu_state, oracle, monkeypatch):
     gpu_state.debug_set("device_huffman_min_bytes", 0)
     gpu_state.debug_set("device_huffman_always", 1)   # (by default a lone request is decoded by its own thread: a CPU is idle)
