@@ -474,7 +474,9 @@ try {
             {
                 std::unique_lock<std::mutex> lk(c->dec_mu);
                 if (!c->dec_limit) c->dec_limit = c->cfg.decode_threads ? c->cfg.decode_threads : usable_cpus();
-                if (policy == 1 && c->decoding < std::max(1u, c->dec_limit / 2u)) on_host = true;
+                // (round 5: a quarter of the CPUs, not half -- the device's decode kernels of a batch went from 1.9 to 1.1 ms, and with 64 callers on
+                // 16 CPUs every host decode beyond that takes 1.8 ms of CPU from threads that stage files: tools/experiments/jh_policy.sh)
+                if (policy == 1 && c->decoding < std::max(1u, c->dec_limit / 4u)) on_host = true;
                 if (on_host) {
                     // (bounded: a file that keeps its decoder busy for long -- a huge progressive picture -- must not park every other
                     // JPEG request behind it; after the deadline the caller decodes anyway, one runnable thread more than CPUs)
