@@ -124,16 +124,17 @@ int main(int argc, char **argv)
     /* CPU the whole process spent in the timed region (callers: decode + staging copies; the library's lane threads; the runtime's waits) */
     const double cpu_ms = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) * 1e3 + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-3 +
                           (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) * 1e3 + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-3;
+    const double user_ms = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) * 1e3 + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-3;
     flgpu_stats stats;
     flgpu_get_stats(g_ctx, &stats);
     qsort(g_lat, (size_t)g_requests, sizeof(double), cmp);
     printf("{\"p50_ms\": %.3f, \"p99_ms\": %.3f, \"requests\": %d, \"caller_threads\": %d, \"images_per_s\": %.1f, \"queue_flushes\": %llu, "
-           "\"failed\": %d, \"pinned\": %d, \"jpeg_sources\": %llu, \"mean_file_bytes\": %.0f, \"mean_upload_bytes\": %.0f, \"entropy_decoded_on_device\": %llu, \"device_entropy_retries\": %llu, \"host_cpu_ms_per_request\": %.3f, "
+           "\"failed\": %d, \"pinned\": %d, \"jpeg_sources\": %llu, \"mean_file_bytes\": %.0f, \"mean_upload_bytes\": %.0f, \"entropy_decoded_on_device\": %llu, \"device_entropy_retries\": %llu, \"host_cpu_ms_per_request\": %.3f, \"host_cpu_user_ms_per_request\": %.3f, "
            "\"path\": \"flgpu_transform from C threads, host buffers (H2D + kernels + D2H), request-batching queue\"}\n",
            g_lat[g_requests / 2], g_lat[(int)(g_requests * 0.99) < g_requests ? (int)(g_requests * 0.99) : g_requests - 1], g_requests, threads,
            g_requests / wall * 1e3, (unsigned long long)stats.queue_flushes, g_failed, g_pinned, (unsigned long long)stats.jpeg_sources,
            stats.jpeg_sources ? (double)stats.jpeg_file_bytes / (double)stats.jpeg_sources : 0.0, stats.jpeg_sources ? (double)stats.jpeg_upload_bytes / (double)stats.jpeg_sources : 0.0,
-           (unsigned long long)stats.jpeg_device_huffman, (unsigned long long)stats.jpeg_device_huffman_retries, cpu_ms / g_requests);
+           (unsigned long long)stats.jpeg_device_huffman, (unsigned long long)stats.jpeg_device_huffman_retries, cpu_ms / g_requests, user_ms / g_requests);
     flgpu_destroy(g_ctx);
     return g_failed ? 6 : 0;
 }
