@@ -59,7 +59,7 @@ constexpr uint32_t kJhMaxSubs = 256u;
 constexpr uint32_t kWinWords = kJhMaxSubs * kJhSubBits / 32u + 8u; // the subsequences + the words a walk may read past its end
 
 // LDS of the walking kernels (dynamic: 4 tables + window + per-block records + states = 69 KB, beyond the static 64 KB)
-constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 8u, kLdsWords = kLdsStates + 2u * (kJhMaxSubs + 2u);
+constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 4u, kLdsWords = kLdsStates + 2u * (kJhMaxSubs + 2u);
 static_assert(kLdsStates % 2u == 0u && kLdsBinfo % 4u == 0u, "LDS alignment of the 64-bit states / 16-byte block records");
 
 __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
@@ -98,13 +98,10 @@ __device__ __forceinline__ void stage_tables(const JhJob &jb, const Ctx &c, uint
         const JpegComponent &cc = c.H->comp[cb];
         // what a walk needs of block jj of the MCU: its AC and DC table (byte offsets in LDS), its component as the shift of its field in the
         // DC sums; and where its block words are: {first, step per MCU column, step per MCU row}
-        binfo[8u * jj] = (uint32_t)c.S->ac_tab[cb] * (4u * TW) | ((uint32_t)c.S->dc_tab[cb] * (4u * TW)) << 16;
-        binfo[8u * jj + 1u] = 21u * cb;
-        binfo[8u * jj + 2u] = binfo[8u * jj + 3u] = 0u;
-        binfo[8u * jj + 4u] = cc.block_base + c.S->blk_v[jj] * cc.bw + c.S->blk_h[jj];
-        binfo[8u * jj + 5u] = cc.h;
-        binfo[8u * jj + 6u] = cc.v * cc.bw;
-        binfo[8u * jj + 7u] = 0u;
+        binfo[4u * jj] = (uint32_t)c.S->ac_tab[cb] * (4u * TW) | ((uint32_t)c.S->dc_tab[cb] * (4u * TW)) << 16;
+        binfo[4u * jj + 1u] = 21u * cb;
+        binfo[4u * jj + 2u] = cc.block_base + c.S->blk_v[jj] * cc.bw + c.S->blk_h[jj];
+        binfo[4u * jj + 3u] = cc.h | (cc.v * cc.bw) << 16; // (a component's block rows are at most 8192 x 2 blocks long)
     }
     __syncthreads();
 }
@@ -138,7 +135,9 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
     const char *lds0 = reinterpret_cast<const char *>(lut); // (the tables start the workgroup's LDS block; block records hold BYTE offsets from here)
     auto look = [&](uint32_t byte_off) { return (uint32_t)*reinterpret_cast<const uint16_t *>(lds0 + byte_off); };
     auto word = [&](uint32_t i) { return c.lwords[i < kWinWords ? i : kWinWords - 1u]; };
-    auto info = [&](uint32_t jj) { return *reinterpret_cast<const uint2 *>(binfo + 8u * jj); }; // {AC table | DC table << 16 (byte offsets), 21 * component}
+    // per block of the MCU: {AC table | DC table << 16 (byte offsets in LDS), 21 * component, first block word, step per MCU column | per MCU row << 16}
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto info = [&](uint32_t jj) { return *reinterpret_cast<const u32x4 *>(binfo + 4u * jj); };
     auto after = [&](uint32_t jj) { return jj + 1u >= c.bpm ? jj + 1u - c.bpm : jj + 1u; };
     uint32_t j = (uint32_t)(state >> 32) & 15u, k = (uint32_t)(state >> 40) & 127u;
     if (j >= c.bpm) j = 0u; // (a state is only ever one a walk produced; this keeps a corrupt one inside the tables)
@@ -151,21 +150,18 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
     auto bits_at = [&](uint32_t pos) { const uint32_t sh = pos & 31u; return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi; };
     uint32_t win = bits_at(pr);
     // block records: of the block the walk is in, of the next one, and (requested in every step) of the one after -- a block can be one step long
-    uint2 cur = info(j), nxt = info(after(j)), nn = info(after(after(j)));
+    u32x4 cur = info(j), nxt = info(after(j)), nn = info(after(after(j)));
     int32_t nblk = 0;
     int64_t dacc = 0;        // MODE 1: the three DC difference sums as 21-bit signed fields of one 64-bit sum (|sum| < 2^20: at most 79 blocks of |difference| <= 2047 fit 1024 bits)
     int32_t d0 = 0, d1 = 0, d2 = 0; // MODE 2: the components' DC predictors
     uint32_t q = q0, gidx = 0, mx = 0, my = 0;
     bool bad = false;
-    auto place = [&](uint32_t jj) { // index of the block word of block jj of MCU (mx, my)
-        const uint4 bi = *reinterpret_cast<const uint4 *>(binfo + 8u * jj + 4u);
-        return bi.x + my * bi.z + mx * bi.y;
-    };
+    auto place = [&](const u32x4 &rec, uint32_t x, uint32_t y) { return rec.z + y * (rec.w >> 16) + x * (rec.w & 0xffffu); }; // block word of the record's block in MCU (x, y)
     if (MODE == 2) {
         d0 = dc0[0]; d1 = dc0[1]; d2 = dc0[2];
         const uint32_t m = q / c.bpm;
         my = m / c.mcux; mx = m - my * c.mcux;
-        gidx = q < c.total_blocks ? place(j) : 0u;
+        gidx = place(cur, mx, my);
     }
     // The table entry of the NEXT symbol is requested as soon as the window has moved past this one -- from the block's AC table and
     // from the next block's DC table at once, since which of the two it is (did this symbol end the block?) comes out of the
@@ -224,20 +220,23 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
         k = done ? 0u : k;
         nblk += done ? 1 : 0;
         j = done ? after(j) : j;
+        if (MODE == 2) { // (straight-line like the rest: the next block's place from the record already in registers, no wait inside a branch)
+            const bool wrap = done && j == 0u;                       // the block that starts now is the first of the next MCU
+            const bool row = wrap && mx + 1u == c.mcux;
+            mx = row ? 0u : mx + (wrap ? 1u : 0u);
+            my += row ? 1u : 0u;
+            gidx = done ? place(nxt, mx, my) : gidx;
+            q += done ? 1u : 0u;
+        }
         cur.x = done ? nxt.x : cur.x; cur.y = done ? nxt.y : cur.y;
         nxt.x = done ? nn.x : nxt.x; nxt.y = done ? nn.y : nxt.y;
+        if (MODE == 2) { nxt.z = done ? nn.z : nxt.z; nxt.w = done ? nn.w : nxt.w; }
         nn = info(after(after(j)));
-        if (MODE == 2 && done) {
-            if (bad) atomicOr(err, 2u); // (an invalid code word inside a real block: the file is broken, or the states were wrong)
-            bad = false;
-            ++q;
-            if (j == 0u && ++mx == c.mcux) { mx = 0u; ++my; }
-            if (q < c.total_blocks) gidx = place(j);
-        }
         e = k == 0u ? e_dc : e_ac; // (e_dc was read from what was then the next block's table: this block's, if the block has just changed)
     }
-    // (a block that straddles the subsequence's end: the next walk continues it with a clean flag, so what this part of it saw is
-    // reported here -- the host decoder rejects the same file, and which of the two runs must not decide whether a corrupt file is served)
+    // Invalid code words, a DC term out of range, a coefficient past 63 -- in any block of the scan this walk decoded (it stops at the scan's
+    // last block: the padding behind it is never looked at): the file is broken, or the states were wrong; the host decodes it, and rejects it
+    // if it is the file.  (Reported once per walk: a block that straddles the subsequence's end is continued by the next walk with its own flag.)
     if (MODE == 2 && bad) atomicOr(err, 2u);
     if (MODE == 1 && cnt4) {
         const int32_t c0 = (int32_t)((dacc << 43) >> 43);
