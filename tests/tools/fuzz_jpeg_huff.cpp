@@ -28,6 +28,19 @@ static int decode(const std::vector<uint8_t> &d, long *ok, long *bad)
         if (used > cap) { fprintf(stderr, "used %zu > capacity %zu\n", used, cap); return 1; }
         ++*ok;
     } else ++*bad;
+    // the staging step of the DEVICE entropy decoder reads the same bytes (header, code tables laid out for the kernels, the segment
+    // with its stuffing removed): whatever it answers, it must stay inside its buffers, and what it stages must describe itself truthfully
+    const size_t scap = fl::jpeg_stage_bound(d.size());
+    std::vector<uint8_t> stage(scap);
+    size_t sused = 0;
+    if (fl::jpeg_entropy_stage(d.data(), d.size(), stage.data(), scap, &sused) == 0) {
+        fl::JpegHuffStage S;
+        memcpy(&S, stage.data() + sizeof(fl::JpegBlobHeader), sizeof(S));
+        if (sused > scap || S.staged_bytes != sused || (size_t)S.stream_off + S.stream_bits / 8u + 16u > sused || S.tables_off + 4u * fl::kJhTableWords * 4u > S.stream_off || S.bpm == 0 || S.bpm > 10) {
+            fprintf(stderr, "staged blob inconsistent: used %zu of %zu, stream at %u + %u bits\n", sused, scap, S.stream_off, S.stream_bits);
+            return 1;
+        }
+    }
     return 0;
 }
 
