@@ -102,7 +102,14 @@ struct alignas(16) JpegHuffStage {
     uint8_t blk_comp[12];     // per block of an MCU: component, and its position inside the MCU's h x v group
     uint8_t blk_h[12], blk_v[12];
     uint8_t dc_tab[4], ac_tab[4]; // per component: table index 0..3 into the four tables above (AC: 2..3)
+    // restart intervals (round 5): the RSTn markers are taken out of the staged segment like the stuffing; what is left of a marker is the
+    // byte offset at which the next interval starts (every interval starts on a byte: the bits in front of it are padding, F.1.2.3)
+    uint32_t rst_mcus;        // MCUs per restart interval (DRI), 0 = none
+    uint32_t n_rst;           // interval starts recorded (= intervals - 1)
+    uint32_t rst_off;         // byte offset (from the start of the staged blob) of n_rst ascending u32 byte offsets into the segment
+    uint32_t pad_[1];
 };
+constexpr uint32_t kJhMaxRestarts = 16384; // files with more restart intervals stay with the host decoder
 
 // One staged picture of a device entropy-decode launch.
 struct alignas(16) JhJob {
@@ -126,6 +133,6 @@ size_t jpeg_stage_bound(size_t file_bytes);
 // Bytes of the device blob / per-subsequence scratch a staged picture needs.
 size_t jh_blob_bytes(const JpegBlobHeader &H);
 uint32_t jh_subsequences(const JpegHuffStage &S);
-hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, hipStream_t st);
+hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, bool restarts, hipStream_t st);
 
 } // namespace fl

@@ -6,6 +6,7 @@
 
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -554,7 +555,7 @@ size_t jpeg_blob_bound(const JpegInfo &I)
 
 size_t jpeg_stage_bound(size_t file_bytes)
 {
-    return sizeof(JpegBlobHeader) + sizeof(JpegHuffStage) + 4u * kJhTableWords * 4u + file_bytes + 96u;
+    return sizeof(JpegBlobHeader) + sizeof(JpegHuffStage) + 4u * kJhTableWords * 4u + file_bytes + 96u + 4u * std::min<size_t>(kJhMaxRestarts, file_bytes / 2u);
 }
 
 // Host half of the DEVICE entropy decoder (fl_jpeghuff_dev.hip): header parse, code tables in the device's layout, the entropy-coded
@@ -564,7 +565,7 @@ int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, 
     Parsed P;
     int rc = parse(data, n, P, true);
     if (rc) return rc;
-    if (!P.info.supported || !P.single_pass || P.info.restart_interval != 0) return -2;
+    if (!P.info.supported || !P.single_pass) return -2;
     const uint32_t nc = P.info.components;
     if (nc != 1 && nc != 3) return -2;
     for (uint32_t i = 0; i < nc; ++i) if (!P.have_qt[P.c[i].tq]) return -1;
@@ -655,9 +656,12 @@ int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, 
     if ((uint64_t)S.mcux * S.mcuy * bpm != H.nblocks) return -2;
     S.tables_off = (uint32_t)(sizeof(JpegBlobHeader) + sizeof(JpegHuffStage));
     S.stream_off = (uint32_t)((S.tables_off + 4u * kJhTableWords * 4u + 15u) & ~15u);
-    // the segment without its stuffing: 0xFF 0x00 -> 0xFF; it ends at the first marker (no restart markers in this path)
+    // the segment without its stuffing: 0xFF 0x00 -> 0xFF; it ends at the first marker that is not a restart marker.  A restart marker
+    // (only in a file that announced an interval) is taken out as well: the next interval starts at the byte that follows in the copy.
     uint8_t *o = out + S.stream_off;
     const uint8_t *p = data + P.scan_pos, *end = data + n;
+    std::vector<uint32_t> rst;
+    uint32_t next_rst = 0; // RSTm markers count modulo 8 (B.2.1)
     while (p < end) {
         const uint8_t *ff = static_cast<const uint8_t *>(memchr(p, 0xFF, (size_t)(end - p)));
         if (!ff) { memcpy(o, p, (size_t)(end - p)); o += end - p; break; }
@@ -665,8 +669,23 @@ int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, 
         if (ff + 1 >= end) break;
         if (ff[1] == 0x00) { *o++ = 0xFF; p = ff + 2; continue; }
         if (ff[1] == 0xFF) { p = ff + 1; continue; }              // fill bytes in front of a marker
-        if (ff[1] >= 0xD0 && ff[1] <= 0xD7) return -2;             // a restart marker without a restart interval: leave it to the host decoder
+        if (ff[1] >= 0xD0 && ff[1] <= 0xD7) {
+            // without an announced interval, out of sequence, or in a number the device's tables are not sized for: the host decoder's case
+            if (!P.info.restart_interval || ff[1] != 0xD0 + next_rst || rst.size() >= kJhMaxRestarts) return -2;
+            next_rst = (next_rst + 1u) & 7u;
+            rst.push_back((uint32_t)(o - (out + S.stream_off)));
+            p = ff + 2;
+            continue;
+        }
         break;                                                      // EOI or any other marker: the scan is over
+    }
+    if (P.info.restart_interval) {
+        // the host decoder wants exactly one marker behind every interval but the last (fl_jpeghuff.cpp jpeg_entropy_decode); a file that
+        // differs is broken one way or another, and which way is for that decoder to say
+        const uint64_t mcus = (uint64_t)S.mcux * S.mcuy, want = (mcus + P.info.restart_interval - 1u) / P.info.restart_interval;
+        if (rst.size() + 1u != want) return -2;
+        for (size_t i = 1; i < rst.size(); ++i) if (rst[i] <= rst[i - 1]) return -2; // (an empty interval)
+        if (!rst.empty() && rst[0] == 0u) return -2;
     }
     const size_t stream_bytes = (size_t)(o - (out + S.stream_off));
     if (stream_bytes > (1u << 28)) return -2;                      // (bit positions are 32-bit on the device)
@@ -678,6 +697,14 @@ int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, 
     memset(o, 0xFF, 32);                                           // the device reads whole words, up to 16 bytes past the end
     S.stream_bits = (uint32_t)(stream_bytes * 8u);
     S.staged_bytes = (uint32_t)(S.stream_off + ((stream_bytes + 16u + 15u) & ~(size_t)15u));
+    S.rst_mcus = P.info.restart_interval;
+    S.n_rst = (uint32_t)rst.size();
+    S.rst_off = S.staged_bytes;
+    if (!rst.empty()) {
+        if ((size_t)S.staged_bytes + rst.size() * 4u + 16u > cap) return -2;
+        memcpy(out + S.rst_off, rst.data(), rst.size() * 4u);
+        S.staged_bytes = (uint32_t)((S.rst_off + rst.size() * 4u + 15u) & ~(size_t)15u);
+    }
     // the header describes the blob the DEVICE builds: block words, then 64 halfwords per block
     H.magic = kJhMagic;
     H.blocks_off = (uint32_t)sizeof(JpegBlobHeader);

@@ -47,6 +47,9 @@ struct Ctx {
     const uint32_t *lwords; // the workgroup's window of it in LDS, byte-swapped: words [lbase, lbase + kWinWords)
     uint32_t lbase;
     uint32_t bpm, total_blocks, mcux;
+    uint32_t rst_blocks;    // blocks per restart interval (0: the file has none)
+    uint32_t n_rst;
+    const uint32_t *rst;    // byte offsets (in the segment) at which the intervals after the first start, ascending
 };
 // The speculative kernel's workgroups also decode the kJhWarm subsequences IN FRONT of their own kJhSubsPerItem (results discarded): by
 // the time the chain of states reaches the workgroup's own first subsequence it has fallen into step (a chain longer than sixteen
@@ -59,7 +62,7 @@ constexpr uint32_t kJhMaxSubs = 256u;
 constexpr uint32_t kWinWords = kJhMaxSubs * kJhSubBits / 32u + 8u; // the subsequences + the words a walk may read past its end
 
 // LDS of the walking kernels (dynamic: 4 tables + window + per-block records + states = 69 KB, beyond the static 64 KB)
-constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 4u, kLdsWords = kLdsStates + 2u * (kJhMaxSubs + 2u);
+constexpr uint32_t kLdsLut = 0, kLdsWin = kLdsLut + 4u * TW, kLdsBinfo = kLdsWin + kWinWords, kLdsStates = kLdsBinfo + 12u * 4u, kLdsRst = kLdsStates + 2u * (kJhMaxSubs + 2u), kRstWords = kWinWords / 8u + 2u, kLdsRstCnt = kLdsRst + kRstWords, kLdsWords = kLdsRstCnt + kRstWords + 4u;
 static_assert(kLdsStates % 2u == 0u && kLdsBinfo % 4u == 0u, "LDS alignment of the 64-bit states / 16-byte block records");
 
 __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
@@ -71,6 +74,8 @@ __device__ __forceinline__ Ctx make_ctx(const JhJob &jb)
     c.nwords = (c.S->stream_bits / 8u + 16u) / 4u; // (the stage is padded with 16 bytes of ones)
     c.lwords = nullptr; c.lbase = 0u;
     c.bpm = c.S->bpm; c.total_blocks = c.S->total_blocks; c.mcux = c.S->mcux;
+    c.rst_blocks = c.S->rst_mcus * c.S->bpm; c.n_rst = c.S->n_rst;
+    c.rst = reinterpret_cast<const uint32_t *>(jb.stage + c.S->rst_off);
     return c;
 }
 
@@ -106,6 +111,42 @@ __device__ __forceinline__ void stage_tables(const JhJob &jb, const Ctx &c, uint
     __syncthreads();
 }
 
+// Restart intervals: one bit per byte of the workgroup's window, set where an interval starts.  (A walk asks "does an interval start at the
+// next byte?" at every block start; the list itself is per picture and would need a search per walk.)
+__device__ __forceinline__ void stage_restarts(const Ctx &c, uint32_t first_sub, uint32_t *rbits, uint32_t nsubs = kJhOwn)
+{
+    // rbits[kRstWords]: the bitmap; behind it rcnt[kRstWords]: interval starts in the window in front of each word; rcnt[kRstWords]: ... in front of the window
+    uint32_t *rcnt = rbits + kRstWords;
+    for (uint32_t k = threadIdx.x; k < kRstWords; k += blockDim.x) rbits[k] = 0u;
+    if (threadIdx.x == 0) rcnt[kRstWords] = 0u;
+    __syncthreads();
+    const uint32_t base = first_sub * (kJhSubBits / 8u), nbytes = nsubs * (kJhSubBits / 8u) + 32u;
+    uint32_t before = 0;
+    for (uint32_t i = threadIdx.x; i < c.n_rst; i += blockDim.x) {
+        const uint32_t b = c.rst[i], rel = b - base;
+        before += b < base ? 1u : 0u;
+        if (rel < nbytes) atomicOr(&rbits[rel >> 5], 1u << (rel & 31u));
+    }
+    if (before) atomicAdd(&rcnt[kRstWords], before);
+    __syncthreads();
+    // exclusive prefix of the words' bit counts (the interval an interval start opens has a number: what the block counter must show there)
+    constexpr uint32_t per = (kRstWords + 255u) / 256u;
+    uint32_t local = 0;
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t w = threadIdx.x * per + k; if (w < kRstWords) local += __popc(rbits[w]); }
+    __shared__ uint32_t scan[256];
+    scan[threadIdx.x] = local;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? scan[threadIdx.x - d] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = scan[threadIdx.x] - local;
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t w = threadIdx.x * per + k; if (w < kRstWords) { rcnt[w] = run; run += __popc(rbits[w]); } }
+    __syncthreads();
+}
+
 __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t j, uint32_t k) { return (uint64_t)p | ((uint64_t)j << 32) | ((uint64_t)k << 40); }
 
 // One walk over the code words from state (p, j, k) until the bit position reaches p_end.
@@ -127,9 +168,13 @@ __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t j, uint32_t 
 // Round 4's walk resolved code + magnitude in one 10-bit lookup and sent everything longer -- one symbol in eight at quality 85 --
 // through a second table and a search; with 64 lanes that path ran in every step: ~350 instructions per step, this one ~90
 // (first kernel 911 -> 650 us, write pass 261 -> 155 us per batch of 17 files; profiles/r05_jpeg_decode_kernels.txt).
-template <int MODE>
-__device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, const uint32_t *binfo, uint64_t state, uint32_t p_end, int32_t *cnt4, uint32_t q0,
-                                            const int32_t *dc0, int16_t *coef, uint32_t *err)
+// RST: the file has restart intervals (rbits = the window's bitmap of interval starts).  At a block start with an interval starting at the
+// next byte boundary, what is left of the byte is padding (F.1.2.3): the walk steps to the boundary, the DC predictors start again at zero
+// (F.2.1.3.1) and the block counter must stand at a multiple of the interval -- for a walk that is out of step this is also where it
+// falls into step for good: position, block of the MCU and coefficient index are all known there.
+template <int MODE, bool RST>
+__device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, const uint32_t *binfo, const uint32_t *rbits, uint64_t state, uint32_t p_end, int32_t *cnt4,
+                                            uint32_t q0, const int32_t *dc0, int16_t *coef, uint32_t *err)
 {
     static_assert(MODE == 1 || MODE == 2, "walk mode");
     const char *lds0 = reinterpret_cast<const char *>(lut); // (the tables start the workgroup's LDS block; block records hold BYTE offsets from here)
@@ -167,10 +212,37 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
     // from the next block's DC table at once, since which of the two it is (did this symbol end the block?) comes out of the
     // bookkeeping that runs while the reads are under way.  The recurrence of a step is then bits -> entry -> lengths -> bits.
     uint32_t e = look((k == 0u ? cur.x >> 16 : cur.x & 0xffffu) + 2u * (win >> (32u - LB)));
+    uint32_t rword = RST ? rbits[((pr + 7u) >> 3) >> 5] : 0u, snapped = 0xffffffffu; // the bitmap word of the next byte boundary (requested with the table entries); the boundary stepped to last
+    bool restarted = false;
     while (pr < pr_end && (MODE != 2 || q < c.total_blocks)) {
 #ifdef FL_JH_TRACE
         if (MODE == 1 && cnt4) ++cnt4[4];
 #endif
+        if (RST) {
+            // An interval starts at the next byte boundary, the walk stands at a block start, and what is left of the byte is all ones: padding
+            // (F.1.2.3).  The ones matter: the interval's LAST block may well start inside its last byte ("DC difference 0, end of block" is four
+            // bits) -- but no block starts with ones only, because no Huffman code is all ones (K.2: the all-ones code word is never assigned).
+            const uint32_t nbyte = (pr + 7u) >> 3, rem = (nbyte << 3) - pr;
+            if (k == 0u && ((rword >> (nbyte & 31u)) & 1u) && nbyte != snapped && (rem == 0u || (~win >> (32u - rem)) == 0u)) {
+                snapped = nbyte;
+                if (MODE == 2) { // the interval that starts here has a number, and the block counter must stand at exactly that many intervals' blocks
+                    const uint32_t *rcnt = rbits + kRstWords;
+                    const uint32_t index = rcnt[kRstWords] + rcnt[nbyte >> 5] + (uint32_t)__popc(rword & ((1u << (nbyte & 31u)) - 1u)); // interval starts in front of this one
+                    if (j != 0u || q != (index + 1u) * c.rst_blocks) bad = true; // (the host decoder wants its marker exactly behind the interval's last MCU)
+                }
+                pr = nbyte << 3; j = 0u;
+                cur = info(0u); nxt = info(after(0u)); nn = info(after(after(0u)));
+                W = pr >> 5; hi = word(W); lo = word(W + 1u); nx = word(W + 2u);
+                win = bits_at(pr);
+                e = look((cur.x >> 16) + 2u * (win >> (32u - LB)));
+                dacc = 0; restarted = true; d0 = d1 = d2 = 0;
+                if (MODE == 2) gidx = place(cur, mx, my);
+                continue; // (the boundary may be this walk's end)
+            }
+            // (a block that is still open where an interval starts: the host decoder finds no marker behind the interval's last MCU and rejects the file)
+            if (MODE == 2 && k != 0u && rem == 0u && ((rword >> (nbyte & 31u)) & 1u)) bad = true;
+        }
+        const uint32_t pr_before = pr;
         const bool isdc = k == 0u;
         // entry: bits 0-4 code length (0: longer than the lookahead), 5-7 length of an END-OF-BLOCK code that follows the symbol's
         // magnitude bits inside the lookahead (0: none there) -- it is consumed with the symbol: one step for the "DC difference, end of
@@ -201,6 +273,17 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
         win = bits_at(pr);
         const uint32_t nidx = 2u * (win >> (32u - LB));
         const uint32_t e_ac = look((cur.x & 0xffffu) + nidx), e_dc = look((nxt.x >> 16) + nidx);
+        if (RST) rword = rbits[((pr + 7u) >> 3) >> 5];
+        if (RST && MODE == 2) {
+            // A code word must not reach across an interval start (pr_before < 8 b < pr for a start byte b): the walk did not step to it -- the
+            // bits in front of it were not padding, or the interval holds more than its MCUs -- and what follows would be decoded with the DC
+            // predictors of the interval before.  At most four byte boundaries lie inside one step's 31 bits.
+            const uint32_t b0 = (pr_before >> 3) + 1u, b1 = (pr - 1u) >> 3;
+            if (b1 >= b0) {
+                const uint64_t two = (uint64_t)rbits[b0 >> 5] | (uint64_t)rbits[(b0 >> 5) + 1u] << 32;
+                if ((two >> (b0 & 31u)) & ((1ull << (b1 - b0 + 1u)) - 1ull)) bad = true;
+            }
+        }
         // RECEIVE + EXTEND: the s bits behind the code; a leading 0 bit means negative, value - 2^s + 1 (s = 0: no bits, 0)
         const int32_t val = (int32_t)((t >> 1) >> (31u - s)) + (((int32_t)t >> 31) ? 0 : (int32_t)((0xffffffffu << s) + 1u));
         if (MODE == 1) dacc += (int64_t)(isdc ? val : 0) << cur.y;
@@ -242,7 +325,8 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
         const int32_t c0 = (int32_t)((dacc << 43) >> 43);
         const int64_t a1 = (dacc - c0) >> 21;
         const int32_t c1 = (int32_t)((a1 << 43) >> 43);
-        cnt4[0] = nblk; cnt4[1] = c0; cnt4[2] = c1; cnt4[3] = (int32_t)((a1 - c1) >> 21);
+        // (bit 31 of the block count: the walk passed an interval start, and the sums are those of the differences behind the last one)
+        cnt4[0] = nblk | (restarted ? (int32_t)0x80000000 : 0); cnt4[1] = c0; cnt4[2] = c1; cnt4[3] = (int32_t)((a1 - c1) >> 21);
     }
     return pack_state(pr + 32u * c.lbase, j, k);
 }
@@ -274,11 +358,11 @@ __global__ __launch_bounds__(256) void jh_init_kernel(const JhJob *jobs, uint32_
 // across workgroups moves once per launch (FIRST, then kJhSyncRounds more); the counting pass checks the result.
 constexpr int kJhInnerRounds = 24;
 
-template <bool FIRST>
+template <bool FIRST, bool RST>
 __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const JhItem *items)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *lut = lds + kLdsLut, *win = lds + kLdsWin, *binfo = lds + kLdsBinfo;
+    uint32_t *lut = lds + kLdsLut, *win = lds + kLdsWin, *binfo = lds + kLdsBinfo, *rbits = lds + kLdsRst;
     uint64_t *st = reinterpret_cast<uint64_t *>(lds + kLdsStates);
     __shared__ int changed;
     const JhItem it = items[blockIdx.x];
@@ -293,6 +377,7 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
     Ctx c = make_ctx(jb);
     stage_tables(jb, c, lut, binfo);
     stage_window(c, base_sub, win, kJhOwn + warm);
+    if (RST) stage_restarts(c, base_sub, rbits, kJhOwn + warm);
     const uint32_t p_end = (sub + 1u) * kJhSubBits;
     uint64_t last_in = ~0ull; // the start state this subsequence was last decoded from
 #ifdef FL_JH_TRACE
@@ -311,7 +396,7 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
         if (t == 0) st[0] = pack_state(base_sub * kJhSubBits, 0u, 0u); // (exact for the picture's first subsequence, a guess for every other workgroup)
         if (active) {
             last_in = pack_state(sub * kJhSubBits, 0u, 0u);
-            st[t + 1u] = jh_walk<1>(c, lut, binfo, last_in, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
+            st[t + 1u] = jh_walk<1, RST>(c, lut, binfo, rbits, last_in, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
             walked = true;
         }
     } else {
@@ -341,7 +426,7 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
         if (active && start != last_in) {
             // (a start beyond this subsequence -- a walk that ran through it -- just passes on)
             if ((uint32_t)start >= p_end) { end = start; cnt4[0] = cnt4[1] = cnt4[2] = cnt4[3] = 0; }
-            else end = jh_walk<1>(c, lut, binfo, start, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
+            else end = jh_walk<1, RST>(c, lut, binfo, rbits, start, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
             walked = true;
             last_in = start;
             redo = end != st[t + 1u];
@@ -374,25 +459,40 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
 // prefix sums of counts[nsub][4]
 __global__ __launch_bounds__(256) void jh_scan_kernel(const JhJob *jobs)
 {
-    __shared__ int32_t part[256][4];
+    // per thread: blocks, the three DC sums, and whether a restart lies in its stretch (then the sums are those behind the last one:
+    // bit 31 of a subsequence's block count says its walk passed an interval start, fl_jpeghuff_dev.hip jh_walk)
+    __shared__ int32_t part[256][5];
     const JhJob jb = jobs[blockIdx.x];
     const uint32_t per = (jb.nsub + 255u) / 256u, lo = threadIdx.x * per, hi = min(lo + per, jb.nsub);
-    int32_t s[4] = {0, 0, 0, 0};
+    auto add = [&](int32_t (&s)[4], const int32_t *cnt, int32_t *any) {
+        const bool restarted = cnt[0] < 0;
+        s[0] += cnt[0] & 0x7fffffff;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) s[k] = restarted ? cnt[k] : s[k] + cnt[k];
+        if (any && restarted) *any = 1;
+    };
+    int32_t s[4] = {0, 0, 0, 0}, any = 0;
     bool unsettled = false;
     for (uint32_t i = lo; i < hi; ++i) {
         unsettled |= jb.used[i] != jb.states[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += jb.counts[i * 4u + k];
+        add(s, jb.counts + i * 4u, &any);
     }
     if (unsettled) atomicOr(jb.err, 1u);
 #pragma unroll
     for (int k = 0; k < 4; ++k) part[threadIdx.x][k] = s[k];
+    part[threadIdx.x][4] = any;
     __syncthreads();
     if (threadIdx.x == 0) {
         int32_t run[4] = {0, 0, 0, 0};
-        for (int t = 0; t < 256; ++t)
+        for (int t = 0; t < 256; ++t) {
+            const int32_t v[4] = {part[t][0], part[t][1], part[t][2], part[t][3]};
+            const bool restarted = part[t][4] != 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int32_t v = part[t][k]; part[t][k] = run[k]; run[k] += v; }
+            for (int k = 0; k < 4; ++k) part[t][k] = run[k];
+            run[0] += v[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) run[k] = restarted ? v[k] : run[k] + v[k];
+        }
         // The segment must hold every block of the scan.  A truncated file (or one cut by a stray marker) whose last walk stops at the
         // segment's end before it meets the padding raises no invalid-code error, and its missing blocks would stay zero -- the host
         // decoder feeds zero bits past the end and carries the DC predictors on, i.e. decodes different pixels: error bit 4, the host
@@ -403,20 +503,24 @@ __global__ __launch_bounds__(256) void jh_scan_kernel(const JhJob *jobs)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) s[k] = part[threadIdx.x][k];
-    for (uint32_t i = lo; i < hi; ++i)
+    for (uint32_t i = lo; i < hi; ++i) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { jb.prefix[i * 4u + k] = s[k]; s[k] += jb.counts[i * 4u + k]; }
+        for (int k = 0; k < 4; ++k) jb.prefix[i * 4u + k] = s[k];
+        add(s, jb.counts + i * 4u, nullptr);
+    }
 }
 
+template <bool RST>
 __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const JhItem *items)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *lut = lds + kLdsLut, *win = lds + kLdsWin, *binfo = lds + kLdsBinfo;
+    uint32_t *lut = lds + kLdsLut, *win = lds + kLdsWin, *binfo = lds + kLdsBinfo, *rbits = lds + kLdsRst;
     const JhItem it = items[blockIdx.x];
     const JhJob jb = jobs[it.job];
     Ctx c = make_ctx(jb);
     stage_tables(jb, c, lut, binfo);
     stage_window(c, it.first_sub, win);
+    if (RST) stage_restarts(c, it.first_sub, rbits);
     const uint32_t sub = it.first_sub + threadIdx.x;
     if (threadIdx.x >= kJhOwn || sub >= jb.nsub) return;
     const uint32_t p_end = (sub + 1u) * kJhSubBits;
@@ -424,7 +528,7 @@ __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const 
     if ((uint32_t)start >= p_end) return;
     const int32_t dc0[3] = {jb.prefix[sub * 4u + 1u], jb.prefix[sub * 4u + 2u], jb.prefix[sub * 4u + 3u]};
     int16_t *coef = reinterpret_cast<int16_t *>(jb.blob + c.H->coef_off);
-    (void)jh_walk<2>(c, lut, binfo, start, p_end, nullptr, (uint32_t)jb.prefix[sub * 4u], dc0, coef, jb.err);
+    (void)jh_walk<2, RST>(c, lut, binfo, rbits, start, p_end, nullptr, (uint32_t)jb.prefix[sub * 4u], dc0, coef, jb.err);
 }
 
 } // namespace
@@ -432,7 +536,7 @@ __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const 
 size_t jh_blob_bytes(const JpegBlobHeader &H) { return (size_t)H.coef_off + (size_t)H.nblocks * 128u + 64u; }
 uint32_t jh_subsequences(const JpegHuffStage &S) { return (S.stream_bits + kJhSubBits - 1u) / kJhSubBits; }
 
-hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, hipStream_t st)
+hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, bool restarts, hipStream_t st)
 {
     (void)h_jobs;
     if (!njobs || !nitems) return hipSuccess;
@@ -442,15 +546,26 @@ hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t n
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (dev < 0 || dev >= 16 || !attr_done[dev]) { // (more than the 64 KB a kernel gets without asking; idempotent, so a race between two lanes only repeats it)
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&jh_sync_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&jh_sync_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&jh_write_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+        const void *fns[6] = {reinterpret_cast<const void *>(&jh_sync_kernel<true, false>), reinterpret_cast<const void *>(&jh_sync_kernel<false, false>),
+                              reinterpret_cast<const void *>(&jh_sync_kernel<true, true>), reinterpret_cast<const void *>(&jh_sync_kernel<false, true>),
+                              reinterpret_cast<const void *>(&jh_write_kernel<false>), reinterpret_cast<const void *>(&jh_write_kernel<true>)};
+        for (const void *f : fns)
+            if (hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
         if (dev >= 0 && dev < 16) attr_done[dev] = true;
     }
-    jh_sync_kernel<true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
-    for (uint32_t r = 0; r < kJhSyncRounds; ++r) jh_sync_kernel<false><<<nitems, 256, lds, st>>>(d_jobs, d_items); // (each moves the chain across one more workgroup boundary)
-    jh_scan_kernel<<<njobs, 256, 0, st>>>(d_jobs);
-    jh_write_kernel<<<nitems, 256, lds, st>>>(d_jobs, d_items);
+    // (one choice per launch: a batch with a restart-interval file in it runs the kernels that look for interval starts -- for its other
+    // files the bitmap is empty and the look-up finds nothing)
+    if (restarts) {
+        jh_sync_kernel<true, true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
+        for (uint32_t r = 0; r < kJhSyncRounds; ++r) jh_sync_kernel<false, true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
+        jh_scan_kernel<<<njobs, 256, 0, st>>>(d_jobs);
+        jh_write_kernel<true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
+    } else {
+        jh_sync_kernel<true, false><<<nitems, 256, lds, st>>>(d_jobs, d_items);
+        for (uint32_t r = 0; r < kJhSyncRounds; ++r) jh_sync_kernel<false, false><<<nitems, 256, lds, st>>>(d_jobs, d_items); // (each moves the chain across one more workgroup boundary)
+        jh_scan_kernel<<<njobs, 256, 0, st>>>(d_jobs);
+        jh_write_kernel<false><<<nitems, 256, lds, st>>>(d_jobs, d_items);
+    }
     return hipGetLastError();
 }
 

@@ -560,6 +560,15 @@ DEVICE_HUFFMAN_FILES = [
     (1000, 1500, 1, 80, 0, "photo"),     # one component: one block per MCU
     (64, 96, 3, 85, 2, "photo"), (37, 53, 3, 70, 0, "photo"), (8, 8, 3, 90, 0, "photo"), (1, 1, 3, 90, 2, "photo"), (9, 300, 3, 95, 2, "uniform"),
 ]
+# round 5: restart intervals on the device -- h, w, c, quality, subsampling, restart interval in blocks (= MCUs for Pillow's writer)
+DEVICE_HUFFMAN_RESTART_FILES = [
+    (1080, 1920, 3, 85, 2, 120),    # one interval per MCU row of a 4:2:0 picture: what cameras write
+    (1080, 1920, 3, 85, 2, 7),      # short intervals that start anywhere in a row (~2,300 bits each: several per 1024-bit subsequence pair)
+    (720, 1280, 3, 92, 0, 1),       # an interval per MCU: 14,400 of them, an interval start in almost every subsequence
+    (1000, 1500, 1, 80, 0, 33),     # one component
+    (1081, 1921, 3, 60, 1, 50),     # 4:2:2, partial MCUs at the edges
+    (64, 96, 3, 85, 2, 5), (37, 53, 3, 70, 0, 2), (200, 301, 3, 40, 0, 3),
+]
 
 
 @pytest.mark.gpu
@@ -581,6 +590,25 @@ def test_device_entropy_decoder_reads_the_host_decoders_coefficients(fl, gpu_sta
     gpu_state.debug_set("host_huffman", 1)                     # the host decoder stays selectable, and agrees
     assert np.array_equal(gpu_state.decode_jpeg(data), got)
     assert gpu_state.stats()["jpeg_device_huffman"] == s1["jpeg_device_huffman"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DEVICE_HUFFMAN_RESTART_FILES)
+def test_device_entropy_decoder_takes_restart_intervals(fl, gpu_state, oracle, case):
+    """Files with restart intervals (DRI + RSTn markers; round 5): the staging step takes the markers out of the segment and records where
+    the intervals start, the device's walks step over the padding in front of an interval start, begin the DC predictors at zero there
+    and check the block counter -- and fall into step there for good, if they were out of step.  Pixels are the oracle decoder's, bit
+    for bit, and the device did the decoding."""
+    h, w, c, q, sub, rst = case
+    gpu_state.debug_set("device_huffman_min_bytes", 0)
+    gpu_state.debug_set("device_huffman_always", 1)
+    data = make_jpeg(h, w, c, q, sub, rst, index=h + rst)
+    assert fl.jpeg_info(data)["restart_interval"] == rst
+    s0 = gpu_state.stats()
+    got = gpu_state.decode_jpeg(data)
+    s1 = gpu_state.stats()
+    assert s1["jpeg_device_huffman"] == s0["jpeg_device_huffman"] + 1 and s1["jpeg_device_huffman_retries"] == s0["jpeg_device_huffman_retries"]
+    assert np.array_equal(got, oracle.jpeg_decode(data))
 
 
 @pytest.mark.gpu
@@ -607,12 +635,12 @@ def test_device_entropy_decoder_in_batches_and_whole_requests(fl, gpu_state, ora
     gpu_state.debug_set("device_huffman_min_bytes", 0)
     gpu_state.debug_set("device_huffman_always", 1)   # (by default a lone request is decoded by its own thread: a CPU is idle)
     files = [make_jpeg(360 + 8 * k, 640 - 16 * k, 3, 60 + 5 * k, k % 3, 0, index=40 + k) for k in range(6)]
-    files.append(make_jpeg(200, 300, 3, 80, 2, 5, index=9))           # a restart interval: this one stays with the host decoder
-    files.append(_save(synth.photo(240, 320, 3, index=3), progressive=True, quality=80))   # progressive: host, too
+    files.append(make_jpeg(200, 300, 3, 80, 2, 5, index=9))           # a restart interval (round 5: on the device as well, in the same launches)
+    files.append(_save(synth.photo(240, 320, 3, index=3), progressive=True, quality=80))   # progressive: this one stays with the host decoder
     p = fl.make_params(150, 100)
     before = gpu_state.stats()["jpeg_device_huffman"]
     outs = gpu_state.process_batch(files, [p] * len(files))            # flgpu_transform_batch: one set of launches for all eight
-    assert gpu_state.stats()["jpeg_device_huffman"] - before == 6
+    assert gpu_state.stats()["jpeg_device_huffman"] - before == 7
     gpu_state.debug_set("host_huffman", 1)
     host = gpu_state.process_batch(files, [p] * len(files))
     gpu_state.debug_set("host_huffman", 0)
@@ -668,5 +696,26 @@ def test_device_entropy_decoder_on_broken_streams(fl, gpu_state, monkeypatch):
     for nsub in (3, 8, 17, 40):
         for delta in (-1, 0, 1, 2):
             same_on_both_sides(bytes(data[:sos + 128 * nsub + delta]) + b"\xff\xd9", ("cut at subsequence", nsub, delta))
+    # a file with restart intervals (round 5: on the device): mutations inside the intervals, markers damaged, removed and doubled, cuts
+    rdata = bytearray(make_jpeg(240, 320, 3, 85, 2, 4, index=22))
+    rsos = rdata.find(b"\xff\xda") + 14
+    for trial in range(30):
+        d = bytearray(rdata)
+        for _ in range(int(rng.integers(1, 4))):
+            d[int(rng.integers(rsos, len(d) - 2))] = int(rng.integers(0, 255))
+        same_on_both_sides(bytes(d), ("restart file, mutation", trial))
+    marks = [i for i in range(rsos, len(rdata) - 1) if rdata[i] == 0xFF and 0xD0 <= rdata[i + 1] <= 0xD7]
+    assert len(marks) > 10
+    for trial in range(12):
+        d = bytearray(rdata)
+        m = marks[int(rng.integers(0, len(marks)))]
+        kind = trial % 4
+        if kind == 0: del d[m:m + 2]                                     # a marker missing
+        elif kind == 1: d[m + 1] = 0xD0 + (d[m + 1] - 0xD0 + 3) % 8        # out of sequence
+        elif kind == 2: d[m:m] = d[m:m + 2]                              # doubled
+        else: d[m - 1] ^= 0x10                                           # the byte in front of it (padding or the last code words)
+        same_on_both_sides(bytes(d), ("restart file, marker", trial, kind))
+    for cut in (len(rdata) // 2, marks[5] + 1, marks[7] + 2, marks[9]):
+        same_on_both_sides(bytes(rdata[:cut]) + b"\xff\xd9", ("restart file, cut", cut))
     good = gpu_state.decode_jpeg(bytes(data))                                   # the context is fine afterwards
     assert good.shape == (240, 320, 3)

@@ -1,5 +1,6 @@
 """One-off fuzzing of the device entropy decoder (csrc/fl_jpeghuff_dev.hip) against the oracle's decoder (not part of the test-suite): Pillow-written
-baseline files of random sizes (8 .. 2600 pixels a side), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, quality 3 .. 98, Annex K tables or optimised ones
+baseline files of random sizes (8 .. 2600 pixels a side), 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, quality 3 .. 98, with and without restart
+intervals of 1 .. 500 MCUs, Annex K tables or optimised ones
 (other code lengths: the 12-bit lookahead, the end-of-block fusing and the long-code search all see tables they were not tuned on), photographs, noise and
 flat pictures.  Every file must come back as the oracle decoder's pixels, bit for bit; which files the device decoded and which ended in the host retry is reported.
    python tests/tools/fuzz_jpegdec.py <cases> <seed>"""
@@ -32,6 +33,7 @@ for i in range(n):
     img = synth.uniform(h, w, c, index=i) if kind == 0 else synth.photo(h, w, c, index=i) if kind < 3 else np.full((h, w, c), int(rng.integers(0, 256)), np.uint8)
     kw = dict(quality=int(rng.integers(3, 99)), optimize=bool(rng.integers(0, 2)))
     if c == 3: kw["subsampling"] = int(rng.integers(0, 3))
+    if rng.integers(0, 3) == 0: kw["restart_marker_blocks"] = int(rng.choice([1, 2, 3, 7, 20, 64, 120, 500]))   # restart intervals (round 5: on the device)
     buf = io.BytesIO()
     Image.fromarray(img[:, :, 0] if c == 1 else img).save(buf, "JPEG", **kw)
     data = buf.getvalue()
