@@ -381,7 +381,7 @@ int device_huffman_policy(const flgpu_ctx *c, uint64_t file_bytes)
 int jpeg_source_to_blob(flgpu_ctx *c, const flgpu_image *src, uint8_t *blob, size_t cap, JpegBlobHeader *hdr, size_t *used, bool host_huffman)
 {
     int rc = -2;
-    // files the device entropy decoder takes (sequential, one interleaved scan, no restart interval) are only STAGED here: header,
+    // files the device entropy decoder takes (sequential, one interleaved scan) are only STAGED here: header,
     // code tables, the segment without its stuffing -- tens of microseconds instead of ~2 ms of Huffman decoding on this thread
     if (!host_huffman && device_huffman_policy(c, src->capacity) != 0) rc = jpeg_entropy_stage(src->data, (size_t)src->capacity, blob, cap, used);
     if (rc == -2) rc = jpeg_entropy_decode(src->data, (size_t)src->capacity, blob, cap, used);

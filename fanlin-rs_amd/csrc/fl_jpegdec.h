@@ -75,7 +75,7 @@ hipError_t launch_jpeg_decode(const JpegDecJob *jobs, uint32_t njobs, uint32_t m
 } // namespace fl
 
 // ---- entropy decoding on the device (round 4; fl_jpeghuff_dev.hip) -------------------------------------------------------------
-// For sequential Huffman files in one interleaved scan without restart intervals the host no longer decodes anything: it parses
+// For sequential Huffman files in one interleaved scan (round 5: with or without restart intervals) the host no longer decodes anything: it parses
 // the header, copies the entropy-coded segment with the 0xFF00 stuffing removed, and hands over the four code tables.  The
 // device then decodes the segment in parallel -- subsequences of kJhSubBits bits decoded speculatively, then re-decoded from
 // their predecessor's end state until the states stop changing (a Huffman decoder that starts at a wrong bit re-synchronises
@@ -126,7 +126,7 @@ struct alignas(16) JhJob {
 constexpr uint32_t kJhSubsPerItem = 240;       // subsequences a workgroup owns (its 256 threads also decode kJhWarm = 16 in front of them in the speculative kernel)
 struct JhItem { uint32_t job, first_sub; }; // one workgroup of the per-subsequence kernels: kJhSubsPerItem consecutive subsequences of one picture
 
-// Host half: parses `data`, and if the file is one the device entropy decoder takes (sequential, one interleaved scan, no restart
+// Host half: parses `data`, and if the file is one the device entropy decoder takes (sequential, one interleaved scan, with or without restart
 // interval, 1 or 3 components) writes the staged blob to `out`: 0 ok (*used = its size), -1 malformed, -2 not for this path.
 int jpeg_entropy_stage(const uint8_t *data, size_t n, uint8_t *out, size_t cap, size_t *used);
 size_t jpeg_stage_bound(size_t file_bytes);
