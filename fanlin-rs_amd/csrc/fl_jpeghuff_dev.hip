@@ -212,22 +212,27 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
     // from the next block's DC table at once, since which of the two it is (did this symbol end the block?) comes out of the
     // bookkeeping that runs while the reads are under way.  The recurrence of a step is then bits -> entry -> lengths -> bits.
     uint32_t e = look((k == 0u ? cur.x >> 16 : cur.x & 0xffffu) + 2u * (win >> (32u - LB)));
-    uint32_t rword = RST ? rbits[((pr + 7u) >> 3) >> 5] : 0u, snapped = 0xffffffffu; // the bitmap word of the next byte boundary (requested with the table entries); the boundary stepped to last
+    // the bitmap words that hold the next byte boundary and the four bytes behind it (requested with the table entries); the boundary stepped to last
+    auto rpair_at = [&](uint32_t pos) { const uint32_t w = ((pos + 7u) >> 3) >> 5; return (uint64_t)rbits[w] | (uint64_t)rbits[w + 1u] << 32; };
+    uint64_t rpair = RST ? rpair_at(pr) : 0ull;
+    uint32_t snapped = 0xffffffffu;
     bool restarted = false;
     while (pr < pr_end && (MODE != 2 || q < c.total_blocks)) {
 #ifdef FL_JH_TRACE
         if (MODE == 1 && cnt4) ++cnt4[4];
 #endif
-        if (RST) {
+        // interval starts at the next byte boundary (bit 0) and at the four bytes behind it (a step moves 31 bits at most): zero almost always
+        const uint32_t nbyte = (pr + 7u) >> 3, near = RST ? (uint32_t)(rpair >> (nbyte & 31u)) & 0x1fu : 0u;
+        if (RST && (near & 1u)) {
             // An interval starts at the next byte boundary, the walk stands at a block start, and what is left of the byte is all ones: padding
             // (F.1.2.3).  The ones matter: the interval's LAST block may well start inside its last byte ("DC difference 0, end of block" is four
             // bits) -- but no block starts with ones only, because no Huffman code is all ones (K.2: the all-ones code word is never assigned).
-            const uint32_t nbyte = (pr + 7u) >> 3, rem = (nbyte << 3) - pr;
-            if (k == 0u && ((rword >> (nbyte & 31u)) & 1u) && nbyte != snapped && (rem == 0u || (~win >> (32u - rem)) == 0u)) {
+            const uint32_t rem = (nbyte << 3) - pr;
+            if (k == 0u && nbyte != snapped && (rem == 0u || (~win >> (32u - rem)) == 0u)) {
                 snapped = nbyte;
                 if (MODE == 2) { // the interval that starts here has a number, and the block counter must stand at exactly that many intervals' blocks
                     const uint32_t *rcnt = rbits + kRstWords;
-                    const uint32_t index = rcnt[kRstWords] + rcnt[nbyte >> 5] + (uint32_t)__popc(rword & ((1u << (nbyte & 31u)) - 1u)); // interval starts in front of this one
+                    const uint32_t index = rcnt[kRstWords] + rcnt[nbyte >> 5] + (uint32_t)__popc((uint32_t)rpair & ((1u << (nbyte & 31u)) - 1u)); // interval starts in front of this one
                     if (j != 0u || q != (index + 1u) * c.rst_blocks) bad = true; // (the host decoder wants its marker exactly behind the interval's last MCU)
                 }
                 pr = nbyte << 3; j = 0u;
@@ -240,7 +245,7 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
                 continue; // (the boundary may be this walk's end)
             }
             // (a block that is still open where an interval starts: the host decoder finds no marker behind the interval's last MCU and rejects the file)
-            if (MODE == 2 && k != 0u && rem == 0u && ((rword >> (nbyte & 31u)) & 1u)) bad = true;
+            if (MODE == 2 && k != 0u && rem == 0u) bad = true;
         }
         const uint32_t pr_before = pr;
         const bool isdc = k == 0u;
@@ -273,16 +278,13 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
         win = bits_at(pr);
         const uint32_t nidx = 2u * (win >> (32u - LB));
         const uint32_t e_ac = look((cur.x & 0xffffu) + nidx), e_dc = look((nxt.x >> 16) + nidx);
-        if (RST) rword = rbits[((pr + 7u) >> 3) >> 5];
-        if (RST && MODE == 2) {
+        if (RST) rpair = rpair_at(pr);
+        if (RST && MODE == 2 && near) {
             // A code word must not reach across an interval start (pr_before < 8 b < pr for a start byte b): the walk did not step to it -- the
             // bits in front of it were not padding, or the interval holds more than its MCUs -- and what follows would be decoded with the DC
-            // predictors of the interval before.  At most four byte boundaries lie inside one step's 31 bits.
+            // predictors of the interval before.  The byte boundaries inside a step's 31 bits are among the five `near` covers.
             const uint32_t b0 = (pr_before >> 3) + 1u, b1 = (pr - 1u) >> 3;
-            if (b1 >= b0) {
-                const uint64_t two = (uint64_t)rbits[b0 >> 5] | (uint64_t)rbits[(b0 >> 5) + 1u] << 32;
-                if ((two >> (b0 & 31u)) & ((1ull << (b1 - b0 + 1u)) - 1ull)) bad = true;
-            }
+            if (b1 >= b0 && ((near >> (b0 - nbyte)) & ((1u << (b1 - b0 + 1u)) - 1u))) bad = true;
         }
         // RECEIVE + EXTEND: the s bits behind the code; a leading 0 bit means negative, value - 2^s + 1 (s = 0: no bits, 0)
         const int32_t val = (int32_t)((t >> 1) >> (31u - s)) + (((int32_t)t >> 31) ? 0 : (int32_t)((0xffffffffu << s) + 1u));
