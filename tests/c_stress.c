@@ -43,7 +43,10 @@ static uint64_t run_request(int id)
     flgpu_image in = {src, n, sw, sh, c, fl, 0}, out = {dst, cap, 0, 0, 0, fl, 0};
     uint64_t h = 0xcbf29ce484222325ull;
     const int st = flgpu_transform(g_ctx, &in, &p, &out);
-    if (st != FLGPU_OK) { __sync_fetch_and_add(&g_failed, 1); h = 0xDEAD0000u + (uint64_t)st; }
+    if (st != FLGPU_OK) {
+        if (__sync_fetch_and_add(&g_failed, 1) < 5) fprintf(stderr, "request %d failed: %s (%s)\n", id, flgpu_strerror(st), flgpu_last_error(g_ctx)); /* which of the two runs, and why, if the hashes differ below */
+        h = 0xDEAD0000u + (uint64_t)st;
+    }
     else {
         for (uint64_t i = 0; i < out.bytes; ++i) h = (h ^ dst[i]) * 0x100000001b3ull;
         h ^= ((uint64_t)out.width << 40) ^ ((uint64_t)out.height << 20) ^ out.channels ^ (out.bytes << 3);
