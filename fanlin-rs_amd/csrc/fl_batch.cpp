@@ -424,12 +424,10 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
             std::vector<JhItem> items;
             std::vector<size_t> blob_off, scratch_off;
             uint32_t max_blocks = 0;
-            bool restarts = false;
             for (size_t i = 0; i < n; ++i) {
                 const JpegBlobHeader *H = srcs[i].hdr;
                 if (!H || H->magic != kJhMagic) continue;
                 const JpegHuffStage &S = srcs[i].stage;
-                restarts |= S.rst_mcus != 0u;
                 const uint32_t nsub = jh_subsequences(S);
                 blob_off.push_back(bytes); bytes += align_up(jh_blob_bytes(*H), 256);
                 scratch_off.push_back(bytes); bytes += align_up((size_t)(nsub + 2) * 8 + (size_t)nsub * 8 + (size_t)nsub * 32 + 32, 256);
@@ -467,7 +465,7 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
             memcpy(static_cast<char *>(c->h_jhjobs.p) + jobs_b, items.data(), nitems * sizeof(JhItem));
             FL_HIP(c, hipMemcpyAsync(c->d_jhjobs.p, c->h_jhjobs.p, jobs_b + nitems * sizeof(JhItem), hipMemcpyHostToDevice, st), "device entropy decode descriptors");
             FL_HIP(c, launch_jpeg_huff(static_cast<const JhJob *>(c->d_jhjobs.p), jobs.data(), (uint32_t)njh,
-                                       reinterpret_cast<const JhItem *>(static_cast<const char *>(c->d_jhjobs.p) + jobs_b), (uint32_t)nitems, max_blocks, restarts, st),
+                                       reinterpret_cast<const JhItem *>(static_cast<const char *>(c->d_jhjobs.p) + jobs_b), (uint32_t)nitems, max_blocks, st),
                    "device entropy decode kernels");
             c->last_jh_n = (uint32_t)njh;
         }

@@ -133,6 +133,6 @@ size_t jpeg_stage_bound(size_t file_bytes);
 // Bytes of the device blob / per-subsequence scratch a staged picture needs.
 size_t jh_blob_bytes(const JpegBlobHeader &H);
 uint32_t jh_subsequences(const JpegHuffStage &S);
-hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, bool restarts, hipStream_t st);
+hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, hipStream_t st);
 
 } // namespace fl

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void jh_init_kernel(const JhJob *jobs, uint32_
 // across workgroups moves once per launch (FIRST, then kJhSyncRounds more); the counting pass checks the result.
 constexpr int kJhInnerRounds = 24;
 
-template <bool FIRST, bool RST>
+template <bool FIRST>
 __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const JhItem *items)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -379,7 +379,12 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
     Ctx c = make_ctx(jb);
     stage_tables(jb, c, lut, binfo);
     stage_window(c, base_sub, win, kJhOwn + warm);
-    if (RST) stage_restarts(c, base_sub, rbits, kJhOwn + warm);
+    // (uniform in a workgroup: it serves one picture.  Files without restart intervals run the loop without the interval-start look-ups.)
+    const bool rst = c.n_rst != 0u;
+    if (rst) stage_restarts(c, base_sub, rbits, kJhOwn + warm);
+    auto walk = [&](uint64_t from, uint32_t to, int32_t *cnt) {
+        return rst ? jh_walk<1, true>(c, lut, binfo, rbits, from, to, cnt, 0u, nullptr, nullptr, nullptr) : jh_walk<1, false>(c, lut, binfo, rbits, from, to, cnt, 0u, nullptr, nullptr, nullptr);
+    };
     const uint32_t p_end = (sub + 1u) * kJhSubBits;
     uint64_t last_in = ~0ull; // the start state this subsequence was last decoded from
 #ifdef FL_JH_TRACE
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
         if (t == 0) st[0] = pack_state(base_sub * kJhSubBits, 0u, 0u); // (exact for the picture's first subsequence, a guess for every other workgroup)
         if (active) {
             last_in = pack_state(sub * kJhSubBits, 0u, 0u);
-            st[t + 1u] = jh_walk<1, RST>(c, lut, binfo, rbits, last_in, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
+            st[t + 1u] = walk(last_in, p_end, cnt4);
             walked = true;
         }
     } else {
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
         if (active && start != last_in) {
             // (a start beyond this subsequence -- a walk that ran through it -- just passes on)
             if ((uint32_t)start >= p_end) { end = start; cnt4[0] = cnt4[1] = cnt4[2] = cnt4[3] = 0; }
-            else end = jh_walk<1, RST>(c, lut, binfo, rbits, start, p_end, cnt4, 0u, nullptr, nullptr, nullptr);
+            else end = walk(start, p_end, cnt4);
             walked = true;
             last_in = start;
             redo = end != st[t + 1u];
@@ -512,7 +517,6 @@ __global__ __launch_bounds__(256) void jh_scan_kernel(const JhJob *jobs)
     }
 }
 
-template <bool RST>
 __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const JhItem *items)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -522,7 +526,8 @@ __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const 
     Ctx c = make_ctx(jb);
     stage_tables(jb, c, lut, binfo);
     stage_window(c, it.first_sub, win);
-    if (RST) stage_restarts(c, it.first_sub, rbits);
+    const bool rst = c.n_rst != 0u;
+    if (rst) stage_restarts(c, it.first_sub, rbits);
     const uint32_t sub = it.first_sub + threadIdx.x;
     if (threadIdx.x >= kJhOwn || sub >= jb.nsub) return;
     const uint32_t p_end = (sub + 1u) * kJhSubBits;
@@ -530,7 +535,8 @@ __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const 
     if ((uint32_t)start >= p_end) return;
     const int32_t dc0[3] = {jb.prefix[sub * 4u + 1u], jb.prefix[sub * 4u + 2u], jb.prefix[sub * 4u + 3u]};
     int16_t *coef = reinterpret_cast<int16_t *>(jb.blob + c.H->coef_off);
-    (void)jh_walk<2, RST>(c, lut, binfo, rbits, start, p_end, nullptr, (uint32_t)jb.prefix[sub * 4u], dc0, coef, jb.err);
+    if (rst) (void)jh_walk<2, true>(c, lut, binfo, rbits, start, p_end, nullptr, (uint32_t)jb.prefix[sub * 4u], dc0, coef, jb.err);
+    else (void)jh_walk<2, false>(c, lut, binfo, rbits, start, p_end, nullptr, (uint32_t)jb.prefix[sub * 4u], dc0, coef, jb.err);
 }
 
 } // namespace
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256) void jh_write_kernel(const JhJob *jobs, const 
 size_t jh_blob_bytes(const JpegBlobHeader &H) { return (size_t)H.coef_off + (size_t)H.nblocks * 128u + 64u; }
 uint32_t jh_subsequences(const JpegHuffStage &S) { return (S.stream_bits + kJhSubBits - 1u) / kJhSubBits; }
 
-hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, bool restarts, hipStream_t st)
+hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t njobs, const JhItem *d_items, uint32_t nitems, uint32_t max_blocks, hipStream_t st)
 {
     (void)h_jobs;
     if (!njobs || !nitems) return hipSuccess;
@@ -548,26 +554,15 @@ hipError_t launch_jpeg_huff(const JhJob *d_jobs, const JhJob *h_jobs, uint32_t n
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (dev < 0 || dev >= 16 || !attr_done[dev]) { // (more than the 64 KB a kernel gets without asking; idempotent, so a race between two lanes only repeats it)
-        const void *fns[6] = {reinterpret_cast<const void *>(&jh_sync_kernel<true, false>), reinterpret_cast<const void *>(&jh_sync_kernel<false, false>),
-                              reinterpret_cast<const void *>(&jh_sync_kernel<true, true>), reinterpret_cast<const void *>(&jh_sync_kernel<false, true>),
-                              reinterpret_cast<const void *>(&jh_write_kernel<false>), reinterpret_cast<const void *>(&jh_write_kernel<true>)};
+        const void *fns[3] = {reinterpret_cast<const void *>(&jh_sync_kernel<true>), reinterpret_cast<const void *>(&jh_sync_kernel<false>), reinterpret_cast<const void *>(&jh_write_kernel)};
         for (const void *f : fns)
             if (hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
         if (dev >= 0 && dev < 16) attr_done[dev] = true;
     }
-    // (one choice per launch: a batch with a restart-interval file in it runs the kernels that look for interval starts -- for its other
-    // files the bitmap is empty and the look-up finds nothing)
-    if (restarts) {
-        jh_sync_kernel<true, true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
-        for (uint32_t r = 0; r < kJhSyncRounds; ++r) jh_sync_kernel<false, true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
-        jh_scan_kernel<<<njobs, 256, 0, st>>>(d_jobs);
-        jh_write_kernel<true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
-    } else {
-        jh_sync_kernel<true, false><<<nitems, 256, lds, st>>>(d_jobs, d_items);
-        for (uint32_t r = 0; r < kJhSyncRounds; ++r) jh_sync_kernel<false, false><<<nitems, 256, lds, st>>>(d_jobs, d_items); // (each moves the chain across one more workgroup boundary)
-        jh_scan_kernel<<<njobs, 256, 0, st>>>(d_jobs);
-        jh_write_kernel<false><<<nitems, 256, lds, st>>>(d_jobs, d_items);
-    }
+    jh_sync_kernel<true><<<nitems, 256, lds, st>>>(d_jobs, d_items);
+    for (uint32_t r = 0; r < kJhSyncRounds; ++r) jh_sync_kernel<false><<<nitems, 256, lds, st>>>(d_jobs, d_items); // (each moves the chain across one more workgroup boundary)
+    jh_scan_kernel<<<njobs, 256, 0, st>>>(d_jobs);
+    jh_write_kernel<<<nitems, 256, lds, st>>>(d_jobs, d_items);
     return hipGetLastError();
 }
 
