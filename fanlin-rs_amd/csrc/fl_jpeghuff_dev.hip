@@ -192,10 +192,11 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
     // the 32 bits at pr: words W and W + 1 of the window in registers, W + 2 requested in every step (it has arrived when a step crosses into W + 1)
     uint32_t W = pr >> 5;
     uint32_t hi = word(W), lo = word(W + 1u), nx = word(W + 2u);
-    auto bits_at = [&](uint32_t pos) { const uint32_t sh = pos & 31u; return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi; };
+    auto bits_at = [&](uint32_t pos) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (32u - (pos & 31u))); }; // (a shift by 1 .. 32: one instruction, no special case for a position on a word boundary)
     uint32_t win = bits_at(pr);
     // block records: of the block the walk is in, of the next one, and (requested in every step) of the one after -- a block can be one step long
-    u32x4 cur = info(j), nxt = info(after(j)), nn = info(after(after(j)));
+    uint32_t j2 = after(after(j)); // the block the record in `nn` belongs to: two on from the walk's (one wrap-around per step instead of three)
+    u32x4 cur = info(j), nxt = info(after(j)), nn = info(j2);
     int32_t nblk = 0;
     int64_t dacc = 0;        // MODE 1: the three DC difference sums as 21-bit signed fields of one 64-bit sum (|sum| < 2^20: at most 79 blocks of |difference| <= 2047 fit 1024 bits)
     int32_t d0 = 0, d1 = 0, d2 = 0; // MODE 2: the components' DC predictors
@@ -236,7 +237,8 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
                     if (j != 0u || q != (index + 1u) * c.rst_blocks) bad = true; // (the host decoder wants its marker exactly behind the interval's last MCU)
                 }
                 pr = nbyte << 3; j = 0u;
-                cur = info(0u); nxt = info(after(0u)); nn = info(after(after(0u)));
+                j2 = after(after(0u));
+                cur = info(0u); nxt = info(after(0u)); nn = info(j2);
                 W = pr >> 5; hi = word(W); lo = word(W + 1u); nx = word(W + 2u);
                 win = bits_at(pr);
                 e = look((cur.x >> 16) + 2u * (win >> (32u - LB)));
@@ -304,7 +306,11 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
         const bool done = k >= 64u; // block complete
         k = done ? 0u : k;
         nblk += done ? 1 : 0;
-        j = done ? after(j) : j;
+        {
+            const uint32_t j3 = after(j2);
+            j = done ? (j + 1u == c.bpm ? 0u : j + 1u) : j;
+            j2 = done ? j3 : j2;
+        }
         if (MODE == 2) { // (straight-line like the rest: the next block's place from the record already in registers, no wait inside a branch)
             const bool wrap = done && j == 0u;                       // the block that starts now is the first of the next MCU
             const bool row = wrap && mx + 1u == c.mcux;
@@ -316,7 +322,7 @@ __device__ __forceinline__ uint64_t jh_walk(const Ctx &c, const uint32_t *lut, c
         cur.x = done ? nxt.x : cur.x; cur.y = done ? nxt.y : cur.y;
         nxt.x = done ? nn.x : nxt.x; nxt.y = done ? nn.y : nxt.y;
         if (MODE == 2) { nxt.z = done ? nn.z : nxt.z; nxt.w = done ? nn.w : nxt.w; }
-        nn = info(after(after(j)));
+        nn = info(j2);
         e = k == 0u ? e_dc : e_ac; // (e_dc was read from what was then the next block's table: this block's, if the block has just changed)
     }
     // Invalid code words, a DC term out of range, a coefficient past 63 -- in any block of the scan this walk decoded (it stops at the scan's
