@@ -106,6 +106,15 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
     // 8 (launcher) = one item per workgroup; -DFL_NINE_PRODUCTS: the ninth digit product, plane 0 x digit 0, is computed too (round 4)
     // (tried and dropped, profiles/r05_kernel_experiments.txt: waves 4-7 started late so that their stages run beside the other waves'
     // vertical passes -- paid for its own delay when the delay was per item, nothing once it was per workgroup)
+    // wave priorities on the SIMD (s_setprio): 3 from a K-block's transposed reads to the next request (round 3), then FL_PRIO_VERT through the
+    // vertical pass and FL_PRIO_STAGE through a tile stage.  Round 5: 2 / 1 instead of 0 / 0 -- the stage's dependent chains go ahead of the
+    // other wave's vertical pass: -0.6 % (1.5405 -> 1.5302 ms; 3 / 1, 3 / 2, 3 / 0 and 1 / 0 measured the same, profiles/r05_kernel_experiments.txt)
+#ifndef FL_PRIO_STAGE
+#define FL_PRIO_STAGE 2
+#endif
+#ifndef FL_PRIO_VERT
+#define FL_PRIO_VERT 1
+#endif
 #ifdef FL_VARIANT
     constexpr uint32_t variant = FL_VARIANT;
 #else
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
             light_next = r.strip_off == it.strip_off && r.vplan_off == it.vplan_off && r.kb0 == it.kb0 && r.kb1 == it.kb1;
             FL_STAMP(3);
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(FL_PRIO_VERT);
         if constexpr (FW) {
             if (pend_li != 0xffffffffu) try_convert(false, false);
         }
@@ -678,8 +687,10 @@ __global__ __launch_bounds__(THREADS, 1) void resample_mfma_kernel(const Job *__
 #undef FL_U01
 #undef FL_U2
                     };
+                    __builtin_amdgcn_s_setprio(FL_PRIO_STAGE);
                     if (HLDS && sp.lds_ops) stage(std::true_type{});
                     else stage(std::false_type{});
+                    __builtin_amdgcn_s_setprio(FL_PRIO_VERT);
                 } else {
                     // ---- packed arithmetic (rounds 2-3) ---------------------------------------------------------------------------
                     u32x4 ahi[4], alo[4];
