@@ -486,6 +486,7 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
         j.blob = dsrc[i].data;
         j.planes = static_cast<uint8_t *>(c->d_dec.p) + off; off += align_up(H.plane_bytes, 256);
         j.dst = static_cast<uint8_t *>(c->d_dec.p) + off; off += align_up(px * H.nc + 64, 256);
+        jpeg_color_job(H, j);
         max_blocks = std::max(max_blocks, H.nblocks); max_w = std::max(max_w, H.width); max_h = std::max(max_h, H.height);
         c->stats.jpeg_sources++;
         c->stats.jpeg_upload_bytes += H.total_bytes;

@@ -68,7 +68,17 @@ struct alignas(16) JpegDecJob {
     const uint8_t *blob;   // device copy of the blob
     uint8_t *planes;       // device scratch, header.plane_bytes
     uint8_t *dst;          // decoded pixels, width*height*nc, tightly packed
+    // what the colour kernel's fast form needs of the header, worked out once on the host (round 5: the kernel spent 435 scalar instructions
+    // and 48 scalar loads per wave on deriving it -- divisions of sampling factors among them -- for 8 pixels per thread)
+    uint32_t mode;         // 0 = pixel-wise from the header; 1 / 2 / 3 = YCbCr with chroma 2x2 / 2x1 / 1x1 and luma at full resolution
+    uint32_t width, height;
+    uint32_t y_off, y_pitch;            // luma plane: byte offset in `planes`, bytes per row
+    uint32_t cb_off, cr_off, c_pitch;   // chroma planes
+    uint32_t c_rows;                    // chroma rows that hold samples (JpegComponent::hpx)
+    uint32_t pad_[3];
 };
+// fills the fields behind `dst` from the header
+void jpeg_color_job(const JpegBlobHeader &H, JpegDecJob &j);
 
 hipError_t launch_jpeg_decode(const JpegDecJob *jobs, uint32_t njobs, uint32_t max_blocks, uint32_t max_w, uint32_t max_h, hipStream_t st);
 

@@ -201,21 +201,19 @@ __device__ __forceinline__ void color_pixel(const JpegDecJob &jb, HdrPtr H, uint
 
 // Four interior pixels x0 .. x0 + 3 (x0 a multiple of 4, 4 <= x0, x0 + 6 <= W) of rows y and y + 1 (y even), SH x SV chroma sampling.
 template <int SH, int SV>
-__device__ __forceinline__ void color_group(const JpegDecJob &jb, HdrPtr H, uint32_t x0, uint32_t y, uint32_t rows)
+__device__ __forceinline__ void color_group(const JpegDecJob &jb, uint32_t x0, uint32_t y, uint32_t rows)
 {
-    const uint32_t W = H->width;
-    CompRef CY = H->comp[0];
-    gcptr8 py = (gcptr8)(jb.planes + CY.plane_off);
-    const uint32_t ypw = CY.bw * 8u;
+    const uint32_t W = jb.width;
+    gcptr8 py = (gcptr8)(jb.planes + jb.y_off);
+    const uint32_t ypw = jb.y_pitch;
     uint32_t yv[2];
     yv[0] = *(const __attribute__((address_space(1))) uint32_t *)(py + (size_t)y * ypw + x0);
     yv[1] = rows > 1u ? *(const __attribute__((address_space(1))) uint32_t *)(py + (size_t)(y + 1u) * ypw + x0) : 0u;
     int cv[2][2][4]; // [Cb, Cr][row][pixel]
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
-        CompRef C = H->comp[1 + ci];
-        gcptr8 pl = (gcptr8)(jb.planes + C.plane_off);
-        const uint32_t pw = C.bw * 8u;
+        gcptr8 pl = (gcptr8)(jb.planes + (ci ? jb.cr_off : jb.cb_off));
+        const uint32_t pw = jb.c_pitch;
         if (SH == 1 && SV == 1) {
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
@@ -237,7 +235,7 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, HdrPtr H, uint
             }
         } else {
             const uint32_t r = y >> 1; // both rows of the pair share the near chroma row; the far ones are r - 1 and r + 1, clamped
-            const uint32_t ru = r ? r - 1u : 0u, rd = min(r + 1u, C.hpx - 1u);
+            const uint32_t ru = r ? r - 1u : 0u, rd = min(r + 1u, jb.c_rows - 1u);
             const uint32_t wn = load4_at(pl + (size_t)r * pw + ix - 1u), wu = load4_at(pl + (size_t)ru * pw + ix - 1u), wd = load4_at(pl + (size_t)rd * pw + ix - 1u);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -277,23 +275,19 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, HdrPtr H, uint
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegDecJob *__restrict__ jobs)
 {
     const JpegDecJob jb = jobs[blockIdx.y];
-    const HdrPtr H = (HdrPtr)(uintptr_t)jb.blob;
-    const uint32_t W = H->width, Hh = H->height, nc = H->nc;
+    const uint32_t W = jb.width, Hh = jb.height;
     const uint32_t ngx = (W + 3u) / 4u, ngy = (Hh + 1u) / 2u;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= ngx * ngy) return;
-    const uint32_t gy = idx / ngx, gx = idx - gy * ngx, x0 = 4u * gx, y = 2u * gy, rows = min(2u, Hh - y);
-    // the fast form: YCbCr, luma at full resolution, both chroma planes 2x2, 2x1 or 1x1, and the group away from the row's ends
-    int mode = 0; // 0 = pixel-wise
-    if (nc == 3u && !H->is_rgb && H->comp[0].h == H->hmax && H->comp[0].v == H->vmax && H->comp[1].h == H->comp[2].h && H->comp[1].v == H->comp[2].v &&
-        x0 >= 4u && x0 + 6u <= W) {
-        const uint32_t sh = H->hmax / H->comp[1].h, sv = H->vmax / H->comp[1].v;
-        mode = (sh == 2u && sv == 2u) ? 1 : (sh == 2u && sv == 1u) ? 2 : (sh == 1u && sv == 1u) ? 3 : 0;
-    }
-    if (mode == 1) color_group<2, 2>(jb, H, x0, y, rows);
-    else if (mode == 2) color_group<2, 1>(jb, H, x0, y, rows);
-    else if (mode == 3) color_group<1, 1>(jb, H, x0, y, rows);
+    const uint32_t gy = idx / ngx, gx = idx - gy * ngx, x0 = 4u * gx, y = 2u * gy;
+    const uint32_t rows = min(2u, Hh - y);
+    // the fast form: YCbCr, luma at full resolution, both chroma planes 2x2, 2x1 or 1x1 (jpeg_color_job), and the group away from the row's ends
+    const uint32_t mode = (x0 >= 4u && x0 + 6u <= W) ? jb.mode : 0u;
+    if (mode == 1u) color_group<2, 2>(jb, x0, y, rows);
+    else if (mode == 2u) color_group<2, 1>(jb, x0, y, rows);
+    else if (mode == 3u) color_group<1, 1>(jb, x0, y, rows);
     else {
+        const HdrPtr H = (HdrPtr)(uintptr_t)jb.blob;
         for (uint32_t rr = 0; rr < rows; ++rr)
             for (uint32_t k = 0; k < 4u && x0 + k < W; ++k) color_pixel(jb, H, x0 + k, y + rr);
     }
