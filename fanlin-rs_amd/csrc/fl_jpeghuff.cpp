@@ -341,17 +341,12 @@ struct Scan {
     uint32_t ss = 0, se = 63, ah = 0, al = 0;
 };
 
-inline int get_bits(BitReader &br, int k)
-{
-    if (!k) return 0;
-    if (br.cnt < k) br.fill();
-    const int v = (int)br.peek(k);
-    br.drop(k);
-    return v;
-}
-
 // One scan into coef[block][64] (zig-zag order).  0 ok, -1 malformed.
-int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const Scan &S, bool progressive, int16_t *coef)
+// nzm[block]: bit k = coefficient k is non-zero (round 5).  The refinement scans of a progressive file visit every coefficient of every
+// block to ask "non-zero already?" -- 2 M look-ups per luma scan of a 1080p picture, most of them "no" -- and the packing step looked
+// for each block's last coefficient the same way; with the mask a correction-bit pass walks the set bits only (count-trailing-zeros).
+// The bit buffer of the two AC loops lives in registers for the length of a block (br is visible to the out-of-line refill).
+int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const Scan &S, bool progressive, int16_t *coef, uint64_t *nzm)
 {
     const bool dc_scan = S.ss == 0;
     uint32_t mcus_x, mcus_y;
@@ -381,81 +376,121 @@ int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const S
                 for (uint32_t v = 0; v < nv; ++v)
                     for (uint32_t h = 0; h < nh; ++h) {
                         const uint32_t bx = mx * nh + h, by = my * nv + v;
-                        int16_t *b = coef + ((size_t)c.block_base + (size_t)by * c.bw + bx) * 64;
+                        const size_t bi = (size_t)c.block_base + (size_t)by * c.bw + bx;
+                        int16_t *b = coef + bi * 64;
+                        uint64_t nz = nzm[bi];
+                        // local bit buffer (see above); `need`, `bit`, `bits`, `sym` keep br's meaning: zeros behind a marker or the end
+                        uint64_t buf = br.buf;
+                        int bc = br.cnt;
+                        auto need = [&](int k) { if (bc < k) { br.buf = buf; br.cnt = bc; br.fill(); buf = br.buf; bc = br.cnt; } };
+                        auto bit = [&]() -> int { need(1); const int v = (int)(buf >> 63); buf <<= 1; --bc; return v; };
+                        auto bits = [&](int k) -> int { if (!k) return 0; need(k); const int v = (int)(buf >> (64 - k)); buf <<= k; bc -= k; return v; };
+                        auto sym = [&](const Huff &h) -> int {
+                            need(16);
+                            const uint32_t f = h.fast[buf >> (64 - kFastBits)];
+                            if (f) { buf <<= (f >> 8); bc -= (int)(f >> 8); return (int)(f & 255u); }
+                            br.buf = buf; br.cnt = bc;
+                            const int r = decode_sym(br, h);
+                            buf = br.buf; bc = br.cnt;
+                            return r;
+                        };
+                        struct Sync { BitReader &br; uint64_t &buf; int &bc; uint64_t *slot; uint64_t &nz; ~Sync() { br.buf = buf; br.cnt = bc; *slot = nz; } } sync_{br, buf, bc, nzm + bi, nz};
                         if (!progressive) {
                             // sequential: DC difference, then the AC coefficients up to the end-of-block code (F.2.2)
                             const Huff &hd = P.ht[0][S.td[k0]], &ha = P.ht[1][S.ta[k0]];
-                            const int t = decode_sym(br, hd);
+                            const int t = sym(hd);
                             if (t < 0 || t > 11) return -1;
-                            pred[ci] += receive_extend(br, t);
+                            { const int v = bits(t); pred[ci] += t ? (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v) : 0; }
                             if (pred[ci] < -32768 || pred[ci] > 32767) return -1;
                             b[0] = (int16_t)pred[ci];
                             for (int k = 1; k < 64;) {
-                                const int rs = decode_sym(br, ha);
+                                const int rs = sym(ha);
                                 if (rs < 0) return -1;
                                 const int r = rs >> 4, sz = rs & 15;
                                 if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
                                 k += r;
                                 if (k > 63) return -1;
-                                b[k++] = (int16_t)receive_extend(br, sz);
+                                const int v = bits(sz);
+                                b[k] = (int16_t)(v < (1 << (sz - 1)) ? v - (1 << sz) + 1 : v);
+                                nz |= 1ull << k;
+                                ++k;
                             }
                         } else if (dc_scan) {
                             if (S.ah == 0) { // G.1.2.1 first DC scan: the difference, scaled by 2^Al
-                                const int t = decode_sym(br, P.ht[0][S.td[k0]]);
+                                const int t = sym(P.ht[0][S.td[k0]]);
                                 if (t < 0 || t > 11) return -1;
-                                pred[ci] += receive_extend(br, t);
+                                { const int v = bits(t); pred[ci] += t ? (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v) : 0; }
                                 const int val = pred[ci] * (1 << S.al);
                                 if (val < -32768 || val > 32767) return -1;
                                 b[0] = (int16_t)val;
-                            } else if (get_bits(br, 1)) b[0] = (int16_t)(b[0] | p1); // refinement: one more bit of every DC term
+                            } else if (bit()) b[0] = (int16_t)(b[0] | p1); // refinement: one more bit of every DC term
                         } else if (S.ah == 0) { // G.1.2.2 first AC scan of the band [ss, se]
                             if (eobrun) { --eobrun; continue; }
                             const Huff &ha = P.ht[1][S.ta[k0]];
                             for (int k = (int)S.ss; k <= (int)S.se;) {
-                                const int rs = decode_sym(br, ha);
+                                const int rs = sym(ha);
                                 if (rs < 0) return -1;
                                 const int r = rs >> 4, sz = rs & 15;
                                 if (sz == 0) {
                                     if (r == 15) { k += 16; continue; }
-                                    eobrun = (1u << r) - 1u + (uint32_t)get_bits(br, r); // EOBr: this block and eobrun more end here
+                                    eobrun = (1u << r) - 1u + (uint32_t)bits(r); // EOBr: this block and eobrun more end here
                                     break;
                                 }
                                 k += r;
                                 if (k > (int)S.se) return -1;
-                                const int val = receive_extend(br, sz) * (1 << S.al);
+                                const int v = bits(sz);
+                                const int val = (v < (1 << (sz - 1)) ? v - (1 << sz) + 1 : v) * (1 << S.al);
                                 if (val < -32768 || val > 32767) return -1;
-                                b[k++] = (int16_t)val;
+                                b[k] = (int16_t)val;
+                                if (val) nz |= 1ull << k;
+                                ++k;
                             }
                         } else { // G.1.2.3 refinement of the band: one more bit of the coefficients already non-zero, and new +-1 << Al ones
                             int k = (int)S.ss;
                             const Huff &ha = P.ht[1][S.ta[k0]];
-                            auto refine = [&](int16_t &cf) {
-                                if (get_bits(br, 1) && !(cf & p1)) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                            const uint64_t band = (~0ull << S.ss) & (S.se >= 63 ? ~0ull : ((1ull << (S.se + 1)) - 1ull));
+                            // correction bits for the non-zero coefficients in `m` (ascending): read together, applied one by one
+                            auto refine_set = [&](uint64_t m) {
+                                int c = __builtin_popcountll(m);
+                                while (c > 0) {
+                                    const int take = c > 32 ? 32 : c;
+                                    const uint32_t corr = (uint32_t)bits(take);
+                                    for (int i = take - 1; i >= 0; --i) {
+                                        const int kk = __builtin_ctzll(m);
+                                        m &= m - 1ull;
+                                        int16_t &cf = b[kk];
+                                        if (((corr >> i) & 1u) && !(cf & p1)) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                                    }
+                                    c -= take;
+                                }
                             };
                             if (!eobrun) {
                                 for (; k <= (int)S.se; ++k) {
-                                    const int rs = decode_sym(br, ha);
+                                    const int rs = sym(ha);
                                     if (rs < 0) return -1;
-                                    int r = rs >> 4;
+                                    const int r = rs >> 4;
                                     const int sz = rs & 15;
                                     int val = 0;
                                     if (sz) {
                                         if (sz != 1) return -1;
-                                        val = get_bits(br, 1) ? p1 : m1;
+                                        val = bit() ? p1 : m1;
                                     } else if (r != 15) {
-                                        eobrun = (1u << r) + (uint32_t)get_bits(br, r); // this block included
+                                        eobrun = (1u << r) + (uint32_t)bits(r); // this block included
                                         break;
                                     }
-                                    // skip r coefficients that are still zero, refining the non-zero ones met on the way
-                                    for (; k <= (int)S.se; ++k) {
-                                        if (b[k]) refine(b[k]);
-                                        else if (--r < 0) break;
-                                    }
-                                    if (sz) { if (k > (int)S.se) return -1; b[k] = (int16_t)val; }
+                                    // skip r coefficients that are still zero, refining the non-zero ones met on the way: the walk ends AT the
+                                    // (r + 1)-th zero from k on (or behind the band) -- r <= 15 zeros dropped from the mask of zeros, then its lowest bit
+                                    uint64_t z = ~nz & band & (~0ull << k);
+                                    for (int i = 0; i < r && z; ++i) z &= z - 1ull;
+                                    const int pos = z ? __builtin_ctzll(z) : (int)S.se + 1;
+                                    refine_set(nz & band & (~0ull << k) & (pos >= 64 ? ~0ull : ((1ull << pos) - 1ull)));
+                                    k = pos;
+                                    if (sz) { if (k > (int)S.se) return -1; b[k] = (int16_t)val; nz |= 1ull << k; }
                                 }
                             }
                             if (eobrun) {
-                                for (; k <= (int)S.se; ++k) if (b[k]) refine(b[k]);
+                                // the rest of the band: correction bits for the coefficients that are non-zero already -- the set bits from k on
+                                if (k <= (int)S.se) refine_set(nz & band & (~0ull << k));
                                 --eobrun;
                             }
                         }
@@ -467,7 +502,7 @@ int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const S
 }
 
 // Walks the segments from the first SOS marker on: tables, scans, EOI.  0 ok, -1 malformed, -2 not covered.
-int decode_scans(const uint8_t *d, size_t n, Parsed &P, const JpegBlobHeader &H, int16_t *coef)
+int decode_scans(const uint8_t *d, size_t n, Parsed &P, const JpegBlobHeader &H, int16_t *coef, uint64_t *nzm)
 {
     const bool progressive = P.info.sof == 0xC2;
     size_t pos = P.sos_marker;
@@ -522,7 +557,7 @@ int decode_scans(const uint8_t *d, size_t n, Parsed &P, const JpegBlobHeader &H,
             if (work_blocks > 32ull * H.nblocks + 4096ull) return -2;
         }
         BitReader br{d, n, pos + len};
-        if (decode_scan(br, P, H, S, progressive, coef) != 0) return -1;
+        if (decode_scan(br, P, H, S, progressive, coef, nzm) != 0) return -1;
         ++scans;
         if (scans > 1000) return -2;
         // the next marker: either the reader ran into it, or it lies in the bytes not yet read
@@ -746,16 +781,26 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
     size_t nhalf = 0;                  // halfwords written
     if (!P.single_pass) {
         // progressive, or sequential in several scans: assemble all coefficients first (decode_scans), then pack them
-        std::vector<int16_t> all((size_t)H.nblocks * 64, 0);
-        rc = decode_scans(data, n, P, H, all.data());
+        // (the two arrays are the thread's: a worker that decodes progressive files one after the other pays for the pages once)
+        thread_local std::vector<int16_t> all;
+        thread_local std::vector<uint64_t> nzm;
+        all.assign((size_t)H.nblocks * 64, 0);
+        nzm.assign(H.nblocks, 0ull);
+        rc = decode_scans(data, n, P, H, all.data(), nzm.data());
+        // (a thread keeps the arrays of ordinary pictures between calls -- up to 64 MB, a 33-megapixel frame -- and gives a larger one back)
+        struct Release { std::vector<int16_t> &a; std::vector<uint64_t> &m; ~Release() { if (a.capacity() > ((size_t)64 << 20) / 2) { std::vector<int16_t>().swap(a); std::vector<uint64_t>().swap(m); } } } release_{all, nzm};
         if (rc) return rc;
         for (uint32_t i = 0; i < nc; ++i) memcpy(H.qt[i], P.qt[P.c[i].tq], 128); // (a table may have been redefined between scans)
         for (uint32_t bi = 0; bi < H.nblocks; ++bi) {
             const int16_t *blk = all.data() + (size_t)bi * 64;
-            int last = 63;
-            while (last > 0 && blk[last] == 0) --last;
+            // the last non-zero coefficient and "every coefficient behind the head fits a byte" from the mask of non-zero ones
+            const uint64_t nz = nzm[bi] & ~1ull;
+            const int last = nz ? 63 - __builtin_clzll(nz) : 0;
             bool narrow = true;
-            for (int k = (int)kJpegWideHead; k <= last; ++k) if (blk[k] < -128 || blk[k] > 127) { narrow = false; break; }
+            for (uint64_t m = kJpegWideHead < 64 ? nz & (~0ull << kJpegWideHead) : 0ull; m; m &= m - 1ull) {
+                const int k = __builtin_ctzll(m);
+                if (blk[k] < -128 || blk[k] > 127) { narrow = false; break; }
+            }
             const uint32_t cnt = (uint32_t)last + 1;
             if (nhalf >= ((size_t)1 << 25)) return -2; // block words carry 25 offset bits
             words[bi] = ((uint32_t)nhalf << 7) | ((cnt - 1u) << 1) | (narrow ? 0u : 1u);
