@@ -341,6 +341,20 @@ struct Scan {
     uint32_t ss = 0, se = 63, ah = 0, al = 0;
 };
 
+// `z` without its r lowest set bits (r <= 15): where a run of r zero coefficients ends.  One PDEP where the CPU has BMI2 (the run length
+// is data: a loop of r steps is a mispredicted branch per symbol of a refinement scan), the loop elsewhere.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__) // (this file is host code, but hipcc also runs its device pass over it)
+__attribute__((target("bmi2"))) static uint64_t select_from_bmi2(uint64_t z, unsigned r) { return __builtin_ia32_pdep_di(~0ull << r, z); }
+#endif
+static uint64_t select_from_loop(uint64_t z, unsigned r) { for (unsigned i = 0; i < r && z; ++i) z &= z - 1ull; return z; }
+static uint64_t (*const select_from)(uint64_t, unsigned) = [] {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("bmi2")) return &select_from_bmi2;
+#endif
+    return &select_from_loop;
+}();
+
 // One scan into coef[block][64] (zig-zag order).  0 ok, -1 malformed.
 // nzm[block]: bit k = coefficient k is non-zero (round 5).  The refinement scans of a progressive file visit every coefficient of every
 // block to ask "non-zero already?" -- 2 M look-ups per luma scan of a 1080p picture, most of them "no" -- and the packing step looked
@@ -458,8 +472,10 @@ int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const S
                                     for (int i = take - 1; i >= 0; --i) {
                                         const int kk = __builtin_ctzll(m);
                                         m &= m - 1ull;
-                                        int16_t &cf = b[kk];
-                                        if (((corr >> i) & 1u) && !(cf & p1)) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                                        // (no branch on the data: the bit, "this bit of the coefficient is still clear" and the sign as arithmetic)
+                                        const int cf = b[kk];
+                                        const int add = (int)((corr >> i) & 1u) & (int)!(cf & p1);
+                                        b[kk] = (int16_t)(cf + add * (cf >= 0 ? p1 : m1));
                                     }
                                     c -= take;
                                 }
@@ -480,8 +496,7 @@ int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const S
                                     }
                                     // skip r coefficients that are still zero, refining the non-zero ones met on the way: the walk ends AT the
                                     // (r + 1)-th zero from k on (or behind the band) -- r <= 15 zeros dropped from the mask of zeros, then its lowest bit
-                                    uint64_t z = ~nz & band & (~0ull << k);
-                                    for (int i = 0; i < r && z; ++i) z &= z - 1ull;
+                                    const uint64_t z = select_from(~nz & band & (~0ull << k), (unsigned)r);
                                     const int pos = z ? __builtin_ctzll(z) : (int)S.se + 1;
                                     refine_set(nz & band & (~0ull << k) & (pos >= 64 ? ~0ull : ((1ull << pos) - 1ull)));
                                     k = pos;
