@@ -5,6 +5,9 @@
 #include "fl_jpegdec.h"
 
 #include <string.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <map>
@@ -821,10 +824,26 @@ int jpeg_entropy_decode(const uint8_t *data, size_t n, uint8_t *blob, size_t cap
             words[bi] = ((uint32_t)nhalf << 7) | ((cnt - 1u) << 1) | (narrow ? 0u : 1u);
             uint8_t *o = coef + nhalf * 2;
             const uint32_t head = narrow ? (cnt < kJpegWideHead ? cnt : kJpegWideHead) : cnt;
-            memcpy(o, blk, head * 2);
             size_t bytes = head * 2;
-            for (uint32_t k = head; k < cnt; ++k) o[bytes++] = (uint8_t)(int8_t)blk[k];
-            if (bytes & 1u) o[bytes++] = 0;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+            if (narrow && cnt > head) {
+                // coefficients head .. 63 as bytes in one go (SSE2: part of x86-64), written at o + 2 head - head so that byte k lands at
+                // o[head + k]; behind the last coefficient they are zeros, the padding byte among them; the blob has 64 bytes of slack
+                // behind its last block (checked above) and the next block overwrites what this one wrote too far
+                for (int q = 0; q < 4; ++q) {
+                    const __m128i lo = _mm_loadu_si128(reinterpret_cast<const __m128i *>(blk + 16 * q)), hi = _mm_loadu_si128(reinterpret_cast<const __m128i *>(blk + 16 * q + 8));
+                    _mm_storeu_si128(reinterpret_cast<__m128i *>(o + head + 16 * q), _mm_packs_epi16(lo, hi));
+                }
+                memcpy(o, blk, head * 2);
+                bytes += cnt - head;
+                bytes += bytes & 1u;
+            } else
+#endif
+            {
+                memcpy(o, blk, head * 2);
+                for (uint32_t k = head; k < cnt; ++k) o[bytes++] = (uint8_t)(int8_t)blk[k];
+                if (bytes & 1u) o[bytes++] = 0;
+            }
             nhalf += bytes / 2;
         }
         size_t ncoef2 = (nhalf + 7) & ~(size_t)7;
