@@ -372,9 +372,29 @@ int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const S
     int pred[4] = {0, 0, 0, 0};
     uint32_t eobrun = 0, rst_left = P.info.restart_interval;
     const int p1 = 1 << S.al, m1 = -(1 << S.al);
+    // The bit buffer lives in registers for the length of the scan (br is visible to the out-of-line refill, so its members are memory to
+    // the compiler); `need`, `bit`, `bits`, `sym` keep br's meaning: zeros behind a marker or the end.  br gets it back around the restart
+    // handling and on every way out (Back).
+    uint64_t buf = br.buf;
+    int bc = br.cnt;
+    auto need = [&](int k) { if (bc < k) { br.buf = buf; br.cnt = bc; br.fill(); buf = br.buf; bc = br.cnt; } };
+    auto bit = [&]() -> int { need(1); const int v = (int)(buf >> 63); buf <<= 1; --bc; return v; };
+    auto bits = [&](int k) -> int { if (!k) return 0; need(k); const int v = (int)(buf >> (64 - k)); buf <<= k; bc -= k; return v; };
+    auto sym = [&](const Huff &h) -> int {
+        need(16);
+        const uint32_t f = h.fast[buf >> (64 - kFastBits)];
+        if (f) { buf <<= (f >> 8); bc -= (int)(f >> 8); return (int)(f & 255u); }
+        br.buf = buf; br.cnt = bc;
+        const int r = decode_sym(br, h);
+        buf = br.buf; bc = br.cnt;
+        return r;
+    };
+    struct Back { BitReader &br; uint64_t &buf; int &bc; ~Back() { br.buf = buf; br.cnt = bc; } } back_{br, buf, bc};
     for (uint32_t my = 0; my < mcus_y; ++my)
         for (uint32_t mx = 0; mx < mcus_x; ++mx) {
             if (P.info.restart_interval && rst_left == 0) {
+                br.buf = buf; br.cnt = bc;
+                struct Reload { BitReader &br; uint64_t &buf; int &bc; ~Reload() { buf = br.buf; bc = br.cnt; } } reload_{br, buf, bc};
                 if (!br.marker) {
                     br.pos -= (size_t)(br.cnt / 8);
                     if (br.pos + 2 > br.n || br.d[br.pos] != 0xFF || br.d[br.pos + 1] < 0xD0 || br.d[br.pos + 1] > 0xD7) return -1;
@@ -396,22 +416,7 @@ int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const S
                         const size_t bi = (size_t)c.block_base + (size_t)by * c.bw + bx;
                         int16_t *b = coef + bi * 64;
                         uint64_t nz = nzm[bi];
-                        // local bit buffer (see above); `need`, `bit`, `bits`, `sym` keep br's meaning: zeros behind a marker or the end
-                        uint64_t buf = br.buf;
-                        int bc = br.cnt;
-                        auto need = [&](int k) { if (bc < k) { br.buf = buf; br.cnt = bc; br.fill(); buf = br.buf; bc = br.cnt; } };
-                        auto bit = [&]() -> int { need(1); const int v = (int)(buf >> 63); buf <<= 1; --bc; return v; };
-                        auto bits = [&](int k) -> int { if (!k) return 0; need(k); const int v = (int)(buf >> (64 - k)); buf <<= k; bc -= k; return v; };
-                        auto sym = [&](const Huff &h) -> int {
-                            need(16);
-                            const uint32_t f = h.fast[buf >> (64 - kFastBits)];
-                            if (f) { buf <<= (f >> 8); bc -= (int)(f >> 8); return (int)(f & 255u); }
-                            br.buf = buf; br.cnt = bc;
-                            const int r = decode_sym(br, h);
-                            buf = br.buf; bc = br.cnt;
-                            return r;
-                        };
-                        struct Sync { BitReader &br; uint64_t &buf; int &bc; uint64_t *slot; uint64_t &nz; ~Sync() { br.buf = buf; br.cnt = bc; *slot = nz; } } sync_{br, buf, bc, nzm + bi, nz};
+                        struct Keep { uint64_t *slot; uint64_t &nz; ~Keep() { *slot = nz; } } keep_{nzm + bi, nz}; // (the mask goes back on every way out of the block)
                         if (!progressive) {
                             // sequential: DC difference, then the AC coefficients up to the end-of-block code (F.2.2)
                             const Huff &hd = P.ht[0][S.td[k0]], &ha = P.ht[1][S.ta[k0]];
