@@ -415,6 +415,17 @@ int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const S
                         const uint32_t bx = mx * nh + h, by = my * nv + v;
                         const size_t bi = (size_t)c.block_base + (size_t)by * c.bw + bx;
                         int16_t *b = coef + bi * 64;
+                        if (progressive && dc_scan) { // (the DC scans do not touch the masks)
+                            if (S.ah == 0) { // G.1.2.1 first DC scan: the difference, scaled by 2^Al
+                                const int t = sym(P.ht[0][S.td[k0]]);
+                                if (t < 0 || t > 11) return -1;
+                                { const int v = bits(t); pred[ci] += t ? (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v) : 0; }
+                                const int val = pred[ci] * (1 << S.al);
+                                if (val < -32768 || val > 32767) return -1;
+                                b[0] = (int16_t)val;
+                            } else if (bit()) b[0] = (int16_t)(b[0] | p1); // refinement: one more bit of every DC term
+                            continue;
+                        }
                         uint64_t nz = nzm[bi];
                         struct Keep { uint64_t *slot; uint64_t &nz; ~Keep() { *slot = nz; } } keep_{nzm + bi, nz}; // (the mask goes back on every way out of the block)
                         if (!progressive) {
@@ -437,15 +448,6 @@ int decode_scan(BitReader &br, const Parsed &P, const JpegBlobHeader &H, const S
                                 nz |= 1ull << k;
                                 ++k;
                             }
-                        } else if (dc_scan) {
-                            if (S.ah == 0) { // G.1.2.1 first DC scan: the difference, scaled by 2^Al
-                                const int t = sym(P.ht[0][S.td[k0]]);
-                                if (t < 0 || t > 11) return -1;
-                                { const int v = bits(t); pred[ci] += t ? (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v) : 0; }
-                                const int val = pred[ci] * (1 << S.al);
-                                if (val < -32768 || val > 32767) return -1;
-                                b[0] = (int16_t)val;
-                            } else if (bit()) b[0] = (int16_t)(b[0] | p1); // refinement: one more bit of every DC term
                         } else if (S.ah == 0) { // G.1.2.2 first AC scan of the band [ss, se]
                             if (eobrun) { --eobrun; continue; }
                             const Huff &ha = P.ht[1][S.ta[k0]];
