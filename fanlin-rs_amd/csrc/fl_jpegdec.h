@@ -75,7 +75,8 @@ struct alignas(16) JpegDecJob {
     uint32_t y_off, y_pitch;            // luma plane: byte offset in `planes`, bytes per row
     uint32_t cb_off, cr_off, c_pitch;   // chroma planes
     uint32_t c_rows;                    // chroma rows that hold samples (JpegComponent::hpx)
-    uint32_t pad_[3];
+    uint32_t c_w;                       // chroma samples per row (JpegComponent::w): the row's last pixel takes sample c_w - 1 as it is
+    uint32_t pad_[2];
 };
 // fills the fields behind `dst` from the header
 void jpeg_color_job(const JpegBlobHeader &H, JpegDecJob &j);

@@ -199,7 +199,12 @@ __device__ __forceinline__ void color_pixel(const JpegDecJob &jb, HdrPtr H, uint
     o[2] = (uint8_t)clamp8(s[0] + ((113 * cb) >> 6));
 }
 
-// Four interior pixels x0 .. x0 + 3 (x0 a multiple of 4, 4 <= x0, x0 + 6 <= W) of rows y and y + 1 (y even), SH x SV chroma sampling.
+// Pixels x0 .. x0 + 3 (x0 a multiple of 4; fewer at the end of a row whose width is not) of rows y and y + 1 (y even), SH x SV chroma sampling.
+// The ends of a row are part of it: zune-jpeg takes the nearest chroma sample as it is for the first pixel and for pixel 2 * c_w - 1
+// (chroma_at above), which is the interpolation formula with the missing neighbour replaced by the sample itself -- (3 a + a + 2) >> 2 = a --
+// so the group at x0 = 0 copies sample 0 over the one in front of the row and the last group copies sample c_w - 1 over those behind it.
+// (Until round 5 the two end groups of every row went through color_pixel, one pixel and one header walk at a time, and one wave in four
+// carried such a lane: more than half of the kernel's vector instructions.)
 template <int SH, int SV>
 __device__ __forceinline__ void color_group(const JpegDecJob &jb, uint32_t x0, uint32_t y, uint32_t rows)
 {
@@ -244,8 +249,12 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, uint32_t x0, u
                 a[1][k] = (3 * n + (int)((wd >> (8 * k)) & 255u) + 2) >> 2;
             }
         }
+        const uint32_t last = jb.c_w - ix; // slot of the row's last sample (slot s holds sample ix - 1 + s): >= 1 for every group that has a pixel
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) { // a[rr][1] = sample ix, a[rr][2] = ix + 1
+            a[rr][0] = x0 ? a[rr][0] : a[rr][1];
+            a[rr][2] = last < 2u ? a[rr][1] : a[rr][2];
+            a[rr][3] = last < 3u ? a[rr][2] : a[rr][3];
             cv[ci][rr][0] = (3 * a[rr][1] + a[rr][0] + 2) >> 2;
             cv[ci][rr][1] = (3 * a[rr][1] + a[rr][2] + 2) >> 2;
             cv[ci][rr][2] = (3 * a[rr][2] + a[rr][1] + 2) >> 2;
@@ -268,7 +277,13 @@ __device__ __forceinline__ void color_group(const JpegDecJob &jb, uint32_t x0, u
         typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
         typedef u32x3 __attribute__((aligned(1))) u32x3_unaligned;
         const u32x3 px = {b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24), b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24)};
-        *(__attribute__((address_space(1))) u32x3_unaligned *)((gptr8)jb.dst + ((size_t)(y + rr) * W + x0) * 3u) = px;
+        gptr8 o = (gptr8)jb.dst + ((size_t)(y + rr) * W + x0) * 3u;
+        if (x0 + 4u <= W) *(__attribute__((address_space(1))) u32x3_unaligned *)o = px;
+        else { // the last one to three pixels of a row
+#pragma unroll
+            for (uint32_t i = 0; i < 9u; ++i)
+                if (i < 3u * (W - x0)) o[i] = (uint8_t)b[i];
+        }
     }
 }
 
@@ -281,8 +296,8 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegDecJob *__res
     if (idx >= ngx * ngy) return;
     const uint32_t gy = idx / ngx, gx = idx - gy * ngx, x0 = 4u * gx, y = 2u * gy;
     const uint32_t rows = min(2u, Hh - y);
-    // the fast form: YCbCr, luma at full resolution, both chroma planes 2x2, 2x1 or 1x1 (jpeg_color_job), and the group away from the row's ends
-    const uint32_t mode = (x0 >= 4u && x0 + 6u <= W) ? jb.mode : 0u;
+    // the fast form: YCbCr, luma at full resolution, both chroma planes 2x2, 2x1 or 1x1 (jpeg_color_job)
+    const uint32_t mode = jb.mode;
     if (mode == 1u) color_group<2, 2>(jb, x0, y, rows);
     else if (mode == 2u) color_group<2, 1>(jb, x0, y, rows);
     else if (mode == 3u) color_group<1, 1>(jb, x0, y, rows);

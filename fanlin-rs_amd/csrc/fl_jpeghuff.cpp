@@ -606,14 +606,14 @@ int jpeg_parse_info(const uint8_t *data, size_t n, JpegInfo &info)
 void jpeg_color_job(const JpegBlobHeader &H, JpegDecJob &j)
 {
     j.mode = 0; j.width = H.width; j.height = H.height;
-    j.y_off = j.y_pitch = j.cb_off = j.cr_off = j.c_pitch = j.c_rows = 0;
+    j.y_off = j.y_pitch = j.cb_off = j.cr_off = j.c_pitch = j.c_rows = j.c_w = 0;
     if (H.nc == 3u && !H.is_rgb && H.comp[0].h == H.hmax && H.comp[0].v == H.vmax && H.comp[1].h == H.comp[2].h && H.comp[1].v == H.comp[2].v &&
         H.comp[1].h && H.comp[1].v) {
         const uint32_t sh = H.hmax / H.comp[1].h, sv = H.vmax / H.comp[1].v;
         j.mode = (sh == 2u && sv == 2u) ? 1u : (sh == 2u && sv == 1u) ? 2u : (sh == 1u && sv == 1u) ? 3u : 0u;
         j.y_off = H.comp[0].plane_off; j.y_pitch = H.comp[0].bw * 8u;
         j.cb_off = H.comp[1].plane_off; j.cr_off = H.comp[2].plane_off; j.c_pitch = H.comp[1].bw * 8u;
-        j.c_rows = H.comp[1].hpx;
+        j.c_rows = H.comp[1].hpx; j.c_w = H.comp[1].w;
     }
 }
 
