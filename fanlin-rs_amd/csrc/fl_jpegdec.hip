@@ -26,6 +26,10 @@ __constant__ uint8_t kUnzig[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 2
                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+// the LDS words (9-word row pitch) coefficients 8 t .. 8 t + 7 of the zig-zag sequence go to, one byte each: ONE 8-byte load per thread of the
+// fast form (eight byte loads from kUnzig before -- vector memory instructions, 720,000 of them per batch)
+__constant__ uint64_t kUnzigTile[8] = {0x0b03020a12090100ull, 0x05040c141c241b13ull, 0x262e362d251d150dull, 0x1f170f07060e161eull, 0x283038403f372f27ull, 0x3931292119101820ull, 0x332b222a323a4241ull, 0x46453d343c44433bull};
+
 constexpr int BLK_PITCH = 73; // 8 rows x 9 words + 1
 constexpr int BLOCKS_PER_WG = 32;
 
@@ -83,27 +87,30 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegDecJob *__rest
     // component of this block (block words are grouped by component)
     uint32_t ci = 0;
     if (live) { for (uint32_t k = 1; k < H->nc; ++k) if (b >= H->comp[k].block_base) ci = k; }
+    const uint32_t word = live ? reinterpret_cast<const uint32_t *>(jb.blob + H->blocks_off)[b] : 0u;
+    const uint32_t cnt = ((word >> 1) & 63u) + 1u, wide = word & 1u, first = word >> 7;
+    const uint8_t *data = jb.blob + H->coef_off + (size_t)first * 2u;
+    const int16_t *c16 = reinterpret_cast<const int16_t *>(data);
+    const int8_t *c8 = reinterpret_cast<const int8_t *>(data) + 2u * kJpegWideHead;
+    const bool full = live && wide && cnt == 64u && (reinterpret_cast<uintptr_t>(c16) & 15u) == 0u; // the same for the block's eight lanes
+    if (!full) { // (a full block writes all 64 words of its tile itself)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) my[t * 9 + k] = 0;
+        for (int k = 0; k < 9; ++k) my[t * 9 + k] = 0;
+    }
     __syncthreads();
     if (live) {
-        const uint32_t word = reinterpret_cast<const uint32_t *>(jb.blob + H->blocks_off)[b];
-        const uint32_t cnt = ((word >> 1) & 63u) + 1u, wide = word & 1u, first = word >> 7;
-        const uint8_t *data = jb.blob + H->coef_off + (size_t)first * 2u;
-        const int16_t *c16 = reinterpret_cast<const int16_t *>(data);
-        const int8_t *c8 = reinterpret_cast<const int8_t *>(data) + 2u * kJpegWideHead;
-        if (wide && cnt == 64u && (reinterpret_cast<uintptr_t>(c16) & 15u) == 0u) {
+        if (full) {
             // a full "wide" block (every block the device's entropy decoder writes): thread t takes coefficients 8 t .. 8 t + 7 of the
             // zig-zag sequence as ONE 16-byte load, their quantiser steps as another (the general loop: eight 2-byte loads each)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 cv = *(const __attribute__((address_space(1))) u32x4 *)(uintptr_t)(c16 + 8u * t);
             const u32x4 qv = *reinterpret_cast<const __attribute__((address_space(4))) u32x4 *>(&H->qt[ci][8u * t]);
+            const uint64_t where = kUnzigTile[t];
 #pragma unroll
             for (uint32_t e = 0; e < 8u; ++e) {
                 const int q = (int)(int16_t)(cv[e >> 1] >> (16u * (e & 1u)));
                 const int v = q * (int)(uint16_t)(qv[e >> 1] >> (16u * (e & 1u)));
-                const uint32_t nat = kUnzig[8u * t + e];
-                my[(nat >> 3) * 9 + (nat & 7u)] = v;
+                my[(uint32_t)(where >> (8u * e)) & 255u] = v;
             }
         } else
         for (uint32_t k = t; k < cnt; k += 8u) {

@@ -350,11 +350,17 @@ __global__ __launch_bounds__(256) void jh_init_kernel(const JhJob *jobs, uint32_
             reinterpret_cast<uint32_t *>(jb.blob)[k] = k == 0u ? 0x31444a46u : reinterpret_cast<const uint32_t *>(jb.stage)[k];
         if (threadIdx.x == 0) { *jb.err = 0u; jb.states[0] = 0ull; }
     }
-    if (b >= H->nblocks) return;
-    reinterpret_cast<uint32_t *>(jb.blob + H->blocks_off)[b] = ((b * 64u) << 7) | (63u << 1) | 1u;
-    uint4 *z = reinterpret_cast<uint4 *>(jb.blob + H->coef_off + (size_t)b * 128u);
+    const uint32_t nblocks = H->nblocks, first = blockIdx.x * blockDim.x;
+    if (first >= nblocks) return;
+    if (b < nblocks) reinterpret_cast<uint32_t *>(jb.blob + H->blocks_off)[b] = ((b * 64u) << 7) | (63u << 1) | 1u;
+    // the coefficients of the workgroup's 256 blocks are one stretch of 32 KB: consecutive lanes zero consecutive 16 bytes (a lane zeroing
+    // its own block's 128 bytes touched 64 different lines per store instruction: 32 us per batch of 13 files)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __attribute__((address_space(1))) u32x4 *z = (__attribute__((address_space(1))) u32x4 *)(uintptr_t)(jb.blob + H->coef_off + (size_t)first * 128u);
+    const uint32_t n16 = min(256u, nblocks - first) * 8u; // 16-byte pieces
 #pragma unroll
-    for (int k = 0; k < 8; ++k) z[k] = uint4{0u, 0u, 0u, 0u};
+    for (uint32_t k = 0; k < 8u; ++k)
+        if (k * 256u + threadIdx.x < n16) z[k * 256u + threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
 }
 
 // Speculative decoding and re-synchronisation.  A workgroup holds the states of its 256 subsequences in LDS and iterates on them:
@@ -473,53 +479,78 @@ __global__ __launch_bounds__(256) void jh_sync_kernel(const JhJob *jobs, const J
 __global__ __launch_bounds__(256) void jh_scan_kernel(const JhJob *jobs)
 {
     // per thread: blocks, the three DC sums, and whether a restart lies in its stretch (then the sums are those behind the last one:
-    // bit 31 of a subsequence's block count says its walk passed an interval start, fl_jpeghuff_dev.hip jh_walk)
+    // bit 31 of a subsequence's block count says its walk passed an interval start, fl_jpeghuff_dev.hip jh_walk).  Stretches combine as
+    // (a, b) -> blocks a + b, sums b's own if b holds a restart, else a + b: associative, so the 256 stretches are scanned in eight doubling
+    // steps (until round 5 thread 0 walked over them: 256 dependent steps, half of the kernel's 32 us).
     __shared__ int32_t part[256][5];
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    typedef i32x4 __attribute__((aligned(4))) i32x4_a4;
     const JhJob jb = jobs[blockIdx.x];
-    const uint32_t per = (jb.nsub + 255u) / 256u, lo = threadIdx.x * per, hi = min(lo + per, jb.nsub);
-    auto add = [&](int32_t (&s)[4], const int32_t *cnt, int32_t *any) {
-        const bool restarted = cnt[0] < 0;
-        s[0] += cnt[0] & 0x7fffffff;
-#pragma unroll
-        for (int k = 1; k < 4; ++k) s[k] = restarted ? cnt[k] : s[k] + cnt[k];
+    const uint32_t per = (jb.nsub + 255u) / 256u, lo = min(threadIdx.x * per, jb.nsub), hi = min(lo + per, jb.nsub);
+    const i32x4_a4 *counts = reinterpret_cast<const i32x4_a4 *>(jb.counts);
+    i32x4_a4 *prefix = reinterpret_cast<i32x4_a4 *>(jb.prefix);
+    auto add = [&](int32_t (&s)[4], const i32x4 &cnt, int32_t *any) {
+        const bool restarted = cnt.x < 0;
+        s[0] += cnt.x & 0x7fffffff;
+        s[1] = restarted ? cnt.y : s[1] + cnt.y; s[2] = restarted ? cnt.z : s[2] + cnt.z; s[3] = restarted ? cnt.w : s[3] + cnt.w;
         if (any && restarted) *any = 1;
     };
     int32_t s[4] = {0, 0, 0, 0}, any = 0;
     bool unsettled = false;
-    for (uint32_t i = lo; i < hi; ++i) {
-        unsettled |= jb.used[i] != jb.states[i];
-        add(s, jb.counts + i * 4u, &any);
+    for (uint32_t i = lo; i < hi; i += 4u) { // (four subsequences' loads under way at once: the stretch is ~10 long and every load a trip to L2)
+        i32x4 cn[4]; uint64_t us[4], st[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t ii = min(i + u, hi - 1u);
+            cn[u] = counts[ii]; us[u] = jb.used[ii]; st[u] = jb.states[ii];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u)
+            if (i + u < hi) { unsettled |= us[u] != st[u]; add(s, cn[u], &any); }
     }
     if (unsettled) atomicOr(jb.err, 1u);
+    int32_t mine[5] = {s[0], s[1], s[2], s[3], any};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) part[threadIdx.x][k] = s[k];
-    part[threadIdx.x][4] = any;
+    for (int k = 0; k < 5; ++k) part[threadIdx.x][k] = mine[k];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int32_t run[4] = {0, 0, 0, 0};
-        for (int t = 0; t < 256; ++t) {
-            const int32_t v[4] = {part[t][0], part[t][1], part[t][2], part[t][3]};
-            const bool restarted = part[t][4] != 0;
+    for (uint32_t d = 1; d < 256u; d <<= 1) { // inclusive scan
+        int32_t l[5] = {0, 0, 0, 0, 0};
+        const bool has = threadIdx.x >= d;
+        if (has) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) part[t][k] = run[k];
-            run[0] += v[0];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) run[k] = restarted ? v[k] : run[k] + v[k];
+            for (int k = 0; k < 5; ++k) l[k] = part[threadIdx.x - d][k];
         }
+        __syncthreads();
+        if (has) {
+            mine[0] += l[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) mine[k] = mine[4] ? mine[k] : l[k] + mine[k];
+            mine[4] |= l[4];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) part[threadIdx.x][k] = mine[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 255u) {
         // The segment must hold every block of the scan.  A truncated file (or one cut by a stray marker) whose last walk stops at the
         // segment's end before it meets the padding raises no invalid-code error, and its missing blocks would stay zero -- the host
         // decoder feeds zero bits past the end and carries the DC predictors on, i.e. decodes different pixels: error bit 4, the host
         // decodes this file.
         const JpegHuffStage *S = reinterpret_cast<const JpegHuffStage *>(jb.stage + sizeof(JpegBlobHeader));
-        if (run[0] < (int32_t)S->total_blocks) atomicOr(jb.err, 4u);
+        if (mine[0] < (int32_t)S->total_blocks) atomicOr(jb.err, 4u);
     }
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] = part[threadIdx.x][k];
-    for (uint32_t i = lo; i < hi; ++i) {
+    for (int k = 0; k < 4; ++k) s[k] = threadIdx.x ? part[threadIdx.x - 1u][k] : 0; // exclusive: everything in front of this stretch
+    for (uint32_t i = lo; i < hi; i += 4u) {
+        i32x4 cn[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) jb.prefix[i * 4u + k] = s[k];
-        add(s, jb.counts + i * 4u, nullptr);
+        for (uint32_t u = 0; u < 4u; ++u) cn[u] = counts[min(i + u, hi - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u)
+            if (i + u < hi) {
+                prefix[i + u] = i32x4{s[0], s[1], s[2], s[3]};
+                add(s, cn[u], nullptr);
+            }
     }
 }
 
