@@ -17,9 +17,17 @@ hipError_t DeviceBuf::reserve(size_t bytes)
 {
     if (bytes <= cap) return hipSuccess;
     if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-    size_t want = std::max(bytes, (size_t)1 << 20);
+    // Twice what is asked for: hipFree + hipMalloc wait for the whole device (every lane's stream), 10-20 ms for everything in flight, and a
+    // buffer that grew to exactly each new largest batch did so dozens of times in a server's first thousand requests
+    // (tools/experiments/jh_tail.sh: the slow requests of a run were the batches that met a growth).  288 GB of HBM pay for the slack.
+    size_t want = std::max(bytes > ((size_t)1 << 34) ? bytes : 2 * bytes, (size_t)1 << 20);
     want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
     hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && want > bytes + ((size_t)1 << 20)) { // no room for the slack: what is asked for
+        (void)hipGetLastError();
+        want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        e = hipMalloc(&p, want);
+    }
     if (e != hipSuccess) { p = nullptr; return e; }
     cap = want;
     return hipSuccess;
@@ -29,9 +37,14 @@ hipError_t PinnedBuf::reserve(size_t bytes)
 {
     if (bytes <= cap) return hipSuccess;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-    size_t want = std::max(bytes, (size_t)1 << 16);
+    size_t want = std::max(bytes > ((size_t)1 << 32) ? bytes : bytes + bytes / 2, (size_t)1 << 16); // (page-locked memory is dearer: half as much again)
     want = (want + 4095) & ~(size_t)4095;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess && want > bytes + 4096) {
+        (void)hipGetLastError();
+        want = (bytes + 4095) & ~(size_t)4095;
+        e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    }
     if (e != hipSuccess) { p = nullptr; return e; }
     cap = want;
     return hipSuccess;

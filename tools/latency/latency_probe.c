@@ -37,10 +37,17 @@ static uint8_t **g_dst; /* one result buffer per caller thread, allocated BEFORE
                            freed) them inside the timed region, and 64 hipHostMalloc / hipHostFree calls behind the driver's
                            lock were what made the page-locked run look slower than the pageable one */
 
+/* The caller threads live through both phases, as a server's worker threads do: until round 5 the timed phase started 64 NEW threads, and the
+   first hundred-odd requests of every run (each thread's first call: its thread-local decode arrays, its first pages) took 20-30 ms -- the
+   whole p99 of the run was that start (tools/experiments/jh_tail.sh). */
+static pthread_barrier_t g_phase;
+
 static void *caller(void *arg)
 {
     uint8_t *dst = g_dst[(size_t)(uintptr_t)arg];
     const uint32_t fl = g_pinned ? FLGPU_IMG_PINNED : 0u;
+    for (int phase = 0; phase < 2; ++phase) {
+    if (phase == 1) { pthread_barrier_wait(&g_phase); /* warm-up done; main resets the counters */ pthread_barrier_wait(&g_phase); }
     for (;;) {
         pthread_mutex_lock(&g_mu);
         const int i = g_next++;
@@ -50,6 +57,7 @@ static void *caller(void *arg)
         const double t0 = now_ms();
         if (flgpu_transform(g_ctx, &in, &g_params, &out) != FLGPU_OK) { pthread_mutex_lock(&g_mu); g_failed++; pthread_mutex_unlock(&g_mu); }
         g_lat[i] = now_ms() - t0;
+    }
     }
     return NULL;
 }
@@ -103,21 +111,22 @@ int main(int argc, char **argv)
         g_src[k] = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, n) : malloc(n));
         for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; g_src[k][i] = (uint8_t)(s >> 24); }
     }
-    g_lat = (double *)calloc((size_t)(g_requests > threads * 2 ? g_requests : threads * 2), sizeof(double));
+    g_lat = (double *)calloc((size_t)(g_requests > threads * 16 ? g_requests : threads * 16), sizeof(double));
     pthread_t *ts = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
     g_dst = (uint8_t **)calloc((size_t)threads, sizeof(uint8_t *));
     for (int t = 0; t < threads; ++t) g_dst[t] = (uint8_t *)(g_pinned ? flgpu_host_alloc(g_ctx, g_plan.max_out_bytes) : malloc(g_plan.max_out_bytes));
     /* warm up: tables, pinned blocks, lanes */
     const int total = g_requests;
-    g_requests = threads * 2; g_next = 0;
+    g_requests = threads * 16; g_next = 0; /* until the staging pools have every block they will use: a page-locked allocation takes 80 ms and holds up every copy */
+    pthread_barrier_init(&g_phase, NULL, (unsigned)threads + 1u);
     for (int t = 0; t < threads; ++t) pthread_create(&ts[t], NULL, caller, (void *)(uintptr_t)t);
-    for (int t = 0; t < threads; ++t) pthread_join(ts[t], NULL);
+    pthread_barrier_wait(&g_phase); /* every caller has left the warm-up loop */
     g_requests = total; g_next = 0;
     flgpu_reset_stats(g_ctx);
     struct rusage ru0, ru1;
     getrusage(RUSAGE_SELF, &ru0);
     const double t0 = now_ms();
-    for (int t = 0; t < threads; ++t) pthread_create(&ts[t], NULL, caller, (void *)(uintptr_t)t);
+    pthread_barrier_wait(&g_phase);
     for (int t = 0; t < threads; ++t) pthread_join(ts[t], NULL);
     const double wall = now_ms() - t0;
     getrusage(RUSAGE_SELF, &ru1);
@@ -127,6 +136,10 @@ int main(int argc, char **argv)
     const double user_ms = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) * 1e3 + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-3;
     flgpu_stats stats;
     flgpu_get_stats(g_ctx, &stats);
+    if (getenv("FL_PROBE_DUMP")) { /* latencies in request order, for looking at where the slow ones are */
+        FILE *f = fopen(getenv("FL_PROBE_DUMP"), "w");
+        if (f) { for (int i = 0; i < g_requests; ++i) fprintf(f, "%.3f\n", g_lat[i]); fclose(f); }
+    }
     qsort(g_lat, (size_t)g_requests, sizeof(double), cmp);
     printf("{\"p50_ms\": %.3f, \"p99_ms\": %.3f, \"requests\": %d, \"caller_threads\": %d, \"images_per_s\": %.1f, \"queue_flushes\": %llu, "
            "\"failed\": %d, \"pinned\": %d, \"jpeg_sources\": %llu, \"mean_file_bytes\": %.0f, \"mean_upload_bytes\": %.0f, \"entropy_decoded_on_device\": %llu, \"device_entropy_retries\": %llu, \"host_cpu_ms_per_request\": %.3f, \"host_cpu_user_ms_per_request\": %.3f, "
