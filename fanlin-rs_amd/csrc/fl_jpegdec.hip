@@ -10,8 +10,8 @@
 // jpeg_color_kernel  round 5: one thread = 4 pixels x 2 rows of a three-component YCbCr picture (4:2:0, 4:2:2 or 4:4:4) -- the luma
 //                    and the three chroma rows the pair needs as unaligned dword loads, Cb / Cr interpolated (separable
 //                    (3a + b + 2) >> 2 steps, vertical first), converted, stored as three dwords per row; a flat grid over
-//                    (width / 4) x (height / 2) groups, so no lane idles on a 1920-pixel row.  Pixels next to the left and right
-//                    edges, grayscale, CMYK / YCCK, RGB and unusual samplings take the pixel-wise form (round 2's kernel).
+//                    (width / 4) x (height / 2) groups, so no lane idles on a 1920-pixel row.  The ends of a row are part of the
+//                    fast form (color_group); grayscale, CMYK / YCCK, RGB and unusual samplings take the pixel-wise form (round 2's kernel).
 // Both are memory-light (a few MB per picture) and sit in front of the resample kernel, whose input they produce in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
