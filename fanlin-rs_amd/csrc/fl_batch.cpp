@@ -678,12 +678,29 @@ int run_batch_device(flgpu_ctx *c, size_t n, const flgpu_image *srcs, const flgp
             if (w.pre == PRE_NONE && !force_generic && !no_mfma && (w.sw * w.cs) % 16u == 0 && (uintptr_t)w.src % 16u == 0 &&
                 (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0) && w.sw * w.cs >= 64u) {
                 Job jtmp; fill_job(w, jtmp);
-                uint32_t nbands = 1;
-                if (forced_bands) nbands = forced_bands;
-                else if (n_resample < 128) nbands = (uint32_t)std::min<size_t>(16, (256 + n_resample * 3 - 1) / (n_resample * 3));
                 MfmaPlan *mp = get_mfma_plan(c, w.vk, *w.va, w.hk, *w.ha, jtmp.cx, jtmp.cy, jtmp.cw, jtmp.ch, w.cs, mfma_arith);
                 if (mp->arena_full || c->h_arena.size() >= c->arena_cap_words - 1024) { full = true; break; }
-                if (mp->ok) { w.s1 = S1_MFMA; w.mplan = mp; w.mitems = &mp->items_for(nbands); continue; }
+                if (mp->ok) {
+                    uint32_t nbands = 1;
+                    if (forced_bands) nbands = forced_bands;
+                    else if (n_resample < 128) {
+                        // A small launch: bands of rows so that every CU has an item -- and so that the items come out in whole rounds of the
+                        // workgroups.  (Until round 5: ceil(256 / (3 n)) bands; 13 files x 3 strips x 7 bands = 273 items on 256 workgroups,
+                        // i.e. two rounds of items a seventh of a strip long where one round of sixths does: 84 us per batch of file requests.)
+                        // The cost of a band count: rounds x (the longest item's K-blocks -- the bands' halos are in there -- + a transition's two).
+                        const uint64_t G = std::max(1u, c->cu_count);
+                        uint64_t best = ~0ull;
+                        for (uint32_t b = 1; b <= std::min<uint32_t>(16u, (uint32_t)mp->tiles.size()); ++b) {
+                            const std::vector<MfmaItem> &cand = mp->items_for(b);
+                            uint32_t longest = 0;
+                            for (const MfmaItem &mi : cand) longest = std::max(longest, mi.kb1 - mi.kb0);
+                            const uint64_t cost = (((uint64_t)n_resample * cand.size() + G - 1) / G) * (longest + 2u);
+                            if (cost < best) { best = cost; nbands = b; }
+                        }
+                    }
+                    w.s1 = S1_MFMA; w.mplan = mp; w.mitems = &mp->items_for(nbands);
+                    continue;
+                }
             }
             if (use_wtile && (w.pre == PRE_NONE || w.pre == PRE_INVERT) && 2u * w.sh >= 5u * w.plan.resized_h && 10u * w.sh < 34u * w.plan.resized_h &&
                 (!w.plan.letterboxed || (uintptr_t)w.s1_dst % 4u == 0)) { // (ratio 2.5 .. 3.4 and no streaming matrix-pipe plan: unaligned rows, a pre-op, a refused geometry)

@@ -143,11 +143,11 @@ int main(int argc, char **argv)
     qsort(g_lat, (size_t)g_requests, sizeof(double), cmp);
     printf("{\"p50_ms\": %.3f, \"p99_ms\": %.3f, \"requests\": %d, \"caller_threads\": %d, \"images_per_s\": %.1f, \"queue_flushes\": %llu, "
            "\"failed\": %d, \"pinned\": %d, \"jpeg_sources\": %llu, \"mean_file_bytes\": %.0f, \"mean_upload_bytes\": %.0f, \"entropy_decoded_on_device\": %llu, \"device_entropy_retries\": %llu, \"host_cpu_ms_per_request\": %.3f, \"host_cpu_user_ms_per_request\": %.3f, "
-           "\"path\": \"flgpu_transform from C threads, host buffers (H2D + kernels + D2H), request-batching queue\"}\n",
+           "\"warmup_requests\": %d, \"path\": \"flgpu_transform from C threads that live through warm-up and timed phase, host buffers (H2D + kernels + D2H), request-batching queue\"}\n",
            g_lat[g_requests / 2], g_lat[(int)(g_requests * 0.99) < g_requests ? (int)(g_requests * 0.99) : g_requests - 1], g_requests, threads,
            g_requests / wall * 1e3, (unsigned long long)stats.queue_flushes, g_failed, g_pinned, (unsigned long long)stats.jpeg_sources,
            stats.jpeg_sources ? (double)stats.jpeg_file_bytes / (double)stats.jpeg_sources : 0.0, stats.jpeg_sources ? (double)stats.jpeg_upload_bytes / (double)stats.jpeg_sources : 0.0,
-           (unsigned long long)stats.jpeg_device_huffman, (unsigned long long)stats.jpeg_device_huffman_retries, cpu_ms / g_requests, user_ms / g_requests);
+           (unsigned long long)stats.jpeg_device_huffman, (unsigned long long)stats.jpeg_device_huffman_retries, cpu_ms / g_requests, user_ms / g_requests, threads * 16);
     flgpu_destroy(g_ctx);
     return g_failed ? 6 : 0;
 }
