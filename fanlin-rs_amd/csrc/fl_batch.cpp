@@ -517,11 +517,20 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
     return FLGPU_OK;
 }
 
-int entropy_failures(flgpu_ctx *c, size_t n, std::vector<uint8_t> &bad, hipStream_t st)
+// Enqueues the copy of the device entropy decoder's error words (final once its kernels have run): a caller that waits for the stream anyway
+// asks for them in front of that wait and passes fetched = true below.
+int entropy_failures_fetch(flgpu_ctx *c, size_t n, hipStream_t st)
+{
+    if (!c->last_jh_n || c->last_jh_slot.size() != n) return FLGPU_OK;
+    FL_HIP(c, hipMemcpyAsync(c->h_jherr.p, c->d_jherr.p, (size_t)c->last_jh_n * 4, hipMemcpyDeviceToHost, st), "device entropy decode: error words D2H");
+    return FLGPU_OK;
+}
+
+int entropy_failures(flgpu_ctx *c, size_t n, std::vector<uint8_t> &bad, hipStream_t st, bool fetched)
 {
     bad.assign(n, 0);
     if (!c->last_jh_n || c->last_jh_slot.size() != n) return 0;
-    if (hipMemcpyAsync(c->h_jherr.p, c->d_jherr.p, (size_t)c->last_jh_n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    if (!fetched && (hipMemcpyAsync(c->h_jherr.p, c->d_jherr.p, (size_t)c->last_jh_n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
         c->set_error("device entropy decode: error words D2H");
         return -FLGPU_ERR_DEVICE;
     }

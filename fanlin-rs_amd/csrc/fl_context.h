@@ -350,7 +350,8 @@ int decode_jpeg_sources(flgpu_ctx *c, size_t n, flgpu_image *dsrc, const JpegSrc
 // After the batch decode_jpeg_sources fed has completed on `st`: bad[i] = 1 where the device entropy decoder gave up on picture i
 // (its states did not settle, or the stream holds an invalid code word): the caller decodes that file on the host instead.
 // Returns the number of such pictures, or a negative FLGPU_ERR_* .
-int entropy_failures(flgpu_ctx *c, size_t n, std::vector<uint8_t> &bad, hipStream_t st);
+int entropy_failures(flgpu_ctx *c, size_t n, std::vector<uint8_t> &bad, hipStream_t st, bool fetched = false);
+int entropy_failures_fetch(flgpu_ctx *c, size_t n, hipStream_t st);
 // internal status of a queued request: run it again with the host entropy decoder
 constexpr int FL_STATUS_RETRY_HOST_HUFFMAN = 1000;
 // Host half for one source: parses + Huffman-decodes `src` (a JPEG file) into `blob`; validates the declared size.

@@ -31,6 +31,22 @@ for f in glob.glob("$R/gpurun_out/jh_hip/**/jh_hip_api_trace.csv", recursive=Tru
     print("process %.0f ms; calls other than allocations that took more than 3 ms (start ms, duration ms):" % end)
     for r in sorted((r for r in rows if r["Function"] not in names and dur(r) > 3.0), key=at):
         print("  %9.1f  %8.2f  %-28s tid %s" % (at(r), dur(r), r["Function"], r["Thread_Id"]))
+    # one lane's cycle in the middle of the run: every call of the thread that launches most kernels, between two of its stream synchronisations
+    from collections import Counter
+    lane = Counter(r["Thread_Id"] for r in rows if r["Function"] == "hipLaunchKernel").most_common(1)[0][0]
+    mine = sorted((r for r in rows if r["Thread_Id"] == lane), key=at)
+    syncs = [i for i, r in enumerate(mine) if r["Function"] == "hipStreamSynchronize"]
+    if len(syncs) > 40:
+        a, b = syncs[len(syncs) // 2], syncs[len(syncs) // 2 + 2]
+        base = at(mine[a]) + dur(mine[a])
+        print("lane thread %s, two cycles from the middle of the run (ms after the first one's start, duration ms):" % lane)
+        prev = None
+        for r in mine[a:b + 1]:
+            # runs of the same call are folded
+            if prev and prev[0] == r["Function"] and r["Function"] != "hipStreamSynchronize": prev[2] += 1; prev[3] = at(r) + dur(r) - base; continue
+            if prev: print("  %8.3f .. %8.3f  %-24s x %d" % (prev[1], prev[3], prev[0], prev[2]))
+            prev = [r["Function"], at(r) - base, 1, at(r) + dur(r) - base]
+        if prev: print("  %8.3f .. %8.3f  %-24s x %d" % (prev[1], prev[3], prev[0], prev[2]))
     alloc = [r for r in rows if r["Function"] in names]
     hist = {}
     for r in alloc: hist[int(at(r) // 50) * 50] = hist.get(int(at(r) // 50) * 50, 0) + 1
