@@ -80,6 +80,7 @@ int main(int argc, char **argv)
     cfg.device = -1;
     cfg.queue_lanes = argc > 7 ? (uint32_t)atoi(argv[7]) : 0;
     cfg.max_batch = argc > 8 ? (uint32_t)atoi(argv[8]) : 0;
+    if (getenv("FL_PROBE_FLUSH_US")) cfg.flush_timeout_us = (uint32_t)atoi(getenv("FL_PROBE_FLUSH_US")); /* the queue's flush timer (experiments) */
     g_pinned = argc > 9 ? atoi(argv[9]) : 0;
     int st = 0;
     g_ctx = flgpu_create(&cfg, &st);
