@@ -1,7 +1,8 @@
 """One-off stress of the request queue with JPEG FILES as sources (not part of the test-suite): good files with and without restart intervals and damaged
 ones, sent by many threads at once through flgpu_transform (device entropy decoding under load, host retries for the damaged ones, batches that mix all of
 them), then the same requests one at a time.  Every request must come out the same both times: the same error, or the same bytes.
-   python tests/tools/fuzz_jpeg_concurrent.py <requests> <threads> <seed> [always]"""
+   python tests/tools/fuzz_jpeg_concurrent.py <requests> <threads> <seed> [always|- [query]]   (a query with a large target, e.g. w=1000&h=800,
+sends streams longer than the 32 KB the queue fetches in front of its wait)"""
 import io
 import os
 import sys
@@ -36,12 +37,13 @@ for i in range(n):
 
 st = fl.State(device=0)
 st.debug_set("device_huffman_min_bytes", 0)
-if len(sys.argv) > 4: st.debug_set("device_huffman_always", 1)   # a fourth argument: every file the device takes goes to it, busy CPUs or not
+QUERY = sys.argv[5] if len(sys.argv) > 5 else "w=120&h=90"
+if len(sys.argv) > 4 and sys.argv[4] != "-": st.debug_set("device_huffman_always", 1)   # a fourth argument: every file the device takes goes to it, busy CPUs or not
 
 
 def run(i):
     try:
-        out = st.process_jpeg(files[i], "w=120&h=90")
+        out = st.process_jpeg(files[i], QUERY)
         return (0, bytes(out[2]) if isinstance(out[2], (bytes, bytearray)) else np.asarray(out[2]).tobytes())
     except fl.FanlinError as e:
         return (e.status, b"")
