@@ -131,6 +131,7 @@ struct Request {
     uint64_t file_bytes = 0;
     int status = 0;
     bool done = false;
+    std::condition_variable cv; // the caller waits here (qmu): a lane wakes the callers of ITS batch, not every waiting caller
 };
 
 // Test and experiment switches of a context (flgpu_debug_set / flgpu_debug_get, include/fanlin_gpu.h).  One block per ROOT context, shared
@@ -279,7 +280,7 @@ struct flgpu_ctx {
     std::condition_variable dec_cv;
     uint32_t decoding = 0, dec_limit = 0;
     std::mutex qmu;
-    std::condition_variable qcv, qdone;
+    std::condition_variable qcv;
     std::deque<fl::Request *> queue;
     bool stop = false;
     bool worker_started = false;

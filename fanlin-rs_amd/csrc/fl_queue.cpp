@@ -243,9 +243,10 @@ void worker_main(flgpu_ctx *c, flgpu_ctx *lane, uint32_t slot)
         }
         {
             std::lock_guard<std::mutex> lk(c->qmu);
-            for (Request *r : batch) { if (rc) r->status = rc; r->done = true; }
+            // (notified under the lock: a caller that has seen `done` returns and its Request, cv included, is gone.  Until round 5 one condition
+            // variable for all callers: every finished batch woke all ~50 waiting threads to look at their flags, one after the other on qmu)
+            for (Request *r : batch) { if (rc) r->status = rc; r->done = true; r->cv.notify_one(); }
         }
-        c->qdone.notify_all();
     }
 }
 
@@ -524,7 +525,7 @@ try {
     c->qcv.notify_all();
     {
         std::unique_lock<std::mutex> lk(c->qmu);
-        c->qdone.wait(lk, [&] { return r.done; });
+        r.cv.wait(lk, [&] { return r.done; });
     }
     if (r.status == FLGPU_OK && !dst_pinned) memcpy(dst->data, r.out.p, std::min<uint64_t>(dst->bytes, r.out_bytes));
     give_back();
