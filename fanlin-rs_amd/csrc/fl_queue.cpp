@@ -94,6 +94,11 @@ uint32_t usable_cpus()
 }
 
 uint32_t lanes_per_device(const flgpu_ctx *c) { return std::min<uint32_t>(std::max<uint32_t>(c->cfg.queue_lanes ? c->cfg.queue_lanes : 4u, 1u), 8u); }
+// Overflow lanes (round 5): with the default shape, four more lanes per device that only ever take a FULL batch that is waiting while the four regular
+// lanes are busy.  At 64 callers they sleep (the regular lanes' 4 x 16 places hold everybody: more lanes there only made smaller batches,
+// profiles/r05_queue_shape.txt); at 128 callers the queue holds full batches and the device has room for them: 30.3 k -> 36-37 k files/s
+// (tools/experiments/jh_capacity.sh).  A caller that sets queue_lanes gets exactly that many lanes and no overflow lanes.
+uint32_t overflow_lanes_per_device(const flgpu_ctx *c) { return c->cfg.queue_lanes ? 0u : 4u; }
 uint32_t batch_per_device(const flgpu_ctx *c) { return c->cfg.max_batch ? c->cfg.max_batch : 16u; } // measured (round 5, tools/experiments/jh_lanes.sh, 64 callers on 16 cores): 4 lanes x 16 against round 4's 3 x 32 -- the same or more requests per second for files, pixels and blurred pixels, p99 14-19 ms -> 12-14 ms; equal at 128 callers
 
 // One shard of a flushed batch on one lane: sources already sit in pinned blocks (copied there by the calling
@@ -183,7 +188,7 @@ int run_batch_queued(flgpu_ctx *c, std::vector<Request *> &batch)
 }
 
 // `slot` = index of this lane's device in the context's device list (0 for a single-device context)
-void worker_main(flgpu_ctx *c, flgpu_ctx *lane, uint32_t slot)
+void worker_main(flgpu_ctx *c, flgpu_ctx *lane, uint32_t slot, bool overflow)
 {
     const uint32_t ndev = c->n_dev();
     const size_t max_batch = (size_t)batch_per_device(c) * ndev;
@@ -192,7 +197,7 @@ void worker_main(flgpu_ctx *c, flgpu_ctx *lane, uint32_t slot)
         std::vector<Request *> batch;
         {
             std::unique_lock<std::mutex> lk(c->qmu);
-            c->qcv.wait(lk, [&] { return c->stop || !c->inbox[slot].empty() || (!c->collecting && !c->queue.empty()); });
+            c->qcv.wait(lk, [&] { return c->stop || !c->inbox[slot].empty() || (!c->collecting && (overflow ? c->queue.size() >= max_batch : !c->queue.empty())); });
             if (!c->inbox[slot].empty()) {
                 // a shard another worker cut for this device
                 batch.swap(c->inbox[slot].front());
@@ -200,6 +205,7 @@ void worker_main(flgpu_ctx *c, flgpu_ctx *lane, uint32_t slot)
             } else {
                 if (c->queue.empty()) { if (c->stop) return; continue; }
                 if (c->collecting) continue;
+                if (overflow && !c->stop && c->queue.size() < max_batch) continue; // (shutting down, it drains the queue like any lane)
                 c->collecting = true;
                 // a first request arrived: wait for company -- but only while somebody is actually on the way (a caller
                 // staging its source), and never beyond the flush timer or a full batch.  A lone caller is served at once.
@@ -254,7 +260,7 @@ void worker_main(flgpu_ctx *c, flgpu_ctx *lane, uint32_t slot)
 int start_workers(flgpu_ctx *c)
 {
     if (c->worker_started) return FLGPU_OK;
-    const uint32_t ndev = c->n_dev(), per = lanes_per_device(c);
+    const uint32_t ndev = c->n_dev(), regular = lanes_per_device(c), per = std::min<uint32_t>(regular + overflow_lanes_per_device(c), 8u);
     for (uint32_t i = 0; i < per * ndev; ++i) {
         const uint32_t slot = i % ndev;
         flgpu_ctx *l = create_child(c, c->devices.empty() ? c->device : c->devices[slot]);
@@ -269,7 +275,7 @@ int start_workers(flgpu_ctx *c)
         c->lanes.clear();
         return FLGPU_ERR_OOM;
     }
-    for (size_t i = 0; i < c->lanes.size(); ++i) c->workers.emplace_back(worker_main, c, c->lanes[i], (uint32_t)(i % ndev));
+    for (size_t i = 0; i < c->lanes.size(); ++i) c->workers.emplace_back(worker_main, c, c->lanes[i], (uint32_t)(i % ndev), i / ndev >= regular);
     c->worker_started = true;
     return FLGPU_OK;
 }

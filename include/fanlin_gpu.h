@@ -155,7 +155,9 @@ typedef struct flgpu_config {
     uint32_t flush_timeout_us; /* request-queue flush timer (0 = default 200) */
     uint32_t profile;          /* 1 = bracket kernels with HIP events and report them in flgpu_stats */
     uint32_t queue_lanes;      /* flgpu_transform: batches kept in flight at once PER DEVICE (each lane has its own stream
-                                  and scratch, so one batch's PCIe transfers overlap another's kernels); 0 = default 4 */
+                                  and scratch, so one batch's PCIe transfers overlap another's kernels); 0 = default: 4 lanes, plus 4 overflow
+                                  lanes that only take a full batch that is waiting while those four are busy (more callers than
+                                  4 x max_batch); a value of 1..8 = exactly that many lanes */
     uint32_t n_devices;        /* 0 or 1: one GPU (`device`).  2..FLGPU_MAX_DEVICES: ONE context for the GPUs of a node, as
                                   the reference shares one Arc<State> between all its workers (src/main.rs:108-112): every
                                   flushed batch of the request queue and every batch call is split into n_devices contiguous
