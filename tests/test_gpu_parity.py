@@ -551,3 +551,29 @@ def test_two_pass_resample_through_an_lds_tile_equals_the_one_through_hbm(fl, gp
     gpu_state.debug_set("no_tile", 1)
     other, _ = parity.device_pixels(fl, gpu_state, img, **kw)
     assert np.array_equal(got, other)
+
+
+def test_more_callers_than_the_regular_lanes_hold(fl, gpu_state):
+    """Default queue: 4 lanes x 16 requests, plus overflow lanes that take the full batches waiting behind them (csrc/fl_queue.cpp).  112 callers at
+    once: every result equals the one the same request gives alone, whichever lane served it."""
+    import threading
+    imgs = [synth.uniform(270, 480, 3, index=200 + i % 7) for i in range(112)]
+    params = [fl.make_params(120 + 8 * (i % 3), 90) for i in range(len(imgs))]
+    alone = {}
+    for i in range(7 * 3):
+        alone[(i % 7, i % 3)] = gpu_state.process_pixels(imgs[i % 7], fl.make_params(120 + 8 * (i % 3), 90))
+    got = [None] * len(imgs)
+    gate = threading.Barrier(len(imgs))
+
+    def call(i):
+        gate.wait()
+        for _ in range(3): got[i] = gpu_state.process_pixels(imgs[i], params[i])
+
+    before = gpu_state.stats()
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(len(imgs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    after = gpu_state.stats()
+    for i, g in enumerate(got):
+        assert np.array_equal(np.asarray(g), np.asarray(alone[(i % 7, i % 3)])), i
+    assert after["queue_flushes"] - before["queue_flushes"] < 3 * len(imgs) // 4
