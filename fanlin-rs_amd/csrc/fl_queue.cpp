@@ -39,6 +39,15 @@ void split_by_weight(const uint64_t *weight, size_t n, uint32_t n_shards, uint32
     }
 }
 
+// Pixel buffers as sources: a flush stops collecting at this many source bytes per device.  Sixteen 1080p buffers are 100 MB of uploads in front of
+// the batch's first kernel, and with four lanes' uploads interleaved on the link a request waited for up to 400 MB: the leg is bound by the link either way
+// (9.1 k images/s), but its p99 went 12-20 -> 8.7-8.9 ms with batches of three (tools/experiments/queue_bytes_cap.sh: 12 / 16 / 24 / 32 MB / none:
+// 8.7 / 8.9 / 9.3-9.6 / 9.7-10.1 / 12-20 ms).  JPEG files do not count: their uploads are small and their decode kernels' time does not depend on the batch.
+#ifndef FL_QUEUE_CAP_MB
+#define FL_QUEUE_CAP_MB 16
+#endif
+constexpr uint64_t kBatchSourceBytes = FL_QUEUE_CAP_MB ? (uint64_t)FL_QUEUE_CAP_MB << 20 : ~0ull >> 8;
+
 constexpr size_t kPinPoolMaxBlock = (size_t)64 << 20; // page-locked staging blocks above this size are freed after use, not pooled
 
 PinBlock pin_acquire(flgpu_ctx *c, size_t bytes)
@@ -214,7 +223,11 @@ void worker_main(flgpu_ctx *c, flgpu_ctx *lane, uint32_t slot, bool overflow)
                     if (c->qcv.wait_until(lk, deadline) == std::cv_status::timeout) break;
                 }
                 std::vector<Request *> all;
-                while (!c->queue.empty() && all.size() < max_batch) { all.push_back(c->queue.front()); c->queue.pop_front(); }
+                // (a batch also ends at kBatchSourceBytes of pixel sources, see above)
+                for (uint64_t bytes = 0; !c->queue.empty() && all.size() < max_batch && (all.empty() || bytes < kBatchSourceBytes * ndev);) {
+                    if (!c->queue.front()->jpeg) bytes += c->queue.front()->src_bytes;
+                    all.push_back(c->queue.front()); c->queue.pop_front();
+                }
                 c->collecting = false;
                 if (ndev <= 1 || all.size() <= 1) batch.swap(all);
                 else {
