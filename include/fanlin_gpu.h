@@ -151,7 +151,8 @@ typedef struct flgpu_plan {
 #define FLGPU_MAX_DEVICES 8
 typedef struct flgpu_config {
     int32_t device;            /* HIP device ordinal; -1 = current device (used when n_devices <= 1) */
-    uint32_t max_batch;        /* request-queue flush size PER DEVICE (0 = default 16) */
+    uint32_t max_batch;        /* request-queue flush size PER DEVICE (0 = default 16); a flush also ends at 16 MB of pixel sources
+                                  per device (three 1080p buffers: the uploads in front of its first kernel), JPEG files not counted */
     uint32_t flush_timeout_us; /* request-queue flush timer (0 = default 200) */
     uint32_t profile;          /* 1 = bracket kernels with HIP events and report them in flgpu_stats */
     uint32_t queue_lanes;      /* flgpu_transform: batches kept in flight at once PER DEVICE (each lane has its own stream
